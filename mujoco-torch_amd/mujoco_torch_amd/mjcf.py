@@ -1,0 +1,1428 @@
+"""MJCF-subset compiler: XML -> arrays with MuJoCo's ``MjModel`` field names.
+
+The reference delegates XML compilation and ``mj_setConst`` to the MuJoCo C
+library (``mujoco.MjModel.from_xml_*`` then reference ``_src/device.py:1045-1080``
+copies every field by name).  That library is not a dependency here, so the
+subset of the compiler the bundled models need is restated in numpy: default
+classes, ``fromto``/``euler``/``xyaxes``/``zaxis`` frames, density -> mass and
+inertia, principal-axis inertial frames, ``autolimits``, degree/radian
+conversion, ``<pair>``/``<exclude>``, motor/position/velocity actuators,
+keyframes, binary-STL convex meshes, and the qpos0 constants ``mj_setConst``
+derives (``dof_invweight0``, ``body_invweight0``, ``dof_M0``,
+``stat.meaninertia``, ``actuator_acc0``, cam/light ``*0`` frames).
+
+Parity of these constants with the real MuJoCo compiler is UNPINNED in this
+repository (no ``mujoco`` wheel offline); ``device_put`` accepts a real
+``mujoco.MjModel`` unchanged when one is available.  This is host-side,
+setup-time code: nothing here runs inside ``step``.
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import struct
+import xml.etree.ElementTree as ET
+from types import SimpleNamespace
+
+import numpy as np
+
+from ._enums import (
+    BiasType,
+    CamLightType,
+    ConeType,
+    DisableBit,
+    DynType,
+    EnableBit,
+    GainType,
+    GeomType,
+    IntegratorType,
+    JacobianType,
+    JointType,
+    SensorType,
+    SolverType,
+    TrnType,
+    mjMINVAL,
+    mjNBIAS,
+    mjNDYN,
+    mjNGAIN,
+)
+
+# --------------------------------------------------------------------------
+# small quaternion / frame helpers (host, float64)
+# --------------------------------------------------------------------------
+
+
+def _quat_mul(u, v):
+    return np.array(
+        [
+            u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3],
+            u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2],
+            u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1],
+            u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0],
+        ]
+    )
+
+
+def _quat_to_mat(q):
+    w, x, y, z = q
+    return np.array(
+        [
+            [w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+            [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+            [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z],
+        ]
+    )
+
+
+def _mat_to_quat(m):
+    """Rotation matrix -> unit quaternion (w >= 0 branch selection as mju_mat2Quat)."""
+    if m[0, 0] + m[1, 1] + m[2, 2] > 0:
+        q0 = 0.5 * math.sqrt(1 + m[0, 0] + m[1, 1] + m[2, 2])
+        q = np.array([q0, 0.25 * (m[2, 1] - m[1, 2]) / q0, 0.25 * (m[0, 2] - m[2, 0]) / q0, 0.25 * (m[1, 0] - m[0, 1]) / q0])
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        q1 = 0.5 * math.sqrt(1 + m[0, 0] - m[1, 1] - m[2, 2])
+        q = np.array([0.25 * (m[2, 1] - m[1, 2]) / q1, q1, 0.25 * (m[0, 1] + m[1, 0]) / q1, 0.25 * (m[0, 2] + m[2, 0]) / q1])
+    elif m[1, 1] > m[2, 2]:
+        q2 = 0.5 * math.sqrt(1 - m[0, 0] + m[1, 1] - m[2, 2])
+        q = np.array([0.25 * (m[0, 2] - m[2, 0]) / q2, 0.25 * (m[0, 1] + m[1, 0]) / q2, q2, 0.25 * (m[1, 2] + m[2, 1]) / q2])
+    else:
+        q3 = 0.5 * math.sqrt(1 - m[0, 0] - m[1, 1] + m[2, 2])
+        q = np.array([0.25 * (m[1, 0] - m[0, 1]) / q3, 0.25 * (m[0, 2] + m[2, 0]) / q3, 0.25 * (m[1, 2] + m[2, 1]) / q3, q3])
+    return q / np.linalg.norm(q)
+
+
+def _rotate(v, q):
+    return _quat_to_mat(q) @ np.asarray(v, dtype=np.float64)
+
+
+def _z_to_quat(vec):
+    """Quaternion rotating +z onto ``vec`` (mjuu_z2quat)."""
+    vec = np.asarray(vec, dtype=np.float64)
+    n = np.linalg.norm(vec)
+    if n < 1e-10:
+        return np.array([1.0, 0, 0, 0])
+    vec = vec / n
+    z = np.array([0.0, 0, 1])
+    axis = np.cross(z, vec)
+    s = np.linalg.norm(axis)
+    if s < 1e-10:
+        axis = np.array([1.0, 0, 0])
+    else:
+        axis = axis / s
+    ang = math.atan2(s, vec[2])
+    return np.concatenate([[math.cos(ang / 2)], axis * math.sin(ang / 2)])
+
+
+def _axisangle_quat(axis, ang):
+    axis = np.asarray(axis, dtype=np.float64)
+    n = np.linalg.norm(axis)
+    if n < 1e-10:
+        return np.array([1.0, 0, 0, 0])
+    axis = axis / n
+    return np.concatenate([[math.cos(ang / 2)], axis * math.sin(ang / 2)])
+
+
+# --------------------------------------------------------------------------
+# attribute parsing helpers
+# --------------------------------------------------------------------------
+
+
+def _floats(s):
+    return np.array([float(x) for x in s.split()], dtype=np.float64)
+
+
+def _bool(s):
+    return s.strip().lower() == "true"
+
+
+_ACT_TAGS = ("motor", "position", "velocity", "general", "intvelocity", "damper")
+
+
+class _Defaults:
+    """One default class: per-tag attribute dicts, inherited from the parent."""
+
+    def __init__(self, parent=None):
+        self.attrs = {} if parent is None else {k: dict(v) for k, v in parent.attrs.items()}
+
+    def update(self, tag, d):
+        key = "actuator" if tag in _ACT_TAGS else tag
+        self.attrs.setdefault(key, {}).update(d)
+        if tag in _ACT_TAGS:
+            self.attrs[key]["__tag__"] = tag
+
+    def get(self, tag):
+        key = "actuator" if tag in _ACT_TAGS else tag
+        return self.attrs.get(key, {})
+
+
+# --------------------------------------------------------------------------
+# geometry: mass / inertia of primitives (mjCGeom::GetVolume / SetInertia)
+# --------------------------------------------------------------------------
+
+
+def _geom_volume(gtype, size):
+    if gtype == GeomType.SPHERE:
+        return 4.0 / 3.0 * math.pi * size[0] ** 3
+    if gtype == GeomType.CAPSULE:
+        h = 2 * size[1]
+        return math.pi * (size[0] ** 2 * h + 4.0 / 3.0 * size[0] ** 3)
+    if gtype == GeomType.CYLINDER:
+        return math.pi * size[0] ** 2 * 2 * size[1]
+    if gtype == GeomType.ELLIPSOID:
+        return 4.0 / 3.0 * math.pi * size[0] * size[1] * size[2]
+    if gtype == GeomType.BOX:
+        return 8.0 * size[0] * size[1] * size[2]
+    return 0.0
+
+
+def _geom_inertia(gtype, size, mass):
+    if gtype == GeomType.SPHERE:
+        i = 2.0 * mass * size[0] ** 2 / 5.0
+        return np.array([i, i, i])
+    if gtype == GeomType.CAPSULE:
+        r, h = size[0], 2 * size[1]
+        sphere_mass = mass * 4 * r / (4 * r + 3 * h)
+        cyl_mass = mass - sphere_mass
+        i0 = cyl_mass * (3 * r * r + h * h) / 12.0
+        i2 = cyl_mass * r * r / 2.0
+        sph = 2.0 * sphere_mass * r * r / 5.0
+        i0 += sph + sphere_mass * h * (3 * r + 2 * h) / 8.0
+        i2 += sph
+        return np.array([i0, i0, i2])
+    if gtype == GeomType.CYLINDER:
+        r, h = size[0], 2 * size[1]
+        i0 = mass * (3 * r * r + h * h) / 12.0
+        return np.array([i0, i0, mass * r * r / 2.0])
+    if gtype == GeomType.ELLIPSOID:
+        a, b, c = size
+        return mass / 5.0 * np.array([b * b + c * c, a * a + c * c, a * a + b * b])
+    if gtype == GeomType.BOX:
+        a, b, c = size
+        return mass / 3.0 * np.array([b * b + c * c, a * a + c * c, a * a + b * b])
+    return np.zeros(3)
+
+
+def _principal_axes(full):
+    """Symmetric 3x3 -> (quat, diag) with eigenvalues in decreasing order, right-handed frame."""
+    w, v = np.linalg.eigh(full)
+    order = np.argsort(-w, kind="stable")
+    w, v = w[order], v[:, order]
+    if np.linalg.det(v) < 0:
+        v[:, 2] = -v[:, 2]
+    return _mat_to_quat(v), w
+
+
+def _read_stl(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    ntri = struct.unpack_from("<I", data, 80)[0]
+    tris = np.zeros((ntri, 3, 3), dtype=np.float64)
+    off = 84
+    for i in range(ntri):
+        vals = struct.unpack_from("<12f", data, off)
+        tris[i] = np.array(vals[3:12]).reshape(3, 3)
+        off += 50
+    return tris
+
+
+def _mesh_mass_props(verts, faces):
+    """Volume, COM and unit-density inertia (about COM) of a closed triangle mesh."""
+    vol = 0.0
+    com = np.zeros(3)
+    # covariance integral via signed tetrahedra (origin apex)
+    canon = np.array([[2, 1, 1], [1, 2, 1], [1, 1, 2]], dtype=np.float64) / 120.0
+    cov = np.zeros((3, 3))
+    for f in faces:
+        a, b, c = verts[f[0]], verts[f[1]], verts[f[2]]
+        A = np.stack([a, b, c], axis=1)
+        det = np.linalg.det(A)
+        vol += det / 6.0
+        com += det / 24.0 * (a + b + c)
+        cov += det * (A @ canon @ A.T)
+    com = com / vol
+    cov = cov - vol * np.outer(com, com)
+    inertia = np.trace(cov) * np.eye(3) - cov
+    return vol, com, inertia
+
+
+# --------------------------------------------------------------------------
+# the compiler
+# --------------------------------------------------------------------------
+
+
+class MjModelLite(SimpleNamespace):
+    """Attribute bag with MuJoCo ``MjModel`` field names (numpy arrays / ints)."""
+
+
+_DISABLE_FLAGS = {
+    "constraint": DisableBit.CONSTRAINT,
+    "equality": DisableBit.EQUALITY,
+    "frictionloss": DisableBit.FRICTIONLOSS,
+    "limit": DisableBit.LIMIT,
+    "contact": DisableBit.CONTACT,
+    "spring": DisableBit.SPRING,
+    "damper": DisableBit.DAMPER,
+    "passive": DisableBit.SPRING | DisableBit.DAMPER,
+    "gravity": DisableBit.GRAVITY,
+    "clampctrl": DisableBit.CLAMPCTRL,
+    "warmstart": DisableBit.WARMSTART,
+    "filterparent": DisableBit.FILTERPARENT,
+    "actuation": DisableBit.ACTUATION,
+    "refsafe": DisableBit.REFSAFE,
+    "sensor": DisableBit.SENSOR,
+    "midphase": DisableBit.MIDPHASE,
+    "eulerdamp": DisableBit.EULERDAMP,
+    "autoreset": DisableBit.AUTORESET,
+    "nativeccd": DisableBit.NATIVECCD,
+    "island": DisableBit.ISLAND,
+}
+_ENABLE_FLAGS = {
+    "override": EnableBit.OVERRIDE,
+    "energy": EnableBit.ENERGY,
+    "fwdinv": EnableBit.FWDINV,
+    "invdiscrete": EnableBit.INVDISCRETE,
+    "multiccd": EnableBit.MULTICCD,
+    "sleep": EnableBit.SLEEP,
+}
+
+_GEOM_TYPES = {
+    "plane": GeomType.PLANE,
+    "hfield": GeomType.HFIELD,
+    "sphere": GeomType.SPHERE,
+    "capsule": GeomType.CAPSULE,
+    "ellipsoid": GeomType.ELLIPSOID,
+    "cylinder": GeomType.CYLINDER,
+    "box": GeomType.BOX,
+    "mesh": GeomType.MESH,
+}
+_JOINT_TYPES = {"free": JointType.FREE, "ball": JointType.BALL, "slide": JointType.SLIDE, "hinge": JointType.HINGE}
+_CAM_MODES = {
+    "fixed": CamLightType.FIXED,
+    "track": CamLightType.TRACK,
+    "trackcom": CamLightType.TRACKCOM,
+    "targetbody": CamLightType.TARGETBODY,
+    "targetbodycom": CamLightType.TARGETBODYCOM,
+}
+_SENSOR_DIMS = {
+    "touch": (SensorType.TOUCH, 1),
+    "accelerometer": (SensorType.ACCELEROMETER, 3),
+    "velocimeter": (SensorType.VELOCIMETER, 3),
+    "gyro": (SensorType.GYRO, 3),
+    "force": (SensorType.FORCE, 3),
+    "torque": (SensorType.TORQUE, 3),
+    "magnetometer": (SensorType.MAGNETOMETER, 3),
+    "rangefinder": (SensorType.RANGEFINDER, 1),
+    "jointpos": (SensorType.JOINTPOS, 1),
+    "jointvel": (SensorType.JOINTVEL, 1),
+}
+
+_DEF_SOLREF = np.array([0.02, 1.0])
+_DEF_SOLIMP = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
+
+
+def _pad(a, n, fill):
+    a = np.asarray(a, dtype=np.float64)
+    out = np.array(fill, dtype=np.float64).copy()
+    out[: len(a)] = a[:n]
+    return out
+
+
+class _Compiler:
+    def __init__(self, root, base_dir):
+        self.root = root
+        self.base_dir = base_dir
+        self.angle_deg = True
+        self.autolimits = True
+        self.eulerseq = "xyz"
+        self.meshdir = ""
+        self.inertiafromgeom = "auto"
+        self.boundmass = 0.0
+        self.boundinertia = 0.0
+        self.settotalmass = -1.0
+        self.defaults = {"main": _Defaults()}
+        self.meshes = {}
+        self.bodies = []  # dicts
+        self.joints = []
+        self.geoms = []
+        self.sites = []
+        self.cams = []
+        self.lights = []
+        self.opt = {}
+        self.stat_meaninertia = None
+
+    # ---- orientation -------------------------------------------------
+    def _ang(self, x):
+        return x * math.pi / 180.0 if self.angle_deg else x
+
+    def _orientation(self, a):
+        if "quat" in a:
+            q = _floats(a["quat"])
+            return q / np.linalg.norm(q)
+        if "axisangle" in a:
+            v = _floats(a["axisangle"])
+            return _axisangle_quat(v[:3], self._ang(v[3]))
+        if "euler" in a:
+            e = _floats(a["euler"])
+            q = np.array([1.0, 0, 0, 0])
+            for i, ch in enumerate(self.eulerseq):
+                ax = {"x": [1.0, 0, 0], "y": [0, 1.0, 0], "z": [0, 0, 1.0]}[ch.lower()]
+                r = _axisangle_quat(ax, self._ang(e[i]))
+                # lower-case: intrinsic (rotating frame) -> post-multiply
+                q = _quat_mul(q, r) if ch.islower() else _quat_mul(r, q)
+            return q / np.linalg.norm(q)
+        if "xyaxes" in a:
+            v = _floats(a["xyaxes"])
+            x = v[:3] / np.linalg.norm(v[:3])
+            y = v[3:] - x * np.dot(x, v[3:])
+            y = y / np.linalg.norm(y)
+            z = np.cross(x, y)
+            return _mat_to_quat(np.stack([x, y, z], axis=1))
+        if "zaxis" in a:
+            return _z_to_quat(_floats(a["zaxis"]))
+        return np.array([1.0, 0, 0, 0])
+
+    # ---- defaults ------------------------------------------------------
+    def _parse_defaults(self, node, parent_name):
+        name = node.get("class", "main" if parent_name is None else None)
+        if parent_name is None:
+            d = self.defaults["main"]
+            name = "main"
+        else:
+            d = _Defaults(self.defaults[parent_name])
+            self.defaults[name] = d
+        for child in node:
+            if child.tag == "default":
+                continue
+            d.update(child.tag, dict(child.attrib))
+        for child in node:
+            if child.tag == "default":
+                self._parse_defaults(child, name)
+
+    def _resolve(self, node, childclass):
+        cls = node.get("class", childclass or "main")
+        if cls not in self.defaults:
+            raise ValueError(f"unknown default class {cls!r}")
+        a = dict(self.defaults[cls].get(node.tag))
+        a.pop("__tag__", None)
+        own = dict(node.attrib)
+        # an element's own orientation / fromto spec replaces (not merges with) a defaulted one
+        orient = ("quat", "axisangle", "euler", "xyaxes", "zaxis")
+        if any(k in own for k in orient) or "fromto" in own:
+            for k in orient:
+                a.pop(k, None)
+        a.update(own)
+        return a
+
+    # ---- top-level sections -------------------------------------------
+    def parse(self):
+        root = self.root
+        for comp in root.findall("compiler"):
+            c = comp.attrib
+            if "angle" in c:
+                self.angle_deg = c["angle"] == "degree"
+            if "autolimits" in c:
+                self.autolimits = _bool(c["autolimits"])
+            if "eulerseq" in c:
+                self.eulerseq = c["eulerseq"]
+            if "meshdir" in c:
+                self.meshdir = c["meshdir"]
+            if "inertiafromgeom" in c:
+                self.inertiafromgeom = c["inertiafromgeom"]
+            if "boundmass" in c:
+                self.boundmass = float(c["boundmass"])
+            if "boundinertia" in c:
+                self.boundinertia = float(c["boundinertia"])
+            if "settotalmass" in c:
+                self.settotalmass = float(c["settotalmass"])
+            if c.get("coordinate", "local") != "local":
+                raise NotImplementedError("only coordinate='local' is supported")
+        for dnode in root.findall("default"):
+            self._parse_defaults(dnode, None)
+        for st in root.findall("statistic"):
+            if "meaninertia" in st.attrib:
+                self.stat_meaninertia = float(st.get("meaninertia"))
+        for asset in root.findall("asset"):
+            for mesh in asset.findall("mesh"):
+                a = dict(self.defaults["main"].get("mesh"))
+                a.update(mesh.attrib)
+                name = a.get("name") or os.path.splitext(os.path.basename(a["file"]))[0]
+                self.meshes[name] = a
+        self._parse_option()
+        wb = root.find("worldbody")
+        world = dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]), inertial=None, mocap=False, gravcomp=0.0, id=0, joints=[], geoms=[])
+        self.bodies.append(world)
+        if wb is not None:
+            self._parse_body_children(wb, 0, None)
+
+    def _parse_option(self):
+        o = dict(
+            timestep=0.002,
+            gravity=np.array([0.0, 0, -9.81]),
+            wind=np.zeros(3),
+            magnetic=np.array([0.0, -0.5, 0.0]),
+            density=0.0,
+            viscosity=0.0,
+            impratio=1.0,
+            tolerance=1e-8,
+            ls_tolerance=0.01,
+            iterations=100,
+            ls_iterations=50,
+            integrator=IntegratorType.EULER,
+            solver=SolverType.NEWTON,
+            cone=ConeType.PYRAMIDAL,
+            jacobian=JacobianType.AUTO,
+            disableflags=0,
+            enableflags=0,
+            o_margin=0.0,
+            o_solref=_DEF_SOLREF.copy(),
+            o_solimp=_DEF_SOLIMP.copy(),
+            o_friction=np.array([1.0, 1.0, 0.005, 0.0001, 0.0001]),
+            disableactuator=0,
+            sdf_initpoints=40,
+        )
+        for on in self.root.findall("option"):
+            a = on.attrib
+            for k in ("timestep", "density", "viscosity", "impratio", "tolerance", "ls_tolerance", "o_margin"):
+                if k in a:
+                    o[k] = float(a[k])
+            for k in ("iterations", "ls_iterations", "sdf_initpoints"):
+                if k in a:
+                    o[k] = int(a[k])
+            for k in ("gravity", "wind", "magnetic", "o_solref", "o_solimp", "o_friction"):
+                if k in a:
+                    o[k] = _floats(a[k])
+            if "integrator" in a:
+                o["integrator"] = {"euler": IntegratorType.EULER, "rk4": IntegratorType.RK4, "implicit": IntegratorType.IMPLICIT, "implicitfast": IntegratorType.IMPLICITFAST}[a["integrator"].lower()]
+            if "solver" in a:
+                o["solver"] = {"pgs": SolverType.PGS, "cg": SolverType.CG, "newton": SolverType.NEWTON}[a["solver"].lower()]
+            if "cone" in a:
+                o["cone"] = {"pyramidal": ConeType.PYRAMIDAL, "elliptic": ConeType.ELLIPTIC}[a["cone"].lower()]
+            if "jacobian" in a:
+                o["jacobian"] = {"dense": JacobianType.DENSE, "sparse": JacobianType.SPARSE, "auto": JacobianType.AUTO}[a["jacobian"].lower()]
+            for fl in on.findall("flag"):
+                for k, v in fl.attrib.items():
+                    if k in _DISABLE_FLAGS:
+                        if v == "disable":
+                            o["disableflags"] |= int(_DISABLE_FLAGS[k])
+                        else:
+                            o["disableflags"] &= ~int(_DISABLE_FLAGS[k])
+                    elif k in _ENABLE_FLAGS:
+                        if v == "enable":
+                            o["enableflags"] |= int(_ENABLE_FLAGS[k])
+                        else:
+                            o["enableflags"] &= ~int(_ENABLE_FLAGS[k])
+        self.opt = o
+
+    # ---- kinematic tree -------------------------------------------------
+    def _parse_body_children(self, node, body_id, childclass):
+        body = self.bodies[body_id]
+        for child in node:
+            tag = child.tag
+            if tag == "inertial":
+                a = child.attrib
+                body["inertial"] = dict(a)
+            elif tag in ("joint", "freejoint"):
+                if tag == "freejoint":
+                    a = dict(child.attrib)
+                    a["type"] = "free"
+                else:
+                    a = self._resolve(child, childclass)
+                a["__body__"] = body_id
+                body["joints"].append(len(self.joints))
+                self.joints.append(a)
+            elif tag == "geom":
+                a = self._resolve(child, childclass)
+                a["__body__"] = body_id
+                body["geoms"].append(len(self.geoms))
+                self.geoms.append(a)
+            elif tag == "site":
+                a = self._resolve(child, childclass)
+                a["__body__"] = body_id
+                self.sites.append(a)
+            elif tag == "camera":
+                a = self._resolve(child, childclass)
+                a["__body__"] = body_id
+                self.cams.append(a)
+            elif tag == "light":
+                a = self._resolve(child, childclass)
+                a["__body__"] = body_id
+                self.lights.append(a)
+        for child in node:
+            if child.tag == "body":
+                a = child.attrib
+                cc = a.get("childclass", childclass)
+                nb = dict(
+                    name=a.get("name", ""),
+                    parent=body_id,
+                    pos=_floats(a["pos"]) if "pos" in a else np.zeros(3),
+                    quat=self._orientation(a),
+                    inertial=None,
+                    mocap=_bool(a.get("mocap", "false")),
+                    gravcomp=float(a.get("gravcomp", 0.0)),
+                    id=len(self.bodies),
+                    joints=[],
+                    geoms=[],
+                )
+                self.bodies.append(nb)
+                self._parse_body_children(child, nb["id"], cc)
+
+    # ---- build ---------------------------------------------------------
+    def build(self) -> MjModelLite:
+        self.parse()
+        m = MjModelLite()
+        m.opt = SimpleNamespace(**self.opt)
+        # MuJoCo numbers bodies depth-first in XML order, which is the parse order
+        # of _parse_body_children only if children are visited right after their
+        # parent's elements: re-number with an explicit pre-order walk.
+        order = []
+        kids = {}
+        for b in self.bodies:
+            if b["id"] != 0:
+                kids.setdefault(b["parent"], []).append(b["id"])
+
+        def walk(i):
+            order.append(i)
+            for k in kids.get(i, []):
+                walk(k)
+
+        walk(0)
+        remap = {old: new for new, old in enumerate(order)}
+        bodies = [self.bodies[i] for i in order]
+        nbody = len(bodies)
+        m.nbody = nbody
+        m.names_body = [b["name"] for b in bodies]
+        m.body_parentid = np.array([remap[b["parent"]] for b in bodies], dtype=np.int32)
+        m.body_pos = np.stack([b["pos"] for b in bodies])
+        m.body_quat = np.stack([b["quat"] for b in bodies])
+        m.body_gravcomp = np.array([b["gravcomp"] for b in bodies])
+        mocap = [b["mocap"] for b in bodies]
+        m.nmocap = int(sum(mocap))
+        mid = -np.ones(nbody, dtype=np.int32)
+        k = 0
+        for i, mc in enumerate(mocap):
+            if mc:
+                mid[i] = k
+                k += 1
+        m.body_mocapid = mid
+
+        # ---- joints / dofs (in body order) ----
+        jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid = [], [], [], []
+        jnt_pos, jnt_axis, jnt_range, jnt_limited, jnt_margin = [], [], [], [], []
+        jnt_stiffness, jnt_solref, jnt_solimp, jnt_actfrcrange, jnt_actfrclimited, jnt_actgravcomp = [], [], [], [], [], []
+        jnt_names = []
+        dof_bodyid, dof_jntid, dof_parentid = [], [], []
+        dof_armature, dof_damping, dof_frictionloss, dof_solref, dof_solimp = [], [], [], [], []
+        qpos0, qpos_spring = [], []
+        body_jntnum = np.zeros(nbody, dtype=np.int32)
+        body_jntadr = -np.ones(nbody, dtype=np.int32)
+        body_dofnum = np.zeros(nbody, dtype=np.int32)
+        body_dofadr = -np.ones(nbody, dtype=np.int32)
+        last_dof_of_body = -np.ones(nbody, dtype=np.int32)
+        nq = nv = 0
+        for bi, b in enumerate(bodies):
+            # last dof of the nearest ancestor that has dofs
+            p = int(m.body_parentid[bi])
+            parent_dof = last_dof_of_body[p] if bi > 0 else -1
+            cur_parent = parent_dof
+            for jl in b["joints"]:
+                a = self.joints[jl]
+                jt = _JOINT_TYPES[a.get("type", "hinge")]
+                jid = len(jnt_type)
+                if body_jntadr[bi] < 0:
+                    body_jntadr[bi] = jid
+                body_jntnum[bi] += 1
+                jnt_names.append(a.get("name", ""))
+                jnt_type.append(int(jt))
+                jnt_qposadr.append(nq)
+                jnt_dofadr.append(nv)
+                jnt_bodyid.append(bi)
+                if jt == JointType.FREE:
+                    jnt_pos.append(np.zeros(3))
+                else:
+                    jnt_pos.append(_floats(a["pos"]) if "pos" in a else np.zeros(3))
+                ax = _floats(a["axis"]) if "axis" in a else np.array([0.0, 0, 1])
+                n = np.linalg.norm(ax)
+                jnt_axis.append(ax / n if n > 0 else np.array([0.0, 0, 1]))
+                has_range = "range" in a
+                rng = _floats(a["range"]) if has_range else np.zeros(2)
+                if jt in (JointType.HINGE, JointType.BALL):
+                    rng = np.array([self._ang(rng[0]), self._ang(rng[1])])
+                lim = a.get("limited", "auto")
+                if lim == "auto":
+                    limited = has_range and self.autolimits
+                else:
+                    limited = _bool(lim)
+                jnt_range.append(rng)
+                jnt_limited.append(limited)
+                jnt_margin.append(float(a.get("margin", 0.0)))
+                jnt_stiffness.append(float(a.get("stiffness", 0.0)))
+                jnt_solref.append(_pad(_floats(a["solreflimit"]), 2, _DEF_SOLREF) if "solreflimit" in a else _DEF_SOLREF.copy())
+                jnt_solimp.append(_pad(_floats(a["solimplimit"]), 5, _DEF_SOLIMP) if "solimplimit" in a else _DEF_SOLIMP.copy())
+                has_afr = "actuatorfrcrange" in a
+                jnt_actfrcrange.append(_floats(a["actuatorfrcrange"]) if has_afr else np.zeros(2))
+                afl = a.get("actuatorfrclimited", "auto")
+                jnt_actfrclimited.append((has_afr and self.autolimits) if afl == "auto" else _bool(afl))
+                jnt_actgravcomp.append(_bool(a.get("actuatorgravcomp", "false")))
+                ref = float(a.get("ref", 0.0))
+                sref = float(a.get("springref", 0.0))
+                if jt == JointType.HINGE:
+                    ref, sref = self._ang(ref), self._ang(sref)
+                if jt == JointType.FREE:
+                    q0 = np.concatenate([b["pos"], b["quat"]])
+                    qpos0.extend(q0)
+                    qpos_spring.extend(q0)
+                elif jt == JointType.BALL:
+                    qpos0.extend([1.0, 0, 0, 0])
+                    qpos_spring.extend([1.0, 0, 0, 0])
+                else:
+                    qpos0.append(ref)
+                    qpos_spring.append(sref)
+                w = jt.dof_width()
+                if body_dofadr[bi] < 0:
+                    body_dofadr[bi] = nv
+                body_dofnum[bi] += w
+                dsolref = _pad(_floats(a["solreffriction"]), 2, _DEF_SOLREF) if "solreffriction" in a else _DEF_SOLREF.copy()
+                dsolimp = _pad(_floats(a["solimpfriction"]), 5, _DEF_SOLIMP) if "solimpfriction" in a else _DEF_SOLIMP.copy()
+                for _ in range(w):
+                    dof_bodyid.append(bi)
+                    dof_jntid.append(jid)
+                    dof_parentid.append(cur_parent)
+                    cur_parent = nv
+                    dof_armature.append(float(a.get("armature", 0.0)))
+                    dof_damping.append(float(a.get("damping", 0.0)))
+                    dof_frictionloss.append(float(a.get("frictionloss", 0.0)))
+                    dof_solref.append(dsolref)
+                    dof_solimp.append(dsolimp)
+                    nv += 1
+                nq += jt.qpos_width()
+            last_dof_of_body[bi] = cur_parent
+        m.nq, m.nv, m.njnt = nq, nv, len(jnt_type)
+        m.names_jnt = jnt_names
+        m.jnt_type = np.array(jnt_type, dtype=np.int32)
+        m.jnt_qposadr = np.array(jnt_qposadr, dtype=np.int32)
+        m.jnt_dofadr = np.array(jnt_dofadr, dtype=np.int32)
+        m.jnt_bodyid = np.array(jnt_bodyid, dtype=np.int32)
+        m.jnt_group = np.zeros(m.njnt, dtype=np.int32)
+        m.jnt_pos = np.array(jnt_pos, dtype=np.float64).reshape(-1, 3)
+        m.jnt_axis = np.array(jnt_axis, dtype=np.float64).reshape(-1, 3)
+        m.jnt_range = np.array(jnt_range, dtype=np.float64).reshape(-1, 2)
+        m.jnt_limited = np.array(jnt_limited, dtype=bool)
+        m.jnt_margin = np.array(jnt_margin, dtype=np.float64)
+        m.jnt_stiffness = np.array(jnt_stiffness, dtype=np.float64)
+        m.jnt_solref = np.array(jnt_solref, dtype=np.float64).reshape(-1, 2)
+        m.jnt_solimp = np.array(jnt_solimp, dtype=np.float64).reshape(-1, 5)
+        m.jnt_actfrcrange = np.array(jnt_actfrcrange, dtype=np.float64).reshape(-1, 2)
+        m.jnt_actfrclimited = np.array(jnt_actfrclimited, dtype=bool)
+        m.jnt_actgravcomp = np.array(jnt_actgravcomp, dtype=np.uint8)
+        m.dof_bodyid = np.array(dof_bodyid, dtype=np.int32)
+        m.dof_jntid = np.array(dof_jntid, dtype=np.int32)
+        m.dof_parentid = np.array(dof_parentid, dtype=np.int32)
+        m.dof_armature = np.array(dof_armature, dtype=np.float64)
+        m.dof_damping = np.array(dof_damping, dtype=np.float64)
+        m.dof_frictionloss = np.array(dof_frictionloss, dtype=np.float64)
+        m.dof_solref = np.array(dof_solref, dtype=np.float64).reshape(-1, 2)
+        m.dof_solimp = np.array(dof_solimp, dtype=np.float64).reshape(-1, 5)
+        m.qpos0 = np.array(qpos0, dtype=np.float64)
+        m.qpos_spring = np.array(qpos_spring, dtype=np.float64)
+        m.body_jntnum, m.body_jntadr = body_jntnum, body_jntadr
+        m.body_dofnum, m.body_dofadr = body_dofnum, body_dofadr
+        # sparse-M addressing (dof_Madr, nM)
+        madr, nM = [], 0
+        for i in range(nv):
+            madr.append(nM)
+            j = i
+            while j >= 0:
+                nM += 1
+                j = int(m.dof_parentid[j])
+        m.dof_Madr = np.array(madr + [nM], dtype=np.int32)[:nv] if nv else np.zeros(0, dtype=np.int32)
+        m.dof_Madr_ext = np.array(madr + [nM], dtype=np.int32)
+        m.nM = nM
+        # weld / root / tree ids
+        weld = np.zeros(nbody, dtype=np.int32)
+        rootid = np.zeros(nbody, dtype=np.int32)
+        for bi in range(1, nbody):
+            p = int(m.body_parentid[bi])
+            weld[bi] = bi if body_jntnum[bi] > 0 else weld[p]
+            rootid[bi] = bi if p == 0 else rootid[p]
+        m.body_weldid, m.body_rootid = weld, rootid
+        treeid = -np.ones(nbody, dtype=np.int32)
+        ntree = 0
+        for bi in range(1, nbody):
+            p = int(m.body_parentid[bi])
+            if body_dofnum[bi] > 0 and treeid[p] < 0 and weld[p] == 0:
+                treeid[bi] = ntree
+                ntree += 1
+            else:
+                treeid[bi] = treeid[p]
+        m.body_treeid = treeid
+        m.dof_treeid = treeid[m.dof_bodyid] if nv else np.zeros(0, dtype=np.int32)
+        m.body_sameframe = np.zeros(nbody, dtype=np.uint8)
+        m.body_simple = np.zeros(nbody, dtype=np.uint8)
+        m.dof_simplenum = np.zeros(nv, dtype=np.int32)
+
+        self._build_meshes(m)
+        self._build_geoms(m, bodies, remap)
+        self._build_inertia(m, bodies)
+        self._build_sites_cams_lights(m, remap)
+        self._build_contact(m)
+        self._build_actuators(m)
+        self._build_sensors(m)
+        self._build_empty_sections(m)
+        self._build_keyframes(m)
+        _set_const(m, self.stat_meaninertia)
+        return m
+
+    # ---- meshes -----------------------------------------------------------
+    def _build_meshes(self, m):
+        """Convex meshes: STL -> scaled verts -> hull -> centred on COM in the principal frame."""
+        m.mesh_names = list(self.meshes.keys())
+        m.nmesh = len(self.meshes)
+        m._mesh_data = {}
+        for name, a in self.meshes.items():
+            from scipy.spatial import ConvexHull  # host-side, setup only
+
+            path = os.path.join(self.base_dir, self.meshdir, a["file"])
+            tris = _read_stl(path)
+            verts = tris.reshape(-1, 3).astype(np.float32).astype(np.float64)
+            verts, inv = np.unique(verts, axis=0, return_inverse=True)
+            faces = inv.reshape(-1, 3)
+            scale = _floats(a["scale"]) if "scale" in a else np.ones(3)
+            verts = verts * scale
+            vol, com, inertia = _mesh_mass_props(verts, faces)
+            if vol < 0:
+                faces = faces[:, ::-1]
+                vol, com, inertia = _mesh_mass_props(verts, faces)
+            quat, diag = _principal_axes(inertia)
+            R = _quat_to_mat(quat)
+            local = (verts - com) @ R  # coordinates in the principal frame
+            hull = ConvexHull(local)
+            m._mesh_data[name] = dict(vert=local, face=faces, hull_vertices=hull.vertices, hull_simplices=hull.simplices, hull_equations=hull.equations, pos=com, quat=quat, volume=vol, inertia_unit=diag)
+
+    # ---- geoms -----------------------------------------------------------
+    def _build_geoms(self, m, bodies, remap):
+        ngeom = len(self.geoms)
+        # geoms are numbered by body order, then XML order within the body
+        order = []
+        for b in bodies:
+            order.extend(b["geoms"])
+        gremap = {old: new for new, old in enumerate(order)}
+        self._geom_remap = gremap
+        G = [self.geoms[i] for i in order]
+        m.ngeom = ngeom
+        m.names_geom = [g.get("name", "") for g in G]
+        gt, gsize, gpos, gquat, gbody = [], [], [], [], []
+        gmass, ginertia = [], []
+        m.geom_dataid = -np.ones(ngeom, dtype=np.int32)
+        f = lambda g, k, d: float(g.get(k, d))
+        for gi, g in enumerate(G):
+            t = _GEOM_TYPES[g.get("type", "sphere")]
+            size = np.zeros(3)
+            if "size" in g:
+                s = _floats(g["size"])
+                size[: len(s)] = s[:3]
+            pos = _floats(g["pos"]) if "pos" in g else np.zeros(3)
+            quat = self._orientation(g)
+            if "fromto" in g:
+                ft = _floats(g["fromto"])
+                vec = ft[:3] - ft[3:]
+                size[1] = np.linalg.norm(vec) / 2.0
+                pos = (ft[:3] + ft[3:]) / 2.0
+                quat = _z_to_quat(vec)
+            mesh_off_pos, mesh_off_quat = None, None
+            if t == GeomType.MESH:
+                md = m._mesh_data[g["mesh"]]
+                m.geom_dataid[gi] = m.mesh_names.index(g["mesh"])
+                # geom frame is composed with the mesh's COM / principal frame
+                mesh_off_pos, mesh_off_quat = md["pos"], md["quat"]
+                pos = pos + _rotate(mesh_off_pos, quat)
+                quat = _quat_mul(quat, mesh_off_quat)
+                ext = md["vert"][md["hull_vertices"]]
+                size = (ext.max(0) - ext.min(0)) / 2.0
+            gt.append(int(t))
+            gsize.append(size)
+            gpos.append(pos)
+            gquat.append(quat / np.linalg.norm(quat))
+            gbody.append(remap[g["__body__"]])
+            # mass
+            if t == GeomType.MESH:
+                vol = md["volume"]
+                unit_inertia = md["inertia_unit"]
+            else:
+                vol = _geom_volume(t, size)
+            if "mass" in g:
+                mass = float(g["mass"])
+            else:
+                mass = f(g, "density", 1000.0) * vol
+            if t == GeomType.MESH:
+                inertia = unit_inertia * (mass / vol if vol > 0 else 0.0)
+            else:
+                inertia = _geom_inertia(t, size, mass)
+            gmass.append(mass)
+            ginertia.append(inertia)
+        m.geom_type = np.array(gt, dtype=np.int32)
+        m.geom_size = np.array(gsize, dtype=np.float64).reshape(-1, 3)
+        m.geom_pos = np.array(gpos, dtype=np.float64).reshape(-1, 3)
+        m.geom_quat = np.array(gquat, dtype=np.float64).reshape(-1, 4)
+        m.geom_bodyid = np.array(gbody, dtype=np.int32)
+        m._geom_mass = np.array(gmass, dtype=np.float64)
+        m._geom_inertia = np.array(ginertia, dtype=np.float64).reshape(-1, 3)
+        m.geom_contype = np.array([int(g.get("contype", 1)) for g in G], dtype=np.int32)
+        m.geom_conaffinity = np.array([int(g.get("conaffinity", 1)) for g in G], dtype=np.int32)
+        m.geom_condim = np.array([int(g.get("condim", 3)) for g in G], dtype=np.int32)
+        m.geom_priority = np.array([int(g.get("priority", 0)) for g in G], dtype=np.int32)
+        m.geom_group = np.array([int(g.get("group", 0)) for g in G], dtype=np.int32)
+        m.geom_solmix = np.array([f(g, "solmix", 1.0) for g in G])
+        m.geom_margin = np.array([f(g, "margin", 0.0) for g in G])
+        m.geom_gap = np.array([f(g, "gap", 0.0) for g in G])
+        m.geom_solref = np.array([_pad(_floats(g["solref"]), 2, _DEF_SOLREF) if "solref" in g else _DEF_SOLREF for g in G]).reshape(-1, 2)
+        m.geom_solimp = np.array([_pad(_floats(g["solimp"]), 5, _DEF_SOLIMP) if "solimp" in g else _DEF_SOLIMP for g in G]).reshape(-1, 5)
+        deff = np.array([1.0, 0.005, 0.0001])
+        m.geom_friction = np.array([_pad(_floats(g["friction"]), 3, deff) if "friction" in g else deff for g in G]).reshape(-1, 3)
+        m.geom_rgba = np.array([_pad(_floats(g["rgba"]), 4, [0.5, 0.5, 0.5, 1]) if "rgba" in g else [0.5, 0.5, 0.5, 1.0] for g in G], dtype=np.float32).reshape(-1, 4)
+        m.geom_matid = -np.ones(ngeom, dtype=np.int32)
+        m.geom_sameframe = np.zeros(ngeom, dtype=np.uint8)
+        m.geom_fluid = np.zeros((ngeom, 12))
+        # bounding radius / aabb (setup-only consumers)
+        rb = []
+        for gi in range(ngeom):
+            t, s = m.geom_type[gi], m.geom_size[gi]
+            if t == GeomType.SPHERE:
+                rb.append(s[0])
+            elif t == GeomType.CAPSULE:
+                rb.append(s[0] + s[1])
+            elif t == GeomType.CYLINDER:
+                rb.append(math.hypot(s[0], s[1]))
+            elif t in (GeomType.BOX, GeomType.ELLIPSOID, GeomType.MESH):
+                rb.append(float(np.linalg.norm(s)) if t != GeomType.ELLIPSOID else float(np.max(s)))
+            else:
+                rb.append(0.0)
+        m.geom_rbound = np.array(rb, dtype=np.float64)
+        m.geom_aabb = np.concatenate([np.zeros((ngeom, 3)), m.geom_size], axis=1) if ngeom else np.zeros((0, 6))
+        geomadr = -np.ones(m.nbody, dtype=np.int32)
+        geomnum = np.zeros(m.nbody, dtype=np.int32)
+        for gi, b in enumerate(m.geom_bodyid):
+            if geomadr[b] < 0:
+                geomadr[b] = gi
+            geomnum[b] += 1
+        m.body_geomadr, m.body_geomnum = geomadr, geomnum
+
+    # ---- body inertial frames ---------------------------------------------
+    def _build_inertia(self, m, bodies):
+        nbody = m.nbody
+        ipos = np.zeros((nbody, 3))
+        iquat = np.tile(np.array([1.0, 0, 0, 0]), (nbody, 1))
+        mass = np.zeros(nbody)
+        inertia = np.zeros((nbody, 3))
+        for bi, b in enumerate(bodies):
+            if bi == 0:
+                continue
+            inr = b["inertial"]
+            use_geoms = self.inertiafromgeom == "true" or (self.inertiafromgeom == "auto" and inr is None)
+            if not use_geoms:
+                if inr is None:
+                    continue
+                ipos[bi] = _floats(inr["pos"]) if "pos" in inr else np.zeros(3)
+                iquat[bi] = self._orientation(inr)
+                mass[bi] = float(inr["mass"])
+                if "diaginertia" in inr:
+                    inertia[bi] = _floats(inr["diaginertia"])
+                elif "fullinertia" in inr:
+                    fi = _floats(inr["fullinertia"])
+                    full = np.array([[fi[0], fi[3], fi[4]], [fi[3], fi[1], fi[5]], [fi[4], fi[5], fi[2]]])
+                    q, d = _principal_axes(full)
+                    iquat[bi] = _quat_mul(iquat[bi], q)
+                    inertia[bi] = d
+                continue
+            gids = [g for g in range(m.ngeom) if m.geom_bodyid[g] == bi and m._geom_mass[g] > 0]
+            if not gids:
+                continue
+            if len(gids) == 1:
+                g = gids[0]
+                ipos[bi] = m.geom_pos[g]
+                iquat[bi] = m.geom_quat[g]
+                mass[bi] = m._geom_mass[g]
+                inertia[bi] = m._geom_inertia[g]
+                continue
+            tot = sum(m._geom_mass[g] for g in gids)
+            com = sum(m._geom_mass[g] * m.geom_pos[g] for g in gids) / tot
+            full = np.zeros((3, 3))
+            for g in gids:
+                R = _quat_to_mat(m.geom_quat[g])
+                full += R @ np.diag(m._geom_inertia[g]) @ R.T
+                d = m.geom_pos[g] - com
+                full += m._geom_mass[g] * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+            q, dg = _principal_axes(full)
+            ipos[bi], iquat[bi], mass[bi], inertia[bi] = com, q, tot, dg
+        if self.boundmass > 0:
+            mass[1:] = np.maximum(mass[1:], self.boundmass)
+        if self.boundinertia > 0:
+            inertia[1:] = np.maximum(inertia[1:], self.boundinertia)
+        if self.settotalmass > 0 and mass.sum() > 0:
+            s = self.settotalmass / mass.sum()
+            mass *= s
+            inertia *= s
+        m.body_ipos, m.body_iquat, m.body_mass, m.body_inertia = ipos, iquat, mass, inertia
+        sub = mass.copy()
+        for bi in range(nbody - 1, 0, -1):
+            sub[m.body_parentid[bi]] += sub[bi]
+        m.body_subtreemass = sub
+
+    # ---- sites / cameras / lights -------------------------------------------
+    def _build_sites_cams_lights(self, m, remap):
+        def by_body(items):
+            idx = sorted(range(len(items)), key=lambda i: (remap[items[i]["__body__"]], i))
+            return [items[i] for i in idx]
+
+        S = by_body(self.sites)
+        m.nsite = len(S)
+        m.names_site = [s.get("name", "") for s in S]
+        m.site_bodyid = np.array([remap[s["__body__"]] for s in S], dtype=np.int32)
+        m.site_type = np.array([int(_GEOM_TYPES[s.get("type", "sphere")]) for s in S], dtype=np.int32)
+        spos, squat, ssize = [], [], []
+        for s in S:
+            pos = _floats(s["pos"]) if "pos" in s else np.zeros(3)
+            quat = self._orientation(s)
+            size = np.array([0.005, 0.005, 0.005])
+            if "size" in s:
+                v = _floats(s["size"])
+                size[: len(v)] = v[:3]
+            if "fromto" in s:
+                ft = _floats(s["fromto"])
+                vec = ft[:3] - ft[3:]
+                size[1] = np.linalg.norm(vec) / 2
+                pos = (ft[:3] + ft[3:]) / 2
+                quat = _z_to_quat(vec)
+            spos.append(pos)
+            squat.append(quat)
+            ssize.append(size)
+        m.site_pos = np.array(spos, dtype=np.float64).reshape(-1, 3)
+        m.site_quat = np.array(squat, dtype=np.float64).reshape(-1, 4)
+        m.site_size = np.array(ssize, dtype=np.float64).reshape(-1, 3)
+        m.site_sameframe = np.zeros(m.nsite, dtype=np.uint8)
+
+        C = by_body(self.cams)
+        m.ncam = len(C)
+        m.names_cam = [c.get("name", "") for c in C]
+        m.cam_bodyid = np.array([remap[c["__body__"]] for c in C], dtype=np.int32)
+        m.cam_mode = np.array([int(_CAM_MODES[c.get("mode", "fixed")]) for c in C], dtype=np.int32)
+        m.cam_targetbodyid = np.array([m.names_body.index(c["target"]) if "target" in c else -1 for c in C], dtype=np.int32)
+        m.cam_pos = np.array([_floats(c["pos"]) if "pos" in c else np.zeros(3) for c in C], dtype=np.float64).reshape(-1, 3)
+        m.cam_quat = np.array([self._orientation(c) for c in C], dtype=np.float64).reshape(-1, 4)
+        m.cam_fovy = np.array([float(c.get("fovy", 45.0)) for c in C], dtype=np.float64)
+        m.cam_resolution = np.ones((m.ncam, 2), dtype=np.int32)
+        m.cam_sensorsize = np.zeros((m.ncam, 2), dtype=np.float32)
+        m.cam_intrinsic = np.tile(np.array([0.01, 0.01, 0, 0], dtype=np.float32), (m.ncam, 1))
+
+        L = by_body(self.lights)
+        m.nlight = len(L)
+        m.light_bodyid = np.array([remap[c["__body__"]] for c in L], dtype=np.int32)
+        m.light_mode = np.array([int(_CAM_MODES[c.get("mode", "fixed")]) for c in L], dtype=np.int32)
+        m.light_targetbodyid = np.array([m.names_body.index(c["target"]) if "target" in c else -1 for c in L], dtype=np.int32)
+        m.light_pos = np.array([_floats(c["pos"]) if "pos" in c else np.zeros(3) for c in L], dtype=np.float64).reshape(-1, 3)
+        ld = []
+        for c in L:
+            d = _floats(c["dir"]) if "dir" in c else np.array([0.0, 0, -1])
+            ld.append(d / np.linalg.norm(d))
+        m.light_dir = np.array(ld, dtype=np.float64).reshape(-1, 3)
+        m.light_type = np.array([1 if _bool(c.get("directional", "false")) else 0 for c in L], dtype=np.int32)
+        m.light_castshadow = np.array([_bool(c.get("castshadow", "true")) for c in L], dtype=bool)
+        m.light_active = np.array([_bool(c.get("active", "true")) for c in L], dtype=bool)
+        m.light_cutoff = np.array([float(c.get("cutoff", 45.0)) for c in L], dtype=np.float32)
+        m.light_exponent = np.array([float(c.get("exponent", 10.0)) for c in L], dtype=np.float32)
+        m.light_attenuation = np.array([_pad(_floats(c["attenuation"]), 3, [1, 0, 0]) if "attenuation" in c else [1.0, 0, 0] for c in L], dtype=np.float32).reshape(-1, 3)
+        m.light_diffuse = np.array([_pad(_floats(c["diffuse"]), 3, [0.7] * 3) if "diffuse" in c else [0.7] * 3 for c in L], dtype=np.float32).reshape(-1, 3)
+        m.light_ambient = np.array([_pad(_floats(c["ambient"]), 3, [0.0] * 3) if "ambient" in c else [0.0] * 3 for c in L], dtype=np.float32).reshape(-1, 3)
+        m.light_specular = np.array([_pad(_floats(c["specular"]), 3, [0.3] * 3) if "specular" in c else [0.3] * 3 for c in L], dtype=np.float32).reshape(-1, 3)
+
+    # ---- contact pairs / excludes --------------------------------------------
+    def _build_contact(self, m):
+        pairs, excl = [], []
+        for cn in self.root.findall("contact"):
+            for p in cn.findall("pair"):
+                a = dict(self.defaults[p.get("class", "main")].get("pair"))
+                a.update(p.attrib)
+                pairs.append(a)
+            for e in cn.findall("exclude"):
+                excl.append(e.attrib)
+        rows = []
+        for a in pairs:
+            g1, g2 = m.names_geom.index(a["geom1"]), m.names_geom.index(a["geom2"])
+            b1, b2 = int(m.geom_bodyid[g1]), int(m.geom_bodyid[g2])
+            if b1 > b2:  # signature is (body1 << 16) + body2 with body1 <= body2
+                g1, g2, b1, b2 = g2, g1, b2, b1
+            dim = int(a["condim"]) if "condim" in a else int(max(m.geom_condim[g1], m.geom_condim[g2]))
+            if "friction" in a:
+                fr = _pad(_floats(a["friction"]), 5, [1, 1, 0.005, 0.0001, 0.0001])
+                fv = _floats(a["friction"])
+                if len(fv) < 2:
+                    fr[1] = fr[0]
+                if len(fv) < 4:
+                    pass
+                if len(fv) < 5 and len(fv) >= 4:
+                    fr[4] = fr[3]
+            else:
+                f3 = np.maximum(m.geom_friction[g1], m.geom_friction[g2])
+                fr = np.array([f3[0], f3[0], f3[1], f3[2], f3[2]])
+            s1, s2 = m.geom_solmix[g1], m.geom_solmix[g2]
+            if s1 >= mjMINVAL and s2 >= mjMINVAL:
+                mix = s1 / (s1 + s2)
+            elif s1 < mjMINVAL and s2 < mjMINVAL:
+                mix = 0.5
+            elif s1 < mjMINVAL:
+                mix = 0.0
+            else:
+                mix = 1.0
+            if "solref" in a:
+                solref = _pad(_floats(a["solref"]), 2, _DEF_SOLREF)
+            elif m.geom_solref[g1][0] > 0 and m.geom_solref[g2][0] > 0:
+                solref = mix * m.geom_solref[g1] + (1 - mix) * m.geom_solref[g2]
+            else:
+                solref = np.minimum(m.geom_solref[g1], m.geom_solref[g2])
+            solimp = _pad(_floats(a["solimp"]), 5, _DEF_SOLIMP) if "solimp" in a else mix * m.geom_solimp[g1] + (1 - mix) * m.geom_solimp[g2]
+            solreffriction = _pad(_floats(a["solreffriction"]), 2, [0, 0]) if "solreffriction" in a else np.zeros(2)
+            margin = float(a["margin"]) if "margin" in a else max(m.geom_margin[g1], m.geom_margin[g2])
+            gap = float(a["gap"]) if "gap" in a else max(m.geom_gap[g1], m.geom_gap[g2])
+            rows.append(dict(g1=g1, g2=g2, sig=(b1 << 16) + b2, dim=dim, friction=fr, solref=solref, solimp=solimp, solreffriction=solreffriction, margin=margin, gap=gap))
+        rows.sort(key=lambda r: r["sig"])  # stable: pairs are ordered by body signature
+        m.npair = len(rows)
+        m.pair_dim = np.array([r["dim"] for r in rows], dtype=np.int32)
+        m.pair_geom1 = np.array([r["g1"] for r in rows], dtype=np.int32)
+        m.pair_geom2 = np.array([r["g2"] for r in rows], dtype=np.int32)
+        m.pair_signature = np.array([r["sig"] for r in rows], dtype=np.int32)
+        m.pair_friction = np.array([r["friction"] for r in rows], dtype=np.float64).reshape(-1, 5)
+        m.pair_solref = np.array([r["solref"] for r in rows], dtype=np.float64).reshape(-1, 2)
+        m.pair_solreffriction = np.array([r["solreffriction"] for r in rows], dtype=np.float64).reshape(-1, 2)
+        m.pair_solimp = np.array([r["solimp"] for r in rows], dtype=np.float64).reshape(-1, 5)
+        m.pair_margin = np.array([r["margin"] for r in rows], dtype=np.float64)
+        m.pair_gap = np.array([r["gap"] for r in rows], dtype=np.float64)
+        sigs = []
+        for e in excl:
+            b1, b2 = m.names_body.index(e["body1"]), m.names_body.index(e["body2"])
+            if b1 > b2:
+                b1, b2 = b2, b1
+            sigs.append((b1 << 16) + b2)
+        m.nexclude = len(sigs)
+        m.exclude_signature = np.array(sorted(sigs), dtype=np.int32)
+
+    # ---- actuators ---------------------------------------------------------
+    def _build_actuators(self, m):
+        acts = []
+        for an in self.root.findall("actuator"):
+            for node in an:
+                if node.tag not in _ACT_TAGS:
+                    raise NotImplementedError(f"actuator <{node.tag}> not supported")
+                a = dict(self.defaults[node.get("class", "main")].get(node.tag))
+                a.pop("__tag__", None)
+                a.update(node.attrib)
+                a["__tag__"] = node.tag
+                acts.append(a)
+        nu = len(acts)
+        m.nu = nu
+        m.names_actuator = [a.get("name", "") for a in acts]
+        m.actuator_trntype = np.zeros(nu, dtype=np.int32)
+        m.actuator_dyntype = np.zeros(nu, dtype=np.int32)
+        m.actuator_gaintype = np.zeros(nu, dtype=np.int32)
+        m.actuator_biastype = np.zeros(nu, dtype=np.int32)
+        m.actuator_trnid = -np.ones((nu, 2), dtype=np.int32)
+        m.actuator_dynprm = np.zeros((nu, mjNDYN))
+        m.actuator_gainprm = np.zeros((nu, mjNGAIN))
+        m.actuator_biasprm = np.zeros((nu, mjNBIAS))
+        m.actuator_gear = np.zeros((nu, 6))
+        m.actuator_ctrlrange = np.zeros((nu, 2))
+        m.actuator_forcerange = np.zeros((nu, 2))
+        m.actuator_actrange = np.zeros((nu, 2))
+        m.actuator_ctrllimited = np.zeros(nu, dtype=bool)
+        m.actuator_forcelimited = np.zeros(nu, dtype=bool)
+        m.actuator_actlimited = np.zeros(nu, dtype=bool)
+        m.actuator_actadr = -np.ones(nu, dtype=np.int32)
+        m.actuator_actnum = np.zeros(nu, dtype=np.int32)
+        m.actuator_group = np.zeros(nu, dtype=np.int32)
+        m.actuator_actearly = np.zeros(nu, dtype=np.uint8)
+        m.actuator_cranklength = np.zeros(nu)
+        m.actuator_lengthrange = np.zeros((nu, 2))
+        m.actuator_acc0 = np.zeros(nu)
+        na = 0
+        for i, a in enumerate(acts):
+            tag = a["__tag__"]
+            if "joint" in a:
+                m.actuator_trntype[i] = TrnType.JOINT
+                m.actuator_trnid[i, 0] = m.names_jnt.index(a["joint"])
+            elif "jointinparent" in a:
+                m.actuator_trntype[i] = TrnType.JOINTINPARENT
+                m.actuator_trnid[i, 0] = m.names_jnt.index(a["jointinparent"])
+            else:
+                raise NotImplementedError("only joint / jointinparent transmissions are supported")
+            g = _floats(a["gear"]) if "gear" in a else np.array([1.0])
+            m.actuator_gear[i, : len(g)] = g
+            if "gear" not in a:
+                m.actuator_gear[i, 0] = 1.0
+            m.actuator_gainprm[i, 0] = 1.0
+            if tag == "motor":
+                pass
+            elif tag == "position":
+                kp = float(a.get("kp", 1.0))
+                kv = float(a.get("kv", 0.0))
+                m.actuator_gainprm[i, 0] = kp
+                m.actuator_biastype[i] = BiasType.AFFINE
+                m.actuator_biasprm[i, :3] = [0.0, -kp, -kv]
+            elif tag == "velocity":
+                kv = float(a.get("kv", 1.0))
+                m.actuator_gainprm[i, 0] = kv
+                m.actuator_biastype[i] = BiasType.AFFINE
+                m.actuator_biasprm[i, :3] = [0.0, 0.0, -kv]
+            elif tag == "general":
+                dt = a.get("dyntype", "none")
+                m.actuator_dyntype[i] = {"none": DynType.NONE, "integrator": DynType.INTEGRATOR, "filter": DynType.FILTER, "filterexact": DynType.FILTEREXACT, "muscle": DynType.MUSCLE}[dt]
+                gt_ = a.get("gaintype", "fixed")
+                m.actuator_gaintype[i] = {"fixed": GainType.FIXED, "affine": GainType.AFFINE, "muscle": GainType.MUSCLE}[gt_]
+                bt = a.get("biastype", "none")
+                m.actuator_biastype[i] = {"none": BiasType.NONE, "affine": BiasType.AFFINE, "muscle": BiasType.MUSCLE}[bt]
+                for key, arr in (("dynprm", m.actuator_dynprm), ("gainprm", m.actuator_gainprm), ("biasprm", m.actuator_biasprm)):
+                    if key in a:
+                        v = _floats(a[key])
+                        arr[i, :] = 0
+                        arr[i, : len(v)] = v
+            else:
+                raise NotImplementedError(f"actuator <{tag}> not supported")
+            for key, arr, limarr, attr in (
+                ("ctrlrange", m.actuator_ctrlrange, m.actuator_ctrllimited, "ctrllimited"),
+                ("forcerange", m.actuator_forcerange, m.actuator_forcelimited, "forcelimited"),
+                ("actrange", m.actuator_actrange, m.actuator_actlimited, "actlimited"),
+            ):
+                has = key in a
+                if has:
+                    arr[i] = _floats(a[key])
+                lim = a.get(attr, "auto")
+                limarr[i] = (has and self.autolimits) if lim == "auto" else _bool(lim)
+            if m.actuator_dyntype[i] != DynType.NONE:
+                m.actuator_actadr[i] = na
+                m.actuator_actnum[i] = 1
+                na += 1
+        m.na = na
+
+    def _build_sensors(self, m):
+        sens = []
+        for sn in self.root.findall("sensor"):
+            for node in sn:
+                if node.tag not in _SENSOR_DIMS:
+                    raise NotImplementedError(f"sensor <{node.tag}> not supported")
+                sens.append(node)
+        m.nsensor = len(sens)
+        dims = [_SENSOR_DIMS[s.tag][1] for s in sens]
+        m.sensor_type = np.array([int(_SENSOR_DIMS[s.tag][0]) for s in sens], dtype=np.int32)
+        m.sensor_dim = np.array(dims, dtype=np.int32)
+        m.sensor_adr = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32) if sens else np.zeros(0, dtype=np.int32)
+        m.nsensordata = int(sum(dims))
+        m.sensor_objid = np.array([m.names_site.index(s.get("site")) if s.get("site") in m.names_site else -1 for s in sens], dtype=np.int32)
+        m.sensor_cutoff = np.array([float(s.get("cutoff", 0.0)) for s in sens], dtype=np.float64)
+
+    def _build_empty_sections(self, m):
+        m.neq = len([e for en in self.root.findall("equality") for e in en])
+        m.ntendon = len([t for tn in self.root.findall("tendon") for t in tn])
+        if m.neq or m.ntendon:
+            raise NotImplementedError("equality constraints and tendons are outside this build's MJCF subset")
+        m.nwrap = 0
+        m.nnumeric = 0
+        m.nuserdata = 0
+        m.eq_type = np.zeros(0, dtype=np.int32)
+        m.eq_obj1id = np.zeros(0, dtype=np.int32)
+        m.eq_obj2id = np.zeros(0, dtype=np.int32)
+        m.eq_active0 = np.zeros(0, dtype=bool)
+        m.eq_solref = np.zeros((0, 2))
+        m.eq_solimp = np.zeros((0, 5))
+        m.eq_data = np.zeros((0, 11))
+        m.tendon_frictionloss = np.zeros(0)
+        m.tendon_limited = np.zeros(0, dtype=bool)
+        m.numeric_adr = np.zeros(0, dtype=np.int32)
+        m.numeric_data = np.zeros(0)
+        m.name_numericadr = np.zeros(0, dtype=np.int32)
+        m.names = b""
+
+    def _build_keyframes(self, m):
+        keys = [k for kn in self.root.findall("keyframe") for k in kn.findall("key")]
+        m.nkey = len(keys)
+        m.key_qpos = np.tile(m.qpos0, (m.nkey, 1)) if m.nkey else np.zeros((0, m.nq))
+        m.key_qvel = np.zeros((m.nkey, m.nv))
+        m.key_ctrl = np.zeros((m.nkey, m.nu))
+        m.key_time = np.zeros(m.nkey)
+        m.names_key = [k.get("name", "") for k in keys]
+        for i, k in enumerate(keys):
+            if "qpos" in k.attrib:
+                m.key_qpos[i] = _floats(k.get("qpos"))
+            if "qvel" in k.attrib:
+                m.key_qvel[i] = _floats(k.get("qvel"))
+            if "ctrl" in k.attrib:
+                m.key_ctrl[i] = _floats(k.get("ctrl"))
+            if "time" in k.attrib:
+                m.key_time[i] = float(k.get("time"))
+
+
+# --------------------------------------------------------------------------
+# mj_setConst restatement (qpos0-derived constants)
+# --------------------------------------------------------------------------
+
+
+def _kinematics0(m, qpos):
+    """World frames at ``qpos`` (numpy, host). Returns xpos, xquat, xmat, xipos, ximat, xanchor, xaxis."""
+    nb = m.nbody
+    xpos = np.zeros((nb, 3))
+    xquat = np.tile(np.array([1.0, 0, 0, 0]), (nb, 1))
+    xanchor = np.zeros((m.njnt, 3))
+    xaxis = np.zeros((m.njnt, 3))
+    for b in range(1, nb):
+        p = int(m.body_parentid[b])
+        pos = xpos[p] + _rotate(m.body_pos[b], xquat[p])
+        quat = _quat_mul(xquat[p], m.body_quat[b])
+        for j in range(int(m.body_jntadr[b]), int(m.body_jntadr[b]) + int(m.body_jntnum[b])) if m.body_jntnum[b] else []:
+            jt = int(m.jnt_type[j])
+            qa = int(m.jnt_qposadr[j])
+            if jt == JointType.FREE:
+                xanchor[j] = qpos[qa : qa + 3]
+                xaxis[j] = [0, 0, 1]
+                pos = qpos[qa : qa + 3].copy()
+                quat = qpos[qa + 3 : qa + 7] / np.linalg.norm(qpos[qa + 3 : qa + 7])
+                continue
+            anchor = _rotate(m.jnt_pos[j], quat) + pos
+            axis = _rotate(m.jnt_axis[j], quat)
+            xanchor[j], xaxis[j] = anchor, axis
+            if jt == JointType.BALL:
+                ql = qpos[qa : qa + 4] / np.linalg.norm(qpos[qa : qa + 4])
+                quat = _quat_mul(quat, ql)
+                pos = anchor - _rotate(m.jnt_pos[j], quat)
+            elif jt == JointType.HINGE:
+                quat = _quat_mul(quat, _axisangle_quat(m.jnt_axis[j], qpos[qa] - m.qpos0[qa]))
+                pos = anchor - _rotate(m.jnt_pos[j], quat)
+            else:
+                pos = pos + axis * (qpos[qa] - m.qpos0[qa])
+        xpos[b], xquat[b] = pos, quat / np.linalg.norm(quat)
+    xmat = np.stack([_quat_to_mat(q) for q in xquat])
+    xipos = np.stack([xpos[b] + xmat[b] @ m.body_ipos[b] for b in range(nb)])
+    ximat = np.stack([_quat_to_mat(_quat_mul(xquat[b], m.body_iquat[b])) for b in range(nb)])
+    return xpos, xquat, xmat, xipos, ximat, xanchor, xaxis
+
+
+def _body_jac(m, body, point, xpos, xmat, xanchor, xaxis):
+    """(3,nv) translational and rotational Jacobians of ``point`` fixed to ``body`` (qvel convention)."""
+    jp = np.zeros((3, m.nv))
+    jr = np.zeros((3, m.nv))
+    b = body
+    while b > 0:
+        for j in range(int(m.body_jntadr[b]), int(m.body_jntadr[b]) + int(m.body_jntnum[b])) if m.body_jntnum[b] else []:
+            jt = int(m.jnt_type[j])
+            d = int(m.jnt_dofadr[j])
+            if jt == JointType.FREE:
+                jp[:, d : d + 3] = np.eye(3)
+                for k in range(3):
+                    ax = xmat[b][:, k]
+                    jr[:, d + 3 + k] = ax
+                    jp[:, d + 3 + k] = np.cross(ax, point - xpos[b])
+            elif jt == JointType.BALL:
+                for k in range(3):
+                    ax = xmat[b][:, k]
+                    jr[:, d + k] = ax
+                    jp[:, d + k] = np.cross(ax, point - xanchor[j])
+            elif jt == JointType.HINGE:
+                jr[:, d] = xaxis[j]
+                jp[:, d] = np.cross(xaxis[j], point - xanchor[j])
+            else:
+                jp[:, d] = xaxis[j]
+        b = int(m.body_parentid[b])
+    return jp, jr
+
+
+def mass_matrix0(m, qpos=None):
+    """Dense joint-space inertia at ``qpos`` (default qpos0), via body Jacobians."""
+    qpos = m.qpos0 if qpos is None else qpos
+    xpos, xquat, xmat, xipos, ximat, xanchor, xaxis = _kinematics0(m, qpos)
+    M = np.diag(m.dof_armature.astype(np.float64)) if m.nv else np.zeros((0, 0))
+    for b in range(1, m.nbody):
+        if m.body_mass[b] == 0 and not m.body_inertia[b].any():
+            continue
+        jp, jr = _body_jac(m, b, xipos[b], xpos, xmat, xanchor, xaxis)
+        I = ximat[b] @ np.diag(m.body_inertia[b]) @ ximat[b].T
+        M = M + m.body_mass[b] * jp.T @ jp + jr.T @ I @ jr
+    return M, (xpos, xquat, xmat, xipos, ximat, xanchor, xaxis)
+
+
+def _set_const(m, stat_meaninertia=None):
+    """qpos0 constants: invweights, dof_M0, meaninertia, acc0, cam/light reference frames."""
+    nv = m.nv
+    M, kin = mass_matrix0(m)
+    xpos, xquat, xmat, xipos, ximat, xanchor, xaxis = kin
+    m.dof_M0 = np.diag(M).copy() if nv else np.zeros(0)
+    Minv = np.linalg.inv(M) if nv else np.zeros((0, 0))
+    # dof_invweight0: diagonal of M^-1, averaged over the dofs of free (3+3) / ball (3) joints
+    diw = np.diag(Minv).copy() if nv else np.zeros(0)
+    for j in range(m.njnt):
+        d = int(m.jnt_dofadr[j])
+        jt = int(m.jnt_type[j])
+        if jt == JointType.FREE:
+            diw[d : d + 3] = diw[d : d + 3].mean()
+            diw[d + 3 : d + 6] = diw[d + 3 : d + 6].mean()
+        elif jt == JointType.BALL:
+            diw[d : d + 3] = diw[d : d + 3].mean()
+    m.dof_invweight0 = diw
+    biw = np.zeros((m.nbody, 2))
+    for b in range(1, m.nbody):
+        if m.body_weldid[b] == 0:
+            continue
+        jp, jr = _body_jac(m, b, xipos[b], xpos, xmat, xanchor, xaxis)
+        biw[b, 0] = np.trace(jp @ Minv @ jp.T) / 3.0
+        biw[b, 1] = np.trace(jr @ Minv @ jr.T) / 3.0
+    m.body_invweight0 = biw
+    meaninertia = float(np.mean(np.diag(M))) if nv else 1.0
+    subtree_com0 = np.zeros(3)
+    tot = m.body_mass.sum()
+    center = (m.body_mass[:, None] * xipos).sum(0) / tot if tot > 0 else np.zeros(3)
+    m.stat = SimpleNamespace(
+        meaninertia=stat_meaninertia if stat_meaninertia is not None else meaninertia,
+        meanmass=float(m.body_mass[1:].mean()) if m.nbody > 1 else 0.0,
+        meansize=float(np.mean(m.geom_rbound)) if m.ngeom else 0.0,
+        extent=float(max(np.linalg.norm(xipos - center, axis=1).max(), 1e-5)) if m.nbody > 1 else 1.0,
+        center=center,
+    )
+    # actuator_acc0 = || M^-1 moment ||
+    for i in range(m.nu):
+        mom = np.zeros(nv)
+        j = int(m.actuator_trnid[i, 0])
+        d = int(m.jnt_dofadr[j])
+        jt = int(m.jnt_type[j])
+        w = JointType(jt).dof_width()
+        if jt in (JointType.SLIDE, JointType.HINGE):
+            mom[d] = m.actuator_gear[i, 0]
+        else:
+            mom[d : d + w] = m.actuator_gear[i, :w]
+        m.actuator_acc0[i] = float(np.linalg.norm(Minv @ mom))
+    # subtree COM per body at qpos0 (for cam/light *com0 offsets)
+    mass = m.body_mass.copy()
+    mpos = mass[:, None] * xipos
+    for b in range(m.nbody - 1, 0, -1):
+        p = int(m.body_parentid[b])
+        mass[p] += mass[b]
+        mpos[p] += mpos[b]
+    sub = np.where(mass[:, None] > mjMINVAL, mpos / np.maximum(mass[:, None], mjMINVAL), xipos)
+    m._subtree_com0 = sub
+    cx = np.stack([xpos[b] + xmat[b] @ m.cam_pos[i] for i, b in enumerate(m.cam_bodyid)]) if m.ncam else np.zeros((0, 3))
+    m.cam_pos0 = np.stack([cx[i] - xpos[b] for i, b in enumerate(m.cam_bodyid)]) if m.ncam else np.zeros((0, 3))
+    m.cam_poscom0 = np.stack([cx[i] - sub[b] for i, b in enumerate(m.cam_bodyid)]) if m.ncam else np.zeros((0, 3))
+    m.cam_mat0 = np.stack([(_quat_to_mat(_quat_mul(xquat[b], m.cam_quat[i]))).reshape(9) for i, b in enumerate(m.cam_bodyid)]) if m.ncam else np.zeros((0, 9))
+    lx = np.stack([xpos[b] + xmat[b] @ m.light_pos[i] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
+    m.light_pos0 = np.stack([lx[i] - xpos[b] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
+    m.light_poscom0 = np.stack([lx[i] - sub[b] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
+    m.light_dir0 = np.stack([xmat[b] @ m.light_dir[i] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
+
+
+# --------------------------------------------------------------------------
+# public entry points
+# --------------------------------------------------------------------------
+
+
+def from_xml_string(xml: str, base_dir: str = ".") -> MjModelLite:
+    return _Compiler(ET.fromstring(xml), base_dir).build()
+
+
+def from_xml_path(path: str) -> MjModelLite:
+    with open(path) as f:
+        xml = f.read()
+    return from_xml_string(xml, os.path.dirname(os.path.abspath(path)))
