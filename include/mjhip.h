@@ -1,0 +1,317 @@
+/*
+ * mjhip.h -- C ABI of the MI355X-native batched stepper behind mujoco_torch.step().
+ *
+ * The reference (vmoens/mujoco-torch) has NO native boundary: its step is pure Python
+ * (mujoco_torch/_src/forward.py:463-496) vectorised with torch.vmap.  This header is the
+ * boundary a maintainer binds instead; each entry point names the reference call it replaces:
+ *
+ *   mjh_model_create   <- Model.to(device) + _build_device_precomp   (_src/types.py:949-1013)
+ *   mjh_forward        <- forward.forward(m, d)                       (_src/forward.py:373-401)
+ *   mjh_step           <- forward.step(m, d, fixed_iterations)        (_src/forward.py:463-496)
+ *
+ * Conventions
+ *  - every Data leaf is batch-major contiguous: shape [B, ...] exactly as
+ *    make_data(mx).expand(B).clone() lays it out (reference benchmarks/_helpers.py:37-41);
+ *  - all pointers in mjhData are DEVICE pointers for the mjh_* entry points and HOST pointers
+ *    for the oracle twin (oracle/mjoracle.c: mjo_forward / mjo_step, same structs);
+ *  - "real" fields are double (dtype 0) or float (dtype 1) for the whole call;
+ *  - functions return 0 on success or a negative errno-style code; they never throw, never
+ *    allocate, never synchronise: work is enqueued on the given hipStream_t (passed as void*);
+ *  - the caller owns every buffer.  `in` and `out` may alias field-by-field only for fields
+ *    the step does not write (qacc/qacc_warmstart outputs must be distinct storage, mirroring
+ *    reference solver.py:541-548).
+ *
+ * The X-macro lists below are the single source of truth for field order; the Python host
+ * side (mujoco_torch_amd/native.py) parses them to build its ctypes structures.
+ */
+#ifndef MJHIP_H_
+#define MJHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJH_ABI_VERSION 1
+
+/* ---- dtype / flags ------------------------------------------------------------------- */
+#define MJH_F64 0
+#define MJH_F32 1
+
+#define MJH_FLAG_FIXED_ITERATIONS 1 /* step(..., fixed_iterations=True), forward.py:463 */
+
+/* stage bits for mjh_forward(stages): run the pipeline up to and including the highest bit */
+#define MJH_STAGE_KINEMATICS 0x001 /* smooth.kinematics + com_pos        smooth.py:34-288   */
+#define MJH_STAGE_CRB 0x002        /* smooth.crb + factor_m              smooth.py:291-332  */
+#define MJH_STAGE_COLLISION 0x004  /* collision_driver.collision         :800-875           */
+#define MJH_STAGE_CONSTRAINT 0x008 /* constraint.make_constraint         :600-768           */
+#define MJH_STAGE_VELOCITY 0x010   /* transmission, _velocity, passive, rne                  */
+#define MJH_STAGE_ACTUATION 0x020  /* forward._actuation + _acceleration :102-228           */
+#define MJH_STAGE_SOLVE 0x040      /* solver.solve                       solver.py:244-553  */
+#define MJH_STAGE_ALL 0x07f
+
+/* pair-function ids of the static collision table (collision_driver.py:106-125) */
+#define MJH_FN_PLANE_SPHERE 0
+#define MJH_FN_PLANE_CAPSULE 1
+#define MJH_FN_SPHERE_SPHERE 2
+#define MJH_FN_SPHERE_CAPSULE 3
+#define MJH_FN_CAPSULE_CAPSULE 4
+#define MJH_FN_PLANE_CONVEX 5
+#define MJH_FN_SPHERE_CONVEX 6
+#define MJH_FN_CAPSULE_CONVEX 7
+#define MJH_FN_CONVEX_CONVEX 8
+#define MJH_MAX_PAIR_CONTACTS 4
+
+/* ---- model description (host arrays; copied into a device blob by mjh_model_create) ---- */
+
+/* int32 scalars */
+#define MJH_MODEL_INTS(X)                                                                        \
+  X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
+  X(ne) X(nf) X(nl) X(ncon) X(nefc) X(npair) X(nconvex)                                          \
+  X(integrator) X(solver) X(cone) X(disableflags) X(iterations) X(ls_iterations)
+
+/* double scalars */
+#define MJH_MODEL_REALS(X)                                                                       \
+  X(timestep) X(impratio) X(tolerance) X(ls_tolerance) X(meaninertia)                            \
+  X(gravity_x) X(gravity_y) X(gravity_z)
+
+/* const int32_t* arrays (length in comment) */
+#define MJH_MODEL_INT_ARRAYS(X)                                                                  \
+  X(body_parentid)  /* nbody */                                                                  \
+  X(body_rootid)    /* nbody */                                                                  \
+  X(body_jntadr)    /* nbody */                                                                  \
+  X(body_jntnum)    /* nbody */                                                                  \
+  X(body_dofadr)    /* nbody */                                                                  \
+  X(body_dofnum)    /* nbody */                                                                  \
+  X(body_mocapid)   /* nbody */                                                                  \
+  X(jnt_type)       /* njnt */                                                                   \
+  X(jnt_qposadr)    /* njnt */                                                                   \
+  X(jnt_dofadr)     /* njnt */                                                                   \
+  X(jnt_bodyid)     /* njnt */                                                                   \
+  X(jnt_actfrclimited) /* njnt */                                                                \
+  X(dof_bodyid)     /* nv */                                                                     \
+  X(dof_jntid)      /* nv */                                                                     \
+  X(dof_parentid)   /* nv */                                                                     \
+  X(geom_type)      /* ngeom */                                                                  \
+  X(geom_bodyid)    /* ngeom */                                                                  \
+  X(geom_convexid)  /* ngeom: index into convex_* tables or -1 */                                \
+  X(site_bodyid)    /* nsite */                                                                  \
+  X(cam_bodyid)     /* ncam */                                                                   \
+  X(cam_mode)       /* ncam */                                                                   \
+  X(cam_targetbodyid) /* ncam */                                                                 \
+  X(light_bodyid)   /* nlight */                                                                 \
+  X(act_trntype)    /* nu */                                                                     \
+  X(act_jnttype)    /* nu */                                                                     \
+  X(act_dofadr)     /* nu */                                                                     \
+  X(act_qposadr)    /* nu */                                                                     \
+  X(act_gaintype)   /* nu */                                                                     \
+  X(act_biastype)   /* nu */                                                                     \
+  X(act_dyntype)    /* nu */                                                                     \
+  X(act_ctrllimited)  /* nu */                                                                   \
+  X(act_forcelimited) /* nu */                                                                   \
+  X(act_actlimited)   /* nu */                                                                   \
+  X(act_actadr)     /* nu */                                                                     \
+  X(act_actnum)     /* nu */                                                                     \
+  X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
+  X(pair_fn)        /* npair: MJH_FN_* */                                                        \
+  X(pair_geom1)     /* npair */                                                                  \
+  X(pair_geom2)     /* npair */                                                                  \
+  X(pair_ncon)      /* npair */                                                                  \
+  X(pair_dst)       /* npair*MJH_MAX_PAIR_CONTACTS: contact slot of each contact of the pair */  \
+  X(con_dim)        /* ncon */                                                                   \
+  X(con_geom1)      /* ncon */                                                                   \
+  X(con_geom2)      /* ncon */                                                                   \
+  X(con_efc_address) /* ncon: cone-aware first row (constraint.py:636-646) */                    \
+  X(convex_nvert)   /* nconvex */                                                                \
+  X(convex_nface)   /* nconvex */                                                                \
+  X(convex_nfv)     /* nconvex: vertices per (padded) face */                                    \
+  X(convex_nedge)   /* nconvex */                                                                \
+  X(convex_vertadr) /* nconvex: offset (in vec3) into convex_vert */                             \
+  X(convex_faceadr) /* nconvex: offset (in ints) into convex_face */                             \
+  X(convex_normadr) /* nconvex: offset (in vec3) into convex_facenormal */                       \
+  X(convex_edgeadr) /* nconvex: offset (in int pairs) into convex_edge */                        \
+  X(convex_face)    /* sum(nface*nfv): vertex ids */                                             \
+  X(convex_edge)    /* sum(nedge)*2 */
+
+/* const double* arrays */
+#define MJH_MODEL_REAL_ARRAYS(X)                                                                 \
+  X(qpos0)          /* nq */                                                                     \
+  X(qpos_spring)    /* nq */                                                                     \
+  X(body_pos)       /* nbody*3 */                                                                \
+  X(body_quat)      /* nbody*4 */                                                                \
+  X(body_ipos)      /* nbody*3 */                                                                \
+  X(body_iquat)     /* nbody*4 */                                                                \
+  X(body_mass)      /* nbody */                                                                  \
+  X(body_inertia)   /* nbody*3 */                                                                \
+  X(body_invweight0) /* nbody (translational component) */                                       \
+  X(jnt_pos)        /* njnt*3 */                                                                 \
+  X(jnt_axis)       /* njnt*3 */                                                                 \
+  X(jnt_stiffness)  /* njnt */                                                                   \
+  X(jnt_range)      /* njnt*2 */                                                                 \
+  X(jnt_margin)     /* njnt */                                                                   \
+  X(jnt_solref)     /* njnt*2 */                                                                 \
+  X(jnt_solimp)     /* njnt*5 */                                                                 \
+  X(jnt_actfrcrange) /* njnt*2 */                                                                \
+  X(dof_armature)   /* nv */                                                                     \
+  X(dof_damping)    /* nv */                                                                     \
+  X(dof_invweight0) /* nv */                                                                     \
+  X(geom_pos)       /* ngeom*3 */                                                                \
+  X(geom_quat)      /* ngeom*4 */                                                                \
+  X(geom_size)      /* ngeom*3 */                                                                \
+  X(site_pos)       /* nsite*3 */                                                                \
+  X(site_quat)      /* nsite*4 */                                                                \
+  X(cam_pos)        /* ncam*3 */                                                                 \
+  X(cam_quat)       /* ncam*4 */                                                                 \
+  X(cam_pos0)       /* ncam*3 */                                                                 \
+  X(cam_mat0)       /* ncam*9 */                                                                 \
+  X(light_pos)      /* nlight*3 */                                                               \
+  X(light_dir)      /* nlight*3 */                                                               \
+  X(act_gear)       /* nu*6 */                                                                   \
+  X(act_gainprm)    /* nu*3 */                                                                   \
+  X(act_biasprm)    /* nu*3 */                                                                   \
+  X(act_dynprm)     /* nu*3 */                                                                   \
+  X(act_ctrlrange)  /* nu*2 */                                                                   \
+  X(act_forcerange) /* nu*2 */                                                                   \
+  X(act_actrange)   /* nu*2 */                                                                   \
+  X(con_includemargin)  /* ncon */                                                               \
+  X(con_friction)       /* ncon*5 */                                                             \
+  X(con_solref)         /* ncon*2 */                                                             \
+  X(con_solreffriction) /* ncon*2 */                                                             \
+  X(con_solimp)         /* ncon*5 */                                                             \
+  X(convex_vert)        /* sum(nvert)*3 */                                                       \
+  X(convex_facenormal)  /* sum(nface)*3 */
+
+typedef struct mjhModelDesc {
+  int32_t abi_version;
+#define X(n) int32_t n;
+  MJH_MODEL_INTS(X)
+#undef X
+#define X(n) double n;
+  MJH_MODEL_REALS(X)
+#undef X
+#define X(n) const int32_t* n;
+  MJH_MODEL_INT_ARRAYS(X)
+#undef X
+#define X(n) const double* n;
+  MJH_MODEL_REAL_ARRAYS(X)
+#undef X
+#define X(n) int64_t len_##n;
+  MJH_MODEL_INT_ARRAYS(X)
+  MJH_MODEL_REAL_ARRAYS(X)
+#undef X
+} mjhModelDesc;
+
+/* ---- Data leaves (reference _src/types.py:1091-1261, Contact :1036-1088) --------------- */
+
+/* real leaves; per-env element count in the comment */
+#define MJH_DATA_REALS(X)                                                                        \
+  X(time)             /* 1 */                                                                    \
+  X(qpos)             /* nq */                                                                   \
+  X(qvel)             /* nv */                                                                   \
+  X(act)              /* na */                                                                   \
+  X(qacc_warmstart)   /* nv */                                                                   \
+  X(ctrl)             /* nu */                                                                   \
+  X(qfrc_applied)     /* nv */                                                                   \
+  X(xfrc_applied)     /* nbody*6 */                                                              \
+  X(mocap_pos)        /* nmocap*3 */                                                             \
+  X(mocap_quat)       /* nmocap*4 */                                                             \
+  X(qacc)             /* nv */                                                                   \
+  X(act_dot)          /* na */                                                                   \
+  X(xpos)             /* nbody*3 */                                                              \
+  X(xquat)            /* nbody*4 */                                                              \
+  X(xmat)             /* nbody*9 */                                                              \
+  X(xipos)            /* nbody*3 */                                                              \
+  X(ximat)            /* nbody*9 */                                                              \
+  X(xanchor)          /* njnt*3 */                                                               \
+  X(xaxis)            /* njnt*3 */                                                               \
+  X(geom_xpos)        /* ngeom*3 */                                                              \
+  X(geom_xmat)        /* ngeom*9 */                                                              \
+  X(site_xpos)        /* nsite*3 */                                                              \
+  X(site_xmat)        /* nsite*9 */                                                              \
+  X(cam_xpos)         /* ncam*3 */                                                               \
+  X(cam_xmat)         /* ncam*9 */                                                               \
+  X(light_xpos)       /* nlight*3 */                                                             \
+  X(light_xdir)       /* nlight*3 */                                                             \
+  X(subtree_com)      /* nbody*3 */                                                              \
+  X(cdof)             /* nv*6 */                                                                 \
+  X(cinert)           /* nbody*10 */                                                             \
+  X(crb)              /* nbody*10 */                                                             \
+  X(actuator_length)  /* nu */                                                                   \
+  X(actuator_moment)  /* nu*nv */                                                                \
+  X(qM)               /* nv*nv (dense) */                                                        \
+  X(qLD)              /* nv*nv (dense Cholesky L) */                                             \
+  X(contact_dist)           /* ncon */                                                           \
+  X(contact_pos)            /* ncon*3 */                                                         \
+  X(contact_frame)          /* ncon*9 */                                                         \
+  X(contact_includemargin)  /* ncon */                                                           \
+  X(contact_friction)       /* ncon*5 */                                                         \
+  X(contact_solref)         /* ncon*2 */                                                         \
+  X(contact_solreffriction) /* ncon*2 */                                                         \
+  X(contact_solimp)         /* ncon*5 */                                                         \
+  X(efc_J)            /* nefc*nv */                                                              \
+  X(efc_frictionloss) /* nefc */                                                                 \
+  X(efc_D)            /* nefc */                                                                 \
+  X(efc_aref)         /* nefc */                                                                 \
+  X(efc_force)        /* nefc */                                                                 \
+  X(actuator_velocity) /* nu */                                                                  \
+  X(cvel)             /* nbody*6 */                                                              \
+  X(cdof_dot)         /* nv*6 */                                                                 \
+  X(qfrc_bias)        /* nv */                                                                   \
+  X(qfrc_passive)     /* nv */                                                                   \
+  X(actuator_force)   /* nu */                                                                   \
+  X(qfrc_actuator)    /* nv */                                                                   \
+  X(qfrc_smooth)      /* nv */                                                                   \
+  X(qacc_smooth)      /* nv */                                                                   \
+  X(qfrc_constraint)  /* nv */
+
+#define MJH_DATA_I32(X) X(contact_dim) /* ncon */
+
+#define MJH_DATA_I64(X)                                                                          \
+  X(contact_geom1)       /* ncon */                                                              \
+  X(contact_geom2)       /* ncon */                                                              \
+  X(contact_geom)        /* ncon*2 */                                                            \
+  X(contact_efc_address) /* ncon */
+
+typedef struct mjhData {
+#define X(n) void* n;
+  MJH_DATA_REALS(X)
+#undef X
+#define X(n) int32_t* n;
+  MJH_DATA_I32(X)
+#undef X
+#define X(n) int64_t* n;
+  MJH_DATA_I64(X)
+#undef X
+} mjhData;
+
+/* ---- entry points ------------------------------------------------------------------------ */
+
+typedef struct mjhModel mjhModel; /* opaque: device-resident constant blob + launch geometry */
+
+/* Builds the device blob for one dtype.  replaces Model.to(device) (types.py:991-1013). */
+int mjh_model_create(const mjhModelDesc* desc, int dtype, mjhModel** out);
+void mjh_model_destroy(mjhModel* m);
+
+/* forward dynamics for B environments (forward.py:373-401), optionally only a prefix of stages. */
+int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int stages, int flags,
+                void* hip_stream);
+
+/* one simulation step for B environments (forward.py:463-496): _check_state, forward, Euler/RK4. */
+int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int flags, void* hip_stream);
+
+/* bytes of dynamic LDS one environment occupies in the fused kernel, and waves per environment */
+int mjh_model_lds_bytes(const mjhModel* m);
+
+/* last error message of the calling thread ("" if none) */
+const char* mjh_last_error(void);
+
+/* comma-separated field lists in ABI order (lets the binding assert it is in sync) */
+const char* mjh_data_fields(void);
+const char* mjh_model_fields(void);
+int mjh_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJHIP_H_ */

@@ -1,0 +1,31 @@
+"""MI355X-native batched physics stepper behind the ``mujoco_torch.step`` API.
+
+Drop-in for the hot path of vmoens/mujoco-torch (``mujoco_torch/__init__.py:41-136``):
+``step``, ``forward``, ``device_put``, ``make_data`` and the ``Model`` / ``Data`` / ``Contact`` /
+``Option`` schema.  Use as ``import mujoco_torch_amd as mujoco_torch``.
+"""
+
+from . import mjcf  # noqa: F401
+from ._enums import (  # noqa: F401
+    BiasType,
+    CamLightType,
+    ConeType,
+    DisableBit,
+    DynType,
+    EnableBit,
+    EqType,
+    GainType,
+    GeomType,
+    IntegratorType,
+    JacobianType,
+    JointType,
+    SolverType,
+    TrnType,
+)
+from .container import MjTensorClass, UnbatchedTensor  # noqa: F401
+from .device import device_put  # noqa: F401
+from .forward import forward, step  # noqa: F401
+from .io import make_data  # noqa: F401
+from .types import Contact, Data, Model, Option, Statistic  # noqa: F401
+
+__version__ = "0.1.0"

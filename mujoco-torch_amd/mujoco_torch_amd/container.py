@@ -1,0 +1,233 @@
+"""Minimal tensorclass container with the semantics the reference relies on.
+
+The reference stores Model/Data/Contact in ``tensordict.TensorClass`` subclasses
+(``_src/dataclasses.py:85-142``).  tensordict is not a dependency of this package, so the
+slice of behaviour callers of ``step`` observe is restated here: attribute fields declared by
+annotation, ``replace`` (shallow copy + field swap), ``update_`` (in-place dict update),
+``tree_replace`` (dot paths), ``clone(recurse=False)``, ``to``, indexing / ``expand`` over the
+leading batch dims, ``torch.stack`` / ``torch.cat``, and ``UnbatchedTensor`` leaves that ignore
+batch operations (``ncon``/``nefc``, reference ``types.py:1172-1178``).
+"""
+
+from __future__ import annotations
+
+import dataclasses
+from typing import Any
+
+import torch
+
+
+class UnbatchedTensor:
+    """A model-constant tensor riding inside a batched container (index/expand/stack keep it)."""
+
+    __slots__ = ("data",)
+
+    def __init__(self, data=None):
+        self.data = data
+
+    def clone(self):
+        return UnbatchedTensor(self.data.clone())
+
+    def to(self, *args, **kwargs):
+        if self.data.is_floating_point():
+            return UnbatchedTensor(self.data.to(*args, **kwargs))
+        args = [a for a in args if not isinstance(a, torch.dtype)]
+        kwargs = {k: v for k, v in kwargs.items() if k != "dtype"}
+        return UnbatchedTensor(self.data.to(*args, **kwargs) if (args or kwargs) else self.data)
+
+    def __int__(self):
+        return int(self.data)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __repr__(self):
+        return f"UnbatchedTensor({self.data!r})"
+
+
+def _is_node(v) -> bool:
+    return isinstance(v, (torch.Tensor, MjTensorClass, UnbatchedTensor))
+
+
+class _Meta(type):
+    def __new__(mcs, name, bases, ns):
+        ns = dict(ns)
+        own_defaults = {}
+        for k in list(ns.get("__annotations__", {})):
+            if k in ns:
+                own_defaults[k] = ns.pop(k)
+        cls = super().__new__(mcs, name, bases, ns)
+        ann, defaults = {}, {}
+        for b in reversed(cls.__mro__):
+            ann.update({k: v for k, v in b.__dict__.get("__annotations__", {}).items() if not k.startswith("_")})
+            defaults.update(b.__dict__.get("_own_defaults", {}))
+        cls._own_defaults = own_defaults
+        defaults.update(own_defaults)
+        cls._field_names = tuple(ann)
+        cls._field_defaults = defaults
+        cls._field_types = ann
+        return cls
+
+
+class MjTensorClass(metaclass=_Meta):
+    """Attribute container over a plain dict of leaves plus a leading ``batch_size``."""
+
+    def __init__(self, *args, batch_size=None, **kwargs):
+        names = type(self)._field_names
+        d = dict(zip(names, args))
+        unknown = set(kwargs) - set(names)
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unknown fields {sorted(unknown)}")
+        d.update(kwargs)
+        for k in names:
+            if k not in d:
+                d[k] = type(self)._field_defaults.get(k)
+        object.__setattr__(self, "_fields", d)
+        object.__setattr__(self, "_bs", tuple(batch_size) if batch_size is not None else ())
+
+    # ---- attribute access ---------------------------------------------------------------
+    def __getattr__(self, name):
+        try:
+            return object.__getattribute__(self, "_fields")[name]
+        except KeyError:
+            raise AttributeError(f"{type(self).__name__} has no field {name!r}") from None
+
+    def __setattr__(self, name, value):
+        if name in type(self)._field_names:
+            self._fields[name] = value
+        else:
+            object.__setattr__(self, name, value)
+
+    @classmethod
+    def fields(cls):
+        return tuple(dataclasses.field() for _ in cls._field_names)
+
+    @classmethod
+    def field_names(cls):
+        return cls._field_names
+
+    @property
+    def batch_size(self):
+        return torch.Size(self._bs)
+
+    def items(self):
+        return self._fields.items()
+
+    # ---- functional updates (reference dataclasses.py:101-127) ---------------------------
+    def _new(self, d, bs=None):
+        new = type(self).__new__(type(self))
+        object.__setattr__(new, "_fields", d)
+        object.__setattr__(new, "_bs", tuple(self._bs if bs is None else bs))
+        for k, v in self.__dict__.items():
+            if k not in ("_fields", "_bs"):
+                object.__setattr__(new, k, v)
+        return new
+
+    def _map(self, fn, bs=None):
+        return self._new({k: (fn(v) if _is_node(v) else v) for k, v in self._fields.items()}, bs)
+
+    def clone(self, recurse: bool = True):
+        if recurse:
+            return self._map(lambda v: v.clone())
+        return self._new(dict(self._fields))
+
+    def replace(self, **kwargs: Any):
+        new = self.clone(recurse=False)
+        new._fields.update(kwargs)
+        return new
+
+    def update_(self, **kwargs: Any):
+        self._fields.update(kwargs)
+        return self
+
+    def tree_replace(self, params: dict):
+        new = self
+        for path, val in params.items():
+            keys = path.split(".")
+            new = new._tree_replace(keys, val)
+        return new
+
+    def _tree_replace(self, keys, val):
+        if len(keys) == 1:
+            return self.replace(**{keys[0]: val})
+        return self.replace(**{keys[0]: getattr(self, keys[0])._tree_replace(keys[1:], val)})
+
+    # ---- device / dtype --------------------------------------------------------------------
+    def to(self, *args, **kwargs):
+        def mv(v):
+            if isinstance(v, torch.Tensor) and not v.is_floating_point():
+                a = [x for x in args if not isinstance(x, torch.dtype)]
+                kw = {k: x for k, x in kwargs.items() if k != "dtype"}
+                return v.to(*a, **kw) if (a or kw) else v
+            return v.to(*args, **kwargs)
+
+        return self._map(mv)
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def contiguous(self):
+        return self._map(lambda v: v if isinstance(v, UnbatchedTensor) else v.contiguous())
+
+    # ---- batch-dim operations ----------------------------------------------------------------
+    def expand(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+            shape = tuple(shape[0])
+        nb = len(self._bs)
+        lead = tuple(shape[: len(shape) - nb]) if nb else tuple(shape)
+
+        def ex(v):
+            if isinstance(v, UnbatchedTensor):
+                return v
+            if isinstance(v, MjTensorClass):
+                return v.expand(*lead, *v._bs)
+            return v.expand(*lead, *v.shape)
+
+        return self._map(ex, bs=lead + tuple(self._bs))
+
+    def __getitem__(self, idx):
+        def ix(v):
+            if isinstance(v, UnbatchedTensor):
+                return v
+            return v[idx]
+
+        probe = torch.empty(self._bs)[idx] if self._bs else None
+        bs = tuple(probe.shape) if probe is not None else ()
+        return self._map(ix, bs=bs)
+
+    def __setitem__(self, idx, value):
+        for k, v in self._fields.items():
+            if isinstance(v, UnbatchedTensor) or not _is_node(v):
+                continue
+            src = getattr(value, k)
+            if isinstance(v, MjTensorClass):
+                v[idx] = src
+            else:
+                v[idx] = src
+
+    def __len__(self):
+        return self._bs[0]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.stack, torch.cat):
+            items = list(args[0])
+            dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
+            first = items[0]
+            out = {}
+            for k, v in first._fields.items():
+                if isinstance(v, UnbatchedTensor) or not _is_node(v):
+                    out[k] = v
+                else:
+                    out[k] = func([it._fields[k] for it in items], dim=dim)
+            bs = list(first._bs)
+            if func is torch.stack:
+                bs.insert(dim, len(items))
+            else:
+                bs[dim] = sum(it._bs[dim] for it in items)
+            return first._new(out, bs)
+        return NotImplemented
+
+    def __repr__(self):
+        return f"{type(self).__name__}(batch_size={list(self._bs)}, fields={len(self._fields)})"

@@ -1,0 +1,292 @@
+"""``device_put``: compiled model -> ``Model`` (+ the static tables the native kernels consume).
+
+Mirrors reference ``_src/device.py``: ``device_put`` :1029-1112, ``_validate`` :919-964,
+``_model_derived`` :632-884, ``_compute_constraint_sizes`` :226-264,
+``_compute_constraint_data`` :267-378 and ``_compute_actuator_static_moment`` :588-629.
+The source model is either this package's MJCF-subset compiler output (``mjcf.MjModelLite``)
+or a real ``mujoco.MjModel`` (duck-typed on MuJoCo's field names).
+
+What is NOT mirrored: the reference's vmap-grouping caches (``scan.precompute_scan_caches``) and
+Dynamo stride workarounds -- the native kernels walk the kinematic tree per environment and
+need neither.  Instead ``Model.tables`` carries the flat integer / real tables declared in
+``include/mjhip.h`` (``mjhModelDesc``).
+"""
+
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+import torch
+
+from . import collision_tables as ct
+from ._enums import (
+    BiasType,
+    ConeType,
+    DisableBit,
+    DynType,
+    GainType,
+    GeomType,
+    IntegratorType,
+    JacobianType,
+    JointType,
+    SolverType,
+    TrnType,
+    SUPPORTED_CONDIM,
+)
+from .container import UnbatchedTensor
+from .types import MODEL_FIELDS, Model, Option, Statistic
+
+_cache_id_counter = itertools.count(1)
+
+
+def _get(value, name, default=None):
+    try:
+        return getattr(value, name)
+    except AttributeError:
+        if default is None:
+            raise
+        return default() if callable(default) else default
+
+
+def _validate(m):
+    """Feature gate (reference device.py:919-964): unsupported options raise NotImplementedError."""
+    opt = m.opt
+    if int(opt.integrator) not in (int(IntegratorType.EULER), int(IntegratorType.RK4)):
+        raise NotImplementedError(f"integrator {IntegratorType(int(opt.integrator)).name} not implemented.")
+    if int(opt.solver) not in (int(SolverType.CG), int(SolverType.NEWTON)):
+        raise NotImplementedError(f"solver {SolverType(int(opt.solver)).name} not implemented.")
+    if int(opt.cone) not in (int(ConeType.PYRAMIDAL), int(ConeType.ELLIPTIC)):
+        raise NotImplementedError("unknown cone type")
+    jac = int(opt.jacobian)
+    if jac == int(JacobianType.SPARSE) or (jac == int(JacobianType.AUTO) and int(m.nv) >= 60):
+        raise NotImplementedError("sparse inertia (nv >= 60 or jacobian=sparse) is a 'next' item; dense only.")
+    if any(int(d) not in SUPPORTED_CONDIM for d in np.asarray(m.geom_condim)) or any(
+        int(d) not in SUPPORTED_CONDIM for d in np.asarray(m.pair_dim)
+    ):
+        raise NotImplementedError("Only condim=1, 3, 4 and 6 are supported.")
+    for name, enum, ok in (
+        ("actuator_trntype", TrnType, (TrnType.JOINT,)),
+        ("actuator_dyntype", DynType, (DynType.NONE, DynType.INTEGRATOR, DynType.FILTER, DynType.FILTEREXACT)),
+        ("actuator_gaintype", GainType, (GainType.FIXED, GainType.AFFINE)),
+        ("actuator_biastype", BiasType, (BiasType.NONE, BiasType.AFFINE)),
+    ):
+        for v in np.asarray(getattr(m, name)).reshape(-1):
+            if int(v) not in [int(x) for x in ok]:
+                raise NotImplementedError(f"{enum(int(v)).name} {name} not implemented.")
+    for i in range(int(m.nu)):
+        j = int(np.asarray(m.actuator_trnid)[i, 0])
+        if int(m.jnt_type[j]) not in (int(JointType.SLIDE), int(JointType.HINGE)):
+            raise NotImplementedError("actuators on free/ball joints are a 'next' item.")
+    if int(_get(m, "neq", 0)) or int(_get(m, "ntendon", 0)):
+        raise NotImplementedError("equality constraints and tendons are 'next' items (SURVEY section 8f).")
+    if int(m.nmocap):
+        raise NotImplementedError("mocap bodies are not supported by the native stepper yet.")
+    if (np.asarray(m.dof_frictionloss) > 0).any() and not (int(opt.disableflags) & DisableBit.FRICTIONLOSS):
+        raise NotImplementedError("dof frictionloss rows are a 'next' item (SURVEY section 8f).")
+    if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
+        raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
+    if np.any(np.asarray(_get(m, "body_gravcomp", lambda: np.zeros(int(m.nbody)))) != 0):
+        raise NotImplementedError("gravity compensation is not supported by the native stepper yet.")
+    if float(opt.density) > 0 or float(opt.viscosity) > 0 or np.any(np.asarray(opt.wind) != 0):
+        raise NotImplementedError("fluid forces are outside the hot-path scope.")
+
+
+def _t(x, dtype):
+    return torch.tensor(np.asarray(x, dtype=np.float64), dtype=dtype)
+
+
+def _option(opt, dtype) -> Option:
+    return Option(
+        iterations=int(opt.iterations),
+        ls_iterations=int(opt.ls_iterations),
+        tolerance=float(opt.tolerance),
+        ls_tolerance=float(opt.ls_tolerance),
+        impratio=_t(opt.impratio, dtype),
+        gravity=_t(opt.gravity, dtype),
+        density=_t(opt.density, dtype),
+        viscosity=_t(opt.viscosity, dtype),
+        magnetic=_t(opt.magnetic, dtype),
+        wind=_t(opt.wind, dtype),
+        jacobian=JacobianType(int(opt.jacobian)),
+        cone=ConeType(int(opt.cone)),
+        disableflags=DisableBit(int(opt.disableflags)),
+        enableflags=int(opt.enableflags),
+        integrator=IntegratorType(int(opt.integrator)),
+        solver=SolverType(int(opt.solver)),
+        timestep=_t(opt.timestep, dtype),
+        o_margin=_t(_get(opt, "o_margin", 0.0), dtype),
+        o_solref=_t(_get(opt, "o_solref", lambda: np.array([0.02, 1.0])), dtype),
+        o_solimp=_t(_get(opt, "o_solimp", lambda: np.array([0.9, 0.95, 0.001, 0.5, 2.0])), dtype),
+        o_friction=_t(_get(opt, "o_friction", lambda: np.array([1, 1, 0.005, 1e-4, 1e-4])), dtype),
+        disableactuator=int(_get(opt, "disableactuator", 0)),
+        sdf_initpoints=int(_get(opt, "sdf_initpoints", 40)),
+        has_fluid_params=False,
+        batch_size=[],
+    )
+
+
+class StaticTables:
+    """Everything about a model that is constant across steps and environments.
+
+    * ``pairs``: ordered geom pairs with their pair-function id and destination contact slots;
+    * ``con_*``: per-contact static fields in FINAL (post-argsort) order;
+    * ``desc_int`` / ``desc_real``: the arrays of ``mjhModelDesc`` (include/mjhip.h);
+    * ``native``: cache of device blobs keyed by (device index, dtype), filled by ``native.py``.
+    """
+
+    def __init__(self):
+        self.native = {}
+
+
+def _build_tables(m, dtype) -> StaticTables:
+    T = StaticTables()
+    flags = int(m.opt.disableflags)
+    cands = ct.collision_candidates(m, convex_shape_key=None)
+    ct.validate_candidates(cands)
+    T.candidates = cands
+    dims_sorted = ct.make_condim(m, cands)
+    sizes = ct.constraint_sizes(m, dims_sorted)
+    if flags & (DisableBit.CONSTRAINT | DisableBit.CONTACT):
+        counts = (0, 0, 0, 0)
+    else:
+        counts = tuple(int(sum(1 for d in dims_sorted if d == c)) for c in (1, 3, 4, 6))
+    T.constraint_sizes = sizes
+    T.condim_counts = counts
+    ne, nf, nl, ncon, nefc = sizes
+    pairs = ct.ordered_pairs(cands) if ncon > 0 else []
+    T.pairs = pairs
+    T.total_contacts = sum(p[1] for p in ct.ordered_pairs(cands))
+    # pre-sort per-contact arrays
+    dims_unsorted, src_pair, src_k = [], [], []
+    for pi, (fn, k, c, _) in enumerate(pairs):
+        for kk in range(k):
+            dims_unsorted.append(c.dim)
+            src_pair.append(pi)
+            src_k.append(kk)
+    perm = ct.contact_order(dims_unsorted)  # final slot s holds pre-sort contact perm[s]
+    T.contact_perm = perm
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(len(perm))
+    pair_dst = -np.ones((len(pairs), 4), dtype=np.int32)
+    for pre, (pi, kk) in enumerate(zip(src_pair, src_k)):
+        pair_dst[pi, kk] = inv[pre]
+    T.pair_dst = pair_dst
+    con_pair = np.array([src_pair[p] for p in perm], dtype=np.int32)
+    T.con_dim = np.array([dims_unsorted[p] for p in perm], dtype=np.int32)
+    T.con_geom1 = np.array([pairs[pi][2].geom1 for pi in con_pair], dtype=np.int32)
+    T.con_geom2 = np.array([pairs[pi][2].geom2 for pi in con_pair], dtype=np.int32)
+    T.con_pair = con_pair
+    elliptic = int(m.opt.cone) == ConeType.ELLIPTIC
+    ns = ne + nf + nl
+    rows = [1 if d == 1 else (d if elliptic else 2 * (d - 1)) for d in T.con_dim]
+    T.con_rows = np.array(rows, dtype=np.int32)
+    T.con_efc_address = (ns + np.concatenate([[0], np.cumsum(rows)[:-1]])).astype(np.int32) if ncon else np.zeros(0, dtype=np.int32)
+    # the address collision() writes first (pyramidal-style, collision_driver.py:847-850) is
+    # overwritten by make_constraint's cone-aware one (constraint.py:636-646): only the latter
+    # reaches the returned Data.
+    lim = []
+    if not (flags & (DisableBit.CONSTRAINT | DisableBit.LIMIT)):
+        jt = np.asarray(m.jnt_type)
+        for j in range(int(m.njnt)):
+            if bool(np.asarray(m.jnt_limited)[j]) and int(jt[j]) in (int(JointType.SLIDE), int(JointType.HINGE)):
+                lim.append(j)
+    T.lim_jnt = np.array(lim, dtype=np.int32)
+    assert len(lim) == nl, (len(lim), nl)
+    return T
+
+
+def static_contact_fields(m_floats: dict, T: StaticTables, dtype):
+    """Per-contact static Contact leaves in final order, evaluated in ``dtype`` (collision_driver.py:691-793)."""
+    ncon = len(T.con_dim)
+    if ncon == 0:
+        z = lambda *s: torch.zeros((0,) + s, dtype=dtype)
+        return dict(includemargin=z(), friction=z(5), solref=z(2), solreffriction=z(2), solimp=z(5))
+    per_pair = ct.static_contact_params(m_floats, T.pairs, dtype)
+    sel = [per_pair[pi] for pi in T.con_pair]
+    return dict(
+        friction=torch.stack([s[0] for s in sel]).contiguous(),
+        solref=torch.stack([s[1] for s in sel]).contiguous(),
+        solreffriction=torch.stack([s[2] for s in sel]).contiguous(),
+        solimp=torch.stack([s[3] for s in sel]).contiguous(),
+        includemargin=torch.stack([s[4] for s in sel]).contiguous(),
+    )
+
+
+def device_put(value, *, dtype: torch.dtype | None = None):
+    """Places a compiled model onto the torch side (reference device.py:1029-1112).
+
+    ``value``: ``mjcf.MjModelLite`` or ``mujoco.MjModel``.  ``dtype`` overrides the floating
+    dtype of every float leaf (default float64, like the reference).
+    """
+    if not hasattr(value, "nq") or not hasattr(value, "opt"):
+        raise NotImplementedError(f"{type(value)} is not supported for device_put.")
+    _validate(value)
+    fdtype = dtype or torch.float64
+    kw = {}
+    for name, kind in MODEL_FIELDS:
+        try:
+            v = getattr(value, name)
+        except AttributeError:
+            continue
+        if kind == "int":
+            kw[name] = int(v)
+        elif kind == "np":
+            kw[name] = np.array(v)
+        elif kind == "t":
+            a = np.asarray(v, dtype=np.float64)
+            if name == "cam_mat0":
+                a = a.reshape(-1, 9)
+            kw[name] = torch.tensor(a, dtype=fdtype)
+        elif kind == "ut":
+            kw[name] = UnbatchedTensor(torch.tensor(np.ascontiguousarray(v)))
+    st = value.stat
+    stat = Statistic(
+        meaninertia=float(st.meaninertia),
+        meanmass=_t(_get(st, "meanmass", 0.0), fdtype),
+        meansize=_t(_get(st, "meansize", 0.0), fdtype),
+        extent=_t(_get(st, "extent", 1.0), fdtype),
+        center=_t(_get(st, "center", lambda: np.zeros(3)), fdtype),
+        batch_size=[],
+    )
+    nv = int(value.nv)
+    ij = []
+    for i in range(nv):
+        j = i
+        while j > -1:
+            ij.append((i, j))
+            j = int(value.dof_parentid[j])
+    rows, cols = zip(*ij) if ij else ((), ())
+    actuator_info = []
+    for i in range(int(value.nu)):
+        trnid = int(np.asarray(value.actuator_trnid)[i, 0])
+        actuator_info.append((int(value.actuator_trntype[i]), trnid, int(value.jnt_type[trnid]), int(value.jnt_dofadr[trnid]), int(value.jnt_qposadr[trnid])))
+    T = _build_tables(value, fdtype)
+    L = lambda a: torch.as_tensor(np.array(a), dtype=torch.long)
+    m = Model(
+        opt=_option(value.opt, fdtype),
+        stat=stat,
+        has_gravcomp=False,
+        dof_tri_row=np.array(rows, dtype=np.int64),
+        dof_tri_col=np.array(cols, dtype=np.int64),
+        actuator_info=tuple(actuator_info),
+        actuator_moment_is_batched_py=False,
+        constraint_sizes_py=T.constraint_sizes,
+        condim_counts_py=T.condim_counts,
+        condim_tensor_py=torch.tensor(sorted(int(d) for d in T.con_dim), dtype=torch.long),
+        collision_max_cp_py=-1,
+        collision_total_contacts_py=int(T.total_contacts),
+        cache_id=next(_cache_id_counter),
+        body_rootid_t=L(value.body_rootid),
+        dof_bodyid_t=L(value.dof_bodyid),
+        dof_jntid_t=L(value.dof_jntid),
+        geom_bodyid_t=L(value.geom_bodyid),
+        site_bodyid_t=L(value.site_bodyid),
+        cam_bodyid_t=L(value.cam_bodyid),
+        light_bodyid_t=L(value.light_bodyid),
+        batch_size=[],
+        **kw,
+    )
+    T.source = value
+    object.__setattr__(m, "_tables", T)
+    return m

@@ -1,0 +1,130 @@
+"""``step`` / ``forward``: the reference's public hot-path API on top of the native library.
+
+Signatures and ownership rules follow reference ``_src/forward.py``: ``step(m, d,
+fixed_iterations=False) -> Data`` (:463-496) and ``forward`` (:373-401).  The caller's ``Data``
+is never mutated; every leaf the step writes is a fresh tensor, untouched leaves alias the
+input (forward.py:473-475, dataclasses.py:112-120).  Unlike the reference, a *batched* ``Data``
+(leading dims on every leaf, exactly what ``make_data(mx).expand(B).clone()`` produces) is
+stepped natively in one launch sequence -- no ``torch.vmap`` -- and an un-batched ``Data`` is the
+B = 1 case.
+
+There is no fallback: tensors must live on a HIP device and ``libmjhip.so`` must be built.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+
+import torch
+
+from . import native
+from .container import UnbatchedTensor
+from .types import Data, Model
+
+# leaves the native step writes (reference Appendix: "Data leaves written by one step")
+_WRITTEN_ALWAYS = (
+    "qpos xpos xquat xmat xipos ximat xanchor xaxis geom_xpos geom_xmat site_xpos site_xmat cam_xpos cam_xmat "
+    "light_xpos light_xdir subtree_com cdof cinert crb actuator_length actuator_moment qM qLD actuator_velocity "
+    "cvel cdof_dot qfrc_bias qfrc_passive actuator_force qfrc_actuator qfrc_smooth qacc_smooth qacc act_dot"
+).split()
+_WRITTEN_CONTACT = (
+    "contact_dist contact_pos contact_frame contact_includemargin contact_friction contact_solref "
+    "contact_solreffriction contact_solimp contact_dim contact_geom1 contact_geom2 contact_geom contact_efc_address"
+).split()
+_WRITTEN_EFC = "efc_J efc_frictionloss efc_D efc_aref efc_force qacc_warmstart qfrc_constraint".split()
+_WRITTEN_STEP = "qvel act time".split()
+
+_ALL_NAMES = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
+_REAL_NAMES = set(native.LISTS["MJH_DATA_REALS"])
+
+
+def _written_names(m: Model, step: bool):
+    ne, nf, nl, ncon, nefc = m.constraint_sizes_py
+    names = list(_WRITTEN_ALWAYS)
+    if ncon > 0:
+        names += _WRITTEN_CONTACT
+    if nefc > 0:
+        names += _WRITTEN_EFC
+    if step:
+        names += _WRITTEN_STEP
+    return names
+
+
+def _fill_ptrs(d: Data, names, dtype, device, check=True):
+    ptrs = native.DataPtrs()
+    keep = []
+    for n in names:
+        t = native.data_field_tensor(d, n)
+        if t is None:
+            continue
+        if check:
+            if t.device != device:
+                raise RuntimeError(f"Data.{n} is on {t.device}, expected {device}")
+            if n in _REAL_NAMES and t.dtype != dtype:
+                raise RuntimeError(f"Data.{n} has dtype {t.dtype}, expected {dtype} (mixed-precision Data is not supported)")
+            if not t.is_contiguous():
+                t = t.contiguous()
+        keep.append(t)
+        setattr(ptrs, n, t.data_ptr() if t.numel() else None)
+    return ptrs, keep
+
+
+def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None = None, stages: int = native.STAGE_ALL) -> Data:
+    qpos = d.qpos
+    if qpos.device.type != "cuda":
+        raise RuntimeError(
+            "mujoco_torch_amd.step/forward run only on a HIP device (tensors on "
+            f"{qpos.device}); there is no CPU or PyTorch fallback. Move Model/Data with .to('cuda')."
+        )
+    dtype = qpos.dtype
+    if dtype not in (torch.float64, torch.float32):
+        raise RuntimeError(f"unsupported Data dtype {dtype}")
+    device = qpos.device
+    batch = tuple(qpos.shape[:-1])
+    B = int(math.prod(batch)) if batch else 1
+    nm = native.get_native_model(m, device, dtype)
+    names = _written_names(m, step)
+    in_ptrs, keep_in = _fill_ptrs(d, _ALL_NAMES, dtype, device)
+    if out is None:
+        new = {}
+        for n in names:
+            src = native.data_field_tensor(d, n)
+            new[n] = torch.empty_like(src, memory_format=torch.contiguous_format)
+        contact_kw = {n[len("contact_"):] if n != "contact_dim" else "contact_dim": t for n, t in new.items() if n.startswith("contact_")}
+        top_kw = {n: t for n, t in new.items() if not n.startswith("contact_")}
+        res = d.replace(**top_kw)
+        if contact_kw:
+            res = res.replace(contact=d.contact.replace(**contact_kw))
+    else:
+        res = out
+    out_ptrs, keep_out = _fill_ptrs(res, names, dtype, device, check=out is not None)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
+    with torch.cuda.device(device):
+        if step:
+            rc = nm.lib.mjh_step(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs), B, flags, ctypes.c_void_p(stream))
+        else:
+            rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs), B, stages, flags, ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"native step failed ({rc}): {nm.lib.mjh_last_error().decode()}")
+    ne, nf, nl, ncon, nefc = m.constraint_sizes_py
+    res.update_(
+        ncon=UnbatchedTensor(torch.full((), ncon, dtype=torch.int32, device=device)),
+        nefc=UnbatchedTensor(torch.full((), nefc, dtype=torch.int32, device=device)),
+    ) if out is None else None
+    return res
+
+
+def step(m: Model, d: Data, fixed_iterations: bool = False, *, out: Data | None = None) -> Data:
+    """Advance simulation by one timestep (reference forward.py:463-496).
+
+    ``out`` (extension): an existing ``Data`` of the same shape whose storage receives the
+    result instead of freshly allocated tensors (ping-pong buffers for tight loops).
+    """
+    return _run(m, d, fixed_iterations, step=True, out=out)
+
+
+def forward(m: Model, d: Data, fixed_iterations: bool = False, *, stages: int = native.STAGE_ALL) -> Data:
+    """Forward dynamics (reference forward.py:373-401)."""
+    return _run(m, d, fixed_iterations, step=False, stages=stages)

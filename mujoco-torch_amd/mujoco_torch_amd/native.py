@@ -1,0 +1,243 @@
+"""ctypes binding of the C ABI declared in ``include/mjhip.h``.
+
+PyTorch is used only for device memory and streams; the step itself is the hand-written HIP
+library ``libmjhip.so`` (built in-tree by ``__graft_entry__.build()``).  There is NO CPU or
+PyTorch fallback: if the library is missing, or the tensors are not on a HIP device, the call
+raises.  The structure layouts are derived from the header's X-macro lists so the binding cannot
+drift from the ABI.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+import numpy as np
+import torch
+
+from .io import model_float_leaves
+from .device import static_contact_fields
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_PKG_DIR))
+HEADER = os.path.join(_ROOT, "include", "mjhip.h")
+LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmjhip.so")
+
+MJH_F64, MJH_F32 = 0, 1
+FLAG_FIXED_ITERATIONS = 1
+STAGE_ALL = 0x7F
+
+
+def _macro_names(text: str, macro: str):
+    m = re.search(r"#define\s+" + macro + r"\(X\)(.*?)(?:\n\s*\n|\n#|\ntypedef)", text, re.S)
+    if m is None:
+        raise RuntimeError(f"{macro} not found in {HEADER}")
+    body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+    return re.findall(r"X\((\w+)\)", body)
+
+
+def _load_lists():
+    with open(HEADER) as f:
+        text = f.read()
+    return {k: _macro_names(text, k) for k in (
+        "MJH_MODEL_INTS", "MJH_MODEL_REALS", "MJH_MODEL_INT_ARRAYS", "MJH_MODEL_REAL_ARRAYS",
+        "MJH_DATA_REALS", "MJH_DATA_I32", "MJH_DATA_I64")}
+
+
+LISTS = _load_lists()
+
+
+def _make_structs():
+    f = [("abi_version", ctypes.c_int32)]
+    f += [(n, ctypes.c_int32) for n in LISTS["MJH_MODEL_INTS"]]
+    f += [(n, ctypes.c_double) for n in LISTS["MJH_MODEL_REALS"]]
+    f += [(n, ctypes.c_void_p) for n in LISTS["MJH_MODEL_INT_ARRAYS"]]
+    f += [(n, ctypes.c_void_p) for n in LISTS["MJH_MODEL_REAL_ARRAYS"]]
+    f += [("len_" + n, ctypes.c_int64) for n in LISTS["MJH_MODEL_INT_ARRAYS"] + LISTS["MJH_MODEL_REAL_ARRAYS"]]
+
+    class ModelDesc(ctypes.Structure):
+        _fields_ = f
+
+    d = [(n, ctypes.c_void_p) for n in LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"]]
+
+    class DataPtrs(ctypes.Structure):
+        _fields_ = d
+
+    return ModelDesc, DataPtrs
+
+
+ModelDesc, DataPtrs = _make_structs()
+
+# Data leaf name -> attribute path on the Data container
+DATA_PATH = {n: (("contact", n[len("contact_"):]) if n.startswith("contact_") else (n,)) for n in
+             LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"]}
+DATA_PATH["contact_dim"] = ("contact", "contact_dim")
+
+
+def pack_model(m, dtype: torch.dtype):
+    """Model -> (ModelDesc, keepalive list of numpy arrays). Floats are evaluated in ``dtype``."""
+    T = m.tables
+    src = T.source
+    ne, nf, nl, ncon, nefc = m.constraint_sizes_py
+    ints = dict(
+        nq=m.nq, nv=m.nv, nu=m.nu, na=m.na, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
+        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=nf, nl=nl, ncon=ncon, nefc=nefc,
+        npair=len(T.pairs), nconvex=0, integrator=int(m.opt.integrator), solver=int(m.opt.solver),
+        cone=int(m.opt.cone), disableflags=int(m.opt.disableflags), iterations=int(m.opt.iterations),
+        ls_iterations=int(m.opt.ls_iterations),
+    )
+    f64 = lambda t: np.ascontiguousarray(t.detach().to("cpu", dtype).to(torch.float64).numpy()).reshape(-1)
+    grav = f64(m.opt.gravity)
+    reals = dict(
+        timestep=float(f64(m.opt.timestep)[0]), impratio=float(f64(m.opt.impratio)[0]),
+        tolerance=float(m.opt.tolerance), ls_tolerance=float(m.opt.ls_tolerance),
+        meaninertia=float(m.stat.meaninertia), gravity_x=float(grav[0]), gravity_y=float(grav[1]), gravity_z=float(grav[2]),
+    )
+    i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32)).reshape(-1)
+    nu = m.nu
+    info = m.actuator_info
+    A = lambda name: np.asarray(getattr(m, name))
+    int_arrays = dict(
+        body_parentid=i32(A("body_parentid")), body_rootid=i32(A("body_rootid")), body_jntadr=i32(A("body_jntadr")),
+        body_jntnum=i32(A("body_jntnum")), body_dofadr=i32(A("body_dofadr")), body_dofnum=i32(A("body_dofnum")),
+        body_mocapid=i32(A("body_mocapid")), jnt_type=i32(m.jnt_type.data.numpy()), jnt_qposadr=i32(A("jnt_qposadr")),
+        jnt_dofadr=i32(A("jnt_dofadr")), jnt_bodyid=i32(A("jnt_bodyid")), jnt_actfrclimited=i32(A("jnt_actfrclimited")),
+        dof_bodyid=i32(A("dof_bodyid")), dof_jntid=i32(A("dof_jntid")), dof_parentid=i32(A("dof_parentid")),
+        geom_type=i32(A("geom_type")), geom_bodyid=i32(A("geom_bodyid")), geom_convexid=-np.ones(m.ngeom, dtype=np.int32),
+        site_bodyid=i32(A("site_bodyid")), cam_bodyid=i32(A("cam_bodyid")), cam_mode=i32(A("cam_mode")),
+        cam_targetbodyid=i32(A("cam_targetbodyid")), light_bodyid=i32(A("light_bodyid")),
+        act_trntype=i32([x[0] for x in info]), act_jnttype=i32([x[2] for x in info]), act_dofadr=i32([x[3] for x in info]),
+        act_qposadr=i32([x[4] for x in info]), act_gaintype=i32(m.actuator_gaintype.data.numpy()),
+        act_biastype=i32(m.actuator_biastype.data.numpy()), act_dyntype=i32(m.actuator_dyntype.data.numpy()),
+        act_ctrllimited=i32(A("actuator_ctrllimited")), act_forcelimited=i32(A("actuator_forcelimited")),
+        act_actlimited=i32(A("actuator_actlimited")), act_actadr=i32(A("actuator_actadr")), act_actnum=i32(A("actuator_actnum")),
+        lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
+        pair_geom2=i32([p[2].geom2 for p in T.pairs]), pair_ncon=i32([p[1] for p in T.pairs]), pair_dst=i32(T.pair_dst),
+        con_dim=i32(T.con_dim), con_geom1=i32(T.con_geom1), con_geom2=i32(T.con_geom2), con_efc_address=i32(T.con_efc_address),
+        convex_nvert=i32([]), convex_nface=i32([]), convex_nfv=i32([]), convex_nedge=i32([]), convex_vertadr=i32([]),
+        convex_faceadr=i32([]), convex_normadr=i32([]), convex_edgeadr=i32([]), convex_face=i32([]), convex_edge=i32([]),
+    )
+    st = static_contact_fields(model_float_leaves(m, dtype), T, dtype)
+    empty = np.zeros(0)
+    real_arrays = dict(
+        qpos0=f64(m.qpos0), qpos_spring=f64(m.qpos_spring), body_pos=f64(m.body_pos), body_quat=f64(m.body_quat),
+        body_ipos=f64(m.body_ipos), body_iquat=f64(m.body_iquat), body_mass=f64(m.body_mass),
+        body_inertia=f64(m.body_inertia), body_invweight0=f64(m.body_invweight0[:, 0]), jnt_pos=f64(m.jnt_pos),
+        jnt_axis=f64(m.jnt_axis), jnt_stiffness=f64(m.jnt_stiffness), jnt_range=f64(m.jnt_range),
+        jnt_margin=f64(m.jnt_margin), jnt_solref=f64(m.jnt_solref), jnt_solimp=f64(m.jnt_solimp),
+        jnt_actfrcrange=f64(m.jnt_actfrcrange), dof_armature=f64(m.dof_armature), dof_damping=f64(m.dof_damping),
+        dof_invweight0=f64(m.dof_invweight0), geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
+        geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
+        cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
+        light_dir=f64(m.light_dir), act_gear=f64(m.actuator_gear) if nu else empty,
+        act_gainprm=f64(m.actuator_gainprm[:, :3]) if nu else empty, act_biasprm=f64(m.actuator_biasprm[:, :3]) if nu else empty,
+        act_dynprm=f64(m.actuator_dynprm[:, :3]) if nu else empty, act_ctrlrange=f64(m.actuator_ctrlrange) if nu else empty,
+        act_forcerange=f64(m.actuator_forcerange) if nu else empty, act_actrange=f64(m.actuator_actrange) if nu else empty,
+        con_includemargin=f64(st["includemargin"]), con_friction=f64(st["friction"]), con_solref=f64(st["solref"]),
+        con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=empty, convex_facenormal=empty,
+    )
+    desc = ModelDesc()
+    desc.abi_version = 1
+    keep = []
+    for n in LISTS["MJH_MODEL_INTS"]:
+        setattr(desc, n, int(ints[n]))
+    for n in LISTS["MJH_MODEL_REALS"]:
+        setattr(desc, n, float(reals[n]))
+    for n in LISTS["MJH_MODEL_INT_ARRAYS"]:
+        a = int_arrays[n]
+        keep.append(a)
+        setattr(desc, n, a.ctypes.data if a.size else None)
+        setattr(desc, "len_" + n, a.size)
+    for n in LISTS["MJH_MODEL_REAL_ARRAYS"]:
+        a = np.ascontiguousarray(real_arrays[n], dtype=np.float64)
+        keep.append(a)
+        setattr(desc, n, a.ctypes.data if a.size else None)
+        setattr(desc, "len_" + n, a.size)
+    return desc, keep
+
+
+def data_field_tensor(d, name):
+    obj = d
+    for p in DATA_PATH[name]:
+        obj = getattr(obj, p)
+    return obj
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """Loads libmjhip.so (once). Raises if it has not been built: no fallback path exists."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"native stepper library not found at {p}; build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). mujoco_torch_amd has no CPU / PyTorch fallback."
+        )
+    lib = ctypes.CDLL(p)
+    lib.mjh_model_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.mjh_model_create.restype = ctypes.c_int
+    lib.mjh_model_destroy.argtypes = [ctypes.c_void_p]
+    lib.mjh_model_destroy.restype = None
+    lib.mjh_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.mjh_forward.restype = ctypes.c_int
+    lib.mjh_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    lib.mjh_step.restype = ctypes.c_int
+    lib.mjh_model_lds_bytes.argtypes = [ctypes.c_void_p]
+    lib.mjh_model_lds_bytes.restype = ctypes.c_int
+    for fn in ("mjh_last_error", "mjh_data_fields", "mjh_model_fields"):
+        getattr(lib, fn).restype = ctypes.c_char_p
+    lib.mjh_abi_version.restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check_abi(lib):
+    """Asserts the header this binding was generated from matches the loaded library."""
+    data = lib.mjh_data_fields().decode().split(",")
+    want = LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"]
+    if data != want:
+        raise RuntimeError("libmjhip.so Data field list does not match include/mjhip.h")
+    model = lib.mjh_model_fields().decode().split(",")
+    wantm = LISTS["MJH_MODEL_INTS"] + LISTS["MJH_MODEL_REALS"] + LISTS["MJH_MODEL_INT_ARRAYS"] + LISTS["MJH_MODEL_REAL_ARRAYS"]
+    if model != wantm:
+        raise RuntimeError("libmjhip.so Model field list does not match include/mjhip.h")
+
+
+class NativeModel:
+    """Device-resident constant blob for one (device, dtype)."""
+
+    def __init__(self, m, device: torch.device, dtype: torch.dtype):
+        self.lib = load_library()
+        check_abi(self.lib)
+        desc, keep = pack_model(m, dtype)
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = self.lib.mjh_model_create(ctypes.byref(desc), MJH_F64 if dtype == torch.float64 else MJH_F32, ctypes.byref(handle))
+        if rc != 0:
+            raise RuntimeError(f"mjh_model_create failed ({rc}): {self.lib.mjh_last_error().decode()}")
+        self.handle = handle
+        self.device = device
+        self.dtype = dtype
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.mjh_model_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def get_native_model(m, device: torch.device, dtype: torch.dtype) -> NativeModel:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), dtype)
+    cache = m.tables.native
+    nm = cache.get(key)
+    if nm is None:
+        nm = NativeModel(m, torch.device("cuda", key[0]), dtype)
+        cache[key] = nm
+    return nm

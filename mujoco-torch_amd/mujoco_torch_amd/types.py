@@ -1,0 +1,250 @@
+"""Model / Data / Contact / Option schema (field names, shapes and dtypes of the reference).
+
+Restates the schema of reference ``_src/types.py``: ``Option`` :503-557, ``Model`` :560-910,
+``Contact`` :1036-1088, ``Data`` :1091-1261.  Field names and per-field shapes/dtypes are kept
+so a ``Data`` produced here is interchangeable with the reference's; the containers are the
+tensordict-free ``MjTensorClass`` of ``container.py``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ._enums import (  # noqa: F401  (re-exported: the reference exposes them from types)
+    BiasType,
+    CamLightType,
+    ConeType,
+    DisableBit,
+    DynType,
+    EnableBit,
+    EqType,
+    GainType,
+    GeomType,
+    IntegratorType,
+    JacobianType,
+    JointType,
+    SensorType,
+    SolverType,
+    TrnType,
+    mjNIMP,
+    mjNREF,
+)
+from .container import MjTensorClass, UnbatchedTensor
+
+
+class Statistic(MjTensorClass):
+    meaninertia: float
+    meanmass: torch.Tensor
+    meansize: torch.Tensor
+    extent: torch.Tensor
+    center: torch.Tensor
+
+
+class Option(MjTensorClass):
+    iterations: int
+    ls_iterations: int
+    tolerance: float
+    ls_tolerance: float
+    impratio: torch.Tensor
+    gravity: torch.Tensor
+    density: torch.Tensor
+    viscosity: torch.Tensor
+    magnetic: torch.Tensor
+    wind: torch.Tensor
+    jacobian: JacobianType
+    cone: ConeType
+    disableflags: DisableBit
+    enableflags: int
+    integrator: IntegratorType
+    solver: SolverType
+    timestep: torch.Tensor
+    o_margin: torch.Tensor
+    o_solref: torch.Tensor
+    o_solimp: torch.Tensor
+    o_friction: torch.Tensor
+    disableactuator: int
+    sdf_initpoints: int
+    has_fluid_params: bool
+
+
+# Model leaves copied by name from the compiled model: (name, kind) with kind in
+# 'int' (python int), 'np' (numpy array kept on host), 't' (float tensor), 'ut' (UnbatchedTensor)
+MODEL_FIELDS = (
+    [(n, "int") for n in (
+        "nq nv nu na nbody njnt ngeom nsite ncam nlight nmesh npair nexclude neq ntendon nwrap nsensor "
+        "nnumeric nmocap nM nsensordata nuserdata").split()]
+    + [(n, "np") for n in (
+        "body_parentid body_mocapid body_rootid body_weldid body_jntnum body_jntadr body_sameframe body_dofnum "
+        "body_dofadr body_treeid body_geomnum body_geomadr body_simple jnt_qposadr jnt_dofadr jnt_bodyid jnt_group "
+        "jnt_limited jnt_actfrclimited jnt_actgravcomp dof_bodyid dof_jntid dof_parentid dof_treeid dof_Madr "
+        "dof_simplenum geom_type geom_contype geom_conaffinity geom_condim geom_bodyid geom_sameframe geom_dataid "
+        "geom_group geom_priority site_type site_bodyid site_sameframe site_size cam_mode cam_bodyid "
+        "cam_targetbodyid cam_fovy cam_resolution cam_sensorsize cam_intrinsic light_mode light_bodyid "
+        "light_targetbodyid pair_dim pair_geom1 pair_geom2 pair_signature exclude_signature eq_type eq_obj1id "
+        "eq_obj2id eq_active0 actuator_trntype actuator_trnid actuator_actadr actuator_actnum actuator_group "
+        "actuator_ctrllimited actuator_forcelimited actuator_actlimited actuator_actearly sensor_type sensor_dim "
+        "sensor_adr sensor_objid sensor_cutoff numeric_adr numeric_data key_time key_qpos key_qvel key_ctrl").split()]
+    + [(n, "t") for n in (
+        "qpos0 qpos_spring body_pos body_quat body_ipos body_iquat body_mass body_subtreemass body_inertia "
+        "body_gravcomp body_invweight0 jnt_solref jnt_solimp jnt_pos jnt_axis jnt_stiffness jnt_range "
+        "jnt_actfrcrange jnt_margin dof_solref dof_solimp dof_frictionloss dof_armature dof_damping "
+        "dof_invweight0 dof_M0 geom_solmix geom_solref geom_solimp geom_size geom_aabb geom_rbound geom_pos "
+        "geom_quat geom_friction geom_margin geom_gap geom_rgba site_pos site_quat cam_pos cam_quat cam_poscom0 "
+        "cam_pos0 cam_mat0 light_pos light_dir light_poscom0 light_pos0 light_dir0 pair_solref "
+        "pair_solreffriction pair_solimp pair_margin pair_gap pair_friction eq_solref eq_solimp eq_data "
+        "actuator_dynprm actuator_gainprm actuator_biasprm actuator_ctrlrange actuator_forcerange "
+        "actuator_actrange actuator_gear actuator_acc0 actuator_lengthrange").split()]
+    + [(n, "ut") for n in "jnt_type actuator_dyntype actuator_gaintype actuator_biastype".split()]
+)
+
+
+class Model(MjTensorClass):
+    """Static model.  Leaves named in ``MODEL_FIELDS`` plus derived host tables (``device.py``)."""
+
+    opt: Option
+    stat: Statistic
+    # derived, host side (reference names; device.py:632-884)
+    has_gravcomp: bool
+    dof_tri_row: np.ndarray
+    dof_tri_col: np.ndarray
+    actuator_info: tuple
+    actuator_moment_is_batched_py: bool
+    constraint_sizes_py: tuple
+    condim_counts_py: tuple
+    condim_tensor_py: torch.Tensor
+    collision_max_cp_py: int
+    collision_total_contacts_py: int
+    cache_id: int
+    body_rootid_t: torch.Tensor
+    dof_bodyid_t: torch.Tensor
+    dof_jntid_t: torch.Tensor
+    geom_bodyid_t: torch.Tensor
+    site_bodyid_t: torch.Tensor
+    cam_bodyid_t: torch.Tensor
+    light_bodyid_t: torch.Tensor
+
+    def to(self, *args, **kwargs):
+        new = super().to(*args, **kwargs)
+        # the native constant blobs are cached per (device, dtype) on the shared tables object
+        return new
+
+    @property
+    def tables(self):
+        """Host-side static tables (contact order, static contact params, native descriptors)."""
+        return self.__dict__["_tables"]
+
+
+# attach the by-name leaves as annotations so they are real fields
+for _n, _k in MODEL_FIELDS:
+    Model._field_names = Model._field_names + (_n,)
+Model._field_names = tuple(dict.fromkeys(Model._field_names))
+
+
+class Contact(MjTensorClass):
+    dist: torch.Tensor
+    pos: torch.Tensor
+    frame: torch.Tensor
+    includemargin: torch.Tensor
+    friction: torch.Tensor
+    solref: torch.Tensor
+    solreffriction: torch.Tensor
+    solimp: torch.Tensor
+    contact_dim: torch.Tensor
+    geom1: torch.Tensor
+    geom2: torch.Tensor
+    geom: torch.Tensor
+    efc_address: torch.Tensor
+
+    @classmethod
+    def zero(cls, shape=(0,), device=None) -> "Contact":
+        shape = tuple(shape)
+        z = lambda *s, dt=None: torch.zeros(shape + s, dtype=dt, device=device)
+        return Contact(
+            dist=z(), pos=z(3), frame=z(3, 3), includemargin=z(), friction=z(5), solref=z(mjNREF),
+            solreffriction=z(mjNREF), solimp=z(mjNIMP), contact_dim=z(dt=torch.int32),
+            geom1=z(dt=torch.int64), geom2=z(dt=torch.int64), geom=z(2, dt=torch.int64),
+            efc_address=z(dt=torch.int64), batch_size=list(shape),
+        )
+
+
+class Data(MjTensorClass):
+    solver_niter: torch.Tensor
+    ne: torch.Tensor
+    nf: torch.Tensor
+    nl: torch.Tensor
+    nefc: UnbatchedTensor
+    ncon: UnbatchedTensor
+    time: torch.Tensor
+    qpos: torch.Tensor
+    qvel: torch.Tensor
+    act: torch.Tensor
+    qacc_warmstart: torch.Tensor
+    ctrl: torch.Tensor
+    qfrc_applied: torch.Tensor
+    xfrc_applied: torch.Tensor
+    eq_active: torch.Tensor
+    mocap_pos: torch.Tensor
+    mocap_quat: torch.Tensor
+    qacc: torch.Tensor
+    act_dot: torch.Tensor
+    userdata: torch.Tensor
+    sensordata: torch.Tensor
+    xpos: torch.Tensor
+    xquat: torch.Tensor
+    xmat: torch.Tensor
+    xipos: torch.Tensor
+    ximat: torch.Tensor
+    xanchor: torch.Tensor
+    xaxis: torch.Tensor
+    ten_length: torch.Tensor
+    geom_xpos: torch.Tensor
+    geom_xmat: torch.Tensor
+    site_xpos: torch.Tensor
+    site_xmat: torch.Tensor
+    cam_xpos: torch.Tensor
+    cam_xmat: torch.Tensor
+    light_xpos: torch.Tensor
+    light_xdir: torch.Tensor
+    subtree_com: torch.Tensor
+    cdof: torch.Tensor
+    cinert: torch.Tensor
+    crb: torch.Tensor
+    actuator_length: torch.Tensor
+    actuator_moment: torch.Tensor
+    qM: torch.Tensor
+    qLD: torch.Tensor
+    qLDiagInv: torch.Tensor
+    ten_wrapadr: torch.Tensor
+    ten_wrapnum: torch.Tensor
+    ten_J: torch.Tensor
+    ten_velocity: torch.Tensor
+    wrap_obj: torch.Tensor
+    wrap_xpos: torch.Tensor
+    contact: Contact
+    efc_type: torch.Tensor
+    efc_J: torch.Tensor
+    efc_pos: torch.Tensor
+    efc_margin: torch.Tensor
+    efc_frictionloss: torch.Tensor
+    efc_D: torch.Tensor
+    efc_aref: torch.Tensor
+    efc_force: torch.Tensor
+    actuator_velocity: torch.Tensor
+    cvel: torch.Tensor
+    cdof_dot: torch.Tensor
+    qfrc_bias: torch.Tensor
+    qfrc_gravcomp: torch.Tensor
+    qfrc_fluid: torch.Tensor
+    qfrc_passive: torch.Tensor
+    actuator_force: torch.Tensor
+    qfrc_actuator: torch.Tensor
+    qfrc_smooth: torch.Tensor
+    qacc_smooth: torch.Tensor
+    qfrc_constraint: torch.Tensor
+    qfrc_inverse: torch.Tensor
+    cacc: torch.Tensor
+    cfrc_int: torch.Tensor
+    cfrc_ext: torch.Tensor
+    subtree_linvel: torch.Tensor
+    subtree_angmom: torch.Tensor

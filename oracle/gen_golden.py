@@ -1,0 +1,124 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python step in the build container.
+
+TEST INFRASTRUCTURE, container-only (needs /root/reference; see oracle/ref_harness.py).  For each
+case: compile the bundled XML with this repo's MJCF-subset compiler, apply the option overrides
+of BASELINE.json's configs, hand the model to the reference's ``device_put`` / ``make_data``, set
+seeded inputs, and record every Data leaf the step writes after each of N reference
+``forward.step`` calls (eager, one environment at a time -- the reference's per-env semantics).
+
+Run:  python oracle/gen_golden.py            (writes tests/golden/<case>.npz, a few hundred KB each)
+"""
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(REPO, "mujoco-torch_amd"))
+
+import ref_harness  # noqa: E402
+
+from mujoco_torch_amd import mjcf, native  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+# name -> (xml, option overrides, dtype, nenv, nsteps, input recipe)
+CASES = {
+    # BASELINE config 1: cartpole, Euler (constraints disabled in the XML), float64
+    "cartpole_f64": ("cartpole", {}, "float64", 3, 4, "cartpole"),
+    # BASELINE config 2/4: humanoid, Euler + CG, XML iterations=1 / ls_iterations=4, float64
+    "humanoid_cg_f64": ("humanoid", {"solver": 1}, "float64", 3, 3, "bench"),
+    "humanoid_cg_f64_perturbed": ("humanoid", {"solver": 1}, "float64", 3, 3, "perturbed"),
+    # bundled XML as is (Newton, the configuration the reference's README numbers were taken on)
+    "humanoid_newton_f64": ("humanoid", {}, "float64", 2, 3, "perturbed"),
+    # full-length solver loops (iterations 100 / ls 50) on the humanoid with CG
+    "humanoid_cg_iter100_f64": ("humanoid", {"solver": 1, "iterations": 100, "ls_iterations": 50}, "float64", 2, 2, "perturbed"),
+    # bundled ant as is (Euler, Newton, pyramidal) and BASELINE config 3 (RK4 + Newton + elliptic)
+    "ant_euler_newton_pyr_f64": ("ant", {}, "float64", 2, 3, "bench_ctrl"),
+    "ant_rk4_newton_ell_f64": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float64", 2, 3, "bench_ctrl"),
+    "ant_rk4_newton_ell_f32": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 2, 3, "bench_ctrl"),
+    "ant_euler_cg_ell_f64": ("ant", {"solver": 1, "cone": 1}, "float64", 2, 2, "bench_ctrl"),
+}
+
+INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
+
+
+def make_inputs(recipe, lite, env):
+    """Seeded per-env input overrides (numpy, float64). ``env`` is the seed index."""
+    rng = np.random.RandomState(1000 + env)
+    nq, nv, nu, nb = lite.nq, lite.nv, lite.nu, lite.nbody
+    out = {}
+    if recipe == "cartpole":
+        out["qpos"] = np.array([0.1 * env, 0.7 - 0.4 * env])
+        out["qvel"] = np.array([0.3, -0.5 + env])
+        out["ctrl"] = np.array([0.5 * env - 0.3])
+    elif recipe == "bench":  # benchmarks/_helpers.py:25-42 : qpos0, qvel = 0.01 * randn, ctrl = 0
+        out["qvel"] = 0.01 * np.random.RandomState(42 + env).randn(nv)
+    elif recipe == "bench_ctrl":
+        out["qvel"] = 0.3 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.8 * rng.randn(nu), -1.5, 1.5)
+        out["qpos"] = lite.qpos0 + 0.2 * rng.randn(nq)
+        out["qfrc_applied"] = 0.5 * rng.randn(nv)
+        out["xfrc_applied"] = 0.5 * rng.randn(nb, 6)
+    elif recipe == "perturbed":
+        q = lite.qpos0.copy()
+        q[7:] += 0.4 * rng.randn(nq - 7)
+        q[2] -= 0.06 + 0.05 * env  # push the feet into the floor
+        q[3:7] += 0.15 * rng.randn(4)  # left un-normalised on purpose: kinematics normalises it
+        out["qpos"] = q
+        out["qvel"] = 0.5 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.7 * rng.randn(nu), -1.5, 1.5)
+        out["qfrc_applied"] = 0.2 * rng.randn(nv)
+        out["xfrc_applied"] = 1.0 * rng.randn(nb, 6)
+        out["qacc_warmstart"] = 0.1 * rng.randn(nv)
+    return out
+
+
+def leaf(d, name):
+    obj = d
+    for p in native.DATA_PATH[name]:
+        obj = getattr(obj, p)
+    return obj
+
+
+def main(only=None):
+    ref = ref_harness.load()
+    os.makedirs(GOLD, exist_ok=True)
+    names = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
+    for case, (xml, overrides, dtype_s, nenv, nsteps, recipe) in CASES.items():
+        if only and case not in only:
+            continue
+        dtype = getattr(torch, dtype_s)
+        lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
+        for k, v in overrides.items():
+            setattr(lite.opt, k, v)
+        mref = ref_harness.put_model(ref, lite, dtype=dtype if dtype != torch.float64 else None)
+        store = {}
+        for env in range(nenv):
+            inp = make_inputs(recipe, lite, env)
+            d = ref.io.make_data(mref)
+            d = d.replace(**{k: torch.tensor(np.asarray(v, dtype=np.float64)) for k, v in inp.items()})
+            if dtype != torch.float64:
+                d = d.to(dtype)
+            for n in INPUT_LEAVES:
+                store[f"in/{env}/{n}"] = leaf(d, n).numpy().copy()
+            for s in range(nsteps):
+                d = ref.forward.step(mref, d)
+                for n in names:
+                    t = leaf(d, n)
+                    store[f"out/{env}/{s}/{n}"] = t.numpy().copy()
+        meta = dict(xml=xml, overrides=overrides, dtype=dtype_s, nenv=nenv, nsteps=nsteps, recipe=recipe,
+                    constraint_sizes=list(mref.constraint_sizes_py), torch=torch.__version__)
+        store["meta"] = np.array(json.dumps(meta))
+        path = os.path.join(GOLD, case + ".npz")
+        np.savez_compressed(path, **store)
+        print(f"{case}: {os.path.getsize(path) / 1024:.0f} KB, sizes {mref.constraint_sizes_py}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or None)

@@ -1,0 +1,65 @@
+/*
+ * mjoracle.c -- CPU oracle for the hot path: mjo_forward / mjo_step (twins of mjh_forward / mjh_step).
+ *
+ * TEST INFRASTRUCTURE ONLY.  A plain-C, one-environment-at-a-time restatement of the reference's
+ * Python step (vmoens/mujoco-torch, mujoco_torch/_src/forward.py:463-496 and the modules it calls).
+ * Used by tests/ as the checker for the HIP kernels, by __graft_entry__.smoke(), and by bench.py
+ * as the "port" cpu_baseline.  The product package never imports, links or calls it.
+ *
+ * Pinning: oracle/gen_golden.py runs the reference's own Python here in the build container
+ * (through oracle/ref_harness.py) and writes tests/golden/ (npz files); tests/test_oracle_golden.py checks
+ * this file against those vectors.  Parity with the MuJoCo C library / MJX is UNPINNED (no mujoco
+ * or jax wheel offline): the model constants come from this repo's MJCF-subset compiler.
+ *
+ * Same structs as the device ABI (include/mjhip.h), with HOST pointers.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/mjhip.h"
+
+#define REAL double
+#define SFX _f64
+#include "mjoracle_impl.h"
+#include "mjoracle_driver.h"
+#undef REAL
+#undef SFX
+#undef R_SQRT
+#undef R_SIN
+#undef R_COS
+#undef R_ATAN2
+#undef R_POW
+#undef R_FABS
+#undef R_EXP
+
+#define REAL float
+#define SFX _f32
+#define REAL_IS_FLOAT 1
+#include "mjoracle_impl.h"
+#include "mjoracle_driver.h"
+#undef REAL
+#undef SFX
+
+/* knife (optional, [B] int32): per-env count of rounding-noise line-search candidates; knife_policy: see mjoracle_impl.h */
+int mjo_forward(const mjhModelDesc* m, const mjhData* in, mjhData* out, int64_t B, int dtype, int stages, int flags, int nthreads, int32_t* knife, int knife_policy) {
+  if (m->abi_version != MJH_ABI_VERSION) return -22;
+  return dtype == MJH_F64 ? mjo_run_f64(m, in, out, B, stages, flags, 0, nthreads, knife, knife_policy) : mjo_run_f32(m, in, out, B, stages, flags, 0, nthreads, knife, knife_policy);
+}
+
+int mjo_step(const mjhModelDesc* m, const mjhData* in, mjhData* out, int64_t B, int dtype, int flags, int nthreads, int32_t* knife, int knife_policy) {
+  if (m->abi_version != MJH_ABI_VERSION) return -22;
+  return dtype == MJH_F64 ? mjo_run_f64(m, in, out, B, MJH_STAGE_ALL, flags, 1, nthreads, knife, knife_policy) : mjo_run_f32(m, in, out, B, MJH_STAGE_ALL, flags, 1, nthreads, knife, knife_policy);
+}
+
+int mjo_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

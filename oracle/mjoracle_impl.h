@@ -1,0 +1,1176 @@
+/*
+ * mjoracle_impl.h -- scalar CPU restatement of the reference step, one environment at a time.
+ *
+ * TEST INFRASTRUCTURE (see oracle/README.md): this is the checker for the HIP path and the
+ * "port" CPU baseline of bench.py.  It is never linked into or called from the product package.
+ * Included twice by mjoracle.c with REAL = double / float and a name suffix SFX.
+ *
+ * Every function cites the reference code it follows (paths under
+ * /root/reference/mujoco_torch/_src/).  Operation order follows the Python expressions; where the
+ * reference calls a BLAS/LAPACK routine (matmul, linalg.cholesky) the textbook loop is used and
+ * agreement is to rounding (tests state the tolerance).
+ */
+
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+#define FN(name) CAT(name, SFX)
+
+#ifndef MJO_COMMON_
+#define MJO_COMMON_
+#define mjMINVAL 1e-15
+#define mjMAXVAL 1e10
+#define mjMINIMP 1e-4
+#define mjMAXIMP 0.9999
+#define JNT_FREE 0
+#define JNT_BALL 1
+#define JNT_SLIDE 2
+#define JNT_HINGE 3
+#define DSBL_CONSTRAINT (1 << 0)
+#define DSBL_SPRING (1 << 5)
+#define DSBL_DAMPER (1 << 6)
+#define DSBL_GRAVITY (1 << 7)
+#define DSBL_CLAMPCTRL (1 << 8)
+#define DSBL_WARMSTART (1 << 9)
+#define DSBL_ACTUATION (1 << 11)
+#define DSBL_REFSAFE (1 << 12)
+#define DSBL_EULERDAMP (1 << 15)
+#define INT_EULER 0
+#define INT_RK4 1
+#define SOL_CG 1
+#define SOL_NEWTON 2
+#define CONE_ELLIPTIC 1
+#define CAM_FIXED 0
+#define CAM_TRACK 1
+#define CAM_TRACKCOM 2
+#define CAM_TARGETBODY 3
+#define CAM_TARGETBODYCOM 4
+#define GAIN_FIXED 0
+#define GAIN_AFFINE 1
+#define BIAS_NONE 0
+#define BIAS_AFFINE 1
+#define DYN_NONE 0
+#define DYN_INTEGRATOR 1
+#define DYN_FILTER 2
+#define DYN_FILTEREXACT 3
+#define INLINE_CHOL_MAX 16 /* math.py:84 */
+/* constants the reference keeps in _CachedConst are float32 literals up-cast to the data dtype */
+#define MINVAL_CACHED ((float)1e-15)
+#endif
+
+#ifdef REAL_IS_FLOAT
+#define R_SQRT sqrtf
+#define R_SIN sinf
+#define R_COS cosf
+#define R_ATAN2 atan2f
+#define R_POW powf
+#define R_FABS fabsf
+#define R_EXP expf
+#else
+#define R_SQRT sqrt
+#define R_SIN sin
+#define R_COS cos
+#define R_ATAN2 atan2
+#define R_POW pow
+#define R_FABS fabs
+#define R_EXP exp
+#endif
+
+/* ---- model constants converted to REAL -------------------------------------------------- */
+typedef struct FN(MjoModel) {
+  const mjhModelDesc* d;
+  REAL timestep, impratio, meaninertia, gravity[3];
+#define X(n) REAL* n;
+  MJH_MODEL_REAL_ARRAYS(X)
+#undef X
+} FN(MjoModel);
+
+/* ---- per-environment workspace (all Data leaves + solver scratch) ------------------------ */
+typedef struct FN(MjoWork) {
+#define X(n) REAL* n;
+  MJH_DATA_REALS(X)
+#undef X
+  /* scratch */
+  REAL *cacc, *cfrc, *sub_mass, *sub_pos, *crb_cdof, *jacdiff, *tmp_nv, *tmp_nv2, *tmp_nefc;
+  REAL *efc_pos, *efc_pos_norm, *efc_invweight, *efc_solref, *efc_solimp;
+  REAL *qM2, *qLD2, *H, *HL;
+  /* solver context (solver.py:95-126) */
+  REAL *s_qacc, *s_qfrc, *s_Jaref, *s_force, *s_Ma, *s_grad, *s_Mgrad, *s_search, *s_mv, *s_jv, *s_quad;
+  REAL *s_prev_grad, *s_prev_Mgrad;
+  unsigned char* s_active;
+  /* rk4 */
+  REAL *rk_qpos0, *rk_qvel0, *rk_act0, *rk_qvel, *rk_qacc, *rk_actdot, *rk_kqvel;
+  REAL* in_subtree_com;
+  /* diagnostic: number of line-search candidates that were distinct points with a derivative that is
+     pure rounding noise (|deriv_0| < 1e-8 of the initial slope).  Whether such a candidate is
+     accepted depends on the sign / exact-zeroness of that noise (solver.py:440-463), so the
+     reference's own result is implementation-defined on these steps; tests exempt them from the
+     tight solver-output tolerance (DESIGN.md "line-search knife edge"). */
+  int knife;
+  int knife_policy; /* <0: natural; j>=0: first j noise candidates read as exact zero, the (j+1)-th as non-zero */
+} FN(MjoWork);
+
+/* ---- small vector math (math.py) ------------------------------------------------------------ */
+static inline void FN(cross3)(const REAL* a, const REAL* b, REAL* o) { /* math.py:63-76 */
+  REAL o0 = a[1] * b[2] - a[2] * b[1];
+  REAL o1 = a[2] * b[0] - a[0] * b[2];
+  REAL o2 = a[0] * b[1] - a[1] * b[0];
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+static inline REAL FN(dot3)(const REAL* a, const REAL* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static inline REAL FN(norm_n)(const REAL* x, int n) { /* math.norm :196-213 */
+  int all_zero = 1;
+  for (int i = 0; i < n; i++) if (x[i] != 0) all_zero = 0;
+  if (all_zero) return 0;
+  REAL s = 0;
+  for (int i = 0; i < n; i++) s += x[i] * x[i];
+  return R_SQRT(s);
+}
+static inline REAL FN(normalize_n)(REAL* x, int n) { /* normalize_with_norm :216-230 */
+  REAL nn = FN(norm_n)(x, n);
+  REAL den = nn + (REAL)1e-6 * (REAL)(nn == 0);
+  for (int i = 0; i < n; i++) x[i] = x[i] / den;
+  return nn;
+}
+static inline void FN(rotate)(const REAL* v, const REAL* q, REAL* o) { /* math.rotate :246-261 */
+  REAL s = q[0];
+  const REAL* u = q + 1;
+  REAL uv = FN(dot3)(u, v), uu = FN(dot3)(u, u);
+  REAL c[3];
+  FN(cross3)(u, v, c);
+  REAL r[3];
+  for (int i = 0; i < 3; i++) r[i] = 2 * (uv * u[i]) + (s * s - uu) * v[i];
+  for (int i = 0; i < 3; i++) o[i] = r[i] + 2 * s * c[i];
+}
+static inline void FN(quat_mul)(const REAL* u, const REAL* v, REAL* o) { /* :283-300 */
+  REAL o0 = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
+  REAL o1 = u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2];
+  REAL o2 = u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1];
+  REAL o3 = u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0];
+  o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+}
+static inline void FN(quat_to_mat)(const REAL* q, REAL* m) { /* :323-351 */
+  REAL p[4][4];
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p[i][j] = q[i] * q[j];
+  m[0] = p[0][0] + p[1][1] - p[2][2] - p[3][3];
+  m[1] = 2 * (p[1][2] - p[0][3]);
+  m[2] = 2 * (p[1][3] + p[0][2]);
+  m[3] = 2 * (p[1][2] + p[0][3]);
+  m[4] = p[0][0] - p[1][1] + p[2][2] - p[3][3];
+  m[5] = 2 * (p[2][3] - p[0][1]);
+  m[6] = 2 * (p[1][3] - p[0][2]);
+  m[7] = 2 * (p[2][3] + p[0][1]);
+  m[8] = p[0][0] - p[1][1] - p[2][2] + p[3][3];
+}
+static inline void FN(axis_angle_to_quat)(const REAL* axis, REAL angle, REAL* q) { /* :363-374 */
+  REAL s = R_SIN(angle * (REAL)0.5), c = R_COS(angle * (REAL)0.5);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+static inline void FN(quat_to_axis_angle)(const REAL* q, REAL* axis, REAL* angle) { /* :354-360 */
+  axis[0] = q[1]; axis[1] = q[2]; axis[2] = q[3];
+  REAL sin_a_2 = FN(normalize_n)(axis, 3);
+  REAL a = 2 * R_ATAN2(sin_a_2, q[0]);
+  if (a > (REAL)M_PI) a = a - 2 * (REAL)M_PI;
+  *angle = a;
+}
+static inline void FN(quat_sub)(const REAL* u, const REAL* v, REAL* o) { /* :276-280 */
+  REAL vi[4] = {v[0], -v[1], -v[2], -v[3]}, q[4], axis[3], angle;
+  FN(quat_mul)(vi, u, q);
+  FN(quat_to_axis_angle)(q, axis, &angle);
+  for (int i = 0; i < 3; i++) o[i] = axis[i] * angle;
+}
+static inline void FN(quat_integrate)(const REAL* q, const REAL* w, REAL dt, REAL* o) { /* :377-383 */
+  REAL v[3] = {w[0], w[1], w[2]};
+  REAL nrm = FN(normalize_n)(v, 3);
+  REAL angle = dt * nrm, qr[4], r[4];
+  FN(axis_angle_to_quat)(v, angle, qr);
+  FN(quat_mul)(q, qr, r);
+  FN(normalize_n)(r, 4);
+  for (int i = 0; i < 4; i++) o[i] = r[i];
+}
+static inline void FN(inert_mul)(const REAL* in, const REAL* v, REAL* o) { /* :415-429 */
+  static const int tri[3][3] = {{0, 3, 4}, {3, 1, 5}, {4, 5, 2}};
+  const REAL* pos = in + 6;
+  REAL mass = in[9];
+  REAL c1[3], c2[3];
+  FN(cross3)(pos, v + 3, c1);
+  FN(cross3)(pos, v, c2);
+  for (int i = 0; i < 3; i++) {
+    REAL s = in[tri[i][0]] * v[0] + in[tri[i][1]] * v[1] + in[tri[i][2]] * v[2];
+    o[i] = s + c1[i];
+  }
+  for (int i = 0; i < 3; i++) o[3 + i] = mass * v[3 + i] - c2[i];
+}
+static inline void FN(motion_cross)(const REAL* u, const REAL* v, REAL* o) { /* :455-467 */
+  REAL a[3], b[3], c[3];
+  FN(cross3)(u, v, a);
+  FN(cross3)(u + 3, v, b);
+  FN(cross3)(u, v + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+static inline void FN(motion_cross_force)(const REAL* v, const REAL* f, REAL* o) { /* :470-482 */
+  REAL a[3], b[3], c[3];
+  FN(cross3)(v, f, a);
+  FN(cross3)(v + 3, f + 3, b);
+  FN(cross3)(v, f + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+static inline void FN(make_frame)(const REAL* a_in, REAL* frame) { /* orthogonals/make_frame :485-500 */
+  REAL a[3] = {a_in[0], a_in[1], a_in[2]};
+  FN(normalize_n)(a, 3);
+  REAL b[3] = {0, 0, 0};
+  if ((REAL)-0.5 < a[1] && a[1] < (REAL)0.5) b[1] = 1; else b[2] = 1;
+  REAL ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  for (int i = 0; i < 3; i++) b[i] = b[i] - a[i] * ab;
+  FN(normalize_n)(b, 3);
+  int any = (a[0] != 0) || (a[1] != 0) || (a[2] != 0);
+  for (int i = 0; i < 3; i++) b[i] = b[i] * (REAL)any;
+  REAL c[3];
+  FN(cross3)(a, b, c);
+  for (int i = 0; i < 3; i++) { frame[i] = a[i]; frame[3 + i] = b[i]; frame[6 + i] = c[i]; }
+}
+
+/* ---- dense Cholesky (math.small_cholesky :87-129 / small_cholesky_solve :132-168) ---------- */
+static void FN(cholesky)(const REAL* A, REAL* L, int n) {
+  for (int i = 0; i < n * n; i++) L[i] = 0;
+  if (n > INLINE_CHOL_MAX) {
+    /* torch.linalg.cholesky(A + 1e-10*I): LAPACK potrf; textbook column loop here */
+    for (int j = 0; j < n; j++) {
+      REAL s = A[j * n + j] + (REAL)1e-10;
+      for (int k = 0; k < j; k++) s -= L[j * n + k] * L[j * n + k];
+      L[j * n + j] = R_SQRT(s);
+      for (int i = j + 1; i < n; i++) {
+        REAL t = A[i * n + j];
+        for (int k = 0; k < j; k++) t -= L[i * n + k] * L[j * n + k];
+        L[i * n + j] = t / L[j * n + j];
+      }
+    }
+    return;
+  }
+  for (int j = 0; j < n; j++) {
+    REAL s = A[j * n + j];
+    for (int k = 0; k < j; k++) s = s - L[j * n + k] * L[j * n + k];
+    L[j * n + j] = R_SQRT(s > (REAL)1e-12 ? s : (REAL)1e-12);
+    for (int i = j + 1; i < n; i++) {
+      REAL t = A[i * n + j];
+      for (int k = 0; k < j; k++) t = t - L[i * n + k] * L[j * n + k];
+      L[i * n + j] = t / L[j * n + j];
+    }
+  }
+}
+static void FN(cholesky_solve)(const REAL* L, const REAL* x, REAL* out, int n, REAL* y) {
+  for (int i = 0; i < n; i++) {
+    REAL s = x[i];
+    for (int k = 0; k < i; k++) s = s - L[i * n + k] * y[k];
+    y[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    REAL s = y[i];
+    for (int k = i + 1; k < n; k++) s = s - L[k * n + i] * out[k];
+    out[i] = s / L[i * n + i];
+  }
+}
+
+/* ---- kinematics (smooth.py:34-207, support.local_to_global :99-108) ------------------------- */
+static void FN(local_to_global)(const REAL* wpos, const REAL* wquat, const REAL* lpos, const REAL* lquat, REAL* pos, REAL* mat) {
+  REAL r[3], q[4];
+  FN(rotate)(lpos, wquat, r);
+  for (int i = 0; i < 3; i++) pos[i] = wpos[i] + r[i];
+  FN(quat_mul)(wquat, lquat, q);
+  FN(quat_to_mat)(q, mat);
+}
+
+static void FN(kinematics)(const FN(MjoModel) * M, FN(MjoWork) * w, int with_cams) {
+  const mjhModelDesc* m = M->d;
+  for (int b = 0; b < m->nbody; b++) {
+    REAL pos[3] = {M->body_pos[3 * b], M->body_pos[3 * b + 1], M->body_pos[3 * b + 2]};
+    REAL quat[4] = {M->body_quat[4 * b], M->body_quat[4 * b + 1], M->body_quat[4 * b + 2], M->body_quat[4 * b + 3]};
+    if (b > 0) {
+      int p = m->body_parentid[b];
+      REAL r[3];
+      FN(rotate)(pos, w->xquat + 4 * p, r);
+      for (int i = 0; i < 3; i++) pos[i] = w->xpos[3 * p + i] + r[i];
+      FN(quat_mul)(w->xquat + 4 * p, quat, quat);
+    }
+    for (int jj = 0; jj < m->body_jntnum[b]; jj++) {
+      int j = m->body_jntadr[b] + jj;
+      int t = m->jnt_type[j], qa = m->jnt_qposadr[j];
+      REAL* anchor = w->xanchor + 3 * j;
+      REAL* axis = w->xaxis + 3 * j;
+      const REAL* jpos = M->jnt_pos + 3 * j;
+      const REAL* jaxis = M->jnt_axis + 3 * j;
+      if (t == JNT_FREE) {
+        for (int i = 0; i < 3; i++) anchor[i] = w->qpos[qa + i];
+        axis[0] = 0; axis[1] = 0; axis[2] = 1;
+        for (int i = 0; i < 3; i++) pos[i] = w->qpos[qa + i];
+        for (int i = 0; i < 4; i++) quat[i] = w->qpos[qa + 3 + i];
+        FN(normalize_n)(quat, 4);
+        for (int i = 0; i < 4; i++) w->qpos[qa + 3 + i] = quat[i];
+      } else {
+        REAL r[3];
+        FN(rotate)(jpos, quat, r);
+        for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
+        FN(rotate)(jaxis, quat, axis);
+        if (t == JNT_BALL) {
+          REAL ql[4];
+          for (int i = 0; i < 4; i++) ql[i] = w->qpos[qa + i];
+          FN(normalize_n)(ql, 4);
+          for (int i = 0; i < 4; i++) w->qpos[qa + i] = ql[i];
+          FN(quat_mul)(quat, ql, quat);
+          FN(rotate)(jpos, quat, r);
+          for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+        } else if (t == JNT_HINGE) {
+          REAL angle = w->qpos[qa] - M->qpos0[qa], ql[4];
+          FN(axis_angle_to_quat)(jaxis, angle, ql);
+          FN(quat_mul)(quat, ql, quat);
+          FN(rotate)(jpos, quat, r);
+          for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+        } else { /* slide */
+          REAL dq = w->qpos[qa] - M->qpos0[qa];
+          for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
+        }
+      }
+    }
+    for (int i = 0; i < 3; i++) w->xpos[3 * b + i] = pos[i];
+    for (int i = 0; i < 4; i++) w->xquat[4 * b + i] = quat[i];
+    FN(quat_to_mat)(quat, w->xmat + 9 * b);
+  }
+  for (int b = 0; b < m->nbody; b++)
+    FN(local_to_global)(w->xpos + 3 * b, w->xquat + 4 * b, M->body_ipos + 3 * b, M->body_iquat + 4 * b, w->xipos + 3 * b, w->ximat + 9 * b);
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    FN(local_to_global)(w->xpos + 3 * b, w->xquat + 4 * b, M->geom_pos + 3 * g, M->geom_quat + 4 * g, w->geom_xpos + 3 * g, w->geom_xmat + 9 * g);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_bodyid[s];
+    FN(local_to_global)(w->xpos + 3 * b, w->xquat + 4 * b, M->site_pos + 3 * s, M->site_quat + 4 * s, w->site_xpos + 3 * s, w->site_xmat + 9 * s);
+  }
+  if (with_cams) {
+    for (int c = 0; c < m->ncam; c++) { /* smooth.py:139-198 */
+      int b = m->cam_bodyid[c], mode = m->cam_mode[c], tgt = m->cam_targetbodyid[c];
+      REAL* cp = w->cam_xpos + 3 * c;
+      REAL* cm = w->cam_xmat + 9 * c;
+      FN(local_to_global)(w->xpos + 3 * b, w->xquat + 4 * b, M->cam_pos + 3 * c, M->cam_quat + 4 * c, cp, cm);
+      if (mode == CAM_TRACK) {
+        for (int i = 0; i < 3; i++) cp[i] = w->xpos[3 * b + i] + M->cam_pos0[3 * c + i];
+        for (int i = 0; i < 9; i++) cm[i] = M->cam_mat0[9 * c + i];
+      } else if (mode == CAM_TRACKCOM) {
+        /* uses the subtree_com the caller passed in (previous step's), smooth.py:162-166 */
+        REAL r[3];
+        FN(rotate)(M->cam_pos + 3 * c, w->xquat + 4 * b, r);
+        for (int i = 0; i < 3; i++) cp[i] = w->in_subtree_com[3 * b + i] + r[i];
+      } else if ((mode == CAM_TARGETBODY || mode == CAM_TARGETBODYCOM) && tgt >= 0) {
+        const REAL* tp = (mode == CAM_TARGETBODY) ? w->xpos + 3 * tgt : w->in_subtree_com + 3 * tgt;
+        REAL f[3] = {tp[0] - cp[0], tp[1] - cp[1], tp[2] - cp[2]};
+        FN(normalize_n)(f, 3);
+        REAL up_hint[3] = {0, 0, 1}, right[3], up[3];
+        FN(cross3)(f, up_hint, right);
+        FN(normalize_n)(right, 3);
+        FN(cross3)(right, f, up);
+        for (int i = 0; i < 3; i++) { cm[3 * i + 0] = right[i]; cm[3 * i + 1] = up[i]; cm[3 * i + 2] = -f[i]; }
+      }
+    }
+    for (int l = 0; l < m->nlight; l++) { /* :200-204 */
+      int b = m->light_bodyid[l];
+      REAL r[3];
+      FN(rotate)(M->light_pos + 3 * l, w->xquat + 4 * b, r);
+      for (int i = 0; i < 3; i++) w->light_xpos[3 * l + i] = w->xpos[3 * b + i] + r[i];
+      FN(rotate)(M->light_dir + 3 * l, w->xquat + 4 * b, w->light_xdir + 3 * l);
+    }
+  }
+}
+
+/* ---- com_pos (smooth.py:210-288) ------------------------------------------------------------ */
+static void FN(com_pos)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  int nb = m->nbody;
+  for (int b = 0; b < nb; b++) {
+    for (int i = 0; i < 3; i++) w->sub_pos[3 * b + i] = w->xipos[3 * b + i] * M->body_mass[b];
+    w->sub_mass[b] = M->body_mass[b];
+  }
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int i = 0; i < 3; i++) w->sub_pos[3 * p + i] += w->sub_pos[3 * b + i];
+    w->sub_mass[p] += w->sub_mass[b];
+  }
+  for (int b = 0; b < nb; b++) {
+    REAL ms = w->sub_mass[b];
+    REAL den = ms > (REAL)MINVAL_CACHED ? ms : (REAL)MINVAL_CACHED;
+    for (int i = 0; i < 3; i++) w->subtree_com[3 * b + i] = (ms < (REAL)mjMINVAL) ? w->xipos[3 * b + i] : w->sub_pos[3 * b + i] / den;
+  }
+  for (int b = 0; b < nb; b++) { /* inert_com :236-243 */
+    const REAL* rc = w->subtree_com + 3 * m->body_rootid[b];
+    REAL off[3] = {w->xipos[3 * b] - rc[0], w->xipos[3 * b + 1] - rc[1], w->xipos[3 * b + 2] - rc[2]};
+    REAL mass = M->body_mass[b];
+    const REAL* xi = w->ximat + 9 * b;
+    const REAL* in = M->body_inertia + 3 * b;
+    REAL h[3][3] = {{0, -off[2], off[1]}, {off[2], 0, -off[0]}, {-off[1], off[0], 0}};
+    REAL A[3][3], I[3][3];
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) A[i][k] = xi[3 * i + k] * in[k];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        REAL s = 0;
+        for (int k = 0; k < 3; k++) s += A[i][k] * xi[3 * j + k];
+        REAL hh = 0;
+        for (int k = 0; k < 3; k++) hh += h[i][k] * h[j][k];
+        I[i][j] = s + hh * mass;
+      }
+    REAL* ci = w->cinert + 10 * b;
+    ci[0] = I[0][0]; ci[1] = I[1][1]; ci[2] = I[2][2]; ci[3] = I[0][1]; ci[4] = I[0][2]; ci[5] = I[1][2];
+    ci[6] = off[0] * mass; ci[7] = off[1] * mass; ci[8] = off[2] * mass; ci[9] = mass;
+  }
+  for (int j = 0; j < m->njnt; j++) { /* cdof_fn :250-273 */
+    int b = m->jnt_bodyid[j], t = m->jnt_type[j], d = m->jnt_dofadr[j];
+    const REAL* rc = w->subtree_com + 3 * m->body_rootid[b];
+    REAL off[3] = {rc[0] - w->xanchor[3 * j], rc[1] - w->xanchor[3 * j + 1], rc[2] - w->xanchor[3 * j + 2]};
+    if (t == JNT_FREE || t == JNT_BALL) {
+      if (t == JNT_FREE) {
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) w->cdof[6 * (d + r) + k] = (k == 3 + r) ? 1 : 0;
+        d += 3;
+      }
+      for (int r = 0; r < 3; r++) {
+        REAL a[3] = {w->xmat[9 * b + 0 + r], w->xmat[9 * b + 3 + r], w->xmat[9 * b + 6 + r]}; /* xmat.T row r */
+        REAL c[3];
+        FN(cross3)(a, off, c);
+        for (int k = 0; k < 3; k++) { w->cdof[6 * (d + r) + k] = a[k]; w->cdof[6 * (d + r) + 3 + k] = c[k]; }
+      }
+    } else if (t == JNT_HINGE) {
+      REAL c[3];
+      FN(cross3)(w->xaxis + 3 * j, off, c);
+      for (int k = 0; k < 3; k++) { w->cdof[6 * d + k] = w->xaxis[3 * j + k]; w->cdof[6 * d + 3 + k] = c[k]; }
+    } else {
+      for (int k = 0; k < 3; k++) { w->cdof[6 * d + k] = 0; w->cdof[6 * d + 3 + k] = w->xaxis[3 * j + k]; }
+    }
+  }
+}
+
+/* ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) --------------------- */
+static void FN(crb_factor)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  int nb = m->nbody, nv = m->nv;
+  for (int i = 0; i < 10 * nb; i++) w->crb[i] = w->cinert[i];
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int i = 0; i < 10; i++) w->crb[10 * p + i] += w->crb[10 * b + i];
+  }
+  for (int i = 0; i < 10; i++) w->crb[i] = 0;
+  for (int d = 0; d < nv; d++) FN(inert_mul)(w->crb + 10 * m->dof_bodyid[d], w->cdof + 6 * d, w->crb_cdof + 6 * d);
+  for (int i = 0; i < nv * nv; i++) w->qM[i] = 0;
+  for (int i = 0; i < nv; i++) {
+    int j = i;
+    while (j >= 0) { /* (i, j) with j an ancestor-or-self dof of i */
+      REAL s = 0;
+      for (int k = 0; k < 6; k++) s += w->crb_cdof[6 * i + k] * w->cdof[6 * j + k];
+      if (i == j) s = s + M->dof_armature[i];
+      w->qM[i * nv + j] = s;
+      if (i != j) w->qM[j * nv + i] = s;
+      j = m->dof_parentid[j];
+    }
+  }
+  FN(cholesky)(w->qM, w->qLD, nv);
+}
+
+/* ---- collision primitives (collision_primitive.py, math.py:506-569) -------------------------- */
+static void FN(plane_sphere_)(const REAL* n, const REAL* ppos, const REAL* spos, REAL r, REAL* dist, REAL* pos) {
+  REAL d[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+  *dist = FN(dot3)(d, n) - r;
+  for (int i = 0; i < 3; i++) pos[i] = spos[i] - n[i] * (r + (REAL)0.5 * (*dist));
+}
+static void FN(sphere_sphere_)(const REAL* p1, REAL r1, const REAL* p2, REAL r2, REAL* dist, REAL* pos, REAL* n) {
+  for (int i = 0; i < 3; i++) n[i] = p2[i] - p1[i];
+  REAL d = FN(normalize_n)(n, 3);
+  if (d == 0) { n[0] = 1; n[1] = 0; n[2] = 0; }
+  d = d - (r1 + r2);
+  for (int i = 0; i < 3; i++) pos[i] = p1[i] + n[i] * (r1 + d * (REAL)0.5);
+  *dist = d;
+}
+static void FN(closest_segment_point)(const REAL* a, const REAL* b, const REAL* pt, REAL* o) { /* math.py:506-510 */
+  REAL ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  REAL pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+  REAL t = FN(dot3)(pa, ab) / (FN(dot3)(ab, ab) + (REAL)1e-6);
+  t = t < 0 ? 0 : (t > 1 ? 1 : t);
+  for (int i = 0; i < 3; i++) o[i] = a[i] + t * ab[i];
+}
+static void FN(closest_segment_to_segment)(const REAL* a0, const REAL* a1, const REAL* b0, const REAL* b1, REAL* best_a, REAL* best_b) { /* :523-569 */
+  REAL dir_a[3], dir_b[3];
+  for (int i = 0; i < 3; i++) { dir_a[i] = a1[i] - a0[i]; dir_b[i] = b1[i] - b0[i]; }
+  REAL len_a = FN(normalize_n)(dir_a, 3), len_b = FN(normalize_n)(dir_b, 3);
+  REAL hla = len_a * (REAL)0.5, hlb = len_b * (REAL)0.5;
+  REAL a_mid[3], b_mid[3], trans[3];
+  for (int i = 0; i < 3; i++) { a_mid[i] = a0[i] + dir_a[i] * hla; b_mid[i] = b0[i] + dir_b[i] * hlb; trans[i] = a_mid[i] - b_mid[i]; }
+  REAL dadb = FN(dot3)(dir_a, dir_b), dat = FN(dot3)(dir_a, trans), dbt = FN(dot3)(dir_b, trans);
+  REAL denom = 1 - dadb * dadb;
+  REAL ota = (-dat + dadb * dbt) / (denom + (REAL)1e-6);
+  REAL otb = dbt + ota * dadb;
+  REAL ta = ota < -hla ? -hla : (ota > hla ? hla : ota);
+  REAL tb = otb < -hlb ? -hlb : (otb > hlb ? hlb : otb);
+  for (int i = 0; i < 3; i++) { best_a[i] = a_mid[i] + dir_a[i] * ta; best_b[i] = b_mid[i] + dir_b[i] * tb; }
+  REAL new_a[3], new_b[3];
+  FN(closest_segment_point)(a0, a1, best_b, new_a);
+  FN(closest_segment_point)(b0, b1, best_a, new_b);
+  REAL d1 = 0, d2 = 0;
+  for (int i = 0; i < 3; i++) { REAL e = best_b[i] - new_a[i]; d1 += e * e; }
+  for (int i = 0; i < 3; i++) { REAL e = best_a[i] - new_b[i]; d2 += e * e; }
+  if (d1 < d2) { for (int i = 0; i < 3; i++) best_a[i] = new_a[i]; }
+  else { for (int i = 0; i < 3; i++) best_b[i] = new_b[i]; }
+}
+
+static void FN(collision)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* collision_driver.py:800-875 */
+  const mjhModelDesc* m = M->d;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], fn = m->pair_fn[p];
+    const REAL *p1 = w->geom_xpos + 3 * g1, *m1 = w->geom_xmat + 9 * g1, *s1 = M->geom_size + 3 * g1;
+    const REAL *p2 = w->geom_xpos + 3 * g2, *m2 = w->geom_xmat + 9 * g2, *s2 = M->geom_size + 3 * g2;
+    REAL dist[MJH_MAX_PAIR_CONTACTS], pos[MJH_MAX_PAIR_CONTACTS][3], frame[MJH_MAX_PAIR_CONTACTS][9];
+    int k = m->pair_ncon[p];
+    if (fn == MJH_FN_PLANE_SPHERE) {
+      REAL n[3] = {m1[2], m1[5], m1[8]};
+      FN(plane_sphere_)(n, p1, p2, s2[0], &dist[0], pos[0]);
+      FN(make_frame)(n, frame[0]);
+    } else if (fn == MJH_FN_PLANE_CAPSULE) { /* collision_primitive.py:48-74 */
+      REAL n[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
+      REAL na = FN(dot3)(n, axis), b[3];
+      for (int i = 0; i < 3; i++) b[i] = axis[i] - n[i] * na;
+      REAL bn = FN(normalize_n)(b, 3);
+      if (bn < (REAL)0.5) {
+        b[0] = 0; b[1] = 0; b[2] = 0;
+        if ((REAL)-0.5 < n[1] && n[1] < (REAL)0.5) b[1] = 1; else b[2] = 1;
+      }
+      REAL c[3];
+      FN(cross3)(n, b, c);
+      REAL seg[3] = {axis[0] * s2[1], axis[1] * s2[1], axis[2] * s2[1]};
+      for (int q = 0; q < 2; q++) {
+        REAL sp[3];
+        for (int i = 0; i < 3; i++) sp[i] = p2[i] + (q == 0 ? seg[i] : -seg[i]);
+        FN(plane_sphere_)(n, p1, sp, s2[0], &dist[q], pos[q]);
+        for (int i = 0; i < 3; i++) { frame[q][i] = n[i]; frame[q][3 + i] = b[i]; frame[q][6 + i] = c[i]; }
+      }
+    } else if (fn == MJH_FN_SPHERE_SPHERE) {
+      REAL n[3];
+      FN(sphere_sphere_)(p1, s1[0], p2, s2[0], &dist[0], pos[0], n);
+      FN(make_frame)(n, frame[0]);
+    } else if (fn == MJH_FN_SPHERE_CAPSULE) { /* :195-201 */
+      REAL axis[3] = {m2[2], m2[5], m2[8]}, a[3], b[3], pt[3], n[3];
+      for (int i = 0; i < 3; i++) { REAL sg = axis[i] * s2[1]; a[i] = p2[i] - sg; b[i] = p2[i] + sg; }
+      FN(closest_segment_point)(a, b, p1, pt);
+      FN(sphere_sphere_)(p1, s1[0], pt, s2[0], &dist[0], pos[0], n);
+      FN(make_frame)(n, frame[0]);
+    } else if (fn == MJH_FN_CAPSULE_CAPSULE) { /* :204-221 */
+      REAL ax1[3] = {m1[2], m1[5], m1[8]}, ax2[3] = {m2[2], m2[5], m2[8]};
+      REAL a0[3], a1[3], b0[3], b1[3], pt1[3], pt2[3], n[3];
+      for (int i = 0; i < 3; i++) {
+        REAL sg1 = ax1[i] * s1[1], sg2 = ax2[i] * s2[1];
+        a0[i] = p1[i] - sg1; a1[i] = p1[i] + sg1; b0[i] = p2[i] - sg2; b1[i] = p2[i] + sg2;
+      }
+      FN(closest_segment_to_segment)(a0, a1, b0, b1, pt1, pt2);
+      FN(sphere_sphere_)(pt1, s1[0], pt2, s2[0], &dist[0], pos[0], n);
+      FN(make_frame)(n, frame[0]);
+    } else {
+      for (int q = 0; q < k; q++) { dist[q] = 1; for (int i = 0; i < 3; i++) pos[q][i] = 0; for (int i = 0; i < 9; i++) frame[q][i] = 0; }
+    }
+    for (int q = 0; q < k; q++) {
+      int c = m->pair_dst[p * MJH_MAX_PAIR_CONTACTS + q];
+      w->contact_dist[c] = dist[q];
+      for (int i = 0; i < 3; i++) w->contact_pos[3 * c + i] = pos[q][i];
+      for (int i = 0; i < 9; i++) w->contact_frame[9 * c + i] = frame[q][i];
+    }
+  }
+  for (int c = 0; c < m->ncon; c++) {
+    w->contact_includemargin[c] = M->con_includemargin[c];
+    for (int i = 0; i < 5; i++) w->contact_friction[5 * c + i] = M->con_friction[5 * c + i];
+    for (int i = 0; i < 2; i++) w->contact_solref[2 * c + i] = M->con_solref[2 * c + i];
+    for (int i = 0; i < 2; i++) w->contact_solreffriction[2 * c + i] = M->con_solreffriction[2 * c + i];
+    for (int i = 0; i < 5; i++) w->contact_solimp[5 * c + i] = M->con_solimp[5 * c + i];
+  }
+}
+
+/* ---- constraint rows (constraint.py) ----------------------------------------------------------- */
+static void FN(kbi)(const FN(MjoModel) * M, const REAL* solref, const REAL* solimp, REAL pos, REAL* k, REAL* b, REAL* imp) { /* :69-113 */
+  REAL timeconst = solref[0], dampratio = solref[1];
+  if (!(M->d->disableflags & DSBL_REFSAFE)) {
+    REAL t2 = 2 * M->timestep;
+    timeconst = (timeconst > t2 ? timeconst : t2) * (REAL)(timeconst > 0);
+  }
+  REAL dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+#define CLAMP_(x, lo, hi) ((x) < (lo) ? (lo) : ((x) > (hi) ? (hi) : (x)))
+  dmin = CLAMP_(dmin, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+  dmax = CLAMP_(dmax, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+  width = width > (REAL)MINVAL_CACHED ? width : (REAL)MINVAL_CACHED;
+  mid = CLAMP_(mid, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+  power = power > 1 ? power : 1;
+  REAL kk = 1 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+  REAL bb = 2 / (dmax * timeconst);
+  if (dampratio <= 0) kk = -dampratio / (dmax * dmax);
+  if (timeconst <= 0) bb = -timeconst / dmax;
+  REAL imp_x = R_FABS(pos) / width;
+  REAL imp_a = (1 / R_POW(mid, power - 1)) * R_POW(imp_x, power);
+  REAL imp_b = 1 - (1 / R_POW(1 - mid, power - 1)) * R_POW(1 - imp_x, power);
+  REAL imp_y = imp_x < mid ? imp_a : imp_b;
+  REAL im = dmin + imp_y * (dmax - dmin);
+  im = CLAMP_(im, dmin, dmax);
+  if (imp_x > 1) im = dmax;
+  *k = kk; *b = bb; *imp = im;
+}
+
+/* support.jac :138-153 : jacp/jacr rows of `point` on `body`, masked to ancestor dofs */
+static void FN(jac_dof)(const FN(MjoModel) * M, const FN(MjoWork) * w, const REAL* point, int body, int dof, REAL* jp, REAL* jr) {
+  const mjhModelDesc* m = M->d;
+  /* mask: dof's body is an ancestor-or-self of `body` */
+  int db = m->dof_bodyid[dof], b = body, on = 0;
+  while (b > 0) { if (b == db) { on = 1; break; } b = m->body_parentid[b]; }
+  const REAL* rc = w->subtree_com + 3 * m->body_rootid[body];
+  REAL off[3] = {point[0] - rc[0], point[1] - rc[1], point[2] - rc[2]};
+  const REAL* cd = w->cdof + 6 * dof;
+  REAL c[3];
+  FN(cross3)(cd, off, c);
+  for (int i = 0; i < 3; i++) { jp[i] = (cd[3 + i] + c[i]) * (REAL)on; jr[i] = cd[i] * (REAL)on; }
+}
+
+static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :600-768 */
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  if (nefc == 0) return;
+  for (int i = 0; i < nefc * nv; i++) w->efc_J[i] = 0;
+  int row = 0;
+  for (int l = 0; l < m->nl; l++, row++) { /* _instantiate_limit_slide_hinge :338-372 */
+    int j = m->lim_jnt[l], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    REAL q = w->qpos[qa];
+    REAL dist_min = q - M->jnt_range[2 * j], dist_max = M->jnt_range[2 * j + 1] - q;
+    REAL val = (REAL)(dist_min < dist_max) * 2 - 1;
+    REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M->jnt_margin[j];
+    REAL active = (REAL)(pos < 0);
+    w->efc_J[row * nv + da] = val * active;
+    w->efc_pos[row] = pos * active;
+    w->efc_pos_norm[row] = pos * active;
+    w->efc_invweight[row] = M->dof_invweight0[da];
+    for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->jnt_solref[2 * j + i];
+    for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->jnt_solimp[5 * j + i];
+  }
+  int elliptic = m->cone == CONE_ELLIPTIC;
+  for (int c = 0; c < m->ncon; c++) {
+    int dim = m->con_dim[c];
+    int b1 = m->geom_bodyid[m->con_geom1[c]], b2 = m->geom_bodyid[m->con_geom2[c]];
+    const REAL* fr = w->contact_frame + 9 * c;
+    const REAL* cpos = w->contact_pos + 3 * c;
+    const REAL* fric = w->contact_friction + 5 * c;
+    REAL dist = w->contact_dist[c] - w->contact_includemargin[c];
+    REAL t = M->body_invweight0[b1] + M->body_invweight0[b2];
+    REAL active = (REAL)(dist < 0);
+    /* diff rows: frame @ (jacp2-jacp1).T  (+ frame @ (jacr2-jacr1).T) -> jacdiff[6][nv] */
+    for (int d = 0; d < nv; d++) {
+      REAL jp1[3], jr1[3], jp2[3], jr2[3];
+      FN(jac_dof)(M, w, cpos, b2, d, jp2, jr2);
+      FN(jac_dof)(M, w, cpos, b1, d, jp1, jr1);
+      REAL dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]};
+      REAL dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
+      for (int r = 0; r < 3; r++) {
+        w->jacdiff[r * nv + d] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2];
+        w->jacdiff[(3 + r) * nv + d] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
+      }
+    }
+    if (dim == 1) { /* _instantiate_contact_frictionless :408-451 */
+      for (int d = 0; d < nv; d++) w->efc_J[row * nv + d] = w->jacdiff[d] * active;
+      w->efc_pos[row] = dist * active;
+      w->efc_pos_norm[row] = dist * active;
+      w->efc_invweight[row] = t;
+      for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = w->contact_solref[2 * c + i];
+      for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = w->contact_solimp[5 * c + i];
+      row++;
+    } else if (!elliptic) { /* _instantiate_contact_pyramidal :454-516 */
+      int nedge = 2 * (dim - 1);
+      REAL mu = fric[0];
+      REAL iw = (t + mu * mu * t) * 2 * mu * mu / M->impratio;
+      for (int e = 0; e < nedge; e++, row++) {
+        REAL f = fric[e / 2] * ((e & 1) ? (REAL)-1 : (REAL)1);
+        for (int d = 0; d < nv; d++) w->efc_J[row * nv + d] = (w->jacdiff[d] + w->jacdiff[(1 + e / 2) * nv + d] * f) * active;
+        w->efc_pos[row] = dist * active;
+        w->efc_pos_norm[row] = dist * active;
+        w->efc_invweight[row] = iw;
+        for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = w->contact_solref[2 * c + i];
+        for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = w->contact_solimp[5 * c + i];
+      }
+    } else { /* _instantiate_contact_elliptic :519-583 */
+      const REAL* sr = w->contact_solref + 2 * c;
+      const REAL* srf0 = w->contact_solreffriction + 2 * c;
+      int any = (srf0[0] != 0) || (srf0[1] != 0);
+      REAL srf[2] = {srf0[0] + sr[0] * (REAL)(!any), srf0[1] + sr[1] * (REAL)(!any)};
+      REAL iwf = t / M->impratio;
+      for (int r = 0; r < dim; r++, row++) {
+        for (int d = 0; d < nv; d++) w->efc_J[row * nv + d] = w->jacdiff[r * nv + d] * active;
+        w->efc_pos[row] = (r == 0 ? dist : 0) * active;
+        w->efc_pos_norm[row] = dist;
+        if (r == 0) w->efc_invweight[row] = t;
+        else if (r == 1) w->efc_invweight[row] = iwf;
+        else w->efc_invweight[row] = iwf * ((fric[0] * fric[0]) / (fric[r - 1] * fric[r - 1]));
+        for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = (r == 0) ? sr[i] : srf[i];
+        for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = w->contact_solimp[5 * c + i];
+      }
+    }
+  }
+  for (int r = 0; r < nefc; r++) { /* :683-693 */
+    REAL k, b, imp;
+    FN(kbi)(M, w->efc_solref + 2 * r, w->efc_solimp + 5 * r, w->efc_pos_norm[r], &k, &b, &imp);
+    REAL rr = w->efc_invweight[r] * (1 - imp) / imp;
+    rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
+    REAL jv = 0;
+    for (int d = 0; d < nv; d++) jv += w->efc_J[r * nv + d] * w->qvel[d];
+    w->efc_aref[r] = -b * jv - k * imp * w->efc_pos[r];
+    w->efc_D[r] = 1 / rr;
+    w->efc_frictionloss[r] = 0;
+  }
+}
+
+/* ---- velocity stage: transmission, com_vel, passive, rne ------------------------------------- */
+static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nb = m->nbody, nu = m->nu;
+  /* smooth.transmission :535-591 (joint transmissions on slide/hinge) */
+  for (int i = 0; i < nu * nv; i++) w->actuator_moment[i] = 0;
+  for (int i = 0; i < nu; i++) {
+    REAL gear = M->act_gear[6 * i];
+    w->actuator_length[i] = w->qpos[m->act_qposadr[i]] * gear;
+    w->actuator_moment[i * nv + m->act_dofadr[i]] = gear;
+  }
+  /* forward._velocity :87-99 */
+  for (int i = 0; i < nu; i++) {
+    REAL s = 0;
+    for (int d = 0; d < nv; d++) s += w->actuator_moment[i * nv + d] * w->qvel[d];
+    w->actuator_velocity[i] = s;
+  }
+  /* smooth.com_vel :385-424 */
+  for (int b = 0; b < nb; b++) {
+    REAL cvel[6] = {0, 0, 0, 0, 0, 0};
+    if (b > 0) for (int k = 0; k < 6; k++) cvel[k] = w->cvel[6 * m->body_parentid[b] + k];
+    for (int jj = 0; jj < m->body_jntnum[b]; jj++) {
+      int j = m->body_jntadr[b] + jj, t = m->jnt_type[j], d = m->jnt_dofadr[j];
+      if (t == JNT_FREE) {
+        REAL s[6];
+        for (int k = 0; k < 6; k++) s[k] = (w->cdof[6 * d + k] * w->qvel[d] + w->cdof[6 * (d + 1) + k] * w->qvel[d + 1]) + w->cdof[6 * (d + 2) + k] * w->qvel[d + 2];
+        for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+        for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) w->cdof_dot[6 * (d + r) + k] = 0;
+        for (int r = 3; r < 6; r++) FN(motion_cross)(cvel, w->cdof + 6 * (d + r), w->cdof_dot + 6 * (d + r));
+        for (int k = 0; k < 6; k++) s[k] = (w->cdof[6 * (d + 3) + k] * w->qvel[d + 3] + w->cdof[6 * (d + 4) + k] * w->qvel[d + 4]) + w->cdof[6 * (d + 5) + k] * w->qvel[d + 5];
+        for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+      } else {
+        int width = (t == JNT_BALL) ? 3 : 1;
+        for (int r = 0; r < width; r++) FN(motion_cross)(cvel, w->cdof + 6 * (d + r), w->cdof_dot + 6 * (d + r));
+        REAL s[6];
+        for (int k = 0; k < 6; k++) {
+          s[k] = w->cdof[6 * d + k] * w->qvel[d];
+          for (int r = 1; r < width; r++) s[k] = s[k] + w->cdof[6 * (d + r) + k] * w->qvel[d + r];
+        }
+        for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+      }
+    }
+    for (int k = 0; k < 6; k++) w->cvel[6 * b + k] = cvel[k];
+  }
+  /* passive.passive :176-200, _spring_damper :80-145 */
+  if (m->disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
+    for (int d = 0; d < nv; d++) w->qfrc_passive[d] = 0;
+  } else {
+    for (int j = 0; j < m->njnt; j++) {
+      int t = m->jnt_type[j], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+      REAL k = M->jnt_stiffness[j];
+      if (t == JNT_FREE) {
+        for (int i = 0; i < 3; i++) w->qfrc_passive[da + i] = -k * (w->qpos[qa + i] - M->qpos_spring[qa + i]);
+        REAL r[3];
+        FN(quat_sub)(w->qpos + qa + 3, M->qpos_spring + qa + 3, r);
+        for (int i = 0; i < 3; i++) w->qfrc_passive[da + 3 + i] = -k * r[i];
+      } else if (t == JNT_BALL) {
+        REAL r[3];
+        FN(quat_sub)(w->qpos + qa, M->qpos_spring + qa, r);
+        for (int i = 0; i < 3; i++) w->qfrc_passive[da + i] = -k * r[i];
+      } else {
+        w->qfrc_passive[da] = -k * (w->qpos[qa] - M->qpos_spring[qa]);
+      }
+    }
+    for (int d = 0; d < nv; d++) w->qfrc_passive[d] = (0 + w->qfrc_passive[d]) - M->dof_damping[d] * w->qvel[d];
+  }
+  /* smooth.rne :427-467 */
+  for (int b = 0; b < nb; b++) {
+    REAL cacc[6];
+    if (b == 0) {
+      int nograv = m->disableflags & DSBL_GRAVITY;
+      for (int k = 0; k < 3; k++) { cacc[k] = 0; cacc[3 + k] = nograv ? 0 : -M->gravity[k]; }
+    } else {
+      for (int k = 0; k < 6; k++) cacc[k] = w->cacc[6 * m->body_parentid[b] + k];
+    }
+    int d0 = m->body_dofadr[b], nd = m->body_dofnum[b];
+    if (nd > 0) {
+      for (int k = 0; k < 6; k++) {
+        REAL s = w->cdof_dot[6 * d0 + k] * w->qvel[d0];
+        for (int r = 1; r < nd; r++) s = s + w->cdof_dot[6 * (d0 + r) + k] * w->qvel[d0 + r];
+        cacc[k] = cacc[k] + s;
+      }
+    }
+    for (int k = 0; k < 6; k++) w->cacc[6 * b + k] = cacc[k];
+    REAL f1[6], f2[6], f3[6];
+    FN(inert_mul)(w->cinert + 10 * b, cacc, f1);
+    FN(inert_mul)(w->cinert + 10 * b, w->cvel + 6 * b, f2);
+    FN(motion_cross_force)(w->cvel + 6 * b, f2, f3);
+    for (int k = 0; k < 6; k++) w->cfrc[6 * b + k] = f1[k] + f3[k];
+  }
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int k = 0; k < 6; k++) w->cfrc[6 * p + k] += w->cfrc[6 * b + k];
+  }
+  for (int d = 0; d < nv; d++) {
+    REAL s = 0;
+    for (int k = 0; k < 6; k++) s += w->cdof[6 * d + k] * w->cfrc[6 * m->dof_bodyid[d] + k];
+    w->qfrc_bias[d] = s;
+  }
+}
+
+/* ---- actuation + acceleration (forward.py:102-228) ---------------------------------------------- */
+static void FN(actuation)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nu = m->nu;
+  if (nu == 0 || (m->disableflags & DSBL_ACTUATION)) {
+    for (int i = 0; i < m->na; i++) w->act_dot[i] = 0;
+    for (int d = 0; d < nv; d++) w->qfrc_actuator[d] = 0;
+  } else {
+    for (int d = 0; d < nv; d++) w->qfrc_actuator[d] = 0;
+    for (int i = 0; i < nu; i++) {
+      REAL ctrl = w->ctrl[i];
+      if (!(m->disableflags & DSBL_CLAMPCTRL) && m->act_ctrllimited[i]) {
+        REAL lo = M->act_ctrlrange[2 * i], hi = M->act_ctrlrange[2 * i + 1];
+        ctrl = ctrl > lo ? ctrl : lo;
+        ctrl = ctrl < hi ? ctrl : hi;
+      }
+      REAL ctrl_act = ctrl;
+      int dyn = m->act_dyntype[i];
+      if (dyn != DYN_NONE) {
+        int a = m->act_actadr[i];
+        REAL act = w->act[a];
+        if (dyn == DYN_INTEGRATOR) w->act_dot[a] = ctrl;
+        else {
+          REAL tau = M->act_dynprm[3 * i];
+          tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
+          w->act_dot[a] = (ctrl - act) / tau;
+        }
+        ctrl_act = w->act[a + m->act_actnum[i] - 1];
+      }
+      REAL len = w->actuator_length[i], vel = w->actuator_velocity[i];
+      const REAL* gp = M->act_gainprm + 3 * i;
+      const REAL* bp = M->act_biasprm + 3 * i;
+      REAL gain = (m->act_gaintype[i] == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
+      REAL bias = (m->act_biastype[i] == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : 0;
+      REAL force = gain * ctrl_act + bias;
+      if (m->act_forcelimited[i]) {
+        REAL lo = M->act_forcerange[2 * i], hi = M->act_forcerange[2 * i + 1];
+        force = force < lo ? lo : (force > hi ? hi : force);
+      }
+      w->actuator_force[i] = force;
+    }
+    for (int d = 0; d < nv; d++) {
+      REAL s = 0;
+      for (int i = 0; i < nu; i++) s += w->actuator_moment[i * nv + d] * w->actuator_force[i];
+      int j = m->dof_jntid[d];
+      if (m->jnt_actfrclimited[j]) {
+        REAL lo = M->jnt_actfrcrange[2 * j], hi = M->jnt_actfrcrange[2 * j + 1];
+        s = s < lo ? lo : (s > hi ? hi : s);
+      }
+      w->qfrc_actuator[d] = s;
+    }
+  }
+  /* _acceleration :222-228, support.xfrc_accumulate :184-194 */
+  for (int d = 0; d < nv; d++) w->tmp_nv[d] = 0;
+  for (int b = 0; b < m->nbody; b++) {
+    const REAL* f = w->xfrc_applied + 6 * b;
+    for (int d = 0; d < nv; d++) {
+      REAL jp[3], jr[3];
+      FN(jac_dof)(M, w, w->xipos + 3 * b, b, d, jp, jr);
+      w->tmp_nv[d] += FN(dot3)(jp, f) + FN(dot3)(jr, f + 3);
+    }
+  }
+  for (int d = 0; d < nv; d++) {
+    REAL applied = w->qfrc_applied[d] + w->tmp_nv[d];
+    w->qfrc_smooth[d] = ((w->qfrc_passive[d] - w->qfrc_bias[d]) + w->qfrc_actuator[d]) + applied;
+  }
+  FN(cholesky_solve)(w->qLD, w->qfrc_smooth, w->qacc_smooth, nv, w->tmp_nv2);
+}
+
+/* ---- solver (solver.py:244-553) ---------------------------------------------------------------- */
+typedef struct FN(LSPoint) { REAL alpha, cost, d0, d1; } FN(LSPoint);
+
+typedef struct FN(SolveCtx) {
+  REAL gauss, cost, prev_cost;
+  int niter;
+} FN(SolveCtx);
+
+static void FN(update_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx) * c) { /* :320-357 */
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  REAL csum = 0;
+  for (int r = 0; r < nefc; r++) {
+    REAL ja = w->s_Jaref[r];
+    int active = ja < 0;
+    w->s_active[r] = (unsigned char)active;
+    w->s_force[r] = w->efc_D[r] * -ja * (REAL)active + 0;
+    csum += w->efc_D[r] * ja * ja * (REAL)active;
+  }
+  for (int d = 0; d < nv; d++) {
+    REAL s = 0;
+    for (int r = 0; r < nefc; r++) s += w->efc_J[r * nv + d] * w->s_force[r];
+    w->s_qfrc[d] = s;
+  }
+  REAL g = 0;
+  for (int d = 0; d < nv; d++) g += (w->s_Ma[d] - w->qfrc_smooth[d]) * (w->s_qacc[d] - w->qacc_smooth[d]);
+  c->gauss = (REAL)0.5 * g;
+  REAL cost = ((REAL)0.5 * csum + c->gauss) + 0;
+  c->prev_cost = c->cost;
+  c->cost = cost;
+}
+
+static void FN(update_gradient)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :359-376 */
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  for (int d = 0; d < nv; d++) w->s_grad[d] = (w->s_Ma[d] - w->qfrc_smooth[d]) - w->s_qfrc[d];
+  if (m->solver == SOL_CG) {
+    FN(cholesky_solve)(w->qLD, w->s_grad, w->s_Mgrad, nv, w->tmp_nv2);
+  } else {
+    for (int i = 0; i < nv; i++)
+      for (int j = 0; j < nv; j++) {
+        REAL s = 0;
+        for (int r = 0; r < nefc; r++) s += (w->efc_J[r * nv + i] * w->efc_D[r] * (REAL)w->s_active[r]) * w->efc_J[r * nv + j];
+        w->H[i * nv + j] = w->qM[i * nv + j] + s;
+      }
+    FN(cholesky)(w->H, w->HL, nv);
+    FN(cholesky_solve)(w->HL, w->s_grad, w->s_Mgrad, nv, w->tmp_nv2);
+  }
+}
+
+static void FN(create_context)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx) * c, const REAL* qacc, int grad_flag) { /* :293-318 */
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  for (int d = 0; d < nv; d++) w->s_qacc[d] = qacc[d];
+  for (int r = 0; r < nefc; r++) {
+    REAL s = 0;
+    for (int d = 0; d < nv; d++) s += w->efc_J[r * nv + d] * qacc[d];
+    w->s_Jaref[r] = s - w->efc_aref[r];
+  }
+  for (int i = 0; i < nv; i++) {
+    REAL s = 0;
+    for (int j = 0; j < nv; j++) s += w->qM[i * nv + j] * qacc[j];
+    w->s_Ma[i] = s;
+  }
+  c->gauss = 0; c->cost = (REAL)INFINITY; c->prev_cost = 0; c->niter = 0;
+  for (int d = 0; d < nv; d++) { w->s_grad[d] = 0; w->s_Mgrad[d] = 0; w->s_search[d] = 0; }
+  FN(update_constraint)(M, w, c);
+  if (grad_flag) {
+    FN(update_gradient)(M, w);
+    for (int d = 0; d < nv; d++) w->s_search[d] = -w->s_Mgrad[d];
+  }
+}
+
+static FN(LSPoint) FN(ls_point)(const FN(MjoWork) * w, int nefc, const REAL* qg, REAL alpha) { /* point_fn :396-422 */
+  REAL q0 = 0, q1 = 0, q2 = 0;
+  for (int r = 0; r < nefc; r++) {
+    REAL x = w->s_Jaref[r] + alpha * w->s_jv[r];
+    REAL a = (REAL)(x < 0);
+    q0 += w->s_quad[3 * r] * a;
+    q1 += w->s_quad[3 * r + 1] * a;
+    q2 += w->s_quad[3 * r + 2] * a;
+  }
+  REAL t0 = (qg[0] + q0) + 0, t1 = (qg[1] + q1) + 0, t2 = (qg[2] + q2) + 0;
+  FN(LSPoint) p;
+  p.alpha = alpha;
+  p.cost = alpha * alpha * t2 + alpha * t1 + t0;
+  p.d0 = 2 * alpha * t2 + t1;
+  p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
+  return p;
+}
+
+static inline int FN(ls_swap)(REAL cur, REAL cand, int not_bracketed) { /* _swap :440-449 */
+  int in_bracket = ((cur < cand) && (cand < 0)) || ((cur > cand) && (cand > 0));
+  return in_bracket || (not_bracketed && (R_FABS(cand) < R_FABS(cur)));
+}
+
+static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx) * c, int fixed_iterations) { /* :378-497 */
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  REAL scale = (REAL)(m->meaninertia * (double)(nv > 1 ? nv : 1)); /* python float, solver.py:288 */
+  REAL smag = FN(norm_n)(w->s_search, nv) * scale;
+  REAL gtol = (REAL)(m->tolerance * m->ls_tolerance) * smag;
+  for (int i = 0; i < nv; i++) {
+    REAL s = 0;
+    for (int j = 0; j < nv; j++) s += w->qM[i * nv + j] * w->s_search[j];
+    w->s_mv[i] = s;
+  }
+  for (int r = 0; r < nefc; r++) {
+    REAL s = 0;
+    for (int d = 0; d < nv; d++) s += w->efc_J[r * nv + d] * w->s_search[d];
+    w->s_jv[r] = s;
+  }
+  REAL sMa = 0, sqs = 0, smv = 0;
+  for (int d = 0; d < nv; d++) { sMa += w->s_search[d] * w->s_Ma[d]; sqs += w->s_search[d] * w->qfrc_smooth[d]; smv += w->s_search[d] * w->s_mv[d]; }
+  REAL qg[3] = {c->gauss, sMa - sqs, (REAL)0.5 * smv};
+  for (int r = 0; r < nefc; r++) {
+    REAL ja = w->s_Jaref[r], jv = w->s_jv[r], D = w->efc_D[r];
+    w->s_quad[3 * r] = ((REAL)0.5 * ja * ja) * D;
+    w->s_quad[3 * r + 1] = (jv * ja) * D;
+    w->s_quad[3 * r + 2] = ((REAL)0.5 * jv * jv) * D;
+  }
+  FN(LSPoint) p0 = FN(ls_point)(w, nefc, qg, 0);
+  FN(LSPoint) p1 = FN(ls_point)(w, nefc, qg, p0.alpha - p0.d0 / p0.d1);
+  int early = R_FABS(p1.d0) < gtol;
+  FN(LSPoint) lo, hi;
+  if (p1.d0 < p0.d0) { hi = p0; lo = p1; } else { hi = p1; lo = p0; }
+  int swap = !early, ls_iter = 0;
+  for (;;) {
+    if (fixed_iterations) { if (ls_iter >= m->ls_iterations) break; }
+    else {
+      int done = ls_iter >= m->ls_iterations;
+      done |= !swap;
+      done |= (lo.d0 < 0) && (lo.d0 > -gtol);
+      done |= (hi.d0 > 0) && (hi.d0 < gtol);
+      if (done) break;
+    }
+    FN(LSPoint) lo_next = FN(ls_point)(w, nefc, qg, lo.alpha - lo.d0 / lo.d1);
+    FN(LSPoint) hi_next = FN(ls_point)(w, nefc, qg, hi.alpha - hi.d0 / hi.d1);
+    FN(LSPoint) mid = FN(ls_point)(w, nefc, qg, (REAL)0.5 * (lo.alpha + hi.alpha));
+    {
+      /* knife-edge bookkeeping (test diagnostics; natural behaviour when knife_policy < 0) */
+#ifdef REAL_IS_FLOAT
+      REAL noise = (REAL)1e-4 * (R_FABS(p0.d0) + (REAL)1e-30);
+#else
+      REAL noise = (REAL)1e-8 * (R_FABS(p0.d0) + (REAL)1e-300);
+#endif
+      FN(LSPoint)* cands[3] = {&lo_next, &hi_next, &mid};
+      for (int q = 0; q < 3; q++) {
+        FN(LSPoint)* cd = cands[q];
+        if (R_FABS(cd->d0) < noise && cd->alpha != lo.alpha && cd->alpha != hi.alpha) {
+          if (w->knife_policy >= 0) {
+            if (w->knife < w->knife_policy) cd->d0 = 0;                       /* "rounded to exactly zero": rejected */
+            else if (w->knife == w->knife_policy && cd->d0 == 0) cd->d0 = -noise * (REAL)1e-6; /* "not exactly zero": accepted */
+          }
+          w->knife++;
+        }
+      }
+    }
+    int nb = (lo.d0 < 0) == (hi.d0 < 0);
+    int s1 = FN(ls_swap)(lo.d0, lo_next.d0, nb); if (s1) lo = lo_next;
+    int s2 = FN(ls_swap)(lo.d0, mid.d0, nb); if (s2) lo = mid;
+    int s3 = FN(ls_swap)(lo.d0, hi_next.d0, nb); if (s3) lo = hi_next;
+    int s4 = FN(ls_swap)(hi.d0, hi_next.d0, nb); if (s4) hi = hi_next;
+    int s5 = FN(ls_swap)(hi.d0, mid.d0, nb); if (s5) hi = mid;
+    int s6 = FN(ls_swap)(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
+    swap = s1 | s2 | s3 | s4 | s5 | s6;
+    ls_iter++;
+  }
+  REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
+  REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  for (int d = 0; d < nv; d++) {
+    w->s_qacc[d] = w->s_qacc[d] + improved * w->s_search[d] * alpha;
+    w->s_Ma[d] = w->s_Ma[d] + improved * w->s_mv[d] * alpha;
+  }
+  for (int r = 0; r < nefc; r++) w->s_Jaref[r] = w->s_Jaref[r] + improved * w->s_jv[r] * alpha;
+}
+
+static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterations) {
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv, nefc = m->nefc;
+  REAL scale = (REAL)(m->meaninertia * (double)(nv > 1 ? nv : 1));
+  FN(SolveCtx) c;
+  const REAL* start = w->qacc_smooth;
+  if (!(m->disableflags & DSBL_WARMSTART)) { /* :526-531 */
+    FN(create_context)(M, w, &c, w->qacc_warmstart, 0);
+    REAL warm_cost = c.cost;
+    FN(create_context)(M, w, &c, w->qacc_smooth, 0);
+    REAL smth_cost = c.cost;
+    start = (warm_cost < smth_cost) ? w->qacc_warmstart : w->qacc_smooth;
+  }
+  for (int d = 0; d < nv; d++) w->tmp_nv[d] = start[d];
+  FN(create_context)(M, w, &c, w->tmp_nv, 1);
+  for (int it = 0;; it++) {
+    if (m->iterations == 1) { if (it >= 1) break; }
+    else if (fixed_iterations) { if (it >= m->iterations) break; }
+    else { /* cond :501-508 */
+      REAL improvement = (c.prev_cost - c.cost) / scale;
+      REAL gradient = FN(norm_n)(w->s_grad, nv) / scale;
+      /* torch.norm has no all-zero special case but agrees: sqrt(0) = 0 */
+      int done = c.niter >= m->iterations;
+      done |= improvement < (REAL)m->tolerance;
+      done |= gradient < (REAL)m->tolerance;
+      if (done) break;
+    }
+    /* body :510-524 */
+    FN(linesearch)(M, w, &c, fixed_iterations);
+    for (int d = 0; d < nv; d++) { w->s_prev_grad[d] = w->s_grad[d]; w->s_prev_Mgrad[d] = w->s_Mgrad[d]; }
+    FN(update_constraint)(M, w, &c);
+    FN(update_gradient)(M, w);
+    if (m->solver == SOL_NEWTON) {
+      for (int d = 0; d < nv; d++) w->s_search[d] = -w->s_Mgrad[d];
+    } else {
+      REAL num = 0, den = 0;
+      for (int d = 0; d < nv; d++) { num += w->s_grad[d] * (w->s_Mgrad[d] - w->s_prev_Mgrad[d]); den += w->s_prev_grad[d] * w->s_prev_Mgrad[d]; }
+      REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+      beta = beta > 0 ? beta : 0;
+      for (int d = 0; d < nv; d++) w->s_search[d] = -w->s_Mgrad[d] + beta * w->s_search[d];
+    }
+    c.niter++;
+  }
+  for (int d = 0; d < nv; d++) { w->qacc[d] = w->s_qacc[d]; w->qacc_warmstart[d] = w->s_qacc[d]; w->qfrc_constraint[d] = w->s_qfrc[d]; }
+  for (int r = 0; r < nefc; r++) w->efc_force[r] = w->s_force[r];
+}
+
+/* ---- forward (forward.py:373-401) ----------------------------------------------------------------- */
+static void FN(forward_env)(const FN(MjoModel) * M, FN(MjoWork) * w, int stages, int flags, int with_cams) {
+  const mjhModelDesc* m = M->d;
+  if (stages & 0x7f) { FN(kinematics)(M, w, with_cams); FN(com_pos)(M, w); }
+  if (stages & 0x7e) FN(crb_factor)(M, w);
+  if (stages & 0x7c) { if (m->ncon > 0) FN(collision)(M, w); }
+  if (stages & 0x78) FN(make_constraint)(M, w);
+  if (stages & 0x70) FN(velocity)(M, w);
+  if (stages & 0x60) FN(actuation)(M, w);
+  if (stages & 0x40) {
+    if (m->nefc == 0) { for (int d = 0; d < m->nv; d++) w->qacc[d] = w->qacc_smooth[d]; }
+    else FN(solve)(M, w, flags & MJH_FLAG_FIXED_ITERATIONS);
+  }
+}
+
+/* ---- integrators (forward.py:231-370) ---------------------------------------------------------------- */
+static void FN(integrate_pos)(const FN(MjoModel) * M, const REAL* qpos, const REAL* qvel, REAL dt, REAL* out) { /* :231-252 */
+  const mjhModelDesc* m = M->d;
+  for (int j = 0; j < m->njnt; j++) {
+    int t = m->jnt_type[j], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (t == JNT_FREE) {
+      for (int i = 0; i < 3; i++) out[qa + i] = qpos[qa + i] + dt * qvel[da + i];
+      FN(quat_integrate)(qpos + qa + 3, qvel + da + 3, dt, out + qa + 3);
+    } else if (t == JNT_BALL) {
+      FN(quat_integrate)(qpos + qa, qvel + da, dt, out + qa);
+    } else {
+      out[qa] = qpos[qa] + dt * qvel[da];
+    }
+  }
+}
+
+static void FN(advance)(const FN(MjoModel) * M, FN(MjoWork) * w, const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0,
+                        const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) { /* _advance :255-310 */
+  const mjhModelDesc* m = M->d;
+  REAL dt = M->timestep;
+  for (int i = 0; i < m->nu; i++) {
+    int dyn = m->act_dyntype[i];
+    if (dyn == DYN_NONE) continue;
+    int a = m->act_actadr[i];
+    REAL act = act0[a];
+    if (dyn == DYN_FILTEREXACT) {
+      REAL tau = M->act_dynprm[3 * i];
+      tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
+      act = act + act_dot[a] * tau * (1 - R_EXP(-dt / tau));
+    } else {
+      act = act + act_dot[a] * dt;
+    }
+    if (m->act_actlimited[i]) {
+      REAL lo = M->act_actrange[2 * i], hi = M->act_actrange[2 * i + 1];
+      act = act < lo ? lo : (act > hi ? hi : act);
+    }
+    w->act[a] = act;
+  }
+  for (int d = 0; d < m->nv; d++) w->tmp_nv[d] = qvel0[d] + qacc[d] * dt;
+  const REAL* vp = qvel_for_pos ? qvel_for_pos : w->tmp_nv;
+  FN(integrate_pos)(M, qpos0, vp, dt, w->tmp_nefc); /* tmp_nefc is sized >= nq */
+  for (int i = 0; i < m->nq; i++) w->qpos[i] = w->tmp_nefc[i];
+  for (int d = 0; d < m->nv; d++) w->qvel[d] = w->tmp_nv[d];
+  w->time[0] = time0 + dt;
+}

@@ -1,0 +1,97 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/libmjoracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  Reuses the product's model packing (``mujoco_torch_amd.native.pack_model``) because the
+oracle takes the very same ``mjhModelDesc`` / ``mjhData`` structs as the device library, with host
+pointers -- the oracle never feeds the product.
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(REPO, "mujoco-torch_amd"))
+
+from mujoco_torch_amd import native  # noqa: E402
+
+LIB = os.path.join(HERE, "_build", "libmjoracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", HERE], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = ctypes.CDLL(LIB)
+        _lib.mjo_step.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        _lib.mjo_forward.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        _lib.mjo_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+ALL_NAMES = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
+
+
+def data_to_numpy(d):
+    """Data (torch, CPU) -> {abi leaf name: contiguous numpy array}."""
+    out = {}
+    for n in ALL_NAMES:
+        t = native.data_field_tensor(d, n)
+        out[n] = np.array(t.detach().cpu().contiguous().numpy(), order="C", copy=True)
+    return out
+
+
+def _ptrs(arrs):
+    p = native.DataPtrs()
+    for n, a in arrs.items():
+        setattr(p, n, a.ctypes.data if a.size else None)
+    return p
+
+
+def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1):
+    """Runs the oracle on a (possibly batched) CPU Data; returns {leaf: numpy array} of outputs.
+
+    ``knife``: optional int32 array [B]; receives per env the number of line-search candidates whose
+    derivative was rounding noise (the reference's result is implementation-defined on such steps).
+    ``knife_policy``: -1 natural rounding; j >= 0 forces the first j such candidates to read as an exact
+    zero (rejected by both bracket tests, solver.py:440-449) and the next one as non-zero (accepted)."""
+    dtype = d.qpos.dtype
+    desc, keep = native.pack_model(m, dtype)
+    inp = data_to_numpy(d)
+    batch = tuple(d.qpos.shape[:-1])
+    B = int(np.prod(batch)) if batch else 1
+    out = {n: np.array(a, copy=True) for n, a in inp.items()}
+    pin, pout = _ptrs(inp), _ptrs(out)
+    flags = 1 if fixed_iterations else 0
+    dt = 0 if dtype == torch.float64 else 1
+    if step:
+        rc = lib().mjo_step(ctypes.byref(desc), ctypes.byref(pin), ctypes.byref(pout), B, dt, flags, nthreads, knife.ctypes.data if knife is not None else None, knife_policy)
+    else:
+        rc = lib().mjo_forward(ctypes.byref(desc), ctypes.byref(pin), ctypes.byref(pout), B, dt, stages, flags, nthreads, knife.ctypes.data if knife is not None else None, knife_policy)
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    return out
+
+
+def apply(d, out):
+    """Returns a new Data with the oracle's output leaves (torch, CPU)."""
+    top, con = {}, {}
+    for n, a in out.items():
+        t = torch.from_numpy(a)
+        path = native.DATA_PATH[n]
+        if len(path) == 2:
+            con[path[1]] = t
+        else:
+            top[n] = t
+    res = d.replace(**top)
+    return res.replace(contact=d.contact.replace(**con))

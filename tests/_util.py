@@ -1,0 +1,100 @@
+"""Shared helpers: load golden cases (tests/golden/*.npz) and compare Data leaves."""
+import json
+import os
+
+import numpy as np
+import torch
+
+import mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+REAL_LEAVES = native.LISTS["MJH_DATA_REALS"]
+INT_LEAVES = native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
+INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
+
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz"))
+
+
+def load_model(xml, overrides=None, dtype=torch.float64):
+    lite = mt.mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
+    for k, v in (overrides or {}).items():
+        setattr(lite.opt, k, v)
+    return mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
+
+
+class Golden:
+    def __init__(self, case):
+        self.z = np.load(os.path.join(GOLD, case + ".npz"))
+        self.meta = json.loads(str(self.z["meta"]))
+        self.dtype = getattr(torch, self.meta["dtype"])
+        self.model = load_model(self.meta["xml"], self.meta["overrides"], self.dtype)
+        self.nenv, self.nsteps = self.meta["nenv"], self.meta["nsteps"]
+
+    def input_data(self, env=None):
+        """Data for one env, or all envs stacked on a leading batch dim (env=None)."""
+        def one(e):
+            d = mt.make_data(self.model)
+            if self.dtype != torch.float64:
+                d = d.to(self.dtype)
+            kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES}
+            return d.replace(**kw)
+
+        if env is not None:
+            return one(env)
+        return torch.stack([one(e) for e in range(self.nenv)])
+
+    def expected(self, env, step, name):
+        return self.z[f"out/{env}/{step}/{name}"]
+
+
+def leaf(d, name):
+    return native.data_field_tensor(d, name)
+
+
+def rel_err(got, want):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    want = np.asarray(want, dtype=np.float64).reshape(-1)
+    if want.size == 0:
+        return 0.0
+    assert got.shape == want.shape, (got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), 1e-9)
+    return float(np.abs(got - want).max() / scale)
+
+
+def assert_leaves_close(get_got, get_want, tol, names=REAL_LEAVES, what=""):
+    bad = []
+    for n in names:
+        e = rel_err(get_got(n), get_want(n))
+        if not (e <= tol):
+            bad.append((n, e))
+    assert not bad, f"{what}: leaves beyond tol {tol:g}: {bad[:8]}"
+
+
+def assert_ints_equal(get_got, get_want, what=""):
+    for n in INT_LEAVES:
+        g, w = np.asarray(get_got(n)), np.asarray(get_want(n))
+        assert g.shape == w.shape and np.array_equal(g, w), f"{what}: integer leaf {n} differs"
+
+SOLVER_LEAVES = ["qacc", "qacc_warmstart", "efc_force", "qfrc_constraint", "qpos", "qvel", "act", "time"]
+MAX_KNIFE_POLICIES = 14
+
+
+def oracle_alternatives(model, d, step=True, **kw):
+    """Oracle outputs under every admissible rounding outcome of the line search's noise candidates.
+
+    The reference accepts a line-search candidate whose derivative is +-1e-13 but rejects one whose
+    derivative rounds to exactly 0.0 (solver.py:440-449); which of the two happens is decided by the
+    summation order of the implementation.  Returns [natural, policy 0, policy 1, ...]."""
+    import pyoracle
+
+    B = int(np.prod(d.qpos.shape[:-1])) if d.qpos.ndim > 1 else 1
+    knife = np.zeros(B, dtype=np.int32)
+    outs = [pyoracle.run(model, d, step=step, knife=knife, **kw)]
+    for pol in range(MAX_KNIFE_POLICIES):
+        outs.append(pyoracle.run(model, d, step=step, knife=knife, knife_policy=pol, **kw))
+        if int(knife.max()) <= pol:  # fewer noise candidates than the policy index: every one was rejected
+            break
+    return outs

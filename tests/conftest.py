@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "mujoco-torch_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    import pyoracle
+
+    pyoracle.build()
+    return pyoracle.lib()

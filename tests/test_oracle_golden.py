@@ -1,0 +1,55 @@
+"""The CPU oracle (oracle/mjoracle.c) against golden vectors recorded from the reference's own
+Python step (oracle/gen_golden.py).  This is what pins the oracle; CPU-only."""
+import numpy as np
+import pytest
+import torch
+
+import pyoracle
+from _util import (GOLDEN_CASES, INT_LEAVES, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+                   assert_leaves_close, oracle_alternatives, rel_err)
+
+# float64: the oracle follows the reference's operation order, differences are summation order in
+# BLAS/LAPACK-backed ops; float32: same, at float32 epsilon amplified by the solver.
+TOL = {torch.float64: 1e-9, torch.float32: 2e-4}
+
+
+PRE_SOLVER = [n for n in REAL_LEAVES if n not in SOLVER_LEAVES]
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_oracle_matches_reference_golden(case, oracle_lib):
+    """Every leaf of every recorded reference step, teacher-forced (each step starts from the
+    reference's own previous output).  Leaves upstream of the solver must agree outright; the
+    solver's outputs must agree with the oracle under ONE admissible rounding outcome of the line
+    search's noise candidates (see _util.oracle_alternatives) -- normally the natural one."""
+    g = Golden(case)
+    tol = TOL[g.dtype]
+    natural = total = 0
+    for env in range(g.nenv):
+        d = g.input_data(env)
+        for s in range(g.nsteps):
+            want = lambda n: g.expected(env, s, n)
+            what = f"{case} env{env} step{s}"
+            alts = oracle_alternatives(g.model, d)
+            assert_leaves_close(lambda n: alts[0][n], want, tol, names=PRE_SOLVER, what=what)
+            assert_ints_equal(lambda n: alts[0][n], want, what=what)
+            errs = [max(rel_err(o[n], want(n)) for n in SOLVER_LEAVES) for o in alts]
+            assert min(errs) <= tol, f"{what}: solver outputs match no admissible branch, errors {errs}"
+            natural += errs[0] <= tol
+            total += 1
+            # teacher forcing: continue from the reference's recorded state
+            out = {n: np.array(want(n)) for n in REAL_LEAVES + INT_LEAVES}
+            d = pyoracle.apply(d, out)
+    print(f"{case}: {natural}/{total} steps matched on the natural branch")
+
+
+@pytest.mark.parametrize("case", ["humanoid_cg_f64", "ant_rk4_newton_ell_f32"])
+def test_oracle_batched_equals_sequential(case, oracle_lib):
+    """batched call == per-env calls bit for bit (reference test/forward_test.py:142-185 analogue)."""
+    g = Golden(case)
+    db = g.input_data()
+    outb = pyoracle.run(g.model, db, step=True, nthreads=2)
+    for env in range(g.nenv):
+        out1 = pyoracle.run(g.model, g.input_data(env), step=True)
+        for n in REAL_LEAVES + INT_LEAVES:
+            assert np.array_equal(outb[n][env], out1[n]), n
