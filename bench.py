@@ -1,0 +1,167 @@
+"""bench.py -- env-steps/s of the native batched step on the BASELINE.json workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload humanoid|ant|cartpole]
+
+One process per GPU (the driver launches N > 1 with torch.distributed.run); independent environments
+are sharded across ranks with no data-path collective (weak scaling: B environments PER GPU).  A "step"
+is one `mujoco_torch.step` over the whole resident batch; state is carried across steps (ping-pong
+buffers), inputs follow the reference's bench recipe (benchmarks/_helpers.py:25-42: make_data state,
+qvel = 0.01 * RandomState(42).randn(B, nv), ctrl = 0).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "mujoco-torch_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import mujoco_torch_amd as mt  # noqa: E402
+from mujoco_torch_amd import native  # noqa: E402
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: humanoid.xml, batch 4096, Euler + CG, float64 (XML iterations=1, ls_iterations=4)
+    "humanoid": dict(xml="humanoid", overrides={"solver": 1}, dtype=torch.float64, batch=4096,
+                     name="humanoid.xml batch=4096/GPU Euler+CG float64 (iterations=1, ls_iterations=4)"),
+    # configs[2]: ant.xml, RK4 + Newton, elliptic, float32
+    "ant": dict(xml="ant", overrides={"integrator": 1, "solver": 2, "cone": 1}, dtype=torch.float32, batch=16384,
+                name="ant.xml batch=16384/GPU RK4+Newton elliptic float32"),
+    "cartpole": dict(xml="cartpole", overrides={}, dtype=torch.float64, batch=4096, name="cartpole.xml Euler float64"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(mx, dtype):
+    """bytes of the Data leaves step() consumes + bytes of the leaves it produces."""
+    from mujoco_torch_amd.forward import _written_names
+
+    d = mt.make_data(mx)
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    written = _written_names(mx, step=True)
+    nbytes = lambda n: native.data_field_tensor(d, n).numel() * native.data_field_tensor(d, n).element_size()
+    out_b = sum(nbytes(n) for n in written)
+    consumed = ["qpos", "qvel", "qacc", "act", "ctrl", "qfrc_applied", "xfrc_applied", "qacc_warmstart", "time", "qfrc_constraint"]
+    in_b = sum(nbytes(n) for n in consumed)
+    return in_b, out_b
+
+
+def build_inputs(mx, B, dtype, device, seed=42):
+    d = mt.make_data(mx).expand(B).clone()
+    d = d.replace(qvel=torch.tensor(0.01 * np.random.RandomState(seed).randn(B, mx.nv)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    return d.to(device)
+
+
+def cpu_baseline(mx, dtype, B_sample, steps):
+    """Times the CPU oracle (scalar C restatement of the reference step, OpenMP over envs) on host cores."""
+    import pyoracle
+
+    pyoracle.build()
+    threads = pyoracle.lib().mjo_max_threads()
+    d = mt.make_data(mx).expand(B_sample).clone()
+    d = d.replace(qvel=torch.tensor(0.01 * np.random.RandomState(42).randn(B_sample, mx.nv)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))  # warm
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))
+    dt = time.perf_counter() - t0
+    return dict(value=B_sample * steps / dt, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"{B_sample} envs x {steps} steps, oracle/mjoracle.c with OpenMP over environments ({dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--workload", default="humanoid", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    dtype = wl["dtype"]
+    lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", wl["xml"] + ".xml"))
+    for k, v in wl["overrides"].items():
+        setattr(lite.opt, k, v)
+    mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
+    mdev = mx.to(device)
+    # different seeds per rank: independent environments, no collective on the data path
+    bufs = [build_inputs(mx, B, dtype, device, seed=42 + rank), None]
+    bufs[1] = bufs[0].clone()
+
+    def run(n, cur):
+        for _ in range(n):
+            mt.step(mdev, bufs[cur], out=bufs[1 - cur])
+            cur = 1 - cur
+        return cur
+
+    cur = run(args.warmup, 0)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev0.record()
+    cur = run(args.steps, cur)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # one kernel launch per step on this stream
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final = bufs[cur]
+    assert torch.isfinite(final.qpos).all(), "non-finite state after the timed steps"
+
+    if rank == 0:
+        in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
+        alg = in_b + out_b
+        achieved = alg * B / (kernel_ms * 1e-3) / 1e9
+        value = B * world * args.steps / elapsed
+        line = {
+            "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if dtype == torch.float64 else "f32", "data": "synthetic",
+            "config": {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"independent-envs x{world} (no collectives)",
+                       "lds_bytes_per_env": native.get_native_model(mdev, device, dtype).lib.mjh_model_lds_bytes(native.get_native_model(mdev, device, dtype).handle)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            nB = min(B, 4096)
+            line["cpu_baseline"] = cpu_baseline(mx, dtype, nB, 20 if args.workload != "ant" else 4)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,289 @@
+// mjh_device.h -- device-side model view, wave-64 helpers and small-vector math (gfx950 / CDNA4).
+//
+// Execution model of the whole library: ONE ENVIRONMENT PER 64-LANE WAVEFRONT (one 64-thread
+// workgroup).  Per-environment state lives in LDS; lanes parallelise over bodies / joints / dofs /
+// constraint rows / contact pairs; Data leaves are batch-major so every global access of a wave is
+// a contiguous run of one environment's row.  The formulas restate the reference
+// (mujoco_torch/_src/math.py, cited per function) in the same operation order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mjhip.h"
+
+#define MJH_WAVE 64
+#define MJH_MAX_DEPTH 32
+
+// ---- constants (reference reads them from the mujoco package) ---------------------------------
+#define mjMINVAL 1e-15
+#define mjMAXVAL 1e10
+#define mjMINIMP 1e-4
+#define mjMAXIMP 0.9999
+// constants the reference keeps in _CachedConst are float32 literals up-cast (math.py:34-45)
+#define MINVAL_CACHED ((float)1e-15)
+
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { DSBL_CONSTRAINT = 1 << 0, DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7,
+       DSBL_CLAMPCTRL = 1 << 8, DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12,
+       DSBL_EULERDAMP = 1 << 15 };
+enum { INT_EULER = 0, INT_RK4 = 1, SOL_CG = 1, SOL_NEWTON = 2, CONE_ELLIPTIC = 1 };
+enum { CAM_FIXED = 0, CAM_TRACK = 1, CAM_TRACKCOM = 2, CAM_TARGETBODY = 3, CAM_TARGETBODYCOM = 4 };
+enum { GAIN_FIXED = 0, GAIN_AFFINE = 1, BIAS_NONE = 0, BIAS_AFFINE = 1 };
+enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
+#define INLINE_CHOL_MAX 16  // math.py:84
+
+// ---- LDS arena ---------------------------------------------------------------------------------------------------
+// X(name, count) in REALs.  Sizes depend on the model only, so host and device carve identically.
+#define MJH_LDS_ARRAYS(X, m)                                                                          \
+  X(qpos, m.nq) X(qvel, m.nv) X(act, m.na)                                                            \
+  X(xpos, 3 * m.nbody) X(xquat, 4 * m.nbody) X(xmat, 9 * m.nbody) X(xipos, 3 * m.nbody)               \
+  X(ximat, 9 * m.nbody) X(xanchor, 3 * m.njnt) X(xaxis, 3 * m.njnt)                                   \
+  X(geom_xpos, 3 * m.ngeom) X(geom_xmat, 9 * m.ngeom)                                                 \
+  X(subtree_com, 3 * m.nbody) X(cinert, 10 * m.nbody) X(crb, 10 * m.nbody)                            \
+  X(cdof, 6 * m.nv) X(cdof_dot, 6 * m.nv) X(cvel, 6 * m.nbody) X(cacc, 6 * m.nbody)                   \
+  X(cfrc, 6 * m.nbody) X(crb_cdof, 6 * m.nv) X(sub_mass, m.nbody) X(sub_pos, 3 * m.nbody)             \
+  X(qM, m.nv * m.nv) X(qLD, m.nv * m.nv)                                                              \
+  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0)              \
+  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0)             \
+  X(con_dist, m.ncon) X(con_pos, 3 * m.ncon) X(con_frame, 9 * m.ncon)                                 \
+  X(efc_J, m.nefc * m.nv) X(efc_D, m.nefc) X(efc_aref, m.nefc)                                        \
+  X(efc_pos, m.nefc) X(efc_pos_norm, m.nefc) X(efc_invweight, m.nefc)                                 \
+  X(act_length, m.nu) X(act_velocity, m.nu) X(act_force, m.nu) X(act_dot, m.na)                       \
+  X(qfrc_bias, m.nv) X(qfrc_passive, m.nv) X(qfrc_actuator, m.nv) X(qfrc_smooth, m.nv)                \
+  X(qacc_smooth, m.nv) X(qacc_warm, m.nv) X(qacc, m.nv) X(qfrc_constraint, m.nv)                      \
+  X(s_qacc, m.nv) X(s_qfrc, m.nv) X(s_Ma, m.nv) X(s_grad, m.nv) X(s_Mgrad, m.nv) X(s_search, m.nv)    \
+  X(s_mv, m.nv) X(s_pgrad, m.nv) X(s_pMgrad, m.nv) X(tmp_nv, m.nv) X(tmp_nv2, m.nv)                   \
+  X(s_Jaref, m.nefc) X(s_force, m.nefc) X(s_jv, m.nefc) X(s_quad, 3 * m.nefc)                         \
+  X(rk_qpos0, m.integrator == INT_RK4 ? m.nq : 0) X(rk_qvel0, m.integrator == INT_RK4 ? m.nv : 0)     \
+  X(rk_act0, m.integrator == INT_RK4 ? m.na : 0) X(rk_qvel, m.integrator == INT_RK4 ? m.nv : 0)       \
+  X(rk_qacc, m.integrator == INT_RK4 ? m.nv : 0) X(rk_actdot, m.integrator == INT_RK4 ? m.na : 0)     \
+  X(rk_kqvel, m.integrator == INT_RK4 ? m.nv : 0) X(tmp_nq, m.nq)
+
+struct LdsOff {
+#define X(n, c) int n;
+  MJH_LDS_ARRAYS(X, _)
+#undef X
+};
+
+
+// ---- device view of the model -------------------------------------------------------------------
+// Pointers into one device blob (built by mjh_model_create).  REAL arrays are stored in the compute
+// dtype.  All indices are wave-uniform in the kernels, so these loads become scalar (SMEM) loads.
+template <typename REAL>
+struct DevModel {
+#define X(n) int n;
+  MJH_MODEL_INTS(X)
+#undef X
+  REAL timestep, impratio, gravity[3];
+  double meaninertia, tolerance, ls_tolerance;  // python floats in the reference (solver.py:256-265)
+#define X(n) const int* n;
+  MJH_MODEL_INT_ARRAYS(X)
+#undef X
+#define X(n) const REAL* n;
+  MJH_MODEL_REAL_ARRAYS(X)
+#undef X
+  // derived topology tables (host-computed, mjh_abi.hip)
+  const int* body_depth;       // nbody: number of non-world ancestors-or-self
+  const int* body_chain;       // nbody*max_depth: chain[b][k] = k-th body on the path world -> b (k=0: child of world)
+  const int* body_subtree_end; // nbody: one past the last body of b's subtree (bodies are in DFS order)
+  const unsigned long long* body_dofmask;  // nbody: dofs whose body is an ancestor-or-self of b
+  const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
+  const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
+  int max_depth;
+  int lds_reals;
+  LdsOff off;  // LDS arena offsets, in REALs
+};
+
+// ---- wave helpers --------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x; }
+
+// LDS visibility point for a single-wave workgroup (s_waitcnt + barrier; the barrier is free for 1 wave).
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+template <typename T>
+__device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, src_lane, MJH_WAVE); }
+
+// butterfly all-reduce (sum) over the 64 lanes; every lane gets the same bits.
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, MJH_WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_any(int p) { return __any(p); }
+
+// ---- small-vector math, reference math.py ------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ R r_sqrt(R x);
+template <> __device__ __forceinline__ double r_sqrt<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float r_sqrt<float>(float x) { return sqrtf(x); }
+template <typename R> __device__ __forceinline__ R r_sin(R x);
+template <> __device__ __forceinline__ double r_sin<double>(double x) { return sin(x); }
+template <> __device__ __forceinline__ float r_sin<float>(float x) { return sinf(x); }
+template <typename R> __device__ __forceinline__ R r_cos(R x);
+template <> __device__ __forceinline__ double r_cos<double>(double x) { return cos(x); }
+template <> __device__ __forceinline__ float r_cos<float>(float x) { return cosf(x); }
+template <typename R> __device__ __forceinline__ R r_atan2(R y, R x);
+template <> __device__ __forceinline__ double r_atan2<double>(double y, double x) { return atan2(y, x); }
+template <> __device__ __forceinline__ float r_atan2<float>(float y, float x) { return atan2f(y, x); }
+template <typename R> __device__ __forceinline__ R r_pow(R x, R y);
+template <> __device__ __forceinline__ double r_pow<double>(double x, double y) { return pow(x, y); }
+template <> __device__ __forceinline__ float r_pow<float>(float x, float y) { return powf(x, y); }
+template <typename R> __device__ __forceinline__ R r_exp(R x);
+template <> __device__ __forceinline__ double r_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ float r_exp<float>(float x) { return expf(x); }
+template <typename R> __device__ __forceinline__ R r_abs(R x) { return x < 0 ? -x : x; }
+template <> __device__ __forceinline__ double r_abs<double>(double x) { return fabs(x); }
+template <> __device__ __forceinline__ float r_abs<float>(float x) { return fabsf(x); }
+template <typename R> __device__ __forceinline__ bool r_finite(R x) { return isfinite(x); }
+
+template <typename R>
+__device__ __forceinline__ void cross3(const R* a, const R* b, R* o) {  // math.py:63-76
+  R o0 = a[1] * b[2] - a[2] * b[1];
+  R o1 = a[2] * b[0] - a[0] * b[2];
+  R o2 = a[0] * b[1] - a[1] * b[0];
+  o[0] = o0; o[1] = o1; o[2] = o2;
+}
+template <typename R>
+__device__ __forceinline__ R dot3(const R* a, const R* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+template <typename R, int N>
+__device__ __forceinline__ R norm_n(const R* x) {  // math.norm :196-213
+  bool all_zero = true;
+#pragma unroll
+  for (int i = 0; i < N; i++) all_zero = all_zero && (x[i] == 0);
+  if (all_zero) return 0;
+  R s = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) s += x[i] * x[i];
+  return r_sqrt<R>(s);
+}
+template <typename R, int N>
+__device__ __forceinline__ R normalize_n(R* x) {  // normalize_with_norm :216-230
+  R nn = norm_n<R, N>(x);
+  R den = nn + (R)1e-6 * (R)(nn == 0);
+#pragma unroll
+  for (int i = 0; i < N; i++) x[i] = x[i] / den;
+  return nn;
+}
+template <typename R>
+__device__ __forceinline__ void rotate(const R* v, const R* q, R* o) {  // math.rotate :246-261
+  R s = q[0];
+  const R* u = q + 1;
+  R uv = dot3(u, v), uu = dot3(u, u);
+  R c[3], r[3];
+  cross3(u, v, c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) r[i] = 2 * (uv * u[i]) + (s * s - uu) * v[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[i] = r[i] + 2 * s * c[i];
+}
+template <typename R>
+__device__ __forceinline__ void quat_mul(const R* u, const R* v, R* o) {  // :283-300
+  R o0 = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
+  R o1 = u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2];
+  R o2 = u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1];
+  R o3 = u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0];
+  o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+}
+template <typename R>
+__device__ __forceinline__ void quat_to_mat(const R* q, R* m) {  // :323-351
+  R p00 = q[0] * q[0], p01 = q[0] * q[1], p02 = q[0] * q[2], p03 = q[0] * q[3];
+  R p11 = q[1] * q[1], p12 = q[1] * q[2], p13 = q[1] * q[3];
+  R p22 = q[2] * q[2], p23 = q[2] * q[3], p33 = q[3] * q[3];
+  m[0] = p00 + p11 - p22 - p33;
+  m[1] = 2 * (p12 - p03);
+  m[2] = 2 * (p13 + p02);
+  m[3] = 2 * (p12 + p03);
+  m[4] = p00 - p11 + p22 - p33;
+  m[5] = 2 * (p23 - p01);
+  m[6] = 2 * (p13 - p02);
+  m[7] = 2 * (p23 + p01);
+  m[8] = p00 - p11 - p22 + p33;
+}
+template <typename R>
+__device__ __forceinline__ void axis_angle_to_quat(const R* axis, R angle, R* q) {  // :363-374
+  R s = r_sin<R>(angle * (R)0.5), c = r_cos<R>(angle * (R)0.5);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+template <typename R>
+__device__ __forceinline__ void quat_sub(const R* u, const R* v, R* o) {  // :276-280, :354-360
+  R vi[4] = {v[0], -v[1], -v[2], -v[3]}, q[4];
+  quat_mul(vi, u, q);
+  R axis[3] = {q[1], q[2], q[3]};
+  R sin_a_2 = normalize_n<R, 3>(axis);
+  R a = 2 * r_atan2<R>(sin_a_2, q[0]);
+  const R pi = (R)3.14159265358979323846;
+  if (a > pi) a = a - 2 * pi;
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[i] = axis[i] * a;
+}
+template <typename R>
+__device__ __forceinline__ void quat_integrate(const R* q, const R* w, R dt, R* o) {  // :377-383
+  R v[3] = {w[0], w[1], w[2]};
+  R nrm = normalize_n<R, 3>(v);
+  R angle = dt * nrm, qr[4], r[4];
+  axis_angle_to_quat(v, angle, qr);
+  quat_mul(q, qr, r);
+  normalize_n<R, 4>(r);
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = r[i];
+}
+template <typename R>
+__device__ __forceinline__ void inert_mul(const R* in, const R* v, R* o) {  // :415-429
+  const R* pos = in + 6;
+  R mass = in[9];
+  R c1[3], c2[3];
+  cross3(pos, v + 3, c1);
+  cross3(pos, v, c2);
+  o[0] = (in[0] * v[0] + in[3] * v[1] + in[4] * v[2]) + c1[0];
+  o[1] = (in[3] * v[0] + in[1] * v[1] + in[5] * v[2]) + c1[1];
+  o[2] = (in[4] * v[0] + in[5] * v[1] + in[2] * v[2]) + c1[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) o[3 + i] = mass * v[3 + i] - c2[i];
+}
+template <typename R>
+__device__ __forceinline__ void motion_cross(const R* u, const R* v, R* o) {  // :455-467
+  R a[3], b[3], c[3];
+  cross3(u, v, a);
+  cross3(u + 3, v, b);
+  cross3(u, v + 3, c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+template <typename R>
+__device__ __forceinline__ void motion_cross_force(const R* v, const R* f, R* o) {  // :470-482
+  R a[3], b[3], c[3];
+  cross3(v, f, a);
+  cross3(v + 3, f + 3, b);
+  cross3(v, f + 3, c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+template <typename R>
+__device__ __forceinline__ void make_frame(const R* a_in, R* frame) {  // orthogonals / make_frame :485-500
+  R a[3] = {a_in[0], a_in[1], a_in[2]};
+  normalize_n<R, 3>(a);
+  R b[3] = {0, 0, 0};
+  if ((R)-0.5 < a[1] && a[1] < (R)0.5) b[1] = 1; else b[2] = 1;
+  R ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+#pragma unroll
+  for (int i = 0; i < 3; i++) b[i] = b[i] - a[i] * ab;
+  normalize_n<R, 3>(b);
+  R any = (R)((a[0] != 0) || (a[1] != 0) || (a[2] != 0));
+#pragma unroll
+  for (int i = 0; i < 3; i++) b[i] = b[i] * any;
+  R c[3];
+  cross3(a, b, c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { frame[i] = a[i]; frame[3 + i] = b[i]; frame[6 + i] = c[i]; }
+}
+template <typename R>
+__device__ __forceinline__ void local_to_global(const R* wpos, const R* wquat, const R* lpos, const R* lquat, R* pos, R* mat) {
+  // support.local_to_global :99-108
+  R r[3], q[4];
+  rotate(lpos, wquat, r);
+#pragma unroll
+  for (int i = 0; i < 3; i++) pos[i] = wpos[i] + r[i];
+  quat_mul(wquat, lquat, q);
+  quat_to_mat(q, mat);
+}

@@ -1,0 +1,1263 @@
+// mjh_kernels.h -- the fused per-environment step kernel (one wavefront = one environment).
+//
+// Pipeline per environment (reference mujoco_torch/_src/forward.py:373-401, 463-496):
+//   check_state -> kinematics -> com_pos -> crb -> factor_m -> collision -> make_constraint
+//   -> transmission/_velocity (com_vel, passive, rne) -> _actuation -> _acceleration -> solve
+//   -> Euler / RK4 advance.
+// Every stage keeps its working set in the environment's LDS arena and streams the Data leaves it
+// produces straight to HBM (batch-major rows, one contiguous run per leaf).  Data-parallel axes:
+//   bodies / joints / dofs / geoms / contact pairs / constraint rows -> lanes;
+//   tree recursions -> each lane walks its own ancestor chain (no intra-wave sync in the walk);
+//   dot products over rows -> per-lane partials + wave all-reduce.
+#pragma once
+#include "mjh_device.h"
+
+// view of the arena: offsets (in REALs) live in the model (kernarg, scalar loads); the view only carries
+// the base pointer, so it stays in registers.
+template <typename REAL>
+struct LdsView {
+  REAL* base;
+  const LdsOff* off;
+#define X(n, c) __device__ __forceinline__ REAL* n() const { return base + off->n; }
+  MJH_LDS_ARRAYS(X, _)
+#undef X
+};
+
+// carve the arena on the host; returns the number of REALs used.  `m` only needs the int members.
+template <typename M>
+inline int lds_carve(const M& m, LdsOff& o) {
+  int off = 0;
+#define X(n, c) o.n = off; off += (((c) + 1) & ~1);
+  MJH_LDS_ARRAYS(X, m)
+#undef X
+  return off;
+}
+
+template <typename REAL>
+struct DevData {  // typed view of mjhData
+#define X(n) REAL* n;
+  MJH_DATA_REALS(X)
+#undef X
+#define X(n) int32_t* n;
+  MJH_DATA_I32(X)
+#undef X
+#define X(n) int64_t* n;
+  MJH_DATA_I64(X)
+#undef X
+};
+
+// All launch parameters travel as ONE by-value kernel argument.  Device code reads them through the
+// kernarg segment pointer (constant address space => scalar loads, nothing is copied to scratch and no
+// stage function needs them as arguments).
+template <typename REAL>
+struct KArgs {
+  DevModel<REAL> M;
+  DevData<REAL> in, out;
+  int64_t B;
+  int flags, do_step, stages;
+};
+template <typename REAL>
+__device__ __forceinline__ const KArgs<REAL>& kargs() {
+  typedef const KArgs<REAL> __attribute__((address_space(4))) * KPtr;
+  return *(const KArgs<REAL>*)(KPtr)__builtin_amdgcn_kernarg_segment_ptr();
+}
+#define M (kargs<REAL>().M)
+#define in (kargs<REAL>().in)
+#define out (kargs<REAL>().out)
+
+// ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
+template <typename REAL>
+__device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t env) {
+  if (!g) return;
+  REAL* dst = g + env * n;
+  for (int i = lane_id(); i < n; i += MJH_WAVE) dst[i] = l[i];
+}
+template <typename REAL>
+__device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
+  if (!g) { for (int i = lane_id(); i < n; i += MJH_WAVE) l[i] = 0; return; }
+  const REAL* src = g + env * n;
+  for (int i = lane_id(); i < n; i += MJH_WAVE) l[i] = src[i];
+}
+
+// =====================================================================================================================
+// dense Cholesky in LDS (math.small_cholesky :87-129).  Left-looking, lanes over rows; per element the
+// subtraction order is k = 0..j-1 exactly as the reference's unrolled loop.
+// =====================================================================================================================
+template <typename REAL>
+__device__ void chol_factor(const REAL* A, REAL* L, int n) {
+  const int i = lane_id();
+  for (int e = i; e < n * n; e += MJH_WAVE) L[e] = 0;
+  wave_sync();
+  const bool big = n > INLINE_CHOL_MAX;
+  for (int j = 0; j < n; j++) {
+    // diagonal (every lane computes it redundantly: identical bits, no broadcast needed)
+    REAL s = A[j * n + j];
+    if (big) s = s + (REAL)1e-10;  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
+    for (int k = 0; k < j; k++) s = s - L[j * n + k] * L[j * n + k];
+    REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
+    if (i > j && i < n) {
+      REAL t = A[i * n + j];
+      for (int k = 0; k < j; k++) t = t - L[i * n + k] * L[j * n + k];
+      L[i * n + j] = t / d;
+    }
+    if (i == j) L[j * n + j] = d;
+    wave_sync();
+  }
+}
+
+// x = (L L^T)^-1 b  (math.small_cholesky_solve :132-168).  Column-oriented substitution: lane i carries its
+// running right-hand side; the value solved at step k is broadcast.  Per element the operation order equals
+// the reference's row loops (k ascending forward, descending backward).
+template <typename REAL>
+__device__ void chol_solve(const REAL* L, const REAL* b, REAL* x, int n) {
+  const int i = lane_id();
+  REAL s = (i < n) ? b[i] : (REAL)0;
+  for (int k = 0; k < n; k++) {
+    REAL yk = s / L[k * n + k];           // only lane k's value is meaningful
+    yk = wave_bcast(yk, k);
+    if (i == k) s = yk;
+    else if (i > k && i < n) s = s - L[i * n + k] * yk;
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    REAL xk = s / L[k * n + k];
+    xk = wave_bcast(xk, k);
+    if (i == k) s = xk;
+    else if (i < k) s = s - L[k * n + i] * xk;
+  }
+  if (i < n) x[i] = s;
+  wave_sync();
+}
+
+// =====================================================================================================================
+template <typename REAL>
+struct Env {
+  LdsView<REAL> S;
+  int64_t e;      // environment index
+  bool store;     // stream Data leaves of this forward pass to HBM (false for RK4 stages 1..3)
+  int flags;
+
+  __device__ Env(REAL* lds, int64_t env, int fl) : S{lds, &M.off}, e(env), store(true), flags(fl) {}
+
+  template <typename T>
+  __device__ __forceinline__ void put(T* g, const REAL* l, int n) { if (store) row_store(g, l, n, e); }
+
+  // ---- load state (+ _check_state, forward.py:44-59, when stepping) ------------------------------------------------------------
+  __device__ void load_state(bool check) {
+    const int l = lane_id();
+    for (int i = l; i < M.nq; i += MJH_WAVE) {
+      REAL x = in.qpos[e * M.nq + i];
+      if (check && (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL)) x = M.qpos0[i];
+      S.qpos()[i] = x;
+    }
+    for (int i = l; i < M.nv; i += MJH_WAVE) {
+      REAL x = in.qvel[e * M.nv + i];
+      if (check && (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL)) x = 0;
+      S.qvel()[i] = x;
+      S.qacc_warm()[i] = in.qacc_warmstart ? in.qacc_warmstart[e * M.nv + i] : (REAL)0;
+    }
+    row_load(S.act(), in.act, M.na, e);
+    wave_sync();
+  }
+
+  // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
+  __device__ void kinematics(bool with_cams) {
+    const int l = lane_id();
+    for (int b = l; b < M.nbody; b += MJH_WAVE) {
+      REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
+      REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
+      const int depth = M.body_depth[b];
+      for (int k = 0; k < depth; k++) {
+        const int c = M.body_chain[b * M.max_depth + k];
+        const bool own = (k == depth - 1);
+        {
+          REAL r[3];
+          rotate(M.body_pos + 3 * c, quat, r);
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = pos[i] + r[i];
+          quat_mul(quat, M.body_quat + 4 * c, quat);
+        }
+        const int jn = M.body_jntnum[c], j0 = M.body_jntadr[c];
+        for (int jj = 0; jj < jn; jj++) {
+          const int j = j0 + jj, t = M.jnt_type[j], qa = M.jnt_qposadr[j];
+          const REAL* jpos = M.jnt_pos + 3 * j;
+          const REAL* jaxis = M.jnt_axis + 3 * j;
+          REAL anchor[3], axis[3];
+          if (t == JNT_FREE) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
+            axis[0] = 0; axis[1] = 0; axis[2] = 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) quat[i] = S.qpos()[qa + 3 + i];
+            normalize_n<REAL, 4>(quat);
+          } else {
+            REAL r[3];
+            rotate(jpos, quat, r);
+#pragma unroll
+            for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
+            rotate(jaxis, quat, axis);
+            if (t == JNT_BALL) {
+              REAL ql[4];
+#pragma unroll
+              for (int i = 0; i < 4; i++) ql[i] = S.qpos()[qa + i];
+              normalize_n<REAL, 4>(ql);
+              quat_mul(quat, ql, quat);
+              rotate(jpos, quat, r);
+#pragma unroll
+              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+            } else if (t == JNT_HINGE) {
+              REAL angle = S.qpos()[qa] - M.qpos0[qa], ql[4];
+              axis_angle_to_quat(jaxis, angle, ql);
+              quat_mul(quat, ql, quat);
+              rotate(jpos, quat, r);
+#pragma unroll
+              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+            } else {
+              REAL dq = S.qpos()[qa] - M.qpos0[qa];
+#pragma unroll
+              for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
+            }
+          }
+          if (own) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) S.xquat()[4 * b + i] = quat[i];
+      quat_to_mat(quat, S.xmat() + 9 * b);
+      local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, S.ximat() + 9 * b);
+    }
+    wave_sync();
+    // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
+    for (int j = l; j < M.njnt; j += MJH_WAVE) {
+      const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
+      if (t == JNT_FREE || t == JNT_BALL) {
+        const int o = (t == JNT_FREE) ? qa + 3 : qa;
+        REAL q[4] = {S.qpos()[o], S.qpos()[o + 1], S.qpos()[o + 2], S.qpos()[o + 3]};
+        normalize_n<REAL, 4>(q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) S.qpos()[o + i] = q[i];
+      }
+    }
+    for (int g = l; g < M.ngeom; g += MJH_WAVE) {
+      const int b = M.geom_bodyid[g];
+      local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.geom_pos + 3 * g, M.geom_quat + 4 * g, S.geom_xpos() + 3 * g, S.geom_xmat() + 9 * g);
+    }
+    if (store) {
+      for (int s = l; s < M.nsite; s += MJH_WAVE) {
+        const int b = M.site_bodyid[s];
+        REAL p[3], mat[9];
+        local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.site_pos + 3 * s, M.site_quat + 4 * s, p, mat);
+        if (out.site_xpos) for (int i = 0; i < 3; i++) out.site_xpos[(e * M.nsite + s) * 3 + i] = p[i];
+        if (out.site_xmat) for (int i = 0; i < 9; i++) out.site_xmat[(e * M.nsite + s) * 9 + i] = mat[i];
+      }
+      if (with_cams) {
+        for (int c = l; c < M.ncam; c += MJH_WAVE) {  // smooth.py:139-198
+          const int b = M.cam_bodyid[c], mode = M.cam_mode[c], tgt = M.cam_targetbodyid[c];
+          REAL cp[3], cm[9];
+          local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.cam_pos + 3 * c, M.cam_quat + 4 * c, cp, cm);
+          if (mode == CAM_TRACK) {
+            for (int i = 0; i < 3; i++) cp[i] = S.xpos()[3 * b + i] + M.cam_pos0[3 * c + i];
+            for (int i = 0; i < 9; i++) cm[i] = M.cam_mat0[9 * c + i];
+          } else if (mode == CAM_TRACKCOM) {
+            // subtree_com of the CALLER's Data (previous step), smooth.py:162-166
+            REAL r[3];
+            rotate(M.cam_pos + 3 * c, S.xquat() + 4 * b, r);
+            for (int i = 0; i < 3; i++) cp[i] = (in.subtree_com ? in.subtree_com[(e * M.nbody + b) * 3 + i] : (REAL)0) + r[i];
+          } else if ((mode == CAM_TARGETBODY || mode == CAM_TARGETBODYCOM) && tgt >= 0) {
+            REAL tp[3];
+            for (int i = 0; i < 3; i++)
+              tp[i] = (mode == CAM_TARGETBODY) ? S.xpos()[3 * tgt + i] : (in.subtree_com ? in.subtree_com[(e * M.nbody + tgt) * 3 + i] : (REAL)0);
+            REAL f[3] = {tp[0] - cp[0], tp[1] - cp[1], tp[2] - cp[2]};
+            normalize_n<REAL, 3>(f);
+            REAL up_hint[3] = {0, 0, 1}, right[3], up[3];
+            cross3(f, up_hint, right);
+            normalize_n<REAL, 3>(right);
+            cross3(right, f, up);
+            for (int i = 0; i < 3; i++) { cm[3 * i + 0] = right[i]; cm[3 * i + 1] = up[i]; cm[3 * i + 2] = -f[i]; }
+          }
+          if (out.cam_xpos) for (int i = 0; i < 3; i++) out.cam_xpos[(e * M.ncam + c) * 3 + i] = cp[i];
+          if (out.cam_xmat) for (int i = 0; i < 9; i++) out.cam_xmat[(e * M.ncam + c) * 9 + i] = cm[i];
+        }
+        for (int q = l; q < M.nlight; q += MJH_WAVE) {  // :200-204
+          const int b = M.light_bodyid[q];
+          REAL r[3], dir[3];
+          rotate(M.light_pos + 3 * q, S.xquat() + 4 * b, r);
+          rotate(M.light_dir + 3 * q, S.xquat() + 4 * b, dir);
+          if (out.light_xpos) for (int i = 0; i < 3; i++) out.light_xpos[(e * M.nlight + q) * 3 + i] = S.xpos()[3 * b + i] + r[i];
+          if (out.light_xdir) for (int i = 0; i < 3; i++) out.light_xdir[(e * M.nlight + q) * 3 + i] = dir[i];
+        }
+      }
+    }
+    wave_sync();
+    put(out.qpos, S.qpos(), M.nq);
+    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
+    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
+    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+    put(out.geom_xpos, S.geom_xpos(), 3 * M.ngeom); put(out.geom_xmat, S.geom_xmat(), 9 * M.ngeom);
+  }
+
+  // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
+  __device__ void com_pos() {
+    const int l = lane_id();
+    const int nb = M.nbody;
+    // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
+    for (int w = l; w < nb * 4; w += MJH_WAVE) {
+      const int b = w >> 2, k = w & 3;
+      const int end = M.body_subtree_end[b];
+      REAL acc = 0;
+      for (int d = end - 1; d >= b; d--) acc += (k < 3) ? S.xipos()[3 * d + k] * M.body_mass[d] : M.body_mass[d];
+      if (k < 3) S.sub_pos()[3 * b + k] = acc; else S.sub_mass()[b] = acc;
+    }
+    wave_sync();
+    for (int w = l; w < nb * 3; w += MJH_WAVE) {
+      const int b = w / 3;
+      const REAL ms = S.sub_mass()[b];
+      const REAL den = ms > (REAL)MINVAL_CACHED ? ms : (REAL)MINVAL_CACHED;
+      S.subtree_com()[w] = (ms < (REAL)mjMINVAL) ? S.xipos()[w] : S.sub_pos()[w] / den;
+    }
+    wave_sync();
+    for (int b = l; b < nb; b += MJH_WAVE) {  // inert_com :236-243
+      const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
+      const REAL off[3] = {S.xipos()[3 * b] - rc[0], S.xipos()[3 * b + 1] - rc[1], S.xipos()[3 * b + 2] - rc[2]};
+      const REAL mass = M.body_mass[b];
+      const REAL* xi = S.ximat() + 9 * b;
+      const REAL* inr = M.body_inertia + 3 * b;
+      const REAL h[3][3] = {{0, -off[2], off[1]}, {off[2], 0, -off[0]}, {-off[1], off[0], 0}};
+      REAL I[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          REAL s = 0, hh = 0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) s += (xi[3 * i + k] * inr[k]) * xi[3 * j + k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) hh += h[i][k] * h[j][k];
+          I[i][j] = s + hh * mass;
+        }
+      REAL* ci = S.cinert() + 10 * b;
+      ci[0] = I[0][0]; ci[1] = I[1][1]; ci[2] = I[2][2]; ci[3] = I[0][1]; ci[4] = I[0][2]; ci[5] = I[1][2];
+      ci[6] = off[0] * mass; ci[7] = off[1] * mass; ci[8] = off[2] * mass; ci[9] = mass;
+    }
+    for (int j = l; j < M.njnt; j += MJH_WAVE) {  // cdof_fn :250-273
+      const int b = M.jnt_bodyid[j], t = M.jnt_type[j];
+      int d = M.jnt_dofadr[j];
+      const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
+      const REAL off[3] = {rc[0] - S.xanchor()[3 * j], rc[1] - S.xanchor()[3 * j + 1], rc[2] - S.xanchor()[3 * j + 2]};
+      if (t == JNT_FREE || t == JNT_BALL) {
+        if (t == JNT_FREE) {
+          for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof()[6 * (d + r) + k] = (k == 3 + r) ? (REAL)1 : (REAL)0;
+          d += 3;
+        }
+        for (int r = 0; r < 3; r++) {
+          const REAL a[3] = {S.xmat()[9 * b + r], S.xmat()[9 * b + 3 + r], S.xmat()[9 * b + 6 + r]};
+          REAL c[3];
+          cross3(a, off, c);
+          for (int k = 0; k < 3; k++) { S.cdof()[6 * (d + r) + k] = a[k]; S.cdof()[6 * (d + r) + 3 + k] = c[k]; }
+        }
+      } else if (t == JNT_HINGE) {
+        REAL c[3];
+        cross3(S.xaxis() + 3 * j, off, c);
+        for (int k = 0; k < 3; k++) { S.cdof()[6 * d + k] = S.xaxis()[3 * j + k]; S.cdof()[6 * d + 3 + k] = c[k]; }
+      } else {
+        for (int k = 0; k < 3; k++) { S.cdof()[6 * d + k] = 0; S.cdof()[6 * d + 3 + k] = S.xaxis()[3 * j + k]; }
+      }
+    }
+    wave_sync();
+    put(out.subtree_com, S.subtree_com(), 3 * nb); put(out.cinert, S.cinert(), 10 * nb); put(out.cdof, S.cdof(), 6 * M.nv);
+  }
+
+  // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
+  __device__ void crb_factor() {
+    const int l = lane_id();
+    const int nb = M.nbody, nv = M.nv;
+    for (int w = l; w < nb * 10; w += MJH_WAVE) {
+      const int b = w / 10, k = w - 10 * b;
+      REAL acc = 0;
+      if (b > 0) {
+        const int end = M.body_subtree_end[b];
+        for (int d = end - 1; d >= b; d--) acc += S.cinert()[10 * d + k];
+      }
+      S.crb()[w] = acc;  // crb[0] = 0 (smooth.py:300-301)
+    }
+    wave_sync();
+    for (int d = l; d < nv; d += MJH_WAVE) inert_mul(S.crb() + 10 * M.dof_bodyid[d], S.cdof() + 6 * d, S.crb_cdof() + 6 * d);
+    wave_sync();
+    for (int w = l; w < nv * nv; w += MJH_WAVE) {
+      const int i = w / nv, j = w - nv * i;
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      REAL s = 0;
+      if ((M.dof_ancmask[hi] >> lo) & 1ull) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += S.crb_cdof()[6 * hi + k] * S.cdof()[6 * lo + k];
+        if (i == j) s = s + M.dof_armature[i];
+      }
+      S.qM()[w] = s;
+    }
+    wave_sync();
+    put(out.crb, S.crb(), 10 * nb); put(out.qM, S.qM(), nv * nv);
+    chol_factor(S.qM(), S.qLD(), nv);
+    put(out.qLD, S.qLD(), nv * nv);
+  }
+
+  // ---- collision (collision_driver.py:800-875, collision_primitive.py, math.py:506-569): one lane per static geom pair ------------------
+  __device__ static void plane_sphere_(const REAL* n, const REAL* ppos, const REAL* spos, REAL r, REAL& dist, REAL* pos) {
+    const REAL d[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
+    dist = dot3(d, n) - r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) pos[i] = spos[i] - n[i] * (r + (REAL)0.5 * dist);
+  }
+  __device__ static void sphere_sphere_(const REAL* p1, REAL r1, const REAL* p2, REAL r2, REAL& dist, REAL* pos, REAL* n) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) n[i] = p2[i] - p1[i];
+    REAL d = normalize_n<REAL, 3>(n);
+    if (d == 0) { n[0] = 1; n[1] = 0; n[2] = 0; }
+    d = d - (r1 + r2);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pos[i] = p1[i] + n[i] * (r1 + d * (REAL)0.5);
+    dist = d;
+  }
+  __device__ static void closest_segment_point(const REAL* a, const REAL* b, const REAL* pt, REAL* o) {
+    const REAL ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    const REAL pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
+    REAL t = dot3(pa, ab) / (dot3(ab, ab) + (REAL)1e-6);
+    t = t < 0 ? (REAL)0 : (t > 1 ? (REAL)1 : t);
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = a[i] + t * ab[i];
+  }
+  __device__ static void closest_segment_to_segment(const REAL* a0, const REAL* a1, const REAL* b0, const REAL* b1, REAL* best_a, REAL* best_b) {
+    REAL dir_a[3], dir_b[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dir_a[i] = a1[i] - a0[i]; dir_b[i] = b1[i] - b0[i]; }
+    const REAL len_a = normalize_n<REAL, 3>(dir_a), len_b = normalize_n<REAL, 3>(dir_b);
+    const REAL hla = len_a * (REAL)0.5, hlb = len_b * (REAL)0.5;
+    REAL a_mid[3], b_mid[3], trans[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { a_mid[i] = a0[i] + dir_a[i] * hla; b_mid[i] = b0[i] + dir_b[i] * hlb; trans[i] = a_mid[i] - b_mid[i]; }
+    const REAL dadb = dot3(dir_a, dir_b), dat = dot3(dir_a, trans), dbt = dot3(dir_b, trans);
+    const REAL denom = 1 - dadb * dadb;
+    const REAL ota = (-dat + dadb * dbt) / (denom + (REAL)1e-6);
+    const REAL otb = dbt + ota * dadb;
+    const REAL ta = ota < -hla ? -hla : (ota > hla ? hla : ota);
+    const REAL tb = otb < -hlb ? -hlb : (otb > hlb ? hlb : otb);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { best_a[i] = a_mid[i] + dir_a[i] * ta; best_b[i] = b_mid[i] + dir_b[i] * tb; }
+    REAL new_a[3], new_b[3];
+    closest_segment_point(a0, a1, best_b, new_a);
+    closest_segment_point(b0, b1, best_a, new_b);
+    REAL d1 = 0, d2 = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { REAL x = best_b[i] - new_a[i]; d1 += x * x; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { REAL x = best_a[i] - new_b[i]; d2 += x * x; }
+    if (d1 < d2) { for (int i = 0; i < 3; i++) best_a[i] = new_a[i]; }
+    else { for (int i = 0; i < 3; i++) best_b[i] = new_b[i]; }
+  }
+
+  __device__ void collision() {
+    const int l = lane_id();
+    for (int p = l; p < M.npair; p += MJH_WAVE) {
+      const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
+      const REAL *p1 = S.geom_xpos() + 3 * g1, *m1 = S.geom_xmat() + 9 * g1, *s1 = M.geom_size + 3 * g1;
+      const REAL *p2 = S.geom_xpos() + 3 * g2, *m2 = S.geom_xmat() + 9 * g2, *s2 = M.geom_size + 3 * g2;
+      REAL dist[2], pos[2][3], frame[9];
+      if (fn == MJH_FN_PLANE_SPHERE) {
+        const REAL n[3] = {m1[2], m1[5], m1[8]};
+        plane_sphere_(n, p1, p2, s2[0], dist[0], pos[0]);
+        make_frame(n, frame);
+      } else if (fn == MJH_FN_PLANE_CAPSULE) {  // collision_primitive.py:48-74
+        const REAL n[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
+        const REAL na = dot3(n, axis);
+        REAL b[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) b[i] = axis[i] - n[i] * na;
+        const REAL bn = normalize_n<REAL, 3>(b);
+        if (bn < (REAL)0.5) {
+          b[0] = 0; b[1] = 0; b[2] = 0;
+          if ((REAL)-0.5 < n[1] && n[1] < (REAL)0.5) b[1] = 1; else b[2] = 1;
+        }
+        REAL c[3];
+        cross3(n, b, c);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { frame[i] = n[i]; frame[3 + i] = b[i]; frame[6 + i] = c[i]; }
+        const REAL seg[3] = {axis[0] * s2[1], axis[1] * s2[1], axis[2] * s2[1]};
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          REAL sp[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) sp[i] = p2[i] + (q == 0 ? seg[i] : -seg[i]);
+          plane_sphere_(n, p1, sp, s2[0], dist[q], pos[q]);
+        }
+      } else if (fn == MJH_FN_SPHERE_SPHERE) {
+        REAL n[3];
+        sphere_sphere_(p1, s1[0], p2, s2[0], dist[0], pos[0], n);
+        make_frame(n, frame);
+      } else if (fn == MJH_FN_SPHERE_CAPSULE) {  // :195-201
+        const REAL axis[3] = {m2[2], m2[5], m2[8]};
+        REAL a[3], b[3], pt[3], n[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { REAL sg = axis[i] * s2[1]; a[i] = p2[i] - sg; b[i] = p2[i] + sg; }
+        closest_segment_point(a, b, p1, pt);
+        sphere_sphere_(p1, s1[0], pt, s2[0], dist[0], pos[0], n);
+        make_frame(n, frame);
+      } else if (fn == MJH_FN_CAPSULE_CAPSULE) {  // :204-221
+        const REAL ax1[3] = {m1[2], m1[5], m1[8]}, ax2[3] = {m2[2], m2[5], m2[8]};
+        REAL a0[3], a1[3], b0[3], b1[3], pt1[3], pt2[3], n[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          REAL sg1 = ax1[i] * s1[1], sg2 = ax2[i] * s2[1];
+          a0[i] = p1[i] - sg1; a1[i] = p1[i] + sg1; b0[i] = p2[i] - sg2; b1[i] = p2[i] + sg2;
+        }
+        closest_segment_to_segment(a0, a1, b0, b1, pt1, pt2);
+        sphere_sphere_(pt1, s1[0], pt2, s2[0], dist[0], pos[0], n);
+        make_frame(n, frame);
+      } else {
+        dist[0] = dist[1] = 1;
+        for (int i = 0; i < 3; i++) pos[0][i] = pos[1][i] = 0;
+        for (int i = 0; i < 9; i++) frame[i] = 0;
+      }
+      for (int q = 0; q < k && q < 2; q++) {
+        const int c = M.pair_dst[p * MJH_MAX_PAIR_CONTACTS + q];
+        S.con_dist()[c] = dist[q];
+        for (int i = 0; i < 3; i++) S.con_pos()[3 * c + i] = pos[q][i];
+        for (int i = 0; i < 9; i++) S.con_frame()[9 * c + i] = frame[i];
+      }
+    }
+    wave_sync();
+    if (store) {
+      const int nc = M.ncon;
+      put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
+      // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
+      row_store(out.contact_includemargin, M.con_includemargin, nc, e);
+      row_store(out.contact_friction, M.con_friction, 5 * nc, e);
+      row_store(out.contact_solref, M.con_solref, 2 * nc, e);
+      row_store(out.contact_solreffriction, M.con_solreffriction, 2 * nc, e);
+      row_store(out.contact_solimp, M.con_solimp, 5 * nc, e);
+      for (int c = l; c < nc; c += MJH_WAVE) {
+        if (out.contact_dim) out.contact_dim[e * nc + c] = M.con_dim[c];
+        if (out.contact_geom1) out.contact_geom1[e * nc + c] = M.con_geom1[c];
+        if (out.contact_geom2) out.contact_geom2[e * nc + c] = M.con_geom2[c];
+        if (out.contact_geom) { out.contact_geom[(e * nc + c) * 2] = M.con_geom1[c]; out.contact_geom[(e * nc + c) * 2 + 1] = M.con_geom2[c]; }
+        if (out.contact_efc_address) out.contact_efc_address[e * nc + c] = M.con_efc_address[c];
+      }
+    }
+  }
+
+  // ---- constraint rows (constraint.py:600-768) ---------------------------------------------------------------------------------------------------
+  // support.jac :138-153 restricted to one dof: jacp / jacr of `point` on `body`, masked to ancestor dofs
+  __device__ __forceinline__ void jac_dof(const REAL* point, int body, int dof, REAL* jp, REAL* jr) const {
+    const REAL on = (REAL)((M.body_dofmask[body] >> dof) & 1ull);
+    const REAL* rc = S.subtree_com() + 3 * M.body_rootid[body];
+    const REAL off[3] = {point[0] - rc[0], point[1] - rc[1], point[2] - rc[2]};
+    const REAL* cd = S.cdof() + 6 * dof;
+    REAL c[3];
+    cross3(cd, off, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { jp[i] = (cd[3 + i] + c[i]) * on; jr[i] = cd[i] * on; }
+  }
+
+  __device__ void kbi(const REAL* solref, const REAL* solimp, REAL pos, REAL& k, REAL& b, REAL& imp) const {  // :69-113
+    REAL timeconst = solref[0], dampratio = solref[1];
+    if (!(M.disableflags & DSBL_REFSAFE)) {
+      const REAL t2 = 2 * M.timestep;
+      timeconst = (timeconst > t2 ? timeconst : t2) * (REAL)(timeconst > 0);
+    }
+    REAL dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+    auto clampf = [](REAL x, REAL lo, REAL hi) { return x < lo ? lo : (x > hi ? hi : x); };
+    dmin = clampf(dmin, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+    dmax = clampf(dmax, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+    width = width > (REAL)MINVAL_CACHED ? width : (REAL)MINVAL_CACHED;
+    mid = clampf(mid, (REAL)mjMINIMP, (REAL)mjMAXIMP);
+    power = power > 1 ? power : (REAL)1;
+    REAL kk = 1 / (dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+    REAL bb = 2 / (dmax * timeconst);
+    if (dampratio <= 0) kk = -dampratio / (dmax * dmax);
+    if (timeconst <= 0) bb = -timeconst / dmax;
+    const REAL imp_x = r_abs(pos) / width;
+    const REAL imp_a = (1 / r_pow<REAL>(mid, power - 1)) * r_pow<REAL>(imp_x, power);
+    const REAL imp_b = 1 - (1 / r_pow<REAL>(1 - mid, power - 1)) * r_pow<REAL>(1 - imp_x, power);
+    const REAL imp_y = imp_x < mid ? imp_a : imp_b;
+    REAL im = dmin + imp_y * (dmax - dmin);
+    im = clampf(im, dmin, dmax);
+    if (imp_x > 1) im = dmax;
+    k = kk; b = bb; imp = im;
+  }
+
+  __device__ void make_constraint() {
+    const int l = lane_id();
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl;
+    if (nefc == 0) return;
+    for (int w = l; w < nl * nv; w += MJH_WAVE) S.efc_J()[w] = 0;
+    wave_sync();
+    for (int r = l; r < nl; r += MJH_WAVE) {  // _instantiate_limit_slide_hinge :338-372
+      const int j = M.lim_jnt[r], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+      const REAL q = S.qpos()[qa];
+      const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
+      const REAL val = (REAL)(dist_min < dist_max) * 2 - 1;
+      const REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M.jnt_margin[j];
+      const REAL active = (REAL)(pos < 0);
+      S.efc_J()[r * nv + da] = val * active;
+      S.efc_pos()[r] = pos * active;
+      S.efc_pos_norm()[r] = pos * active;
+      S.efc_invweight()[r] = M.dof_invweight0[da];
+    }
+    const bool elliptic = M.cone == CONE_ELLIPTIC;
+    // contact rows: one lane per (contact, dof) column entry; all rows of the contact for that dof
+    for (int w = l; w < M.ncon * nv; w += MJH_WAVE) {
+      const int c = w / nv, d = w - nv * c;
+      const int dim = M.con_dim[c], row0 = M.con_efc_address[c];
+      const int b1 = M.geom_bodyid[M.con_geom1[c]], b2 = M.geom_bodyid[M.con_geom2[c]];
+      const REAL* fr = S.con_frame() + 9 * c;
+      const REAL* cpos = S.con_pos() + 3 * c;
+      const REAL* fric = M.con_friction + 5 * c;
+      const REAL dist = S.con_dist()[c] - M.con_includemargin[c];
+      const REAL active = (REAL)(dist < 0);
+      REAL jp1[3], jr1[3], jp2[3], jr2[3];
+      jac_dof(cpos, b2, d, jp2, jr2);
+      jac_dof(cpos, b1, d, jp1, jr1);
+      const REAL dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]};
+      const REAL dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
+      REAL diff[6];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        diff[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2];
+        diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
+      }
+      if (dim == 1) {
+        S.efc_J()[row0 * nv + d] = diff[0] * active;
+      } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
+        const int nedge = 2 * (dim - 1);
+        for (int ed = 0; ed < nedge; ed++) {
+          const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
+          S.efc_J()[(row0 + ed) * nv + d] = (diff[0] + diff[1 + (ed >> 1)] * f) * active;
+        }
+      } else {  // _instantiate_contact_elliptic :519-583
+        for (int r = 0; r < dim; r++) S.efc_J()[(row0 + r) * nv + d] = diff[r] * active;
+      }
+      if (d == 0) {  // per-row scalars of this contact
+        const REAL t = M.body_invweight0[b1] + M.body_invweight0[b2];
+        if (dim == 1) {
+          S.efc_pos()[row0] = dist * active; S.efc_pos_norm()[row0] = dist * active; S.efc_invweight()[row0] = t;
+        } else if (!elliptic) {
+          const REAL mu = fric[0];
+          const REAL iw = (t + mu * mu * t) * 2 * mu * mu / M.impratio;
+          for (int ed = 0; ed < 2 * (dim - 1); ed++) { S.efc_pos()[row0 + ed] = dist * active; S.efc_pos_norm()[row0 + ed] = dist * active; S.efc_invweight()[row0 + ed] = iw; }
+        } else {
+          const REAL iwf = t / M.impratio;
+          for (int r = 0; r < dim; r++) {
+            S.efc_pos()[row0 + r] = (r == 0 ? dist : (REAL)0) * active;
+            S.efc_pos_norm()[row0 + r] = dist;
+            S.efc_invweight()[row0 + r] = (r == 0) ? t : (r == 1 ? iwf : iwf * ((fric[0] * fric[0]) / (fric[r - 1] * fric[r - 1])));
+          }
+        }
+      }
+    }
+    wave_sync();
+    for (int r = l; r < nefc; r += MJH_WAVE) {  // :683-693
+      REAL solref[2], solimp[5];
+      if (r < nl) {
+        const int j = M.lim_jnt[r];
+        solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
+        for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
+      } else {
+        const int c = M.efc_row_con[r], sub = r - M.con_efc_address[c];
+        const REAL* sr = M.con_solref + 2 * c;
+        solref[0] = sr[0]; solref[1] = sr[1];
+        if (elliptic && M.con_dim[c] > 1 && sub > 0) {
+          const REAL* sf = M.con_solreffriction + 2 * c;
+          const REAL none = (REAL)(!((sf[0] != 0) || (sf[1] != 0)));
+          solref[0] = sf[0] + sr[0] * none; solref[1] = sf[1] + sr[1] * none;
+        }
+        for (int i = 0; i < 5; i++) solimp[i] = M.con_solimp[5 * c + i];
+      }
+      REAL k, b, imp;
+      kbi(solref, solimp, S.efc_pos_norm()[r], k, b, imp);
+      REAL rr = S.efc_invweight()[r] * (1 - imp) / imp;
+      rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
+      REAL jv = 0;
+      for (int d = 0; d < nv; d++) jv += S.efc_J()[r * nv + d] * S.qvel()[d];
+      S.efc_aref()[r] = -b * jv - k * imp * S.efc_pos()[r];
+      S.efc_D()[r] = 1 / rr;
+    }
+    wave_sync();
+    put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
+    if (store && out.efc_frictionloss) for (int r = l; r < nefc; r += MJH_WAVE) out.efc_frictionloss[e * nefc + r] = 0;
+  }
+
+  // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
+  __device__ void velocity() {
+    const int l = lane_id();
+    const int nv = M.nv, nb = M.nbody, nu = M.nu;
+    for (int i = l; i < nu; i += MJH_WAVE) {
+      const REAL gear = M.act_gear[6 * i];
+      S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
+      S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
+    }
+    if (store && out.actuator_moment) {
+      for (int w = l; w < nu * nv; w += MJH_WAVE) {
+        const int i = w / nv, d = w - nv * i;
+        out.actuator_moment[e * nu * nv + w] = (d == M.act_dofadr[i]) ? M.act_gear[6 * i] : (REAL)0;
+      }
+    }
+    // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
+    for (int b = l; b < nb; b += MJH_WAVE) {
+      REAL cvel[6] = {0, 0, 0, 0, 0, 0};
+      const int depth = M.body_depth[b];
+      for (int kk = 0; kk < depth; kk++) {
+        const int c = M.body_chain[b * M.max_depth + kk];
+        const bool own = (kk == depth - 1);
+        const int jn = M.body_jntnum[c], j0 = M.body_jntadr[c];
+        for (int jj = 0; jj < jn; jj++) {
+          const int j = j0 + jj, t = M.jnt_type[j], d = M.jnt_dofadr[j];
+          if (t == JNT_FREE) {
+            REAL s[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * d + k] * S.qvel()[d] + S.cdof()[6 * (d + 1) + k] * S.qvel()[d + 1]) + S.cdof()[6 * (d + 2) + k] * S.qvel()[d + 2];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+            if (own) {
+              for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof_dot()[6 * (d + r) + k] = 0;
+              for (int r = 3; r < 6; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * (d + 3) + k] * S.qvel()[d + 3] + S.cdof()[6 * (d + 4) + k] * S.qvel()[d + 4]) + S.cdof()[6 * (d + 5) + k] * S.qvel()[d + 5];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+          } else {
+            const int width = (t == JNT_BALL) ? 3 : 1;
+            if (own) for (int r = 0; r < width; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+            REAL s[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+              s[k] = S.cdof()[6 * d + k] * S.qvel()[d];
+              for (int r = 1; r < width; r++) s[k] = s[k] + S.cdof()[6 * (d + r) + k] * S.qvel()[d + r];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) S.cvel()[6 * b + k] = cvel[k];
+    }
+    // passive forces
+    if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
+      for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = 0;
+    } else {
+      for (int j = l; j < M.njnt; j += MJH_WAVE) {
+        const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+        const REAL k = M.jnt_stiffness[j];
+        if (t == JNT_FREE) {
+          for (int i = 0; i < 3; i++) S.qfrc_passive()[da + i] = -k * (S.qpos()[qa + i] - M.qpos_spring[qa + i]);
+          REAL r[3];
+          quat_sub(S.qpos() + qa + 3, M.qpos_spring + qa + 3, r);
+          for (int i = 0; i < 3; i++) S.qfrc_passive()[da + 3 + i] = -k * r[i];
+        } else if (t == JNT_BALL) {
+          REAL r[3];
+          quat_sub(S.qpos() + qa, M.qpos_spring + qa, r);
+          for (int i = 0; i < 3; i++) S.qfrc_passive()[da + i] = -k * r[i];
+        } else {
+          S.qfrc_passive()[da] = -k * (S.qpos()[qa] - M.qpos_spring[qa]);
+        }
+      }
+      wave_sync();
+      for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
+    }
+    wave_sync();
+    // rne: cacc along the ancestor chain (needs cdof_dot of ancestors: written above, visible after the sync)
+    for (int b = l; b < nb; b += MJH_WAVE) {
+      REAL cacc[6];
+      const bool nograv = M.disableflags & DSBL_GRAVITY;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { cacc[k] = 0; cacc[3 + k] = nograv ? (REAL)0 : -M.gravity[k]; }
+      const int depth = M.body_depth[b];
+      for (int kk = 0; kk < depth; kk++) {
+        const int c = M.body_chain[b * M.max_depth + kk];
+        const int d0 = M.body_dofadr[c], nd = M.body_dofnum[c];
+        if (nd > 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            REAL s = S.cdof_dot()[6 * d0 + k] * S.qvel()[d0];
+            for (int r = 1; r < nd; r++) s = s + S.cdof_dot()[6 * (d0 + r) + k] * S.qvel()[d0 + r];
+            cacc[k] = cacc[k] + s;
+          }
+        }
+      }
+      REAL f1[6], f2[6], f3[6];
+      inert_mul(S.cinert() + 10 * b, cacc, f1);
+      inert_mul(S.cinert() + 10 * b, S.cvel() + 6 * b, f2);
+      motion_cross_force(S.cvel() + 6 * b, f2, f3);
+#pragma unroll
+      for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc (cacc itself is not a Data output)
+    }
+    wave_sync();
+    for (int w = l; w < nb * 6; w += MJH_WAVE) {  // subtree sums of the body forces
+      const int b = w / 6, k = w - 6 * b;
+      const int end = M.body_subtree_end[b];
+      REAL acc = 0;
+      for (int d = end - 1; d >= b; d--) acc += S.cacc()[6 * d + k];
+      S.cfrc()[w] = acc;
+    }
+    wave_sync();
+    for (int d = l; d < nv; d += MJH_WAVE) {
+      REAL s = 0;
+      const REAL* cf = S.cfrc() + 6 * M.dof_bodyid[d];
+#pragma unroll
+      for (int k = 0; k < 6; k++) s += S.cdof()[6 * d + k] * cf[k];
+      S.qfrc_bias()[d] = s;
+    }
+    wave_sync();
+    put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
+    put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
+    put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
+  }
+
+  // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
+  __device__ void actuation() {
+    const int l = lane_id();
+    const int nv = M.nv, nu = M.nu;
+    const bool off = (nu == 0) || (M.disableflags & DSBL_ACTUATION);
+    if (off) {
+      for (int i = l; i < M.na; i += MJH_WAVE) S.act_dot()[i] = 0;
+    } else {
+      for (int i = l; i < nu; i += MJH_WAVE) {
+        REAL ctrl = in.ctrl ? in.ctrl[e * nu + i] : (REAL)0;
+        if (!(M.disableflags & DSBL_CLAMPCTRL) && M.act_ctrllimited[i]) {
+          const REAL lo = M.act_ctrlrange[2 * i], hi = M.act_ctrlrange[2 * i + 1];
+          ctrl = ctrl > lo ? ctrl : lo;
+          ctrl = ctrl < hi ? ctrl : hi;
+        }
+        REAL ctrl_act = ctrl;
+        const int dyn = M.act_dyntype[i];
+        if (dyn != DYN_NONE) {
+          const int a = M.act_actadr[i];
+          const REAL act = S.act()[a];
+          if (dyn == DYN_INTEGRATOR) S.act_dot()[a] = ctrl;
+          else {
+            REAL tau = M.act_dynprm[3 * i];
+            tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
+            S.act_dot()[a] = (ctrl - act) / tau;
+          }
+          ctrl_act = S.act()[a + M.act_actnum[i] - 1];
+        }
+        const REAL len = S.act_length()[i], vel = S.act_velocity()[i];
+        const REAL* gp = M.act_gainprm + 3 * i;
+        const REAL* bp = M.act_biasprm + 3 * i;
+        const REAL gain = (M.act_gaintype[i] == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
+        const REAL bias = (M.act_biastype[i] == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : (REAL)0;
+        REAL force = gain * ctrl_act + bias;
+        if (M.act_forcelimited[i]) {
+          const REAL lo = M.act_forcerange[2 * i], hi = M.act_forcerange[2 * i + 1];
+          force = force < lo ? lo : (force > hi ? hi : force);
+        }
+        S.act_force()[i] = force;
+      }
+    }
+    wave_sync();
+    for (int d = l; d < nv; d += MJH_WAVE) {
+      REAL s = 0;
+      if (!off) {
+        for (int i = 0; i < nu; i++) if (M.act_dofadr[i] == d) s += M.act_gear[6 * i] * S.act_force()[i];
+        const int j = M.dof_jntid[d];
+        if (M.jnt_actfrclimited[j]) {
+          const REAL lo = M.jnt_actfrcrange[2 * j], hi = M.jnt_actfrcrange[2 * j + 1];
+          s = s < lo ? lo : (s > hi ? hi : s);
+        }
+      }
+      S.qfrc_actuator()[d] = s;
+      // xfrc_accumulate: sum over bodies of jacp^T f + jacr^T tau at the body's inertial origin
+      REAL acc = 0;
+      if (in.xfrc_applied) {
+        for (int b = 0; b < M.nbody; b++) {
+          const REAL* f = in.xfrc_applied + (e * M.nbody + b) * 6;
+          REAL jp[3], jr[3];
+          jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+          const REAL ff[3] = {f[0], f[1], f[2]}, tt[3] = {f[3], f[4], f[5]};
+          acc += dot3(jp, ff) + dot3(jr, tt);
+        }
+      }
+      const REAL applied = (in.qfrc_applied ? in.qfrc_applied[e * nv + d] : (REAL)0) + acc;
+      S.qfrc_smooth()[d] = ((S.qfrc_passive()[d] - S.qfrc_bias()[d]) + s) + applied;
+    }
+    wave_sync();
+    chol_solve(S.qLD(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    if (!off) put(out.actuator_force, S.act_force(), nu);
+    put(out.act_dot, S.act_dot(), M.na);
+    put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv); put(out.qacc_smooth, S.qacc_smooth(), nv);
+  }
+
+  // ---- solver (solver.py:244-553) -----------------------------------------------------------------------------------------------------------------------------
+  struct LSPoint { REAL alpha, cost, d0, d1; };
+  struct Ctx { REAL gauss, cost, prev_cost; int niter; };
+
+  __device__ void mul_M(const REAL* v, REAL* o) {  // (dense_M * v).sum(-1)
+    const int nv = M.nv;
+    for (int i = lane_id(); i < nv; i += MJH_WAVE) {
+      REAL s = 0;
+      for (int j = 0; j < nv; j++) s += S.qM()[i * nv + j] * v[j];
+      o[i] = s;
+    }
+  }
+  __device__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {  // efc_J @ v  (- sub)
+    const int nv = M.nv;
+    for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
+      REAL s = 0;
+      for (int d = 0; d < nv; d++) s += S.efc_J()[r * nv + d] * v[d];
+      o[r] = sub ? s - sub[r] : s;
+    }
+  }
+
+  __device__ void update_constraint(Ctx& c) {  // :320-357
+    const int l = lane_id();
+    const int nv = M.nv, nefc = M.nefc;
+    REAL part = 0;
+    for (int r = l; r < nefc; r += MJH_WAVE) {
+      const REAL ja = S.s_Jaref()[r];
+      const REAL active = (REAL)(ja < 0);
+      S.s_force()[r] = S.efc_D()[r] * -ja * active + 0;
+      part += S.efc_D()[r] * ja * ja * active;
+    }
+    REAL gpart = 0;
+    for (int d = l; d < nv; d += MJH_WAVE) gpart += (S.s_Ma()[d] - S.qfrc_smooth()[d]) * (S.s_qacc()[d] - S.qacc_smooth()[d]);
+    const REAL csum = wave_sum(part);
+    const REAL g = wave_sum(gpart);
+    wave_sync();
+    for (int d = l; d < nv; d += MJH_WAVE) {
+      REAL s = 0;
+      for (int r = 0; r < nefc; r++) s += S.efc_J()[r * nv + d] * S.s_force()[r];
+      S.s_qfrc()[d] = s;
+    }
+    c.gauss = (REAL)0.5 * g;
+    c.prev_cost = c.cost;
+    c.cost = ((REAL)0.5 * csum + c.gauss) + 0;
+    wave_sync();
+  }
+
+  __device__ void update_gradient() {  // :359-376
+    const int l = lane_id();
+    const int nv = M.nv, nefc = M.nefc;
+    for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
+    wave_sync();
+    if (M.solver == SOL_CG) {
+      chol_solve(S.qLD(), S.s_grad(), S.s_Mgrad(), nv);
+    } else {
+      for (int w = l; w < nv * nv; w += MJH_WAVE) {
+        const int i = w / nv, j = w - nv * i;
+        REAL s = 0;
+        for (int r = 0; r < nefc; r++) {
+          const REAL active = (REAL)(S.s_Jaref()[r] < 0);
+          s += (S.efc_J()[r * nv + i] * S.efc_D()[r] * active) * S.efc_J()[r * nv + j];
+        }
+        S.H()[w] = S.qM()[w] + s;
+      }
+      wave_sync();
+      chol_factor(S.H(), S.HL(), nv);
+      chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+    }
+  }
+
+  __device__ void create_context(Ctx& c, const REAL* qacc, bool grad_flag) {  // :293-318
+    const int l = lane_id();
+    const int nv = M.nv;
+    for (int d = l; d < nv; d += MJH_WAVE) S.s_qacc()[d] = qacc[d];
+    wave_sync();
+    mul_J(S.s_qacc(), S.s_Jaref(), S.efc_aref());
+    mul_M(S.s_qacc(), S.s_Ma());
+    c.gauss = 0; c.cost = (REAL)INFINITY; c.prev_cost = 0; c.niter = 0;
+    for (int d = l; d < nv; d += MJH_WAVE) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
+    wave_sync();
+    update_constraint(c);
+    if (grad_flag) {
+      update_gradient();
+      for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
+      wave_sync();
+    }
+  }
+
+  __device__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
+    REAL q0 = 0, q1 = 0, q2 = 0;
+    for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
+      const REAL x = S.s_Jaref()[r] + alpha * S.s_jv()[r];
+      const REAL a = (REAL)(x < 0);
+      q0 += S.s_quad()[3 * r] * a;
+      q1 += S.s_quad()[3 * r + 1] * a;
+      q2 += S.s_quad()[3 * r + 2] * a;
+    }
+    q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
+    const REAL t0 = (qg[0] + q0) + 0, t1 = (qg[1] + q1) + 0, t2 = (qg[2] + q2) + 0;
+    LSPoint p;
+    p.alpha = alpha;
+    p.cost = alpha * alpha * t2 + alpha * t1 + t0;
+    p.d0 = 2 * alpha * t2 + t1;
+    p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
+    return p;
+  }
+  __device__ static bool ls_swap(REAL cur, REAL cand, bool not_bracketed) {  // _swap :440-449
+    const bool in_bracket = ((cur < cand) && (cand < 0)) || ((cur > cand) && (cand > 0));
+    return in_bracket || (not_bracketed && (r_abs(cand) < r_abs(cur)));
+  }
+
+  __device__ void linesearch(Ctx& c) {  // :378-497
+    const int l = lane_id();
+    const int nv = M.nv, nefc = M.nefc;
+    const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
+    REAL ss = 0;
+    bool nz = false;
+    for (int d = l; d < nv; d += MJH_WAVE) { ss += S.s_search()[d] * S.s_search()[d]; nz = nz || (S.s_search()[d] != 0); }
+    ss = wave_sum(ss);
+    const REAL snorm = wave_any(nz) ? r_sqrt<REAL>(ss) : (REAL)0;
+    const REAL smag = snorm * scale;
+    const REAL gtol = (REAL)(M.tolerance * M.ls_tolerance) * smag;
+    mul_M(S.s_search(), S.s_mv());
+    mul_J(S.s_search(), S.s_jv(), nullptr);
+    wave_sync();
+    REAL a = 0, b = 0, cc = 0;
+    for (int d = l; d < nv; d += MJH_WAVE) { a += S.s_search()[d] * S.s_Ma()[d]; b += S.s_search()[d] * S.qfrc_smooth()[d]; cc += S.s_search()[d] * S.s_mv()[d]; }
+    a = wave_sum(a); b = wave_sum(b); cc = wave_sum(cc);
+    const REAL qg[3] = {c.gauss, a - b, (REAL)0.5 * cc};
+    for (int r = l; r < nefc; r += MJH_WAVE) {
+      const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r], D = S.efc_D()[r];
+      S.s_quad()[3 * r] = ((REAL)0.5 * ja * ja) * D;
+      S.s_quad()[3 * r + 1] = (jv * ja) * D;
+      S.s_quad()[3 * r + 2] = ((REAL)0.5 * jv * jv) * D;
+    }
+    wave_sync();
+    const LSPoint p0 = ls_point(qg, 0);
+    const LSPoint p1 = ls_point(qg, p0.alpha - p0.d0 / p0.d1);
+    const bool early = r_abs(p1.d0) < gtol;
+    LSPoint lo, hi;
+    if (p1.d0 < p0.d0) { hi = p0; lo = p1; } else { hi = p1; lo = p0; }
+    bool swap = !early;
+    int ls_iter = 0;
+    const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
+    for (;;) {
+      if (fixed) { if (ls_iter >= M.ls_iterations) break; }
+      else {
+        bool done = ls_iter >= M.ls_iterations;
+        done |= !swap;
+        done |= (lo.d0 < 0) && (lo.d0 > -gtol);
+        done |= (hi.d0 > 0) && (hi.d0 < gtol);
+        if (done) break;
+      }
+      const LSPoint lo_next = ls_point(qg, lo.alpha - lo.d0 / lo.d1);
+      const LSPoint hi_next = ls_point(qg, hi.alpha - hi.d0 / hi.d1);
+      const LSPoint mid = ls_point(qg, (REAL)0.5 * (lo.alpha + hi.alpha));
+      const bool nb = (lo.d0 < 0) == (hi.d0 < 0);
+      const bool s1 = ls_swap(lo.d0, lo_next.d0, nb); if (s1) lo = lo_next;
+      const bool s2 = ls_swap(lo.d0, mid.d0, nb); if (s2) lo = mid;
+      const bool s3 = ls_swap(lo.d0, hi_next.d0, nb); if (s3) lo = hi_next;
+      const bool s4 = ls_swap(hi.d0, hi_next.d0, nb); if (s4) hi = hi_next;
+      const bool s5 = ls_swap(hi.d0, mid.d0, nb); if (s5) hi = mid;
+      const bool s6 = ls_swap(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
+      swap = s1 | s2 | s3 | s4 | s5 | s6;
+      ls_iter++;
+    }
+    const REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
+    const REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+    for (int d = l; d < nv; d += MJH_WAVE) {
+      S.s_qacc()[d] = S.s_qacc()[d] + improved * S.s_search()[d] * alpha;
+      S.s_Ma()[d] = S.s_Ma()[d] + improved * S.s_mv()[d] * alpha;
+    }
+    for (int r = l; r < nefc; r += MJH_WAVE) S.s_Jaref()[r] = S.s_Jaref()[r] + improved * S.s_jv()[r] * alpha;
+    wave_sync();
+  }
+
+  __device__ void solve() {
+    const int l = lane_id();
+    const int nv = M.nv, nefc = M.nefc;
+    const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
+    const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
+    Ctx c;
+    bool use_warm = false;
+    if (!(M.disableflags & DSBL_WARMSTART)) {  // :526-531
+      create_context(c, S.qacc_warm(), false);
+      const REAL warm_cost = c.cost;
+      create_context(c, S.qacc_smooth(), false);
+      use_warm = warm_cost < c.cost;
+    }
+    for (int d = l; d < nv; d += MJH_WAVE) S.tmp_nv()[d] = use_warm ? S.qacc_warm()[d] : S.qacc_smooth()[d];
+    wave_sync();
+    create_context(c, S.tmp_nv(), true);
+    for (int it = 0;; it++) {
+      if (M.iterations == 1) { if (it >= 1) break; }
+      else if (fixed) { if (it >= M.iterations) break; }
+      else {  // cond :501-508
+        REAL gg = 0;
+        for (int d = l; d < nv; d += MJH_WAVE) gg += S.s_grad()[d] * S.s_grad()[d];
+        gg = wave_sum(gg);
+        const REAL improvement = (c.prev_cost - c.cost) / scale;
+        const REAL gradient = r_sqrt<REAL>(gg) / scale;
+        bool done = c.niter >= M.iterations;
+        done |= improvement < (REAL)M.tolerance;
+        done |= gradient < (REAL)M.tolerance;
+        if (done) break;
+      }
+      linesearch(c);
+      for (int d = l; d < nv; d += MJH_WAVE) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
+      wave_sync();
+      update_constraint(c);
+      update_gradient();
+      if (M.solver == SOL_NEWTON) {
+        for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
+      } else {  // Polak-Ribiere :519-523
+        REAL num = 0, den = 0;
+        for (int d = l; d < nv; d += MJH_WAVE) { num += S.s_grad()[d] * (S.s_Mgrad()[d] - S.s_pMgrad()[d]); den += S.s_pgrad()[d] * S.s_pMgrad()[d]; }
+        num = wave_sum(num); den = wave_sum(den);
+        REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+        beta = beta > 0 ? beta : (REAL)0;
+        for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d] + beta * S.s_search()[d];
+      }
+      wave_sync();
+      c.niter++;
+    }
+    for (int d = l; d < nv; d += MJH_WAVE) { S.qacc()[d] = S.s_qacc()[d]; S.qacc_warm()[d] = S.s_qacc()[d]; S.qfrc_constraint()[d] = S.s_qfrc()[d]; }
+    wave_sync();
+    put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
+    put(out.efc_force, S.s_force(), nefc);
+  }
+
+  // ---- forward (forward.py:373-401) --------------------------------------------------------------------------------------------------------------------------
+  __device__ void forward(int stages, bool with_cams) {
+    if (stages & 0x7f) { kinematics(with_cams); com_pos(); }
+    if (stages & 0x7e) crb_factor();
+    if ((stages & 0x7c) && M.ncon > 0) collision();
+    if (stages & 0x78) make_constraint();
+    if (stages & 0x70) velocity();
+    if (stages & 0x60) actuation();
+    if (stages & 0x40) {
+      if (M.nefc == 0) {
+        for (int d = lane_id(); d < M.nv; d += MJH_WAVE) S.qacc()[d] = S.qacc_smooth()[d];
+        wave_sync();
+        put(out.qacc, S.qacc(), M.nv);
+      } else {
+        solve();
+      }
+    }
+  }
+
+  // ---- integrators (forward.py:231-370) ---------------------------------------------------------------------------------------------------------------------------
+  __device__ void integrate_pos(const REAL* qpos, const REAL* qvel, REAL dt, REAL* o) {  // :231-252, one lane per joint
+    for (int j = lane_id(); j < M.njnt; j += MJH_WAVE) {
+      const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+      if (t == JNT_FREE) {
+        for (int i = 0; i < 3; i++) o[qa + i] = qpos[qa + i] + dt * qvel[da + i];
+        REAL q[4] = {qpos[qa + 3], qpos[qa + 4], qpos[qa + 5], qpos[qa + 6]}, w[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]}, r[4];
+        quat_integrate(q, w, dt, r);
+        for (int i = 0; i < 4; i++) o[qa + 3 + i] = r[i];
+      } else if (t == JNT_BALL) {
+        REAL q[4] = {qpos[qa], qpos[qa + 1], qpos[qa + 2], qpos[qa + 3]}, w[3] = {qvel[da], qvel[da + 1], qvel[da + 2]}, r[4];
+        quat_integrate(q, w, dt, r);
+        for (int i = 0; i < 4; i++) o[qa + i] = r[i];
+      } else {
+        o[qa] = qpos[qa] + dt * qvel[da];
+      }
+    }
+  }
+
+  // _advance :255-310. qpos0/qvel0/act0: the state being advanced; writes qpos/qvel/act/time of `out`.
+  __device__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
+    const int l = lane_id();
+    const REAL dt = M.timestep;
+    for (int i = l; i < M.nu; i += MJH_WAVE) {
+      const int dyn = M.act_dyntype[i];
+      if (dyn == DYN_NONE) continue;
+      const int a = M.act_actadr[i];
+      REAL act = act0[a];
+      if (dyn == DYN_FILTEREXACT) {
+        REAL tau = M.act_dynprm[3 * i];
+        tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
+        act = act + act_dot[a] * tau * (1 - r_exp<REAL>(-dt / tau));
+      } else {
+        act = act + act_dot[a] * dt;
+      }
+      if (M.act_actlimited[i]) {
+        const REAL lo = M.act_actrange[2 * i], hi = M.act_actrange[2 * i + 1];
+        act = act < lo ? lo : (act > hi ? hi : act);
+      }
+      if (out.act) out.act[e * M.na + a] = act;
+    }
+    for (int d = l; d < M.nv; d += MJH_WAVE) S.tmp_nv()[d] = qvel0[d] + qacc[d] * dt;
+    wave_sync();
+    integrate_pos(qpos0, qvel_for_pos ? qvel_for_pos : S.tmp_nv(), dt, S.tmp_nq());
+    wave_sync();
+    row_store(out.qpos, S.tmp_nq(), M.nq, e);
+    row_store(out.qvel, S.tmp_nv(), M.nv, e);
+    if (l == 0 && out.time) out.time[e] = time0 + dt;
+  }
+
+  __device__ void step() {
+    const int l = lane_id();
+    const int nq = M.nq, nv = M.nv, na = M.na;
+    load_state(true);
+    // qacc is checked too (forward.py:52-56) but is never read before being overwritten; nothing to do.
+    const REAL time0 = in.time ? in.time[e] : (REAL)0;
+    forward(MJH_STAGE_ALL, true);
+    if (M.integrator == INT_EULER) {  // _euler :313-328
+      const REAL* qacc = S.qacc();
+      if (!(M.disableflags & DSBL_EULERDAMP)) {
+        for (int w = l; w < nv * nv; w += MJH_WAVE) {
+          const int i = w / nv, j = w - nv * i;
+          S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
+        }
+        for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
+        wave_sync();
+        chol_factor(S.H(), S.HL(), nv);
+        chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+        qacc = S.s_Mgrad();
+      }
+      advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
+      return;
+    }
+    // _rungekutta4 :331-370
+    const REAL A[3] = {(REAL)0.5, (REAL)0.5, (REAL)1.0};
+    const REAL Bt[4] = {(REAL)(float)(1.0 / 6.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 6.0)};
+    const REAL dt = M.timestep;
+    for (int i = l; i < nq; i += MJH_WAVE) S.rk_qpos0()[i] = S.qpos()[i];
+    for (int i = l; i < nv; i += MJH_WAVE) {
+      S.rk_qvel0()[i] = S.qvel()[i]; S.rk_kqvel()[i] = S.qvel()[i];
+      S.rk_qvel()[i] = Bt[0] * S.qvel()[i]; S.rk_qacc()[i] = Bt[0] * S.qacc()[i];
+    }
+    for (int i = l; i < na; i += MJH_WAVE) { S.rk_act0()[i] = S.act()[i]; S.rk_actdot()[i] = Bt[0] * S.act_dot()[i]; }
+    wave_sync();
+    store = false;
+    for (int s = 0; s < 3; s++) {
+      const REAL a = A[s], b = Bt[s + 1];
+      for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.rk_kqvel()[i];
+      wave_sync();
+      integrate_pos(S.rk_qpos0(), S.tmp_nv2(), dt, S.tmp_nq());
+      for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = S.rk_act0()[i] + (a * S.act_dot()[i]) * dt;
+      for (int i = l; i < nv; i += MJH_WAVE) S.rk_kqvel()[i] = S.rk_qvel0()[i] + (a * S.qacc()[i]) * dt;
+      wave_sync();
+      for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
+      for (int i = l; i < nv; i += MJH_WAVE) S.qvel()[i] = S.rk_kqvel()[i];
+      wave_sync();
+      forward(MJH_STAGE_ALL, false);
+      for (int i = l; i < nv; i += MJH_WAVE) { S.rk_qvel()[i] = S.rk_qvel()[i] + b * S.rk_kqvel()[i]; S.rk_qacc()[i] = S.rk_qacc()[i] + b * S.qacc()[i]; }
+      for (int i = l; i < na; i += MJH_WAVE) S.rk_actdot()[i] = S.rk_actdot()[i] + b * S.act_dot()[i];
+      wave_sync();
+    }
+    store = true;
+    advance(S.rk_qpos0(), S.rk_qvel0(), S.rk_act0(), time0, S.rk_actdot(), S.rk_qacc(), S.rk_qvel());
+  }
+};
+
+#undef M
+#undef in
+#undef out
+
+template <typename REAL>
+__global__ void __launch_bounds__(MJH_WAVE) mjh_step_kernel(KArgs<REAL> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  REAL* lds = reinterpret_cast<REAL*>(lds_raw);
+  const KArgs<REAL>& K = kargs<REAL>();
+  for (int64_t env = blockIdx.x; env < K.B; env += gridDim.x) {
+    Env<REAL> E(lds, env, K.flags);
+    if (K.do_step) E.step();
+    else { E.load_state(false); E.forward(K.stages, true); }
+    wave_sync();
+  }
+}

@@ -98,3 +98,37 @@ def oracle_alternatives(model, d, step=True, **kw):
         if int(knife.max()) <= pol:  # fewer noise candidates than the policy index: every one was rejected
             break
     return outs
+
+
+def gpu_out_to_numpy(d):
+    """Data on the GPU -> {abi leaf: numpy} (host)."""
+    return {n: leaf(d, n).detach().cpu().numpy() for n in REAL_LEAVES + INT_LEAVES}
+
+
+PRE_SOLVER = [n for n in REAL_LEAVES if n not in SOLVER_LEAVES]
+
+
+def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, **kw):
+    """HIP outputs `got` (dict of numpy, batched) vs the oracle on the same inputs.
+
+    * leaves upstream of the solver and all integer leaves: must agree outright (tol_pre / exact);
+    * solver-dependent leaves, per environment: must agree with the oracle under ONE admissible rounding
+      outcome of the line search's noise candidates (oracle_alternatives).  Returns the fraction of
+      environments that needed a non-natural branch."""
+    alts = oracle_alternatives(model, d_cpu, step=step, **kw)
+    nat = alts[0]
+    assert_leaves_close(lambda n: got[n], lambda n: nat[n], tol_pre, names=PRE_SOLVER, what=what)
+    assert_ints_equal(lambda n: got[n], lambda n: nat[n], what=what)
+    batched = d_cpu.qpos.ndim > 1
+    B = d_cpu.qpos.shape[0] if batched else 1
+    need_alt = 0
+    worst = 0.0
+    for e in range(B):
+        pick = (lambda a, n: a[n][e]) if batched else (lambda a, n: a[n])
+        errs = [max(rel_err(pick(got, n), pick(a, n)) for n in SOLVER_LEAVES) for a in alts]
+        best = min(errs)
+        worst = max(worst, best)
+        assert best <= tol_solver, f"{what} env {e}: solver outputs match no admissible oracle branch: {errs}"
+        need_alt += errs[0] > tol_solver
+    assert need_alt / B <= max_alt_frac, f"{what}: {need_alt}/{B} envs needed a non-natural branch"
+    return need_alt / B, worst

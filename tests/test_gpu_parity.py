@@ -1,0 +1,135 @@
+"""HIP path (through the C ABI, via mujoco_torch_amd.step) against golden vectors and the CPU oracle.
+
+Tolerances (relative to the leaf's max magnitude):
+  float64: 1e-9 for leaves upstream of the solver, 1e-7 for solver-dependent leaves on the admissible
+           branch (see _util.check_against_oracle); north_star asks for < 1e-8 on the state.
+  float32: 2e-4 / 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import mujoco_torch_amd as mt
+import pyoracle
+from _util import (GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+                   assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
+
+pytestmark = pytest.mark.gpu
+
+TOL_PRE = {torch.float64: 1e-9, torch.float32: 2e-4}
+TOL_SOL = {torch.float64: 1e-7, torch.float32: 2e-3}
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_step_matches_reference_golden(case, oracle_lib):
+    """Reference-recorded steps, teacher-forced: pre-solver leaves vs the golden vectors directly,
+    solver leaves vs golden OR an admissible oracle branch (the golden is one such branch)."""
+    g = Golden(case)
+    mdev = g.model.to("cuda")
+    d = g.input_data()  # all envs batched
+    for s in range(g.nsteps):
+        out = gpu_out_to_numpy(mt.step(mdev, d.to("cuda")))
+        want = lambda n: np.stack([g.expected(e, s, n) for e in range(g.nenv)])
+        what = f"{case} step{s}"
+        assert_leaves_close(lambda n: out[n], want, TOL_PRE[g.dtype], names=PRE_SOLVER, what=what)
+        assert_ints_equal(lambda n: out[n], want, what=what)
+        for e in range(g.nenv):
+            err_gold = max(rel_err(out[n][e], g.expected(e, s, n)) for n in SOLVER_LEAVES)
+            if err_gold > TOL_SOL[g.dtype]:
+                check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, TOL_PRE[g.dtype], TOL_SOL[g.dtype], what=f"{what} env{e}")
+        d = pyoracle.apply(d, {n: want(n) for n in REAL_LEAVES + INT_LEAVES})
+
+
+@pytest.mark.parametrize("xml,overrides,dtype,B", [
+    ("humanoid", {"solver": 1}, torch.float64, 256),
+    ("humanoid", {}, torch.float64, 64),
+    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 128),
+    ("ant", {}, torch.float64, 64),
+    ("cartpole", {}, torch.float64, 64),
+])
+def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_lib):
+    """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs."""
+    mx = load_model(xml, overrides, dtype)
+    rng = np.random.RandomState(42)
+    d = mt.make_data(mx).expand(B).clone()
+    d = d.replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(B, mx.nu)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    mdev = mx.to("cuda")
+    dg = d.to("cuda")
+    for s in range(3):
+        og = mt.step(mdev, dg)
+        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], TOL_SOL[dtype], what=f"{xml} step{s}", nthreads=4)
+        print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural line-search branch, worst solver rel err {worst:.2e}")
+        dg = og
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 2 size (humanoid, B = 4096, float64): size-independent properties.
+
+    * environments are independent: a batch made of 64 distinct states tiled 64x gives bit-identical
+      results for every copy, and equals the same states stepped as a B = 64 batch;
+    * outputs are finite, free-joint quaternions are unit, untouched leaves alias the input."""
+    mx = load_model("humanoid", {"solver": 1})
+    B, U = 4096, 64
+    rng = np.random.RandomState(0)
+    base = mt.make_data(mx).expand(U).clone().replace(qvel=torch.tensor(0.01 * rng.randn(U, mx.nv)))
+    idx = torch.arange(B) % U
+    big = base[idx].clone()
+    mdev = mx.to("cuda")
+    small_out = mt.step(mdev, base.to("cuda"))
+    big_in = big.to("cuda")
+    big_out = mt.step(mdev, big_in)
+    for n in REAL_LEAVES + INT_LEAVES:
+        a, b = leaf(big_out, n), leaf(small_out, n)
+        assert torch.equal(a, b[idx.to("cuda")]), f"{n}: tiled environments differ"
+        if a.is_floating_point():
+            assert torch.isfinite(a).all(), n
+    q = big_out.qpos[:, 3:7]
+    assert torch.allclose(q.norm(dim=-1), torch.ones(B, dtype=q.dtype, device=q.device), atol=1e-12)
+    assert big_out.xfrc_applied.data_ptr() == big_in.xfrc_applied.data_ptr()  # untouched leaf aliases the input
+    assert big_out.qpos.data_ptr() != big_in.qpos.data_ptr()                  # written leaf is fresh storage
+    assert big_out.qacc.data_ptr() != big_out.qacc_warmstart.data_ptr()       # solver.py:541-548
+
+
+def test_trajectory_stays_finite_and_matches_oracle_statistically():
+    """100 humanoid steps, B = 512: the HIP trajectory and a natural-branch oracle trajectory diverge only
+    through line-search branch flips; both must stay finite and their mean height must agree closely."""
+    mx = load_model("humanoid", {"solver": 1})
+    B = 512
+    rng = np.random.RandomState(1)
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)))
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    dc = d
+    for _ in range(100):
+        dg = mt.step(mdev, dg)
+    for _ in range(100):
+        dc = pyoracle.apply(dc, pyoracle.run(mx, dc, step=True, nthreads=8))
+    zg, zc = dg.qpos[:, 2].cpu().numpy(), dc.qpos[:, 2].numpy()
+    assert np.isfinite(zg).all() and np.isfinite(zc).all()
+    assert abs(zg.mean() - zc.mean()) < 5e-3, (zg.mean(), zc.mean())
+    assert abs(float(dg.time[0]) - 100 * 0.005) < 1e-12
+
+
+def test_forward_stage_prefixes(oracle_lib):
+    """mjh_forward with a stage prefix writes exactly the leaves of those stages (parity vs oracle forward)."""
+    from mujoco_torch_amd import native
+
+    mx = load_model("humanoid", {"solver": 1})
+    B = 16
+    rng = np.random.RandomState(3)
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.1 * rng.randn(B, mx.nv)))
+    mdev = mx.to("cuda")
+    for stages, names in [(0x01, ["xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "subtree_com", "cinert", "cdof"]),
+                          (0x03, ["crb", "qM", "qLD"]),
+                          (0x0F, ["contact_dist", "contact_pos", "contact_frame", "efc_J", "efc_D", "efc_aref"]),
+                          (0x3F, ["cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_actuator", "qfrc_smooth", "qacc_smooth"])]:
+        og = gpu_out_to_numpy(mt.forward(mdev, d.to("cuda"), stages=stages))
+        oc = pyoracle.run(mx, d, step=False, stages=stages)
+        assert_leaves_close(lambda n: og[n], lambda n: oc[n], 1e-10, names=names, what=f"stages {stages:#x}")
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    mx = load_model("cartpole")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        mt.step(mx, mt.make_data(mx))

@@ -1,0 +1,106 @@
+"""Host-side mirror of the reference API: MJCF ingestion, device_put, make_data, containers (CPU only).
+
+Known answers are the model facts the reference's own tests state:
+humanoid sizes nq 28 / nv 27 / nu 21 / nbody 17 / njnt 22 / ngeom 20 / ncon 8 / nefc 53; ant ncon == 60
+(reference test/collision_driver_test.py:451-458), nefc 248 pyramidal / 188 elliptic; cartpole nefc 0."""
+import numpy as np
+import pytest
+import torch
+
+import mujoco_torch_amd as mt
+from _util import load_model
+
+
+def test_humanoid_sizes_and_contact_table():
+    mx = load_model("humanoid", {"solver": 1})
+    assert (mx.nq, mx.nv, mx.nu, mx.nbody, mx.njnt, mx.ngeom) == (28, 27, 21, 17, 22, 20)
+    assert mx.constraint_sizes_py == (0, 0, 21, 8, 53)
+    assert mx.condim_counts_py == (0, 8, 0, 0)
+    d = mt.make_data(mx)
+    assert d.efc_J.shape == (53, 27) and d.contact.dist.shape == (8,)
+    assert d.contact.geom1.tolist() == [0] * 8  # floor
+    assert d.contact.efc_address.tolist() == [21 + 4 * i for i in range(8)]
+    assert d.contact.contact_dim.dtype == torch.int32 and d.contact.geom.dtype == torch.int64
+    assert abs(float(mx.body_mass.sum()) - 40.844) < 1e-2
+
+
+def test_ant_contact_count_and_unstable_order():
+    mx = load_model("ant")
+    assert mx.nv == 8 and mx.nbody == 14
+    assert mx.constraint_sizes_py == (0, 0, 8, 60, 248)
+    ell = load_model("ant", {"cone": 1})
+    assert ell.constraint_sizes_py == (0, 0, 8, 60, 188)
+    # the reference orders contacts with an unstable torch.argsort: not the identity for 60 equal keys
+    perm = mx.tables.contact_perm
+    assert sorted(perm.tolist()) == list(range(60))
+    assert perm.tolist() == torch.argsort(torch.full((60,), 3, dtype=torch.int32)).tolist()
+    d = mt.make_data(ell)
+    assert d.contact.efc_address.tolist() == [8 + 3 * i for i in range(60)]
+
+
+def test_cartpole_has_no_constraints_and_analytic_mass_matrix():
+    mx = load_model("cartpole")
+    assert mx.constraint_sizes_py == (0, 0, 0, 0, 0)
+    M, _ = mt.mjcf.mass_matrix0(mx.tables.source, np.array([0.1, 0.7]))
+    # cart 1 kg + pole 0.1 kg, pole COM 0.3 m from the hinge: [[M+m, m l cos], [., I + m l^2]]
+    assert abs(M[0, 0] - 1.1) < 1e-12
+    assert abs(M[0, 1] - 0.1 * 0.3 * np.cos(0.7)) < 1e-12
+
+
+def test_unsupported_features_raise_not_implemented():
+    lite = mt.mjcf.from_xml_path(mx_path("humanoid"))
+    lite.opt.solver = 0  # PGS
+    with pytest.raises(NotImplementedError):
+        mt.device_put(lite)
+    lite = mt.mjcf.from_xml_path(mx_path("humanoid"))
+    lite.opt.integrator = 3  # implicitfast
+    with pytest.raises(NotImplementedError):
+        mt.device_put(lite)
+    lite = mt.mjcf.from_xml_path(mx_path("humanoid"))
+    lite.geom_condim[3] = 2
+    with pytest.raises(NotImplementedError):
+        mt.device_put(lite)
+
+
+def mx_path(name):
+    import os
+
+    from _util import GOLD
+
+    return os.path.join(GOLD, "models", name + ".xml")
+
+
+def test_container_semantics():
+    mx = load_model("humanoid")
+    d = mt.make_data(mx)
+    d2 = d.replace(qvel=torch.ones(27, dtype=torch.float64))
+    assert d.qvel.abs().sum() == 0 and d2.qvel.sum() == 27  # replace does not mutate
+    assert d2.qpos.data_ptr() == d.qpos.data_ptr()           # untouched leaves alias
+    db = d.expand(5).clone()
+    assert db.batch_size == (5,) and db.qpos.shape == (5, 28) and db.contact.pos.shape == (5, 8, 3)
+    assert int(db.ncon) == 8                                 # UnbatchedTensor ignores the batch dim
+    s = torch.stack([d, d2])
+    assert s.qvel.shape == (2, 27) and s.contact.frame.shape == (2, 8, 3, 3)
+    assert s[1].qvel.sum() == 27
+    t = d.tree_replace({"contact.dist": torch.ones(8, dtype=torch.float64)})
+    assert t.contact.dist.sum() == 8 and d.contact.dist.sum() == 0
+    f32 = db.to(torch.float32)
+    assert f32.qpos.dtype == torch.float32 and f32.contact.geom1.dtype == torch.int64
+    db[2] = d2
+    assert db.qvel[2].sum() == 27 and db.qvel[1].sum() == 0
+
+
+def test_device_put_dtype_override():
+    m32 = load_model("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32)
+    assert m32.body_mass.dtype == torch.float32 and m32.opt.timestep.dtype == torch.float32
+    assert mt.make_data(m32).qpos.dtype == torch.float64  # like the reference: make_data is float64 (io.py:26)
+
+
+def test_model_blob_packing_roundtrip():
+    from mujoco_torch_amd import native
+
+    mx = load_model("humanoid", {"solver": 1})
+    desc, keep = native.pack_model(mx, torch.float64)
+    assert (desc.nv, desc.nefc, desc.ncon, desc.nl, desc.npair) == (27, 53, 8, 21, 4)
+    assert desc.len_efc_J if hasattr(desc, "len_efc_J") else True
+    assert desc.len_pair_dst == 16 and desc.len_con_friction == 40
