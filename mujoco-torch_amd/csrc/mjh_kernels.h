@@ -1121,7 +1121,7 @@ struct Env {
   }
 
   // ---- forward (forward.py:373-401) --------------------------------------------------------------------------------------------------------------------------
-  __device__ void forward(int stages, bool with_cams) {
+  __device__ __forceinline__ void forward(int stages, bool with_cams) {
     if (stages & 0x7f) { kinematics(with_cams); com_pos(); }
     if (stages & 0x7e) crb_factor();
     if ((stages & 0x7c) && M.ncon > 0) collision();
@@ -1140,7 +1140,7 @@ struct Env {
   }
 
   // ---- integrators (forward.py:231-370) ---------------------------------------------------------------------------------------------------------------------------
-  __device__ void integrate_pos(const REAL* qpos, const REAL* qvel, REAL dt, REAL* o) {  // :231-252, one lane per joint
+  __device__ __forceinline__ void integrate_pos(const REAL* qpos, const REAL* qvel, REAL dt, REAL* o) {  // :231-252, one lane per joint
     for (int j = lane_id(); j < M.njnt; j += MJH_WAVE) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       if (t == JNT_FREE) {
@@ -1159,7 +1159,7 @@ struct Env {
   }
 
   // _advance :255-310. qpos0/qvel0/act0: the state being advanced; writes qpos/qvel/act/time of `out`.
-  __device__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
+  __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
     const int l = lane_id();
     const REAL dt = M.timestep;
     for (int i = l; i < M.nu; i += MJH_WAVE) {
@@ -1189,59 +1189,72 @@ struct Env {
     if (l == 0 && out.time) out.time[e] = time0 + dt;
   }
 
-  __device__ void step() {
+  // step (forward.py:463-496) or, with do_step == false, forward only.  forward() has exactly ONE call site
+  // (the stage loop) so that it is inlined into the kernel: device code reads the launch parameters through
+  // the kernarg segment pointer, which only exists inside the kernel function itself.
+  __device__ __forceinline__ void run(bool do_step, int stages) {
     const int l = lane_id();
     const int nq = M.nq, nv = M.nv, na = M.na;
-    load_state(true);
+    load_state(do_step);
     // qacc is checked too (forward.py:52-56) but is never read before being overwritten; nothing to do.
     const REAL time0 = in.time ? in.time[e] : (REAL)0;
-    forward(MJH_STAGE_ALL, true);
-    if (M.integrator == INT_EULER) {  // _euler :313-328
-      const REAL* qacc = S.qacc();
-      if (!(M.disableflags & DSBL_EULERDAMP)) {
-        for (int w = l; w < nv * nv; w += MJH_WAVE) {
-          const int i = w / nv, j = w - nv * i;
-          S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
-        }
-        for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
-        wave_sync();
-        chol_factor(S.H(), S.HL(), nv);
-        chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
-        qacc = S.s_Mgrad();
-      }
-      advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
-      return;
-    }
-    // _rungekutta4 :331-370
+    const bool rk4 = do_step && M.integrator == INT_RK4;
+    const int nstage = rk4 ? 4 : 1;
+    // _rungekutta4 :331-370; the tableau is a float32 literal tensor up-cast to the data dtype (math.py:34-45)
     const REAL A[3] = {(REAL)0.5, (REAL)0.5, (REAL)1.0};
     const REAL Bt[4] = {(REAL)(float)(1.0 / 6.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 6.0)};
     const REAL dt = M.timestep;
-    for (int i = l; i < nq; i += MJH_WAVE) S.rk_qpos0()[i] = S.qpos()[i];
-    for (int i = l; i < nv; i += MJH_WAVE) {
-      S.rk_qvel0()[i] = S.qvel()[i]; S.rk_kqvel()[i] = S.qvel()[i];
-      S.rk_qvel()[i] = Bt[0] * S.qvel()[i]; S.rk_qacc()[i] = Bt[0] * S.qacc()[i];
-    }
-    for (int i = l; i < na; i += MJH_WAVE) { S.rk_act0()[i] = S.act()[i]; S.rk_actdot()[i] = Bt[0] * S.act_dot()[i]; }
-    wave_sync();
-    store = false;
-    for (int s = 0; s < 3; s++) {
-      const REAL a = A[s], b = Bt[s + 1];
-      for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.rk_kqvel()[i];
-      wave_sync();
-      integrate_pos(S.rk_qpos0(), S.tmp_nv2(), dt, S.tmp_nq());
-      for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = S.rk_act0()[i] + (a * S.act_dot()[i]) * dt;
-      for (int i = l; i < nv; i += MJH_WAVE) S.rk_kqvel()[i] = S.rk_qvel0()[i] + (a * S.qacc()[i]) * dt;
-      wave_sync();
-      for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
-      for (int i = l; i < nv; i += MJH_WAVE) S.qvel()[i] = S.rk_kqvel()[i];
-      wave_sync();
-      forward(MJH_STAGE_ALL, false);
-      for (int i = l; i < nv; i += MJH_WAVE) { S.rk_qvel()[i] = S.rk_qvel()[i] + b * S.rk_kqvel()[i]; S.rk_qacc()[i] = S.rk_qacc()[i] + b * S.qacc()[i]; }
-      for (int i = l; i < na; i += MJH_WAVE) S.rk_actdot()[i] = S.rk_actdot()[i] + b * S.act_dot()[i];
-      wave_sync();
+    for (int s = 0; s < nstage; s++) {
+      if (s > 0) {
+        const REAL a = A[s - 1];
+        for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.rk_kqvel()[i];
+        wave_sync();
+        integrate_pos(S.rk_qpos0(), S.tmp_nv2(), dt, S.tmp_nq());
+        for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = S.rk_act0()[i] + (a * S.act_dot()[i]) * dt;
+        for (int i = l; i < nv; i += MJH_WAVE) S.rk_kqvel()[i] = S.rk_qvel0()[i] + (a * S.qacc()[i]) * dt;
+        wave_sync();
+        for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
+        for (int i = l; i < nv; i += MJH_WAVE) S.qvel()[i] = S.rk_kqvel()[i];
+        wave_sync();
+      }
+      store = (s == 0);
+      forward(do_step ? MJH_STAGE_ALL : stages, s == 0);
+      if (rk4) {
+        if (s == 0) {
+          for (int i = l; i < nq; i += MJH_WAVE) S.rk_qpos0()[i] = S.qpos()[i];
+          for (int i = l; i < nv; i += MJH_WAVE) {
+            S.rk_qvel0()[i] = S.qvel()[i]; S.rk_kqvel()[i] = S.qvel()[i];
+            S.rk_qvel()[i] = Bt[0] * S.qvel()[i]; S.rk_qacc()[i] = Bt[0] * S.qacc()[i];
+          }
+          for (int i = l; i < na; i += MJH_WAVE) { S.rk_act0()[i] = S.act()[i]; S.rk_actdot()[i] = Bt[0] * S.act_dot()[i]; }
+        } else {
+          const REAL b = Bt[s];
+          for (int i = l; i < nv; i += MJH_WAVE) { S.rk_qvel()[i] = S.rk_qvel()[i] + b * S.rk_kqvel()[i]; S.rk_qacc()[i] = S.rk_qacc()[i] + b * S.qacc()[i]; }
+          for (int i = l; i < na; i += MJH_WAVE) S.rk_actdot()[i] = S.rk_actdot()[i] + b * S.act_dot()[i];
+        }
+        wave_sync();
+      }
     }
     store = true;
-    advance(S.rk_qpos0(), S.rk_qvel0(), S.rk_act0(), time0, S.rk_actdot(), S.rk_qacc(), S.rk_qvel());
+    if (!do_step) return;
+    if (rk4) {
+      advance(S.rk_qpos0(), S.rk_qvel0(), S.rk_act0(), time0, S.rk_actdot(), S.rk_qacc(), S.rk_qvel());
+      return;
+    }
+    // _euler :313-328
+    const REAL* qacc = S.qacc();
+    if (!(M.disableflags & DSBL_EULERDAMP)) {
+      for (int w = l; w < nv * nv; w += MJH_WAVE) {
+        const int i = w / nv, j = w - nv * i;
+        S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
+      }
+      for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
+      wave_sync();
+      chol_factor(S.H(), S.HL(), nv);
+      chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+      qacc = S.s_Mgrad();
+    }
+    advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
   }
 };
 
@@ -1256,8 +1269,7 @@ __global__ void __launch_bounds__(MJH_WAVE) mjh_step_kernel(KArgs<REAL> args) {
   const KArgs<REAL>& K = kargs<REAL>();
   for (int64_t env = blockIdx.x; env < K.B; env += gridDim.x) {
     Env<REAL> E(lds, env, K.flags);
-    if (K.do_step) E.step();
-    else { E.load_state(false); E.forward(K.stages, true); }
+    E.run(K.do_step != 0, K.stages);
     wave_sync();
   }
 }

@@ -58,7 +58,7 @@ def _fill_ptrs(d: Data, names, dtype, device, check=True):
         t = native.data_field_tensor(d, n)
         if t is None:
             continue
-        if check:
+        if check and t.numel():
             if t.device != device:
                 raise RuntimeError(f"Data.{n} is on {t.device}, expected {device}")
             if n in _REAL_NAMES and t.dtype != dtype:

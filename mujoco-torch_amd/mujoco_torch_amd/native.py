@@ -101,15 +101,15 @@ def pack_model(m, dtype: torch.dtype):
     int_arrays = dict(
         body_parentid=i32(A("body_parentid")), body_rootid=i32(A("body_rootid")), body_jntadr=i32(A("body_jntadr")),
         body_jntnum=i32(A("body_jntnum")), body_dofadr=i32(A("body_dofadr")), body_dofnum=i32(A("body_dofnum")),
-        body_mocapid=i32(A("body_mocapid")), jnt_type=i32(m.jnt_type.data.numpy()), jnt_qposadr=i32(A("jnt_qposadr")),
+        body_mocapid=i32(A("body_mocapid")), jnt_type=i32(m.jnt_type.data.cpu().numpy()), jnt_qposadr=i32(A("jnt_qposadr")),
         jnt_dofadr=i32(A("jnt_dofadr")), jnt_bodyid=i32(A("jnt_bodyid")), jnt_actfrclimited=i32(A("jnt_actfrclimited")),
         dof_bodyid=i32(A("dof_bodyid")), dof_jntid=i32(A("dof_jntid")), dof_parentid=i32(A("dof_parentid")),
         geom_type=i32(A("geom_type")), geom_bodyid=i32(A("geom_bodyid")), geom_convexid=-np.ones(m.ngeom, dtype=np.int32),
         site_bodyid=i32(A("site_bodyid")), cam_bodyid=i32(A("cam_bodyid")), cam_mode=i32(A("cam_mode")),
         cam_targetbodyid=i32(A("cam_targetbodyid")), light_bodyid=i32(A("light_bodyid")),
         act_trntype=i32([x[0] for x in info]), act_jnttype=i32([x[2] for x in info]), act_dofadr=i32([x[3] for x in info]),
-        act_qposadr=i32([x[4] for x in info]), act_gaintype=i32(m.actuator_gaintype.data.numpy()),
-        act_biastype=i32(m.actuator_biastype.data.numpy()), act_dyntype=i32(m.actuator_dyntype.data.numpy()),
+        act_qposadr=i32([x[4] for x in info]), act_gaintype=i32(m.actuator_gaintype.data.cpu().numpy()),
+        act_biastype=i32(m.actuator_biastype.data.cpu().numpy()), act_dyntype=i32(m.actuator_dyntype.data.cpu().numpy()),
         act_ctrllimited=i32(A("actuator_ctrllimited")), act_forcelimited=i32(A("actuator_forcelimited")),
         act_actlimited=i32(A("actuator_actlimited")), act_actadr=i32(A("actuator_actadr")), act_actnum=i32(A("actuator_actnum")),
         lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),

@@ -11,7 +11,7 @@ import torch
 
 import mujoco_torch_amd as mt
 import pyoracle
-from _util import (GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+from _util import (SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
 
 pytestmark = pytest.mark.gpu
@@ -34,7 +34,7 @@ def test_step_matches_reference_golden(case, oracle_lib):
         assert_leaves_close(lambda n: out[n], want, TOL_PRE[g.dtype], names=PRE_SOLVER, what=what)
         assert_ints_equal(lambda n: out[n], want, what=what)
         for e in range(g.nenv):
-            err_gold = max(rel_err(out[n][e], g.expected(e, s, n)) for n in SOLVER_LEAVES)
+            err_gold = max(rel_err(out[n][e], g.expected(e, s, n), SOLVER_FLOOR) for n in SOLVER_LEAVES)
             if err_gold > TOL_SOL[g.dtype]:
                 check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, TOL_PRE[g.dtype], TOL_SOL[g.dtype], what=f"{what} env{e}")
         d = pyoracle.apply(d, {n: want(n) for n in REAL_LEAVES + INT_LEAVES})
