@@ -131,7 +131,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # one kernel launch per step on this stream
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time of one step (its phase kernels) on this stream
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -151,9 +151,9 @@ def main():
             "dtype": "f64" if dtype == torch.float64 else "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"independent-envs x{world} (no collectives)",
-                       "lds_bytes_per_env": native.get_native_model(mdev, device, dtype).lib.mjh_model_lds_bytes(native.get_native_model(mdev, device, dtype).handle)},
+                       "lds_bytes_per_env_by_phase": native.get_native_model(mdev, device, dtype).lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": "mjh_step_kernel", "kernel_ms": kernel_ms},
+                         "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": "mjh_phase_kernel x5 (one step)", "kernel_ms": kernel_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             nB = min(B, 4096)

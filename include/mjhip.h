@@ -297,11 +297,16 @@ void mjh_model_destroy(mjhModel* m);
 int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int stages, int flags,
                 void* hip_stream);
 
-/* one simulation step for B environments (forward.py:463-496): _check_state, forward, Euler/RK4. */
-int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int flags, void* hip_stream);
+/* one simulation step for B environments (forward.py:463-496): _check_state, forward, Euler/RK4.
+ * `work`: caller-owned device scratch of mjh_model_work_bytes(m) * B bytes (contents undefined, may be
+ * NULL when that is 0).  RK4 keeps its stage Data (stages 1..3 of forward.py:356-367) and the running
+ * sums there; Euler needs none. */
+int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* hip_stream);
+int64_t mjh_model_work_bytes(const mjhModel* m);
 
-/* bytes of dynamic LDS one environment occupies in the fused kernel, and waves per environment */
-int mjh_model_lds_bytes(const mjhModel* m);
+/* bytes of dynamic LDS one environment occupies in pipeline phase `phase` (0..4: kinematics, crb/factor,
+ * collision/constraint, velocity/acceleration, solve/integrate); the number of phases is 5. */
+int mjh_model_lds_bytes(const mjhModel* m, int phase);
 
 /* last error message of the calling thread ("" if none) */
 const char* mjh_last_error(void);

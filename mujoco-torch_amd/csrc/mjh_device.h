@@ -32,35 +32,48 @@ enum { GAIN_FIXED = 0, GAIN_AFFINE = 1, BIAS_NONE = 0, BIAS_AFFINE = 1 };
 enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 #define INLINE_CHOL_MAX 16  // math.py:84
 
-// ---- LDS arena ---------------------------------------------------------------------------------------------------
-// X(name, count) in REALs.  Sizes depend on the model only, so host and device carve identically.
-#define MJH_LDS_ARRAYS(X, m)                                                                          \
-  X(qpos, m.nq) X(qvel, m.nv) X(act, m.na)                                                            \
-  X(xpos, 3 * m.nbody) X(xquat, 4 * m.nbody) X(xmat, 9 * m.nbody) X(xipos, 3 * m.nbody)               \
-  X(ximat, 9 * m.nbody) X(xanchor, 3 * m.njnt) X(xaxis, 3 * m.njnt)                                   \
-  X(geom_xpos, 3 * m.ngeom) X(geom_xmat, 9 * m.ngeom)                                                 \
-  X(subtree_com, 3 * m.nbody) X(cinert, 10 * m.nbody) X(crb, 10 * m.nbody)                            \
-  X(cdof, 6 * m.nv) X(cdof_dot, 6 * m.nv) X(cvel, 6 * m.nbody) X(cacc, 6 * m.nbody)                   \
-  X(cfrc, 6 * m.nbody) X(crb_cdof, 6 * m.nv) X(sub_mass, m.nbody) X(sub_pos, 3 * m.nbody)             \
-  X(qM, m.nv * m.nv) X(qLD, m.nv * m.nv)                                                              \
-  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0)              \
-  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0)             \
-  X(con_dist, m.ncon) X(con_pos, 3 * m.ncon) X(con_frame, 9 * m.ncon)                                 \
-  X(efc_J, m.nefc * m.nv) X(efc_D, m.nefc) X(efc_aref, m.nefc)                                        \
-  X(efc_pos, m.nefc) X(efc_pos_norm, m.nefc) X(efc_invweight, m.nefc)                                 \
-  X(act_length, m.nu) X(act_velocity, m.nu) X(act_force, m.nu) X(act_dot, m.na)                       \
-  X(qfrc_bias, m.nv) X(qfrc_passive, m.nv) X(qfrc_actuator, m.nv) X(qfrc_smooth, m.nv)                \
-  X(qacc_smooth, m.nv) X(qacc_warm, m.nv) X(qacc, m.nv) X(qfrc_constraint, m.nv)                      \
-  X(s_qacc, m.nv) X(s_qfrc, m.nv) X(s_Ma, m.nv) X(s_grad, m.nv) X(s_Mgrad, m.nv) X(s_search, m.nv)    \
-  X(s_mv, m.nv) X(s_pgrad, m.nv) X(s_pMgrad, m.nv) X(tmp_nv, m.nv) X(tmp_nv2, m.nv)                   \
-  X(s_Jaref, m.nefc) X(s_force, m.nefc) X(s_jv, m.nefc) X(s_quad, 3 * m.nefc)                         \
-  X(rk_qpos0, m.integrator == INT_RK4 ? m.nq : 0) X(rk_qvel0, m.integrator == INT_RK4 ? m.nv : 0)     \
-  X(rk_act0, m.integrator == INT_RK4 ? m.na : 0) X(rk_qvel, m.integrator == INT_RK4 ? m.nv : 0)       \
-  X(rk_qacc, m.integrator == INT_RK4 ? m.nv : 0) X(rk_actdot, m.integrator == INT_RK4 ? m.na : 0)     \
-  X(rk_kqvel, m.integrator == INT_RK4 ? m.nv : 0) X(tmp_nq, m.nq)
+// ---- LDS arenas ------------------------------------------------------------------------------------------
+// The step is a pipeline of five kernels ("phases"); each phase carves its own per-environment LDS arena
+// holding only its working set, so small phases run at high occupancy.  X(name, count, phases): count in
+// REALs, phases = bitmask of the phases that keep the array in LDS.
+#define PH_KIN 1   /* kinematics + com_pos                      */
+#define PH_CRB 2   /* crb + make_m + factor_m                   */
+#define PH_CON 4   /* collision + make_constraint               */
+#define PH_VEL 8   /* transmission, _velocity, _actuation, _acceleration */
+#define PH_SOL 16  /* solve + Euler / RK4 bookkeeping           */
+#define MJH_NPHASE 5
+#define MJH_LDS_ARRAYS(X, m)                                                                                   \
+  X(qpos, m.nq, PH_KIN | PH_CON | PH_VEL | PH_SOL) X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL)                     \
+  X(act, m.na, PH_VEL | PH_SOL)                                                                                \
+  X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, 9 * m.nbody, PH_KIN)                      \
+  X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
+  X(xanchor, 3 * m.njnt, PH_KIN) X(xaxis, 3 * m.njnt, PH_KIN)                                                  \
+  X(geom_xpos, 3 * m.ngeom, PH_CON) X(geom_xmat, 9 * m.ngeom, PH_CON)                                          \
+  X(subtree_com, 3 * m.nbody, PH_KIN | PH_CON | PH_VEL) X(cinert, 10 * m.nbody, PH_KIN | PH_CRB | PH_VEL)      \
+  X(crb, 10 * m.nbody, PH_CRB) X(cdof, 6 * m.nv, PH_KIN | PH_CRB | PH_CON | PH_VEL)                            \
+  X(cdof_dot, 6 * m.nv, PH_VEL) X(cvel, 6 * m.nbody, PH_VEL) X(cacc, 6 * m.nbody, PH_VEL)                      \
+  X(cfrc, 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
+  X(sub_pos, 3 * m.nbody, PH_KIN)                                                                              \
+  X(qM, m.nv * m.nv, PH_CRB | PH_SOL) X(qLD, m.nv * m.nv, PH_CRB | PH_VEL | PH_SOL)                            \
+  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)               \
+  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
+  X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
+  X(efc_J, m.nefc * m.nv, PH_CON | PH_SOL) X(efc_D, m.nefc, PH_CON | PH_SOL)                                   \
+  X(efc_aref, m.nefc, PH_CON | PH_SOL)                                                                         \
+  X(efc_pos, m.nefc, PH_CON) X(efc_pos_norm, m.nefc, PH_CON) X(efc_invweight, m.nefc, PH_CON)                  \
+  X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
+  X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
+  X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL)                      \
+  X(qfrc_smooth, m.nv, PH_VEL | PH_SOL) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
+  X(qacc_warm, m.nv, PH_SOL) X(qacc, m.nv, PH_SOL) X(qfrc_constraint, m.nv, PH_SOL)                            \
+  X(s_qacc, m.nv, PH_SOL) X(s_qfrc, m.nv, PH_SOL) X(s_Ma, m.nv, PH_SOL) X(s_grad, m.nv, PH_SOL)                \
+  X(s_Mgrad, m.nv, PH_SOL) X(s_search, m.nv, PH_SOL) X(s_mv, m.nv, PH_SOL) X(s_pgrad, m.nv, PH_SOL)            \
+  X(s_pMgrad, m.nv, PH_SOL) X(tmp_nv, m.nv, PH_SOL) X(tmp_nv2, m.nv, PH_SOL)                                   \
+  X(s_Jaref, m.nefc, PH_SOL) X(s_force, m.nefc, PH_SOL) X(s_jv, m.nefc, PH_SOL) X(s_quad, 3 * m.nefc, PH_SOL)  \
+  X(tmp_nq, m.nq, PH_SOL)
 
 struct LdsOff {
-#define X(n, c) int n;
+#define X(n, c, p) int n;
   MJH_LDS_ARRAYS(X, _)
 #undef X
 };
@@ -90,8 +103,6 @@ struct DevModel {
   const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
-  int lds_reals;
-  LdsOff off;  // LDS arena offsets, in REALs
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------------

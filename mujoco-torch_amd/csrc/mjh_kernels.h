@@ -1,33 +1,37 @@
-// mjh_kernels.h -- the fused per-environment step kernel (one wavefront = one environment).
+// mjh_kernels.h -- the per-environment step pipeline (one wavefront = one environment, five phase kernels).
 //
 // Pipeline per environment (reference mujoco_torch/_src/forward.py:373-401, 463-496):
-//   check_state -> kinematics -> com_pos -> crb -> factor_m -> collision -> make_constraint
-//   -> transmission/_velocity (com_vel, passive, rne) -> _actuation -> _acceleration -> solve
-//   -> Euler / RK4 advance.
-// Every stage keeps its working set in the environment's LDS arena and streams the Data leaves it
-// produces straight to HBM (batch-major rows, one contiguous run per leaf).  Data-parallel axes:
-//   bodies / joints / dofs / geoms / contact pairs / constraint rows -> lanes;
-//   tree recursions -> each lane walks its own ancestor chain (no intra-wave sync in the walk);
-//   dot products over rows -> per-lane partials + wave all-reduce.
+//   PH_KIN  check_state -> kinematics -> com_pos
+//   PH_CRB  crb -> make_m -> factor_m
+//   PH_CON  collision -> make_constraint
+//   PH_VEL  transmission/_velocity (com_vel, passive, rne) -> _actuation -> _acceleration
+//   PH_SOL  solve -> Euler advance / RK4 stage bookkeeping
+// Each phase is its own launch of the same kernel template: it loads the Data leaves it consumes from HBM/L2
+// (they are leaves the previous phases had to write anyway) into a small LDS arena, computes, and streams the
+// leaves it produces back as contiguous batch-major rows.  Splitting by phase keeps every arena small
+// (6..30 KB per environment instead of 51 KB for the fused pipeline), which is what buys occupancy: the
+// per-environment work is a chain of dependent small ops, so waves-in-flight per SIMD hide the latency.
+// Data-parallel axes: bodies / joints / dofs / geoms / contact pairs / constraint rows -> lanes;
+// tree recursions -> each lane walks its own ancestor chain; dot products -> per-lane partials + wave all-reduce.
 #pragma once
 #include "mjh_device.h"
 
-// view of the arena: offsets (in REALs) live in the model (kernarg, scalar loads); the view only carries
-// the base pointer, so it stays in registers.
+// view of the arena: offsets (in REALs) come with the launch (kernarg, scalar loads); the view only carries the
+// base pointer, so it stays in registers.
 template <typename REAL>
 struct LdsView {
   REAL* base;
   const LdsOff* off;
-#define X(n, c) __device__ __forceinline__ REAL* n() const { return base + off->n; }
+#define X(n, c, p) __device__ __forceinline__ REAL* n() const { return base + off->n; }
   MJH_LDS_ARRAYS(X, _)
 #undef X
 };
 
-// carve the arena on the host; returns the number of REALs used.  `m` only needs the int members.
-template <typename M>
-inline int lds_carve(const M& m, LdsOff& o) {
+// carve the arena of one phase on the host; returns the number of REALs used.
+template <typename MM>
+inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
   int off = 0;
-#define X(n, c) o.n = off; off += (((c) + 1) & ~1);
+#define X(n, c, p) o.n = off; if ((p) & phase_bit) off += (((c) + 1) & ~1);
   MJH_LDS_ARRAYS(X, m)
 #undef X
   return off;
@@ -46,15 +50,32 @@ struct DevData {  // typed view of mjhData
 #undef X
 };
 
-// All launch parameters travel as ONE by-value kernel argument.  Device code reads them through the
-// kernarg segment pointer (constant address space => scalar loads, nothing is copied to scratch and no
-// stage function needs them as arguments).
+// per-environment RK4 bookkeeping rows kept in the caller's workspace ([B, n] each)
+template <typename REAL>
+struct RkWork {
+  REAL *qvel0, *act0, *kqvel, *sum_qvel, *sum_qacc, *sum_actdot;
+};
+
+// All launch parameters travel as ONE by-value kernel argument.  Device code reads them through the kernarg
+// segment pointer (constant address space => scalar loads, nothing is copied to scratch).  That pointer only
+// exists inside the kernel function itself, so everything below must inline into the kernel (build.sh checks
+// the ISA for calls).
 template <typename REAL>
 struct KArgs {
   DevModel<REAL> M;
-  DevData<REAL> in, out;
+  LdsOff off;          // arena of this launch's phase
+  DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
+  DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
+  DevData<REAL> nxt;   // where an RK stage writes the next stage's state (workspace Data)
+  DevData<REAL> fin;   // the returned Data (final advance)
+  RkWork<REAL> W;
   int64_t B;
-  int flags, do_step, stages;
+  int flags;
+  int stages;          // MJH_STAGE_* prefix mask
+  int do_step;
+  int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
+  int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
+  const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
 };
 template <typename REAL>
 __device__ __forceinline__ const KArgs<REAL>& kargs() {
@@ -63,7 +84,8 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 }
 #define M (kargs<REAL>().M)
 #define in (kargs<REAL>().in)
-#define out (kargs<REAL>().out)
+#define out (kargs<REAL>().cur)
+#define KA (kargs<REAL>())
 
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
 template <typename REAL>
@@ -133,30 +155,34 @@ template <typename REAL>
 struct Env {
   LdsView<REAL> S;
   int64_t e;      // environment index
-  bool store;     // stream Data leaves of this forward pass to HBM (false for RK4 stages 1..3)
   int flags;
 
-  __device__ Env(REAL* lds, int64_t env, int fl) : S{lds, &M.off}, e(env), store(true), flags(fl) {}
+  __device__ Env(REAL* lds, int64_t env, int fl) : S{lds, &KA.off}, e(env), flags(fl) {}
 
+  // every phase streams the leaves it produces to the Data being computed (`out` == KArgs::cur)
   template <typename T>
-  __device__ __forceinline__ void put(T* g, const REAL* l, int n) { if (store) row_store(g, l, n, e); }
+  __device__ __forceinline__ void put(T* g, const REAL* l, int n) { row_store(g, l, n, e); }
 
-  // ---- load state (+ _check_state, forward.py:44-59, when stepping) ------------------------------------------------------------
-  __device__ void load_state(bool check) {
-    const int l = lane_id();
-    for (int i = l; i < M.nq; i += MJH_WAVE) {
-      REAL x = in.qpos[e * M.nq + i];
-      if (check && (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL)) x = M.qpos0[i];
-      S.qpos()[i] = x;
-    }
-    for (int i = l; i < M.nv; i += MJH_WAVE) {
-      REAL x = in.qvel[e * M.nv + i];
-      if (check && (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL)) x = 0;
-      S.qvel()[i] = x;
-      S.qacc_warm()[i] = in.qacc_warmstart ? in.qacc_warmstart[e * M.nv + i] : (REAL)0;
-    }
-    row_load(S.act(), in.act, M.na, e);
-    wave_sync();
+  // ---- state loads (+ _check_state, forward.py:44-59, on the caller's state) ------------------------------------------------
+  __device__ __forceinline__ REAL checked(REAL x, REAL fallback) const {
+    return (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL) ? fallback : x;
+  }
+  // raw: the caller's qpos (kinematics normalises it); otherwise the normalised qpos this pass already wrote
+  __device__ void load_qpos(bool raw) {
+    const bool from_in = raw && !KA.state_from_cur;
+    const REAL* src = (raw ? (KA.state_from_cur ? KA.cur.qpos : in.qpos) : KA.cur.qpos) + e * M.nq;
+    const bool check = from_in && KA.do_step;
+    for (int i = lane_id(); i < M.nq; i += MJH_WAVE) S.qpos()[i] = check ? checked(src[i], M.qpos0[i]) : src[i];
+  }
+  __device__ void load_qvel() {
+    const bool from_in = !KA.state_from_cur;
+    const REAL* src = (from_in ? in.qvel : KA.cur.qvel) + e * M.nv;
+    const bool check = from_in && KA.do_step;
+    for (int i = lane_id(); i < M.nv; i += MJH_WAVE) S.qvel()[i] = check ? checked(src[i], (REAL)0) : src[i];
+  }
+  __device__ void load_act() {
+    const REAL* src = KA.state_from_cur ? KA.cur.act : in.act;
+    row_load(S.act(), src, M.na, e);
   }
 
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
@@ -244,9 +270,12 @@ struct Env {
     }
     for (int g = l; g < M.ngeom; g += MJH_WAVE) {
       const int b = M.geom_bodyid[g];
-      local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.geom_pos + 3 * g, M.geom_quat + 4 * g, S.geom_xpos() + 3 * g, S.geom_xmat() + 9 * g);
+      REAL p[3], mat[9];
+      local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.geom_pos + 3 * g, M.geom_quat + 4 * g, p, mat);
+      if (out.geom_xpos) for (int i = 0; i < 3; i++) out.geom_xpos[(e * M.ngeom + g) * 3 + i] = p[i];
+      if (out.geom_xmat) for (int i = 0; i < 9; i++) out.geom_xmat[(e * M.ngeom + g) * 9 + i] = mat[i];
     }
-    if (store) {
+    {
       for (int s = l; s < M.nsite; s += MJH_WAVE) {
         const int b = M.site_bodyid[s];
         REAL p[3], mat[9];
@@ -297,7 +326,6 @@ struct Env {
     put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
     put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
     put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
-    put(out.geom_xpos, S.geom_xpos(), 3 * M.ngeom); put(out.geom_xmat, S.geom_xmat(), 9 * M.ngeom);
   }
 
   // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
@@ -375,6 +403,9 @@ struct Env {
   __device__ void crb_factor() {
     const int l = lane_id();
     const int nb = M.nbody, nv = M.nv;
+    row_load(S.cinert(), out.cinert, 10 * nb, e);
+    row_load(S.cdof(), out.cdof, 6 * nv, e);
+    wave_sync();
     for (int w = l; w < nb * 10; w += MJH_WAVE) {
       const int b = w / 10, k = w - 10 * b;
       REAL acc = 0;
@@ -460,6 +491,9 @@ struct Env {
 
   __device__ void collision() {
     const int l = lane_id();
+    row_load(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
+    row_load(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
+    wave_sync();
     for (int p = l; p < M.npair; p += MJH_WAVE) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
       const REAL *p1 = S.geom_xpos() + 3 * g1, *m1 = S.geom_xmat() + 9 * g1, *s1 = M.geom_size + 3 * g1;
@@ -528,7 +562,7 @@ struct Env {
       }
     }
     wave_sync();
-    if (store) {
+    {
       const int nc = M.ncon;
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
@@ -591,6 +625,9 @@ struct Env {
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc, nl = M.nl;
     if (nefc == 0) return;
+    load_qpos(false); load_qvel();
+    row_load(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
+    row_load(S.cdof(), out.cdof, 6 * nv, e);
     for (int w = l; w < nl * nv; w += MJH_WAVE) S.efc_J()[w] = 0;
     wave_sync();
     for (int r = l; r < nl; r += MJH_WAVE) {  // _instantiate_limit_slide_hinge :338-372
@@ -685,19 +722,26 @@ struct Env {
     }
     wave_sync();
     put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
-    if (store && out.efc_frictionloss) for (int r = l; r < nefc; r += MJH_WAVE) out.efc_frictionloss[e * nefc + r] = 0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += MJH_WAVE) out.efc_frictionloss[e * nefc + r] = 0;
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
   __device__ void velocity() {
     const int l = lane_id();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
+    load_qpos(false); load_qvel(); load_act();
+    row_load(S.cdof(), out.cdof, 6 * nv, e);
+    row_load(S.cinert(), out.cinert, 10 * nb, e);
+    row_load(S.subtree_com(), out.subtree_com, 3 * nb, e);
+    row_load(S.xipos(), out.xipos, 3 * nb, e);
+    row_load(S.qLD(), out.qLD, nv * nv, e);
+    wave_sync();
     for (int i = l; i < nu; i += MJH_WAVE) {
       const REAL gear = M.act_gear[6 * i];
       S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
       S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
     }
-    if (store && out.actuator_moment) {
+    if (out.actuator_moment) {
       for (int w = l; w < nu * nv; w += MJH_WAVE) {
         const int i = w / nv, d = w - nv * i;
         out.actuator_moment[e * nu * nv + w] = (d == M.act_dofadr[i]) ? M.act_gear[6 * i] : (REAL)0;
@@ -1066,6 +1110,21 @@ struct Env {
     wave_sync();
   }
 
+  __device__ void load_solver_inputs() {
+    const int nv = M.nv, nefc = M.nefc;
+    row_load(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
+    row_load(S.qacc_smooth(), out.qacc_smooth, nv, e);
+    row_load(S.qM(), out.qM, nv * nv, e);
+    if (nefc > 0) {
+      row_load(S.qLD(), out.qLD, nv * nv, e);
+      row_load(S.efc_J(), out.efc_J, nefc * nv, e);
+      row_load(S.efc_D(), out.efc_D, nefc, e);
+      row_load(S.efc_aref(), out.efc_aref, nefc, e);
+      row_load(S.qacc_warm(), KA.warm_src, nv, e);
+    }
+    wave_sync();
+  }
+
   __device__ void solve() {
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
@@ -1120,25 +1179,6 @@ struct Env {
     put(out.efc_force, S.s_force(), nefc);
   }
 
-  // ---- forward (forward.py:373-401) --------------------------------------------------------------------------------------------------------------------------
-  __device__ __forceinline__ void forward(int stages, bool with_cams) {
-    if (stages & 0x7f) { kinematics(with_cams); com_pos(); }
-    if (stages & 0x7e) crb_factor();
-    if ((stages & 0x7c) && M.ncon > 0) collision();
-    if (stages & 0x78) make_constraint();
-    if (stages & 0x70) velocity();
-    if (stages & 0x60) actuation();
-    if (stages & 0x40) {
-      if (M.nefc == 0) {
-        for (int d = lane_id(); d < M.nv; d += MJH_WAVE) S.qacc()[d] = S.qacc_smooth()[d];
-        wave_sync();
-        put(out.qacc, S.qacc(), M.nv);
-      } else {
-        solve();
-      }
-    }
-  }
-
   // ---- integrators (forward.py:231-370) ---------------------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void integrate_pos(const REAL* qpos, const REAL* qvel, REAL dt, REAL* o) {  // :231-252, one lane per joint
     for (int j = lane_id(); j < M.njnt; j += MJH_WAVE) {
@@ -1158,11 +1198,10 @@ struct Env {
     }
   }
 
-  // _advance :255-310. qpos0/qvel0/act0: the state being advanced; writes qpos/qvel/act/time of `out`.
-  __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
-    const int l = lane_id();
+  // act <- act + act_dot * dt (or exact filter), clamped (forward.py:267-294); one lane per actuator
+  __device__ __forceinline__ void advance_act(const REAL* act0, const REAL* act_dot, REAL* dst) {
     const REAL dt = M.timestep;
-    for (int i = l; i < M.nu; i += MJH_WAVE) {
+    for (int i = lane_id(); i < M.nu; i += MJH_WAVE) {
       const int dyn = M.act_dyntype[i];
       if (dyn == DYN_NONE) continue;
       const int a = M.act_actadr[i];
@@ -1178,98 +1217,138 @@ struct Env {
         const REAL lo = M.act_actrange[2 * i], hi = M.act_actrange[2 * i + 1];
         act = act < lo ? lo : (act > hi ? hi : act);
       }
-      if (out.act) out.act[e * M.na + a] = act;
+      if (dst) dst[e * M.na + a] = act;
     }
+  }
+
+  // _advance :255-310 into the RETURNED Data (KArgs::out): qvel += qacc dt, qpos integrated with qvel_for_pos
+  // (the new qvel when null), act, time.
+  __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
+    const int l = lane_id();
+    const REAL dt = M.timestep;
+    const DevData<REAL>& fin = KA.fin;
+    advance_act(act0, act_dot, fin.act);
     for (int d = l; d < M.nv; d += MJH_WAVE) S.tmp_nv()[d] = qvel0[d] + qacc[d] * dt;
     wave_sync();
     integrate_pos(qpos0, qvel_for_pos ? qvel_for_pos : S.tmp_nv(), dt, S.tmp_nq());
     wave_sync();
-    row_store(out.qpos, S.tmp_nq(), M.nq, e);
-    row_store(out.qvel, S.tmp_nv(), M.nv, e);
-    if (l == 0 && out.time) out.time[e] = time0 + dt;
+    row_store(fin.qpos, S.tmp_nq(), M.nq, e);
+    row_store(fin.qvel, S.tmp_nv(), M.nv, e);
+    if (l == 0 && fin.time) fin.time[e] = time0 + dt;
   }
 
-  // step (forward.py:463-496) or, with do_step == false, forward only.  forward() has exactly ONE call site
-  // (the stage loop) so that it is inlined into the kernel: device code reads the launch parameters through
-  // the kernarg segment pointer, which only exists inside the kernel function itself.
-  __device__ __forceinline__ void run(bool do_step, int stages) {
+  // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
+  __device__ __forceinline__ void run_kin() {
+    load_qpos(true);
+    wave_sync();
+    kinematics(KA.rk_stage <= 0);
+    com_pos();
+  }
+  __device__ __forceinline__ void run_crb() { crb_factor(); }
+  __device__ __forceinline__ void run_con() {
+    if (M.ncon > 0) collision();
+    if (KA.stages & 0x78) make_constraint();
+  }
+  __device__ __forceinline__ void run_vel() {
+    velocity();
+    if (KA.stages & 0x60) actuation();
+  }
+
+  // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.
+  __device__ __forceinline__ void run_sol() {
     const int l = lane_id();
     const int nq = M.nq, nv = M.nv, na = M.na;
-    load_state(do_step);
-    // qacc is checked too (forward.py:52-56) but is never read before being overwritten; nothing to do.
-    const REAL time0 = in.time ? in.time[e] : (REAL)0;
-    const bool rk4 = do_step && M.integrator == INT_RK4;
-    const int nstage = rk4 ? 4 : 1;
-    // _rungekutta4 :331-370; the tableau is a float32 literal tensor up-cast to the data dtype (math.py:34-45)
-    const REAL A[3] = {(REAL)0.5, (REAL)0.5, (REAL)1.0};
-    const REAL Bt[4] = {(REAL)(float)(1.0 / 6.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 6.0)};
-    const REAL dt = M.timestep;
-    for (int s = 0; s < nstage; s++) {
-      if (s > 0) {
-        const REAL a = A[s - 1];
-        for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.rk_kqvel()[i];
-        wave_sync();
-        integrate_pos(S.rk_qpos0(), S.tmp_nv2(), dt, S.tmp_nq());
-        for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = S.rk_act0()[i] + (a * S.act_dot()[i]) * dt;
-        for (int i = l; i < nv; i += MJH_WAVE) S.rk_kqvel()[i] = S.rk_qvel0()[i] + (a * S.qacc()[i]) * dt;
-        wave_sync();
-        for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
-        for (int i = l; i < nv; i += MJH_WAVE) S.qvel()[i] = S.rk_kqvel()[i];
-        wave_sync();
-      }
-      store = (s == 0);
-      forward(do_step ? MJH_STAGE_ALL : stages, s == 0);
-      if (rk4) {
-        if (s == 0) {
-          for (int i = l; i < nq; i += MJH_WAVE) S.rk_qpos0()[i] = S.qpos()[i];
-          for (int i = l; i < nv; i += MJH_WAVE) {
-            S.rk_qvel0()[i] = S.qvel()[i]; S.rk_kqvel()[i] = S.qvel()[i];
-            S.rk_qvel()[i] = Bt[0] * S.qvel()[i]; S.rk_qacc()[i] = Bt[0] * S.qacc()[i];
-          }
-          for (int i = l; i < na; i += MJH_WAVE) { S.rk_act0()[i] = S.act()[i]; S.rk_actdot()[i] = Bt[0] * S.act_dot()[i]; }
-        } else {
-          const REAL b = Bt[s];
-          for (int i = l; i < nv; i += MJH_WAVE) { S.rk_qvel()[i] = S.rk_qvel()[i] + b * S.rk_kqvel()[i]; S.rk_qacc()[i] = S.rk_qacc()[i] + b * S.qacc()[i]; }
-          for (int i = l; i < na; i += MJH_WAVE) S.rk_actdot()[i] = S.rk_actdot()[i] + b * S.act_dot()[i];
-        }
-        wave_sync();
-      }
+    load_qpos(false); load_qvel(); load_act();
+    row_load(S.act_dot(), out.act_dot, na, e);
+    load_solver_inputs();
+    if (M.nefc == 0) {
+      for (int d = l; d < nv; d += MJH_WAVE) S.qacc()[d] = S.qacc_smooth()[d];
+      wave_sync();
+      put(out.qacc, S.qacc(), nv);
+    } else {
+      solve();
     }
-    store = true;
-    if (!do_step) return;
-    if (rk4) {
-      advance(S.rk_qpos0(), S.rk_qvel0(), S.rk_act0(), time0, S.rk_actdot(), S.rk_qacc(), S.rk_qvel());
+    if (!KA.do_step) return;
+    const REAL dt = M.timestep;
+    const REAL time0 = in.time ? in.time[e] : (REAL)0;
+    const int rk = KA.rk_stage;
+    if (rk < 0) {  // Euler
+      const REAL* qacc = S.qacc();
+      if (!(M.disableflags & DSBL_EULERDAMP)) {
+        for (int w = l; w < nv * nv; w += MJH_WAVE) {
+          const int i = w / nv, j = w - nv * i;
+          S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
+        }
+        for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
+        wave_sync();
+        chol_factor(S.H(), S.HL(), nv);
+        chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+        qacc = S.s_Mgrad();
+      }
+      advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
       return;
     }
-    // _euler :313-328
-    const REAL* qacc = S.qacc();
-    if (!(M.disableflags & DSBL_EULERDAMP)) {
-      for (int w = l; w < nv * nv; w += MJH_WAVE) {
-        const int i = w / nv, j = w - nv * i;
-        S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
-      }
-      for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
-      wave_sync();
-      chol_factor(S.H(), S.HL(), nv);
-      chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
-      qacc = S.s_Mgrad();
+    // RK4: the tableau is a float32 literal tensor up-cast to the data dtype (forward.py:63-70, math.py:34-45)
+    const REAL A[3] = {(REAL)0.5, (REAL)0.5, (REAL)1.0};
+    const REAL Bt[4] = {(REAL)(float)(1.0 / 6.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 6.0)};
+    const RkWork<REAL>& W = KA.W;
+    const REAL b = Bt[rk];
+    // this stage's state: S.qvel() is kqvel_s, S.qacc() / S.act_dot() are this pass's results
+    for (int i = l; i < nv; i += MJH_WAVE) {
+      const REAL kq = S.qvel()[i], qa = S.qacc()[i];
+      if (rk == 0) { W.qvel0[e * nv + i] = kq; W.sum_qvel[e * nv + i] = b * kq; W.sum_qacc[e * nv + i] = b * qa; }
+      else { W.sum_qvel[e * nv + i] = W.sum_qvel[e * nv + i] + b * kq; W.sum_qacc[e * nv + i] = W.sum_qacc[e * nv + i] + b * qa; }
     }
-    advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
+    for (int i = l; i < na; i += MJH_WAVE) {
+      const REAL ad = S.act_dot()[i];
+      if (rk == 0) { W.act0[e * na + i] = S.act()[i]; W.sum_actdot[e * na + i] = b * ad; }
+      else W.sum_actdot[e * na + i] = W.sum_actdot[e * na + i] + b * ad;
+    }
+    // d_t0's state: the stage-0 normalised qpos lives in the returned Data until the final advance overwrites it
+    const REAL* qpos0g = KA.fin.qpos + e * nq;
+    for (int i = l; i < nq; i += MJH_WAVE) S.tmp_nq()[i] = (rk == 0) ? S.qpos()[i] : qpos0g[i];
+    for (int i = l; i < nv; i += MJH_WAVE) S.s_pgrad()[i] = (rk == 0) ? S.qvel()[i] : W.qvel0[e * nv + i];  // qvel0
+    for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = (rk == 0) ? S.act()[i] : W.act0[e * na + i];         // act0
+    wave_sync();
+    if (rk < 3) {  // state of the next stage (forward.py:356-362)
+      const REAL a = A[rk];
+      for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.qvel()[i];
+      wave_sync();
+      for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];  // qpos0 (integrate_pos output goes to tmp_nq)
+      wave_sync();
+      integrate_pos(S.qpos(), S.tmp_nv2(), dt, S.tmp_nq());
+      for (int i = l; i < na; i += MJH_WAVE) KA.nxt.act[e * na + i] = S.act()[i] + (a * S.act_dot()[i]) * dt;
+      for (int i = l; i < nv; i += MJH_WAVE) KA.nxt.qvel[e * nv + i] = S.s_pgrad()[i] + (a * S.qacc()[i]) * dt;
+      wave_sync();
+      row_store(KA.nxt.qpos, S.tmp_nq(), nq, e);
+      return;
+    }
+    // final _advance(d_t0, act_dot_sum, qacc_sum, qvel_sum)
+    for (int i = l; i < nv; i += MJH_WAVE) { S.s_mv()[i] = W.sum_qacc[e * nv + i]; S.tmp_nv2()[i] = W.sum_qvel[e * nv + i]; }
+    for (int i = l; i < na; i += MJH_WAVE) S.act_dot()[i] = W.sum_actdot[e * na + i];
+    for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
+    wave_sync();
+    advance(S.qpos(), S.s_pgrad(), S.act(), time0, S.act_dot(), S.s_mv(), S.tmp_nv2());
   }
 };
 
 #undef M
 #undef in
 #undef out
+#undef KA
 
-template <typename REAL>
-__global__ void __launch_bounds__(MJH_WAVE) mjh_step_kernel(KArgs<REAL> args) {
+template <typename REAL, int PHASE>
+__global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   REAL* lds = reinterpret_cast<REAL*>(lds_raw);
   const KArgs<REAL>& K = kargs<REAL>();
   for (int64_t env = blockIdx.x; env < K.B; env += gridDim.x) {
     Env<REAL> E(lds, env, K.flags);
-    E.run(K.do_step != 0, K.stages);
+    if (PHASE == 0) E.run_kin();
+    else if (PHASE == 1) E.run_crb();
+    else if (PHASE == 2) E.run_con();
+    else if (PHASE == 3) E.run_vel();
+    else E.run_sol();
     wave_sync();
   }
 }

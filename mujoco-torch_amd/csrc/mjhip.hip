@@ -1,7 +1,8 @@
-// mjhip.hip -- C ABI of the MI355X-native stepper (see include/mjhip.h) and the host side of the launch.
+// mjhip.hip -- C ABI of the MI355X-native stepper (see include/mjhip.h) and the host side of the launches.
 //
-// Host work per call: fill two kernarg structs and one hipLaunchKernelGGL on the caller's stream.  No
-// allocation, no synchronisation, no PyTorch types: the binding (ctypes) passes raw device pointers.
+// Host work per call: fill the kernarg struct of each pipeline phase and enqueue it on the caller's stream
+// (5 launches per forward pass; 20 for an RK4 step).  No allocation, no synchronisation, no PyTorch types:
+// the binding (ctypes) passes raw device pointers.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -23,7 +24,10 @@ struct mjhModel {
   int dtype;
   void* blob;          // device allocation holding every table
   size_t blob_bytes;
-  int lds_bytes;
+  LdsOff off[MJH_NPHASE];
+  int lds_bytes[MJH_NPHASE];
+  int64_t work_reals;                      // per-environment REALs of RK4 workspace (0 for Euler)
+  std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
   DevModel<float> m32;
 };
@@ -39,6 +43,33 @@ struct BlobBuilder {
     return off;
   }
 };
+
+std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
+  const int64_t nq = m->nq, nv = m->nv, nu = m->nu, na = m->na, nb = m->nbody, nj = m->njnt, ng = m->ngeom;
+  const int64_t ncon = m->ncon, nefc = m->nefc;
+  std::vector<int64_t> v;
+#define F(n, c) v.push_back(c);
+  F(time, 1) F(qpos, nq) F(qvel, nv) F(act, na) F(qacc_warmstart, nv) F(ctrl, nu) F(qfrc_applied, nv)
+  F(xfrc_applied, nb * 6) F(mocap_pos, m->nmocap * 3) F(mocap_quat, m->nmocap * 4) F(qacc, nv) F(act_dot, na)
+  F(xpos, nb * 3) F(xquat, nb * 4) F(xmat, nb * 9) F(xipos, nb * 3) F(ximat, nb * 9) F(xanchor, nj * 3) F(xaxis, nj * 3)
+  F(geom_xpos, ng * 3) F(geom_xmat, ng * 9) F(site_xpos, m->nsite * 3) F(site_xmat, m->nsite * 9)
+  F(cam_xpos, m->ncam * 3) F(cam_xmat, m->ncam * 9) F(light_xpos, m->nlight * 3) F(light_xdir, m->nlight * 3)
+  F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(actuator_length, nu)
+  F(actuator_moment, nu * nv) F(qM, nv * nv) F(qLD, nv * nv) F(contact_dist, ncon) F(contact_pos, ncon * 3)
+  F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
+  F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
+  F(efc_D, nefc) F(efc_aref, nefc) F(efc_force, nefc) F(actuator_velocity, nu) F(cvel, nb * 6) F(cdof_dot, nv * 6)
+  F(qfrc_bias, nv) F(qfrc_passive, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
+  F(qacc_smooth, nv) F(qfrc_constraint, nv)
+#undef F
+  return v;
+}
+
+// leaves an RK stage pass needs as storage between its phases (everything a forward pass writes except
+// frames that no later phase reads)
+const char* const kStageLeaves[] = {
+    "qpos", "qvel", "act", "qacc_warmstart", "qacc", "act_dot", "xipos", "geom_xpos", "geom_xmat", "subtree_com", "cdof",
+    "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint"};
 
 template <typename REAL>
 int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
@@ -83,8 +114,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     if (sub_end[b] < b + 1) sub_end[b] = b + 1;
     if (b > 0) { int p = d->body_parentid[b]; if (sub_end[p] < sub_end[b]) sub_end[p] = sub_end[b]; }
   }
-  // DFS order check: every body in [b, sub_end[b]) must descend from b
-  for (int b = 1; b < nb; b++)
+  for (int b = 1; b < nb; b++)  // DFS order check: every body in [b, sub_end[b]) must descend from b
     for (int c = b + 1; c < sub_end[b]; c++) {
       int a = c;
       while (a > b) a = d->body_parentid[a];
@@ -122,9 +152,23 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   for (int p = 0; p < d->npair; p++)
     if (d->pair_fn[p] > MJH_FN_CAPSULE_CAPSULE) return fail(-38, "convex (box/mesh) pair functions are not built yet");
 
-  M.lds_reals = lds_carve(M, M.off);
-  out->lds_bytes = M.lds_reals * (int)sizeof(REAL);
-  if (out->lds_bytes > 160 * 1024) return fail(-12, "model does not fit the 160 KiB LDS arena of one CU");
+  for (int p = 0; p < MJH_NPHASE; p++) {
+    out->lds_bytes[p] = lds_carve(M, 1 << p, out->off[p]) * (int)sizeof(REAL);
+    if (out->lds_bytes[p] > 160 * 1024) return fail(-12, "model does not fit the 160 KiB LDS of one CU");
+  }
+  out->leaf_count = leaf_counts(d);
+  out->work_reals = 0;
+  if (d->integrator == INT_RK4) {
+    const char* names[] = {
+#define X(n) #n,
+        MJH_DATA_REALS(X)
+#undef X
+    };
+    for (size_t i = 0; i < out->leaf_count.size(); i++)
+      for (const char* s : kStageLeaves)
+        if (!strcmp(s, names[i])) out->work_reals += out->leaf_count[i];
+    out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
+  }
 
   void* dev = nullptr;
   HIP_TRY(hipMalloc(&dev, bb.host.size() + 16));
@@ -132,24 +176,86 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   for (auto& f : fix) *f.first = (const unsigned char*)dev + f.second;
   out->blob = dev;
   out->blob_bytes = bb.host.size();
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_step_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes));
+#define SET_ATTR(P) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[P]));
+  SET_ATTR(0) SET_ATTR(1) SET_ATTR(2) SET_ATTR(3) SET_ATTR(4)
+#undef SET_ATTR
+  return 0;
+}
+
+template <typename REAL, int P>
+int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  a.off = m->off[P];
+  const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
+  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->lds_bytes[P], stream, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// one forward pass = the phases selected by `stages`
+template <typename REAL>
+int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  int rc = 0;
+  const int st = a.stages;
+  if ((st & 0x7f) && (rc = launch_phase<REAL, 0>(m, a, stream))) return rc;
+  if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
+  if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
+  if ((st & 0x70) && (rc = launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x40) && (rc = launch_phase<REAL, 4>(m, a, stream))) return rc;
   return 0;
 }
 
 template <typename REAL>
-int launch(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* out, int64_t B, int flags, int do_step, int stages, void* stream) {
+int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, int do_step, int stages, void* stream) {
   if (B <= 0) return 0;
   static_assert(sizeof(DevData<REAL>) == sizeof(mjhData), "DevData must mirror mjhData");
   static_assert(sizeof(KArgs<REAL>) <= 4096, "kernel arguments exceed the 4 KiB kernarg segment");
-  KArgs<REAL> args;
-  args.M = M;
-  memcpy(&args.in, in, sizeof(args.in));
-  memcpy(&args.out, out, sizeof(args.out));
-  args.B = B; args.flags = flags; args.do_step = do_step; args.stages = stages;
-  if (!args.in.qpos || !args.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
-  const int64_t grid = B < (int64_t)1 << 20 ? B : (int64_t)1 << 20;
-  hipLaunchKernelGGL(mjh_step_kernel<REAL>, dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->lds_bytes, (hipStream_t)stream, args);
-  HIP_TRY(hipGetLastError());
+  KArgs<REAL> a;
+  memset(&a, 0, sizeof(a));
+  a.M = M;
+  memcpy(&a.in, in, sizeof(a.in));
+  memcpy(&a.fin, out, sizeof(a.fin));
+  a.cur = a.fin;
+  a.B = B; a.flags = flags; a.do_step = do_step; a.stages = do_step ? MJH_STAGE_ALL : stages;
+  a.rk_stage = -1; a.state_from_cur = 0;
+  a.warm_src = a.in.qacc_warmstart;
+  if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
+  hipStream_t s = (hipStream_t)stream;
+  if (!do_step || M.integrator == INT_EULER) return forward_pass<REAL>(m, a, s);
+
+  // ---- RK4 (forward.py:331-370): stage 0 computes the returned Data; stages 1..3 run in the workspace Data ----
+  if (!work) return fail(-22, "RK4 needs a workspace of mjh_model_work_bytes(m) * B bytes");
+  DevData<REAL> scr;
+  memset(&scr, 0, sizeof(scr));
+  REAL* w = (REAL*)work;
+  {
+    REAL** slots = reinterpret_cast<REAL**>(&scr);
+    const char* names[] = {
+#define X(n) #n,
+        MJH_DATA_REALS(X)
+#undef X
+    };
+    for (size_t i = 0; i < m->leaf_count.size(); i++)
+      for (const char* nm : kStageLeaves)
+        if (!strcmp(nm, names[i])) { slots[i] = w; w += m->leaf_count[i] * B; }
+  }
+  a.W.qvel0 = w; w += (int64_t)M.nv * B;
+  a.W.kqvel = w; w += (int64_t)M.nv * B;
+  a.W.sum_qvel = w; w += (int64_t)M.nv * B;
+  a.W.sum_qacc = w; w += (int64_t)M.nv * B;
+  a.W.act0 = w; w += (int64_t)M.na * B;
+  a.W.sum_actdot = w; w += (int64_t)M.na * B;
+  a.nxt = scr;
+  int rc = 0;
+  for (int stage = 0; stage < 4; stage++) {
+    a.rk_stage = stage;
+    if (stage == 0) {
+      a.cur = a.fin; a.state_from_cur = 0; a.warm_src = a.in.qacc_warmstart;
+    } else {
+      a.cur = scr; a.state_from_cur = 1;
+      a.warm_src = (stage == 1) ? a.fin.qacc_warmstart : scr.qacc_warmstart;  // solver.py:547-552 writes it every pass
+    }
+    if ((rc = forward_pass<REAL>(m, a, s))) return rc;
+  }
   return 0;
 }
 
@@ -180,17 +286,18 @@ void mjh_model_destroy(mjhModel* m) {
 
 int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int stages, int flags, void* stream) {
   if (!m || !in || !out) return fail(-22, "null argument");
-  return m->dtype == MJH_F64 ? launch<double>(m, m->m64, in, out, B, flags, 0, stages, stream)
-                             : launch<float>(m, m->m32, in, out, B, flags, 0, stages, stream);
+  return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, nullptr, B, flags, 0, stages, stream)
+                             : run<float>(m, m->m32, in, out, nullptr, B, flags, 0, stages, stream);
 }
 
-int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int flags, void* stream) {
+int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* stream) {
   if (!m || !in || !out) return fail(-22, "null argument");
-  return m->dtype == MJH_F64 ? launch<double>(m, m->m64, in, out, B, flags, 1, MJH_STAGE_ALL, stream)
-                             : launch<float>(m, m->m32, in, out, B, flags, 1, MJH_STAGE_ALL, stream);
+  return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream)
+                             : run<float>(m, m->m32, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream);
 }
 
-int mjh_model_lds_bytes(const mjhModel* m) { return m ? m->lds_bytes : 0; }
+int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
+int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NPHASE) ? m->lds_bytes[phase] : 0; }
 const char* mjh_last_error(void) { return g_err.c_str(); }
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
 

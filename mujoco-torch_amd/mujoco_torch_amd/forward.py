@@ -103,7 +103,9 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
     flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
     with torch.cuda.device(device):
         if step:
-            rc = nm.lib.mjh_step(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs), B, flags, ctypes.c_void_p(stream))
+            work = nm.workspace(B)
+            rc = nm.lib.mjh_step(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs),
+                                 ctypes.c_void_p(work.data_ptr() if work is not None else None), B, flags, ctypes.c_void_p(stream))
         else:
             rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs), B, stages, flags, ctypes.c_void_p(stream))
     if rc != 0:

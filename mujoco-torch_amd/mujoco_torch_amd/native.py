@@ -185,10 +185,12 @@ def load_library(path: str | None = None):
     lib.mjh_model_destroy.restype = None
     lib.mjh_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.mjh_forward.restype = ctypes.c_int
-    lib.mjh_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    lib.mjh_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     lib.mjh_step.restype = ctypes.c_int
-    lib.mjh_model_lds_bytes.argtypes = [ctypes.c_void_p]
+    lib.mjh_model_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.mjh_model_lds_bytes.restype = ctypes.c_int
+    lib.mjh_model_work_bytes.argtypes = [ctypes.c_void_p]
+    lib.mjh_model_work_bytes.restype = ctypes.c_int64
     for fn in ("mjh_last_error", "mjh_data_fields", "mjh_model_fields"):
         getattr(lib, fn).restype = ctypes.c_char_p
     lib.mjh_abi_version.restype = ctypes.c_int
@@ -224,6 +226,19 @@ class NativeModel:
         self.handle = handle
         self.device = device
         self.dtype = dtype
+        self.work_bytes = int(self.lib.mjh_model_work_bytes(handle))
+        self.lds_bytes = [int(self.lib.mjh_model_lds_bytes(handle, p)) for p in range(5)]
+        self._work = {}
+
+    def workspace(self, B: int):
+        """Caller-owned scratch for RK4 (stage Data + running sums), cached per batch size."""
+        if self.work_bytes == 0:
+            return None
+        w = self._work.get(B)
+        if w is None:
+            w = torch.empty(self.work_bytes * B, dtype=torch.uint8, device=self.device)
+            self._work = {B: w}
+        return w
 
     def __del__(self):
         try:
