@@ -1,8 +1,22 @@
 #!/bin/bash
-# Builds libmjhip.so for gfx950 in-tree (mujoco-torch_amd/lib/).  -ffp-contract=off: keep the reference's
-# separate multiply/add rounding (no FMA contraction) so results track the float64 oracle to ~1e-15.
+# Builds libmjhip.so for gfx950 in-tree (mujoco-torch_amd/lib/).
+#  -ffp-contract=off : keep the reference's separate multiply/add rounding (no FMA contraction) so results
+#                      track the float64 oracle to ~1e-15.
+# Device code reads its launch parameters through the kernarg segment pointer, which is only valid inside
+# the kernel function itself: the build FAILS if any device function was left un-inlined.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
 mkdir -p "$HERE/../lib"
-/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off "$@" \
-  -o "$HERE/../lib/libmjhip.so" "$HERE/mjhip.hip"
+LOG="$(mktemp)"
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -shared -std=c++17 -ffp-contract=off \
+  -Rpass-analysis=kernel-resource-usage "$@" -o "$HERE/../lib/libmjhip.so" "$HERE/mjhip.hip" 2> "$LOG" || { cat "$LOG"; exit 1; }
+grep -E "error|warning: " "$LOG" || true
+NFUNC=$(grep -c "Function Name:" "$LOG" || true)
+NKERN=$(grep "Function Name:" "$LOG" | grep -c "mjh_phase_kernel" || true)
+if [ "$NFUNC" != "$NKERN" ]; then
+  echo "build.sh: device functions were not inlined into the kernels:" >&2
+  grep "Function Name:" "$LOG" | grep -v mjh_phase_kernel >&2
+  exit 1
+fi
+grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" "$LOG" | sed 's/.*remark: *//' | paste - - - - | sed 's/\[-Rpass[^]]*\]//g' > "$HERE/../lib/resource_usage.txt"
+rm -f "$LOG"

@@ -55,6 +55,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(cfrc, 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
   X(sub_pos, 3 * m.nbody, PH_KIN)                                                                              \
   X(qM, m.nv * m.nv, PH_CRB | PH_SOL) X(qLD, m.nv * m.nv, PH_CRB | PH_VEL | PH_SOL)                            \
+  X(qLD_inv, m.nv, PH_VEL | PH_SOL) X(HL_inv, m.nv, PH_SOL)                                                    \
   X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)               \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
@@ -114,12 +115,43 @@ __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 template <typename T>
 __device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, src_lane, MJH_WAVE); }
 
-// butterfly all-reduce (sum) over the 64 lanes; every lane gets the same bits.
+// ---- wave all-reduce (sum) on DPP: quad_perm xor-1 / xor-2, row_half_mirror, row_mirror give every lane the
+// sum of its 16-lane row without touching LDS; the four row sums are read back as scalars (v_readlane) and
+// added uniformly, so every lane ends with the same bits.  EXEC must be all ones (callers are wave-uniform).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  int lo = (int)(u & 0xffffffffull), hi = (int)(u >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  int lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane);
+  int hi = __builtin_amdgcn_readlane((int)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
+#ifdef MJH_NO_DPP
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, MJH_WAVE);
   return v;
+#else
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);  // row_half_mirror
+  v += dpp_move<0x140>(v);  // row_mirror
+  return ((read_lane(v, 0) + read_lane(v, 16)) + read_lane(v, 32)) + read_lane(v, 48);
+#endif
 }
 __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 

@@ -76,6 +76,7 @@ struct KArgs {
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
+  unsigned long long* stamps;  // diagnostic builds (-DMJH_STAMPS): [B, 128] s_memtime stamps, else unused
 };
 template <typename REAL>
 __device__ __forceinline__ const KArgs<REAL>& kargs() {
@@ -86,68 +87,262 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define in (kargs<REAL>().in)
 #define out (kargs<REAL>().cur)
 #define KA (kargs<REAL>())
+// In-kernel stamps (diagnostic build only, never in the shipped library): lane 0 records the shader clock at
+// section boundaries into a buffer of its own; tools/stamps.py turns them into a per-section cycle profile.
+#ifdef MJH_STAMPS
+#define STAMP(slot)                                                                                  \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
+    if (KA.stamps && lane_id() == 0) KA.stamps[e * 128 + (slot)] = t_;                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
+// Four independent transfers are issued per trip so one HBM/L2 (or LDS) round trip covers 256 elements.
 template <typename REAL>
 __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t env) {
   if (!g) return;
   REAL* dst = g + env * n;
-  for (int i = lane_id(); i < n; i += MJH_WAVE) dst[i] = l[i];
+  int i = lane_id();
+  for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
+    const REAL a = l[i], b = l[i + MJH_WAVE], c = l[i + 2 * MJH_WAVE], d = l[i + 3 * MJH_WAVE];
+    dst[i] = a; dst[i + MJH_WAVE] = b; dst[i + 2 * MJH_WAVE] = c; dst[i + 3 * MJH_WAVE] = d;
+  }
+  for (; i < n; i += MJH_WAVE) dst[i] = l[i];
 }
 template <typename REAL>
 __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
   if (!g) { for (int i = lane_id(); i < n; i += MJH_WAVE) l[i] = 0; return; }
   const REAL* src = g + env * n;
-  for (int i = lane_id(); i < n; i += MJH_WAVE) l[i] = src[i];
+  int i = lane_id();
+  for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
+    const REAL a = src[i], b = src[i + MJH_WAVE], c = src[i + 2 * MJH_WAVE], d = src[i + 3 * MJH_WAVE];
+    l[i] = a; l[i + MJH_WAVE] = b; l[i + 2 * MJH_WAVE] = c; l[i + 3 * MJH_WAVE] = d;
+  }
+  for (; i < n; i += MJH_WAVE) l[i] = src[i];
 }
 
 // =====================================================================================================================
-// dense Cholesky in LDS (math.small_cholesky :87-129).  Left-looking, lanes over rows; per element the
-// subtraction order is k = 0..j-1 exactly as the reference's unrolled loop.
+// dense Cholesky in LDS (math.small_cholesky :87-129).  Right-looking: once column j is final, every row
+// subtracts its rank-1 contribution from the trailing columns.  Each element still receives its updates in
+// the order k = 0, 1, ... -- the subtraction order of the reference's unrolled loop -- but the updates of one
+// column are independent, so their LDS traffic pipelines instead of forming one long dependent chain.
 // =====================================================================================================================
 template <typename REAL>
-__device__ void chol_factor(const REAL* A, REAL* L, int n) {
+__device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
   const int i = lane_id();
-  for (int e = i; e < n * n; e += MJH_WAVE) L[e] = 0;
+  for (int w = i; w < n * n; w += MJH_WAVE) {
+    const int r = w / n, c = w - n * r;
+    L[w] = (c <= r) ? A[w] : (REAL)0;
+  }
   wave_sync();
   const bool big = n > INLINE_CHOL_MAX;
   for (int j = 0; j < n; j++) {
-    // diagonal (every lane computes it redundantly: identical bits, no broadcast needed)
-    REAL s = A[j * n + j];
+    REAL s = L[j * n + j];
     if (big) s = s + (REAL)1e-10;  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
-    for (int k = 0; k < j; k++) s = s - L[j * n + k] * L[j * n + k];
-    REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
-    if (i > j && i < n) {
-      REAL t = A[i * n + j];
-      for (int k = 0; k < j; k++) t = t - L[i * n + k] * L[j * n + k];
-      L[i * n + j] = t / d;
-    }
+    const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
+    REAL lij = 0;
+    if (i > j && i < n) { lij = L[i * n + j] / d; }
+    wave_sync();  // everyone has read column j before it is overwritten
+    if (i > j && i < n) L[i * n + j] = lij;
     if (i == j) L[j * n + j] = d;
+    wave_sync();
+    {  // trailing update L[r][c] -= L[r][j] * L[c][j] for j < c <= r < n, spread over all lanes (2D index)
+      const int m = n - j - 1;
+      const float inv_m = 1.0f / (float)(m > 0 ? m : 1);
+      const int total = m * m;
+      for (int t0 = 0; t0 < total; t0 += 2 * MJH_WAVE) {
+        const int ta = t0 + i, tb = t0 + MJH_WAVE + i;
+        const int ra = (int)(((float)ta + 0.5f) * inv_m), rb = (int)(((float)tb + 0.5f) * inv_m);
+        const int ca = ta - ra * m, cb = tb - rb * m;
+        const bool oka = ta < total && ca <= ra, okb = tb < total && cb <= rb;
+        const int ia = (j + 1 + ra) * n, ka = j + 1 + ca, ib = (j + 1 + rb) * n, kb = j + 1 + cb;
+        REAL va = 0, vb = 0, la = 0, lb = 0, ua = 0, ub = 0;
+        if (oka) { va = L[ia + ka]; la = L[ia + j]; ua = L[ka * n + j]; }
+        if (okb) { vb = L[ib + kb]; lb = L[ib + j]; ub = L[kb * n + j]; }
+        if (oka) L[ia + ka] = va - la * ua;
+        if (okb) L[ib + kb] = vb - lb * ub;
+      }
+    }
     wave_sync();
   }
 }
 
+template <typename REAL, int MAXREG>
+__device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n);
+
+// reciprocal diagonal of a Cholesky factor (one lane per row); consumed by chol_solve
+template <typename REAL>
+__device__ __forceinline__ void chol_inv_diag(const REAL* L, REAL* inv, int n) {
+  for (int k = lane_id(); k < n; k += MJH_WAVE) inv[k] = 1 / L[k * n + k];
+}
+
 // x = (L L^T)^-1 b  (math.small_cholesky_solve :132-168).  Column-oriented substitution: lane i carries its
 // running right-hand side; the value solved at step k is broadcast.  Per element the operation order equals
-// the reference's row loops (k ascending forward, descending backward).
+// the reference's row loops (k ascending forward, descending backward); the divisions by L[k][k] are
+// multiplications by the precomputed reciprocal (<= 1 ulp per step off the reference's quotient).
 template <typename REAL>
-__device__ void chol_solve(const REAL* L, const REAL* b, REAL* x, int n) {
+__device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
   const int i = lane_id();
   REAL s = (i < n) ? b[i] : (REAL)0;
-  for (int k = 0; k < n; k++) {
-    REAL yk = s / L[k * n + k];           // only lane k's value is meaningful
-    yk = wave_bcast(yk, k);
-    if (i == k) s = yk;
-    else if (i > k && i < n) s = s - L[i * n + k] * yk;
+  const REAL myinv = (i < n) ? inv[i] : (REAL)0;
+  // forward: eight columns of this lane's row are fetched at once, then consumed by eight dependent steps
+  for (int k0 = 0; k0 < n; k0 += 8) {
+    REAL r[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) r[t] = (i > k0 + t && i < n && k0 + t < n) ? L[i * n + k0 + t] : (REAL)0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int k = k0 + t;
+      if (k < n) {
+        const REAL yk = read_lane(s * myinv, k);
+        if (i == k) s = yk;
+        else if (i > k && i < n) s = s - r[t] * yk;
+      }
+    }
   }
-  for (int k = n - 1; k >= 0; k--) {
-    REAL xk = s / L[k * n + k];
-    xk = wave_bcast(xk, k);
-    if (i == k) s = xk;
-    else if (i < k) s = s - L[k * n + i] * xk;
+  for (int k1 = n - 1; k1 >= 0; k1 -= 8) {
+    REAL r[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) r[t] = (k1 - t >= 0 && i < k1 - t) ? L[(k1 - t) * n + i] : (REAL)0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int k = k1 - t;
+      if (k >= 0) {
+        const REAL xk = read_lane(s * myinv, k);
+        if (i == k) s = xk;
+        else if (i < k) s = s - r[t] * xk;
+      }
+    }
   }
   if (i < n) x[i] = s;
   wave_sync();
+}
+
+// =====================================================================================================================
+// Register-resident triangular kernels for n <= NMAX (8 / 16 / 32).  Lane i owns row i of the matrix in
+// registers; everything another lane needs from it travels by v_readlane (a scalar broadcast), so the
+// factorisation and the substitutions run without LDS round trips or barriers.  Loops are fully unrolled
+// over NMAX so every register index is a compile-time constant.  Operation order per element is the
+// reference's (math.small_cholesky :117-127, small_cholesky_solve :152-166).
+// =====================================================================================================================
+template <typename REAL, int NMAX>
+struct TriReg {
+  REAL row[NMAX];  // row[k] = L[i][k], k <= i
+  REAL col[NMAX];  // col[k] = L[k][i], k >= i  (row i of L^T)
+  REAL inv;        // 1 / L[i][i]
+};
+
+template <typename REAL, int NMAX>
+__device__ __forceinline__ void tri_load(TriReg<REAL, NMAX>& T, const REAL* L, int n) {
+  const int i = lane_id();
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    T.row[k] = (k < n && i < n && k <= i) ? L[i * n + k] : (REAL)0;
+    T.col[k] = (k < n && i < n && k >= i) ? L[k * n + i] : (REAL)0;
+  }
+  T.inv = (i < n) ? 1 / L[i * n + i] : (REAL)0;
+}
+
+// x = (L L^T)^-1 b with b, x distributed one element per lane
+template <typename REAL, int NMAX>
+__device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, int n) {
+  const int i = lane_id();
+  REAL s = (i < n) ? bi : (REAL)0;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    if (k < n) {
+      const REAL yk = read_lane(s * T.inv, k);
+      if (i == k) s = yk;
+      else if (i > k && i < n) s = s - T.row[k] * yk;
+    }
+  }
+#pragma unroll
+  for (int k = NMAX - 1; k >= 0; k--) {
+    if (k < n) {
+      const REAL xk = read_lane(s * T.inv, k);
+      if (i == k) s = xk;
+      else if (i < k) s = s - T.col[k] * xk;
+    }
+  }
+  return s;
+}
+
+// Cholesky of the symmetric matrix A (LDS, n x n) into L (LDS, lower triangle, zeros above)
+template <typename REAL, int NMAX>
+__device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
+  const int i = lane_id();
+  REAL row[NMAX];
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) row[k] = (k < n && i < n && k <= i) ? A[i * n + k] : (REAL)0;
+  const bool big = n > INLINE_CHOL_MAX;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      REAL s = read_lane(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
+      if (big) s = s + (REAL)1e-10;                  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
+      const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
+      const REAL lij = (i == j) ? d : row[j] / d;    // lanes i < j hold zeros: harmless
+      row[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < NMAX; k++) {
+        if (k < n) {
+          const REAL lkj = read_lane(lij, k);        // L[k][j]
+          row[k] = row[k] - lij * lkj;               // only k <= i is ever read back
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NMAX; k++)
+    if (k < n && i < n) L[i * n + k] = (k <= i) ? row[k] : (REAL)0;
+  wave_sync();
+}
+
+template <typename REAL, int NMAX>
+__device__ __forceinline__ void chol_solve_reg(const REAL* L, const REAL* b, REAL* x, int n) {
+  TriReg<REAL, NMAX> T;
+  tri_load(T, L, n);
+  const int i = lane_id();
+  const REAL xi = tri_solve(T, (i < n) ? b[i] : (REAL)0, n);
+  if (i < n) x[i] = xi;
+  wave_sync();
+}
+template <typename REAL>
+__device__ __forceinline__ void chol_solve(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
+  // register variants only up to 16: at 32 the two register triangles push the solver phases to 256 VGPRs
+  // (one wave per SIMD), which costs more than the substitution saves
+  if (n <= 8) chol_solve_reg<REAL, 8>(L, b, x, n);
+  else if (n <= 16) chol_solve_reg<REAL, 16>(L, b, x, n);
+  else chol_solve_lds(L, inv, b, x, n);
+}
+
+template <typename REAL, int MAXREG = 32>
+__device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n) {
+  if (n <= 8) chol_factor_reg<REAL, 8>(A, L, n);
+  else if (n <= 16) chol_factor_reg<REAL, 16>(A, L, n);
+  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<REAL, 32>(A, L, n);
+  else chol_factor_lds(A, L, n);
+}
+
+// sum_k a[k * sa] * b[k * sb] accumulated in index order (the reference's reduction order for its explicit
+// loops); the loads of four terms are issued together so one LDS round trip covers four multiply-adds.
+template <typename REAL>
+__device__ __forceinline__ REAL dot_seq(const REAL* a, int sa, const REAL* b, int sb, int n) {
+  REAL s = 0;
+  int k = 0;
+  for (; k + 4 <= n; k += 4) {
+    const REAL a0 = a[k * sa], a1 = a[(k + 1) * sa], a2 = a[(k + 2) * sa], a3 = a[(k + 3) * sa];
+    const REAL b0 = b[k * sb], b1 = b[(k + 1) * sb], b2 = b[(k + 2) * sb], b3 = b[(k + 3) * sb];
+    s += a0 * b0; s += a1 * b1; s += a2 * b2; s += a3 * b3;
+  }
+  for (; k < n; k++) s += a[k * sa] * b[k * sb];
+  return s;
 }
 
 // =====================================================================================================================
@@ -157,7 +352,7 @@ struct Env {
   int64_t e;      // environment index
   int flags;
 
-  __device__ Env(REAL* lds, int64_t env, int fl) : S{lds, &KA.off}, e(env), flags(fl) {}
+  __device__ __forceinline__ Env(REAL* lds, int64_t env, int fl) : S{lds, &KA.off}, e(env), flags(fl) {}
 
   // every phase streams the leaves it produces to the Data being computed (`out` == KArgs::cur)
   template <typename T>
@@ -168,25 +363,25 @@ struct Env {
     return (!r_finite(x) || r_abs(x) > (REAL)mjMAXVAL) ? fallback : x;
   }
   // raw: the caller's qpos (kinematics normalises it); otherwise the normalised qpos this pass already wrote
-  __device__ void load_qpos(bool raw) {
+  __device__ __forceinline__ void load_qpos(bool raw) {
     const bool from_in = raw && !KA.state_from_cur;
     const REAL* src = (raw ? (KA.state_from_cur ? KA.cur.qpos : in.qpos) : KA.cur.qpos) + e * M.nq;
     const bool check = from_in && KA.do_step;
     for (int i = lane_id(); i < M.nq; i += MJH_WAVE) S.qpos()[i] = check ? checked(src[i], M.qpos0[i]) : src[i];
   }
-  __device__ void load_qvel() {
+  __device__ __forceinline__ void load_qvel() {
     const bool from_in = !KA.state_from_cur;
     const REAL* src = (from_in ? in.qvel : KA.cur.qvel) + e * M.nv;
     const bool check = from_in && KA.do_step;
     for (int i = lane_id(); i < M.nv; i += MJH_WAVE) S.qvel()[i] = check ? checked(src[i], (REAL)0) : src[i];
   }
-  __device__ void load_act() {
+  __device__ __forceinline__ void load_act() {
     const REAL* src = KA.state_from_cur ? KA.cur.act : in.act;
     row_load(S.act(), src, M.na, e);
   }
 
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
-  __device__ void kinematics(bool with_cams) {
+  __device__ __forceinline__ void kinematics(bool with_cams) {
     const int l = lane_id();
     for (int b = l; b < M.nbody; b += MJH_WAVE) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
@@ -257,6 +452,7 @@ struct Env {
       local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, S.ximat() + 9 * b);
     }
     wave_sync();
+    STAMP(2);
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += MJH_WAVE) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -322,14 +518,16 @@ struct Env {
       }
     }
     wave_sync();
+    STAMP(3);
     put(out.qpos, S.qpos(), M.nq);
     put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
     put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
     put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+    STAMP(4);
   }
 
   // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
-  __device__ void com_pos() {
+  __device__ __forceinline__ void com_pos() {
     const int l = lane_id();
     const int nb = M.nbody;
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
@@ -348,6 +546,7 @@ struct Env {
       S.subtree_com()[w] = (ms < (REAL)mjMINVAL) ? S.xipos()[w] : S.sub_pos()[w] / den;
     }
     wave_sync();
+    STAMP(5);
     for (int b = l; b < nb; b += MJH_WAVE) {  // inert_com :236-243
       const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
       const REAL off[3] = {S.xipos()[3 * b] - rc[0], S.xipos()[3 * b + 1] - rc[1], S.xipos()[3 * b + 2] - rc[2]};
@@ -396,16 +595,20 @@ struct Env {
       }
     }
     wave_sync();
+    STAMP(6);
     put(out.subtree_com, S.subtree_com(), 3 * nb); put(out.cinert, S.cinert(), 10 * nb); put(out.cdof, S.cdof(), 6 * M.nv);
+    STAMP(7);
   }
 
   // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
-  __device__ void crb_factor() {
+  __device__ __forceinline__ void crb_factor() {
     const int l = lane_id();
     const int nb = M.nbody, nv = M.nv;
+    STAMP(10);
     row_load(S.cinert(), out.cinert, 10 * nb, e);
     row_load(S.cdof(), out.cdof, 6 * nv, e);
     wave_sync();
+    STAMP(11);
     for (int w = l; w < nb * 10; w += MJH_WAVE) {
       const int b = w / 10, k = w - 10 * b;
       REAL acc = 0;
@@ -416,8 +619,10 @@ struct Env {
       S.crb()[w] = acc;  // crb[0] = 0 (smooth.py:300-301)
     }
     wave_sync();
+    STAMP(12);
     for (int d = l; d < nv; d += MJH_WAVE) inert_mul(S.crb() + 10 * M.dof_bodyid[d], S.cdof() + 6 * d, S.crb_cdof() + 6 * d);
     wave_sync();
+    STAMP(13);
     for (int w = l; w < nv * nv; w += MJH_WAVE) {
       const int i = w / nv, j = w - nv * i;
       const int hi = i > j ? i : j, lo = i > j ? j : i;
@@ -430,19 +635,23 @@ struct Env {
       S.qM()[w] = s;
     }
     wave_sync();
+    STAMP(14);
     put(out.crb, S.crb(), 10 * nb); put(out.qM, S.qM(), nv * nv);
-    chol_factor(S.qM(), S.qLD(), nv);
+    STAMP(15);
+    chol_factor<REAL, 32>(S.qM(), S.qLD(), nv);
+    STAMP(16);
     put(out.qLD, S.qLD(), nv * nv);
+    STAMP(17);
   }
 
   // ---- collision (collision_driver.py:800-875, collision_primitive.py, math.py:506-569): one lane per static geom pair ------------------
-  __device__ static void plane_sphere_(const REAL* n, const REAL* ppos, const REAL* spos, REAL r, REAL& dist, REAL* pos) {
+  __device__ __forceinline__ static void plane_sphere_(const REAL* n, const REAL* ppos, const REAL* spos, REAL r, REAL& dist, REAL* pos) {
     const REAL d[3] = {spos[0] - ppos[0], spos[1] - ppos[1], spos[2] - ppos[2]};
     dist = dot3(d, n) - r;
 #pragma unroll
     for (int i = 0; i < 3; i++) pos[i] = spos[i] - n[i] * (r + (REAL)0.5 * dist);
   }
-  __device__ static void sphere_sphere_(const REAL* p1, REAL r1, const REAL* p2, REAL r2, REAL& dist, REAL* pos, REAL* n) {
+  __device__ __forceinline__ static void sphere_sphere_(const REAL* p1, REAL r1, const REAL* p2, REAL r2, REAL& dist, REAL* pos, REAL* n) {
 #pragma unroll
     for (int i = 0; i < 3; i++) n[i] = p2[i] - p1[i];
     REAL d = normalize_n<REAL, 3>(n);
@@ -452,7 +661,7 @@ struct Env {
     for (int i = 0; i < 3; i++) pos[i] = p1[i] + n[i] * (r1 + d * (REAL)0.5);
     dist = d;
   }
-  __device__ static void closest_segment_point(const REAL* a, const REAL* b, const REAL* pt, REAL* o) {
+  __device__ __forceinline__ static void closest_segment_point(const REAL* a, const REAL* b, const REAL* pt, REAL* o) {
     const REAL ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     const REAL pa[3] = {pt[0] - a[0], pt[1] - a[1], pt[2] - a[2]};
     REAL t = dot3(pa, ab) / (dot3(ab, ab) + (REAL)1e-6);
@@ -460,7 +669,7 @@ struct Env {
 #pragma unroll
     for (int i = 0; i < 3; i++) o[i] = a[i] + t * ab[i];
   }
-  __device__ static void closest_segment_to_segment(const REAL* a0, const REAL* a1, const REAL* b0, const REAL* b1, REAL* best_a, REAL* best_b) {
+  __device__ __forceinline__ static void closest_segment_to_segment(const REAL* a0, const REAL* a1, const REAL* b0, const REAL* b1, REAL* best_a, REAL* best_b) {
     REAL dir_a[3], dir_b[3];
 #pragma unroll
     for (int i = 0; i < 3; i++) { dir_a[i] = a1[i] - a0[i]; dir_b[i] = b1[i] - b0[i]; }
@@ -489,7 +698,7 @@ struct Env {
     else { for (int i = 0; i < 3; i++) best_b[i] = new_b[i]; }
   }
 
-  __device__ void collision() {
+  __device__ __forceinline__ void collision() {
     const int l = lane_id();
     row_load(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
     row_load(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
@@ -562,9 +771,11 @@ struct Env {
       }
     }
     wave_sync();
+    STAMP(20);
     {
       const int nc = M.ncon;
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
+      STAMP(21);
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
       row_store(out.contact_includemargin, M.con_includemargin, nc, e);
       row_store(out.contact_friction, M.con_friction, 5 * nc, e);
@@ -594,7 +805,7 @@ struct Env {
     for (int i = 0; i < 3; i++) { jp[i] = (cd[3 + i] + c[i]) * on; jr[i] = cd[i] * on; }
   }
 
-  __device__ void kbi(const REAL* solref, const REAL* solimp, REAL pos, REAL& k, REAL& b, REAL& imp) const {  // :69-113
+  __device__ __forceinline__ void kbi(const REAL* solref, const REAL* solimp, REAL pos, REAL& k, REAL& b, REAL& imp) const {  // :69-113
     REAL timeconst = solref[0], dampratio = solref[1];
     if (!(M.disableflags & DSBL_REFSAFE)) {
       const REAL t2 = 2 * M.timestep;
@@ -621,7 +832,7 @@ struct Env {
     k = kk; b = bb; imp = im;
   }
 
-  __device__ void make_constraint() {
+  __device__ __forceinline__ void make_constraint() {
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc, nl = M.nl;
     if (nefc == 0) return;
@@ -630,6 +841,7 @@ struct Env {
     row_load(S.cdof(), out.cdof, 6 * nv, e);
     for (int w = l; w < nl * nv; w += MJH_WAVE) S.efc_J()[w] = 0;
     wave_sync();
+    STAMP(23);
     for (int r = l; r < nl; r += MJH_WAVE) {  // _instantiate_limit_slide_hinge :338-372
       const int j = M.lim_jnt[r], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = S.qpos()[qa];
@@ -694,6 +906,7 @@ struct Env {
       }
     }
     wave_sync();
+    STAMP(25);
     for (int r = l; r < nefc; r += MJH_WAVE) {  // :683-693
       REAL solref[2], solimp[5];
       if (r < nl) {
@@ -715,18 +928,19 @@ struct Env {
       kbi(solref, solimp, S.efc_pos_norm()[r], k, b, imp);
       REAL rr = S.efc_invweight()[r] * (1 - imp) / imp;
       rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
-      REAL jv = 0;
-      for (int d = 0; d < nv; d++) jv += S.efc_J()[r * nv + d] * S.qvel()[d];
+      const REAL jv = dot_seq(S.efc_J() + r * nv, 1, S.qvel(), 1, nv);
       S.efc_aref()[r] = -b * jv - k * imp * S.efc_pos()[r];
       S.efc_D()[r] = 1 / rr;
     }
     wave_sync();
+    STAMP(26);
     put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
+    STAMP(27);
     if (out.efc_frictionloss) for (int r = l; r < nefc; r += MJH_WAVE) out.efc_frictionloss[e * nefc + r] = 0;
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
-  __device__ void velocity() {
+  __device__ __forceinline__ void velocity() {
     const int l = lane_id();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     load_qpos(false); load_qvel(); load_act();
@@ -736,6 +950,9 @@ struct Env {
     row_load(S.xipos(), out.xipos, 3 * nb, e);
     row_load(S.qLD(), out.qLD, nv * nv, e);
     wave_sync();
+    chol_inv_diag(S.qLD(), S.qLD_inv(), nv);
+    wave_sync();
+    STAMP(31);
     for (int i = l; i < nu; i += MJH_WAVE) {
       const REAL gear = M.act_gear[6 * i];
       S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
@@ -747,6 +964,7 @@ struct Env {
         out.actuator_moment[e * nu * nv + w] = (d == M.act_dofadr[i]) ? M.act_gear[6 * i] : (REAL)0;
       }
     }
+    STAMP(32);
     // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
     for (int b = l; b < nb; b += MJH_WAVE) {
       REAL cvel[6] = {0, 0, 0, 0, 0, 0};
@@ -788,6 +1006,7 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < 6; k++) S.cvel()[6 * b + k] = cvel[k];
     }
+    STAMP(33);
     // passive forces
     if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
       for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = 0;
@@ -812,6 +1031,7 @@ struct Env {
       for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
     }
     wave_sync();
+    STAMP(35);
     // rne: cacc along the ancestor chain (needs cdof_dot of ancestors: written above, visible after the sync)
     for (int b = l; b < nb; b += MJH_WAVE) {
       REAL cacc[6];
@@ -839,6 +1059,7 @@ struct Env {
       for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc (cacc itself is not a Data output)
     }
     wave_sync();
+    STAMP(36);
     for (int w = l; w < nb * 6; w += MJH_WAVE) {  // subtree sums of the body forces
       const int b = w / 6, k = w - 6 * b;
       const int end = M.body_subtree_end[b];
@@ -847,6 +1068,7 @@ struct Env {
       S.cfrc()[w] = acc;
     }
     wave_sync();
+    STAMP(37);
     for (int d = l; d < nv; d += MJH_WAVE) {
       REAL s = 0;
       const REAL* cf = S.cfrc() + 6 * M.dof_bodyid[d];
@@ -855,13 +1077,15 @@ struct Env {
       S.qfrc_bias()[d] = s;
     }
     wave_sync();
+    STAMP(38);
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
     put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
     put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
+    STAMP(39);
   }
 
   // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
-  __device__ void actuation() {
+  __device__ __forceinline__ void actuation() {
     const int l = lane_id();
     const int nv = M.nv, nu = M.nu;
     const bool off = (nu == 0) || (M.disableflags & DSBL_ACTUATION);
@@ -902,6 +1126,7 @@ struct Env {
       }
     }
     wave_sync();
+    STAMP(40);
     for (int d = l; d < nv; d += MJH_WAVE) {
       REAL s = 0;
       if (!off) {
@@ -928,34 +1153,31 @@ struct Env {
       S.qfrc_smooth()[d] = ((S.qfrc_passive()[d] - S.qfrc_bias()[d]) + s) + applied;
     }
     wave_sync();
-    chol_solve(S.qLD(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    STAMP(41);
+    chol_solve(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
     if (!off) put(out.actuator_force, S.act_force(), nu);
     put(out.act_dot, S.act_dot(), M.na);
     put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv); put(out.qacc_smooth, S.qacc_smooth(), nv);
+    STAMP(42);
   }
 
   // ---- solver (solver.py:244-553) -----------------------------------------------------------------------------------------------------------------------------
   struct LSPoint { REAL alpha, cost, d0, d1; };
   struct Ctx { REAL gauss, cost, prev_cost; int niter; };
 
-  __device__ void mul_M(const REAL* v, REAL* o) {  // (dense_M * v).sum(-1)
+  __device__ __forceinline__ void mul_M(const REAL* v, REAL* o) {  // (dense_M * v).sum(-1)
     const int nv = M.nv;
-    for (int i = lane_id(); i < nv; i += MJH_WAVE) {
-      REAL s = 0;
-      for (int j = 0; j < nv; j++) s += S.qM()[i * nv + j] * v[j];
-      o[i] = s;
-    }
+    for (int i = lane_id(); i < nv; i += MJH_WAVE) o[i] = dot_seq(S.qM() + i * nv, 1, v, 1, nv);
   }
-  __device__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {  // efc_J @ v  (- sub)
+  __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {  // efc_J @ v  (- sub)
     const int nv = M.nv;
     for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
-      REAL s = 0;
-      for (int d = 0; d < nv; d++) s += S.efc_J()[r * nv + d] * v[d];
+      const REAL s = dot_seq(S.efc_J() + r * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
     }
   }
 
-  __device__ void update_constraint(Ctx& c) {  // :320-357
+  __device__ __forceinline__ void update_constraint(Ctx& c) {  // :320-357
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
     REAL part = 0;
@@ -970,10 +1192,20 @@ struct Env {
     const REAL csum = wave_sum(part);
     const REAL g = wave_sum(gpart);
     wave_sync();
-    for (int d = l; d < nv; d += MJH_WAVE) {
+    {  // qfrc = J^T force, rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
-      for (int r = 0; r < nefc; r++) s += S.efc_J()[r * nv + d] * S.s_force()[r];
-      S.s_qfrc()[d] = s;
+      for (int base = 0; base < nefc; base += MJH_WAVE) {
+        const int r = base + l;
+        const REAL f = (r < nefc) ? S.s_force()[r] : (REAL)0;
+        unsigned long long mask = __ballot(f != 0);
+        while (mask) {
+          const int bit = __ffsll((long long)mask) - 1;
+          mask &= mask - 1;
+          const REAL fr = read_lane(f, bit);
+          if (l < nv) s += S.efc_J()[(base + bit) * nv + l] * fr;
+        }
+      }
+      if (l < nv) S.s_qfrc()[l] = s;
     }
     c.gauss = (REAL)0.5 * g;
     c.prev_cost = c.cost;
@@ -981,30 +1213,39 @@ struct Env {
     wave_sync();
   }
 
-  __device__ void update_gradient() {  // :359-376
+  __device__ __forceinline__ void update_gradient() {  // :359-376
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
     for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
     wave_sync();
     if (M.solver == SOL_CG) {
-      chol_solve(S.qLD(), S.s_grad(), S.s_Mgrad(), nv);
+      chol_solve(S.qLD(), S.qLD_inv(), S.s_grad(), S.s_Mgrad(), nv);
     } else {
-      for (int w = l; w < nv * nv; w += MJH_WAVE) {
-        const int i = w / nv, j = w - nv * i;
+      // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
+      for (int w0 = 0; w0 < nv * nv; w0 += MJH_WAVE) {
+        const int w = w0 + l;
+        const int i = (w < nv * nv) ? w / nv : 0, j = (w < nv * nv) ? w - nv * i : 0;
         REAL s = 0;
-        for (int r = 0; r < nefc; r++) {
-          const REAL active = (REAL)(S.s_Jaref()[r] < 0);
-          s += (S.efc_J()[r * nv + i] * S.efc_D()[r] * active) * S.efc_J()[r * nv + j];
+        for (int base = 0; base < nefc; base += MJH_WAVE) {
+          const int r = base + l;
+          unsigned long long mask = __ballot(r < nefc && S.s_Jaref()[r] < 0);
+          while (mask) {
+            const int row = base + __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            s += (S.efc_J()[row * nv + i] * S.efc_D()[row] * (REAL)1) * S.efc_J()[row * nv + j];
+          }
         }
-        S.H()[w] = S.qM()[w] + s;
+        if (w < nv * nv) S.H()[w] = S.qM()[w] + s;
       }
       wave_sync();
-      chol_factor(S.H(), S.HL(), nv);
-      chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+      chol_factor<REAL, 16>(S.H(), S.HL(), nv);
+      chol_inv_diag(S.HL(), S.HL_inv(), nv);
+      wave_sync();
+      chol_solve(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
     }
   }
 
-  __device__ void create_context(Ctx& c, const REAL* qacc, bool grad_flag) {  // :293-318
+  __device__ __forceinline__ void create_context(Ctx& c, const REAL* qacc, bool grad_flag) {  // :293-318
     const int l = lane_id();
     const int nv = M.nv;
     for (int d = l; d < nv; d += MJH_WAVE) S.s_qacc()[d] = qacc[d];
@@ -1022,7 +1263,7 @@ struct Env {
     }
   }
 
-  __device__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
+  __device__ __forceinline__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
     REAL q0 = 0, q1 = 0, q2 = 0;
     for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
       const REAL x = S.s_Jaref()[r] + alpha * S.s_jv()[r];
@@ -1040,12 +1281,12 @@ struct Env {
     p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
     return p;
   }
-  __device__ static bool ls_swap(REAL cur, REAL cand, bool not_bracketed) {  // _swap :440-449
+  __device__ __forceinline__ static bool ls_swap(REAL cur, REAL cand, bool not_bracketed) {  // _swap :440-449
     const bool in_bracket = ((cur < cand) && (cand < 0)) || ((cur > cand) && (cand > 0));
     return in_bracket || (not_bracketed && (r_abs(cand) < r_abs(cur)));
   }
 
-  __device__ void linesearch(Ctx& c) {  // :378-497
+  __device__ __forceinline__ void linesearch(Ctx& c) {  // :378-497
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
@@ -1059,6 +1300,7 @@ struct Env {
     mul_M(S.s_search(), S.s_mv());
     mul_J(S.s_search(), S.s_jv(), nullptr);
     wave_sync();
+    STAMP(57);
     REAL a = 0, b = 0, cc = 0;
     for (int d = l; d < nv; d += MJH_WAVE) { a += S.s_search()[d] * S.s_Ma()[d]; b += S.s_search()[d] * S.qfrc_smooth()[d]; cc += S.s_search()[d] * S.s_mv()[d]; }
     a = wave_sum(a); b = wave_sum(b); cc = wave_sum(cc);
@@ -1070,6 +1312,7 @@ struct Env {
       S.s_quad()[3 * r + 2] = ((REAL)0.5 * jv * jv) * D;
     }
     wave_sync();
+    STAMP(58);
     const LSPoint p0 = ls_point(qg, 0);
     const LSPoint p1 = ls_point(qg, p0.alpha - p0.d0 / p0.d1);
     const bool early = r_abs(p1.d0) < gtol;
@@ -1108,9 +1351,10 @@ struct Env {
     }
     for (int r = l; r < nefc; r += MJH_WAVE) S.s_Jaref()[r] = S.s_Jaref()[r] + improved * S.s_jv()[r] * alpha;
     wave_sync();
+    STAMP(59);
   }
 
-  __device__ void load_solver_inputs() {
+  __device__ __forceinline__ void load_solver_inputs() {
     const int nv = M.nv, nefc = M.nefc;
     row_load(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
     row_load(S.qacc_smooth(), out.qacc_smooth, nv, e);
@@ -1123,9 +1367,11 @@ struct Env {
       row_load(S.qacc_warm(), KA.warm_src, nv, e);
     }
     wave_sync();
+    if (nefc > 0) chol_inv_diag(S.qLD(), S.qLD_inv(), nv);
+    wave_sync();
   }
 
-  __device__ void solve() {
+  __device__ __forceinline__ void solve() {
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
@@ -1140,7 +1386,9 @@ struct Env {
     }
     for (int d = l; d < nv; d += MJH_WAVE) S.tmp_nv()[d] = use_warm ? S.qacc_warm()[d] : S.qacc_smooth()[d];
     wave_sync();
+    STAMP(54);
     create_context(c, S.tmp_nv(), true);
+    STAMP(55);
     for (int it = 0;; it++) {
       if (M.iterations == 1) { if (it >= 1) break; }
       else if (fixed) { if (it >= M.iterations) break; }
@@ -1156,6 +1404,7 @@ struct Env {
         if (done) break;
       }
       linesearch(c);
+      STAMP(60);
       for (int d = l; d < nv; d += MJH_WAVE) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
       wave_sync();
       update_constraint(c);
@@ -1175,8 +1424,10 @@ struct Env {
     }
     for (int d = l; d < nv; d += MJH_WAVE) { S.qacc()[d] = S.s_qacc()[d]; S.qacc_warm()[d] = S.s_qacc()[d]; S.qfrc_constraint()[d] = S.s_qfrc()[d]; }
     wave_sync();
+    STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
     put(out.efc_force, S.s_force(), nefc);
+    STAMP(62);
   }
 
   // ---- integrators (forward.py:231-370) ---------------------------------------------------------------------------------------------------------------------------
@@ -1239,17 +1490,21 @@ struct Env {
 
   // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void run_kin() {
+    STAMP(0);
     load_qpos(true);
     wave_sync();
+    STAMP(1);
     kinematics(KA.rk_stage <= 0);
     com_pos();
   }
   __device__ __forceinline__ void run_crb() { crb_factor(); }
   __device__ __forceinline__ void run_con() {
+    STAMP(19);
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
   __device__ __forceinline__ void run_vel() {
+    STAMP(30);
     velocity();
     if (KA.stages & 0x60) actuation();
   }
@@ -1258,9 +1513,11 @@ struct Env {
   __device__ __forceinline__ void run_sol() {
     const int l = lane_id();
     const int nq = M.nq, nv = M.nv, na = M.na;
+    STAMP(50);
     load_qpos(false); load_qvel(); load_act();
     row_load(S.act_dot(), out.act_dot, na, e);
     load_solver_inputs();
+    STAMP(51);
     if (M.nefc == 0) {
       for (int d = l; d < nv; d += MJH_WAVE) S.qacc()[d] = S.qacc_smooth()[d];
       wave_sync();
@@ -1281,8 +1538,10 @@ struct Env {
         }
         for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
-        chol_factor(S.H(), S.HL(), nv);
-        chol_solve(S.HL(), S.s_grad(), S.s_Mgrad(), nv);
+        chol_factor<REAL, 16>(S.H(), S.HL(), nv);
+        chol_inv_diag(S.HL(), S.HL_inv(), nv);
+        wave_sync();
+        chol_solve(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
         qacc = S.s_Mgrad();
       }
       advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
@@ -1336,6 +1595,7 @@ struct Env {
 #undef in
 #undef out
 #undef KA
+#undef STAMP
 
 template <typename REAL, int PHASE>
 __global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {

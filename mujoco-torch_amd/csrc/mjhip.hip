@@ -13,6 +13,7 @@
 #include "mjh_kernels.h"
 
 static thread_local std::string g_err;
+static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIP_TRY(x)                                                                                         \
   do {                                                                                                     \
@@ -218,6 +219,7 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
   a.B = B; a.flags = flags; a.do_step = do_step; a.stages = do_step ? MJH_STAGE_ALL : stages;
   a.rk_stage = -1; a.state_from_cur = 0;
   a.warm_src = a.in.qacc_warmstart;
+  a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
   hipStream_t s = (hipStream_t)stream;
   if (!do_step || M.integrator == INT_EULER) return forward_pass<REAL>(m, a, s);
@@ -295,6 +297,9 @@ int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int
   return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream)
                              : run<float>(m, m->m32, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream);
 }
+
+/* diagnostic (-DMJH_STAMPS builds): device buffer [B, 128] of uint64 receiving in-kernel clock stamps */
+void mjh_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
 int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NPHASE) ? m->lds_bytes[phase] : 0; }

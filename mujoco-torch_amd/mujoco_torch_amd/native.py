@@ -22,7 +22,7 @@ from .device import static_contact_fields
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_PKG_DIR))
 HEADER = os.path.join(_ROOT, "include", "mjhip.h")
-LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmjhip.so")
+LIB_PATH = os.environ.get("MJH_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmjhip.so")  # MJH_LIB: A/B builds
 
 MJH_F64, MJH_F32 = 0, 1
 FLAG_FIXED_ITERATIONS = 1

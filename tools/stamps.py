@@ -1,0 +1,49 @@
+"""Per-section shader-clock profile of the phase kernels from a -DMJH_STAMPS diagnostic build.
+
+    (GPU box)  python tools/stamps.py [humanoid|ant] [B]
+Builds lib/libmjhip_stamps.so (never shipped, never loaded by the package), runs a few steps with a stamp
+buffer and prints mean cycles between consecutive stamps of each phase (lane-0 s_memtime; diagnostic build
+times are not comparable with the production build -- read shares, not totals)."""
+import ctypes, os, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("tests", "mujoco-torch_amd", "oracle"):
+    sys.path.insert(0, os.path.join(R, p))
+import numpy as np, torch
+lib = os.path.join(R, "mujoco-torch_amd", "lib", "libmjhip_stamps.so")
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-DMJH_STAMPS",
+                "-o", lib, os.path.join(R, "mujoco-torch_amd", "csrc", "mjhip.hip")], check=True)
+from mujoco_torch_amd import native
+native.LIB_PATH = lib
+import mujoco_torch_amd as mt
+from _util import load_model
+which = sys.argv[1] if len(sys.argv) > 1 else "humanoid"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+cfg = {"humanoid": ("humanoid", {"solver": 1}, torch.float64), "ant": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32)}[which]
+mx = load_model(*cfg)
+d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.01 * np.random.RandomState(42).randn(B, mx.nv)))
+if cfg[2] != torch.float64: d = d.to(cfg[2])
+mdev, dg = mx.to("cuda"), d.to("cuda")
+for _ in range(3): dg = mt.step(mdev, dg)
+stamps = torch.zeros((B, 128), dtype=torch.int64, device="cuda")
+native.load_library().mjh_debug_set_stamps.argtypes = [ctypes.c_void_p]
+native.load_library().mjh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+dg = mt.step(mdev, dg); torch.cuda.synchronize()
+native.load_library().mjh_debug_set_stamps(None)
+st = stamps.cpu().numpy().astype(np.float64)
+names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, geoms, sites, cams", 4: "stores kin", 5: "subtree com", 6: "cinert + cdof", 7: "stores com",
+         10: "CRB start", 11: "loads", 12: "crb subtree sums", 13: "inert_mul", 14: "qM", 15: "stores", 16: "chol_factor", 17: "store qLD",
+         19: "CON start", 20: "load geoms + narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
+         30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
+         50: "SOL start", 51: "loads", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
+last = {}
+for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 79)]:
+    prev = None; tot = 0
+    for k in range(lo, hi + 1):
+        if st[:, k].max() == 0: continue
+        if prev is not None:
+            dlt = (st[:, k] - st[:, prev]).mean(); tot += dlt
+            print(f"  [{k:2d}] {names.get(k, ''):40s} {dlt:10.0f} cycles")
+        else:
+            print(f"phase @{k}: {names.get(k, '')}")
+        prev = k
+    print(f"  phase total {tot:10.0f} cycles")
