@@ -140,6 +140,11 @@ def main():
     assert torch.isfinite(final.qpos).all(), "non-finite state after the timed steps"
 
     if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", f"hbm_traffic_{args.workload}_b{B}_{'f64' if dtype == torch.float64 else 'f32'}.json")
+        if os.path.exists(tfile):  # PMC counters cannot be collected from inside this process: committed rocprofv3 result
+            with open(tfile) as f:
+                traffic = json.load(f)["hbm_bytes_per_step"]
         in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
         alg = in_b + out_b
         achieved = alg * B / (kernel_ms * 1e-3) / 1e9
@@ -153,7 +158,9 @@ def main():
                        "parallelism": f"independent-envs x{world} (no collectives)",
                        "lds_bytes_per_env_by_phase": native.get_native_model(mdev, device, dtype).lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_env_step": alg, "kernel": "mjh_phase_kernel x5 (one step)", "kernel_ms": kernel_ms},
+                         "traffic": traffic, "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_per_step": alg * B,
+                         "kernel": "mjh_phase_kernel<REAL,0..4>: the five phase launches of one step (HIP events on the launch stream)",
+                         "kernel_ms": kernel_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             nB = min(B, 4096)

@@ -1597,6 +1597,8 @@ struct Env {
 #undef KA
 #undef STAMP
 
+// No minimum-waves launch bound: capping the allocator at 128 VGPRs (4 waves/SIMD) was measured 3-11 % slower
+// than letting it use ~180-230 VGPRs (2 waves/SIMD) because of scratch spills (profiles/r01/notes.md).
 template <typename REAL, int PHASE>
 __global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
