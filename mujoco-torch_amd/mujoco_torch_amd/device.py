@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import collision_tables as ct
+from . import convex
 from ._enums import (
     BiasType,
     ConeType,
@@ -142,7 +143,8 @@ class StaticTables:
 def _build_tables(m, dtype) -> StaticTables:
     T = StaticTables()
     flags = int(m.opt.disableflags)
-    cands = ct.collision_candidates(m, convex_shape_key=None)
+    T.convex = convex.geom_convex_tables(m)
+    cands = ct.collision_candidates(m, convex_shape_key=lambda g: convex.shape_key(T.convex, g))
     ct.validate_candidates(cands)
     T.candidates = cands
     dims_sorted = ct.make_condim(m, cands)
@@ -284,6 +286,10 @@ def device_put(value, *, dtype: torch.dtype | None = None):
         site_bodyid_t=L(value.site_bodyid),
         cam_bodyid_t=L(value.cam_bodyid),
         light_bodyid_t=L(value.light_bodyid),
+        geom_convex_face=tuple(None if c is None else torch.tensor(c["face"]) for c in T.convex),
+        geom_convex_vert=tuple(None if c is None else torch.tensor(c["vert"], dtype=fdtype) for c in T.convex),
+        geom_convex_edge=tuple(None if c is None else torch.tensor(c["edge"]) for c in T.convex),
+        geom_convex_facenormal=tuple(None if c is None else torch.tensor(c["facenormal"], dtype=fdtype) for c in T.convex),
         batch_size=[],
         **kw,
     )

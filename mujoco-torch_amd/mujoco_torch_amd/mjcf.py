@@ -251,6 +251,34 @@ def _mesh_mass_props(verts, faces):
 # --------------------------------------------------------------------------
 
 
+def _hull_graph(d):
+    """mjModel.mesh_graph record of one mesh: numvert, numface, vert_edgeadr[numvert],
+    vert_globalid[numvert], edge_localid[numvert + 3 numface] (neighbour lists, -1 terminated),
+    face_globalid[3 numface]."""
+    vid = np.sort(np.asarray(d["hull_vertices"]))
+    local = {int(v): i for i, v in enumerate(vid)}
+    simp = np.array(d["hull_simplices"])
+    for i, eq in enumerate(np.asarray(d["hull_equations"])):  # outward-facing triangles
+        a, b, c = d["vert"][simp[i]]
+        if np.dot(np.cross(b - a, c - a), eq[:3]) < 0:
+            simp[i] = simp[i][[0, 2, 1]]
+    nbr = [[] for _ in vid]
+    for t in simp:
+        for k in range(3):
+            a, b = local[int(t[k])], local[int(t[(k + 1) % 3])]
+            if b not in nbr[a]:
+                nbr[a].append(b)
+            if a not in nbr[b]:
+                nbr[b].append(a)
+    edgeadr, edges = [], []
+    for lst in nbr:
+        edgeadr.append(len(edges))
+        edges.extend(lst + [-1])
+    assert len(edges) == len(vid) + 3 * len(simp)
+    faces = np.array([[local[int(v)] for v in t] for t in simp])
+    return np.concatenate([[len(vid), len(simp)], edgeadr, vid, edges, vid[faces].reshape(-1)]).astype(np.int32)
+
+
 class MjModelLite(SimpleNamespace):
     """Attribute bag with MuJoCo ``MjModel`` field names (numpy arrays / ints)."""
 
@@ -797,7 +825,24 @@ class _Compiler:
             R = _quat_to_mat(quat)
             local = (verts - com) @ R  # coordinates in the principal frame
             hull = ConvexHull(local)
+            local = local.astype(np.float32).astype(np.float64)  # MuJoCo keeps mesh_vert in float32
+            hull = ConvexHull(local)
             m._mesh_data[name] = dict(vert=local, face=faces, hull_vertices=hull.vertices, hull_simplices=hull.simplices, hull_equations=hull.equations, pos=com, quat=quat, volume=vol, inertia_unit=diag)
+        # MuJoCo-layout flat arrays (mjModel.mesh_*)
+        D = [m._mesh_data[n] for n in m.mesh_names]
+        cat = lambda xs, shape, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(shape, dtype=dt)
+        adr = lambda ns: np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int32) if ns else np.zeros(0, dtype=np.int32)
+        m.mesh_vertnum = np.array([len(d["vert"]) for d in D], dtype=np.int32)
+        m.mesh_facenum = np.array([len(d["face"]) for d in D], dtype=np.int32)
+        m.mesh_vertadr = adr([len(d["vert"]) for d in D])
+        m.mesh_faceadr = adr([len(d["face"]) for d in D])
+        m.mesh_vert = cat([d["vert"] for d in D], (0, 3), np.float32)
+        m.mesh_face = cat([d["face"] for d in D], (0, 3), np.int32)
+        m.mesh_pos = cat([d["pos"].reshape(1, 3) for d in D], (0, 3), np.float64)
+        m.mesh_quat = cat([d["quat"].reshape(1, 4) for d in D], (0, 4), np.float64)
+        graphs = [_hull_graph(d) for d in D]
+        m.mesh_graphadr = adr([len(g) for g in graphs])
+        m.mesh_graph = cat(graphs, (0,), np.int32)
 
     # ---- geoms -----------------------------------------------------------
     def _build_geoms(self, m, bodies, remap):

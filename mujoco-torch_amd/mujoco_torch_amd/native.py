@@ -118,8 +118,24 @@ def pack_model(m, dtype: torch.dtype):
         convex_nvert=i32([]), convex_nface=i32([]), convex_nfv=i32([]), convex_nedge=i32([]), convex_vertadr=i32([]),
         convex_faceadr=i32([]), convex_normadr=i32([]), convex_edgeadr=i32([]), convex_face=i32([]), convex_edge=i32([]),
     )
+    # convex tables (box / mesh geoms): one record per convex geom, flat arrays with offsets
+    cv = [(g, c) for g, c in enumerate(T.convex) if c is not None]
+    convexid = -np.ones(m.ngeom, dtype=np.int32)
+    for i, (g, _) in enumerate(cv):
+        convexid[g] = i
+    off = lambda ns: np.concatenate([[0], np.cumsum(ns)[:-1]]) if ns else []
+    int_arrays.update(
+        geom_convexid=convexid, convex_nvert=i32([len(c["vert"]) for _, c in cv]), convex_nface=i32([c["face"].shape[0] for _, c in cv]),
+        convex_nfv=i32([c["face"].shape[1] for _, c in cv]), convex_nedge=i32([len(c["edge"]) for _, c in cv]),
+        convex_vertadr=i32(off([len(c["vert"]) for _, c in cv])), convex_faceadr=i32(off([c["face"].size for _, c in cv])),
+        convex_normadr=i32(off([c["face"].shape[0] for _, c in cv])), convex_edgeadr=i32(off([len(c["edge"]) for _, c in cv])),
+        convex_face=i32(np.concatenate([c["face"].reshape(-1) for _, c in cv]) if cv else []),
+        convex_edge=i32(np.concatenate([c["edge"].reshape(-1) for _, c in cv]) if cv else []),
+    )
+    ints["nconvex"] = len(cv)
     st = static_contact_fields(model_float_leaves(m, dtype), T, dtype)
     empty = np.zeros(0)
+    cvf = lambda k: f64(torch.tensor(np.concatenate([c[k].reshape(-1) for _, c in cv]))) if cv else empty
     real_arrays = dict(
         qpos0=f64(m.qpos0), qpos_spring=f64(m.qpos_spring), body_pos=f64(m.body_pos), body_quat=f64(m.body_quat),
         body_ipos=f64(m.body_ipos), body_iquat=f64(m.body_iquat), body_mass=f64(m.body_mass),
@@ -135,7 +151,7 @@ def pack_model(m, dtype: torch.dtype):
         act_dynprm=f64(m.actuator_dynprm[:, :3]) if nu else empty, act_ctrlrange=f64(m.actuator_ctrlrange) if nu else empty,
         act_forcerange=f64(m.actuator_forcerange) if nu else empty, act_actrange=f64(m.actuator_actrange) if nu else empty,
         con_includemargin=f64(st["includemargin"]), con_friction=f64(st["friction"]), con_solref=f64(st["solref"]),
-        con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=empty, convex_facenormal=empty,
+        con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
     desc.abi_version = 1

@@ -116,6 +116,11 @@ class Model(MjTensorClass):
     collision_max_cp_py: int
     collision_total_contacts_py: int
     cache_id: int
+    # convex tables of box / mesh geoms, None elsewhere (reference types.py:852-855; mesh.py:405-447)
+    geom_convex_face: tuple
+    geom_convex_vert: tuple
+    geom_convex_edge: tuple
+    geom_convex_facenormal: tuple
     body_rootid_t: torch.Tensor
     dof_bodyid_t: torch.Tensor
     dof_jntid_t: torch.Tensor

@@ -43,6 +43,14 @@ CASES = {
     "ant_rk4_newton_ell_f64": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float64", 2, 3, "bench_ctrl"),
     "ant_rk4_newton_ell_f32": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 2, 3, "bench_ctrl"),
     "ant_euler_cg_ell_f64": ("ant", {"solver": 1, "cone": 1}, "float64", 2, 2, "bench_ctrl"),
+    # BASELINE config 5: plane + free box + free dodecahedron mesh, condim 6, Newton (pyramidal), float32 (+ float64 twin)
+    "mesh_contact_newton_f32": ("mesh_contact", {}, "float32", 4, 3, "convex"),
+    "mesh_contact_newton_f64": ("mesh_contact", {}, "float64", 4, 3, "convex"),
+    "mesh_contact_cg_ell_f64": ("mesh_contact", {"solver": 1, "cone": 1}, "float64", 2, 2, "convex"),
+    # every convex pair function: mesh stack (plane/convex-convex) and box / sphere / capsule mixes
+    "convex_meshes_f64": ("convex_meshes", {}, "float64", 4, 3, "convex"),
+    "convex_primitives_f64": ("convex_primitives", {}, "float64", 4, 3, "convex"),
+    "convex_primitives_f32": ("convex_primitives", {}, "float32", 3, 2, "convex"),
 }
 
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
@@ -65,6 +73,15 @@ def make_inputs(recipe, lite, env):
         out["qpos"] = lite.qpos0 + 0.2 * rng.randn(nq)
         out["qfrc_applied"] = 0.5 * rng.randn(nv)
         out["xfrc_applied"] = 0.5 * rng.randn(nb, 6)
+    elif recipe == "convex":  # free bodies resting on each other: jitter the poses (env 0 keeps the XML pose) and add velocity
+        q = lite.qpos0.copy()
+        for j in range(lite.njnt):
+            a = int(lite.jnt_qposadr[j])
+            if int(lite.jnt_type[j]) == 0 and env > 0:
+                q[a : a + 3] += 0.01 * rng.randn(3)
+                q[a + 3 : a + 7] += 0.03 * rng.randn(4)  # un-normalised on purpose
+        out["qpos"] = q
+        out["qvel"] = 0.2 * rng.randn(nv)
     elif recipe == "perturbed":
         q = lite.qpos0.copy()
         q[7:] += 0.4 * rng.randn(nq - 7)
@@ -97,8 +114,20 @@ def main(only=None):
         lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
         for k, v in overrides.items():
             setattr(lite.opt, k, v)
-        mref = ref_harness.put_model(ref, lite, dtype=dtype if dtype != torch.float64 else None)
+        has_convex = any(int(t) in (6, 7) for t in lite.geom_type)
+        if has_convex:
+            # the reference's device_put(dtype=float32) leaves the convex tables in float64 and its step then fails on
+            # mixed dtypes (constraint.py:475); Model.to(float32) is the route that works
+            mref = ref_harness.put_model(ref, lite)
+            if dtype != torch.float64:
+                mref = mref.to(dtype)
+        else:
+            mref = ref_harness.put_model(ref, lite, dtype=dtype if dtype != torch.float64 else None)
         store = {}
+        for g in range(lite.ngeom):  # the convex tables the reference derived (mesh.py:405-447, on oracle/ref_stubs/trimesh)
+            if mref.geom_convex_face[g] is not None:
+                for k in ("face", "vert", "edge", "facenormal"):
+                    store[f"convex/{g}/{k}"] = getattr(mref, "geom_convex_" + k)[g].numpy().copy()
         for env in range(nenv):
             inp = make_inputs(recipe, lite, env)
             d = ref.io.make_data(mref)

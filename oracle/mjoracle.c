@@ -23,6 +23,14 @@
 
 #include "../include/mjhip.h"
 
+/* contact hint of the next run (see "narrow-phase ties" in mjoracle_impl.h): the caller's expected contact leaves
+   [B, ncon(,3|,9)] in the run's dtype, and an int32 [B] that receives the number of pairs resolved non-naturally */
+static const void *g_hint_dist, *g_hint_pos, *g_hint_frame;
+static int32_t* g_tie_pairs;
+void mjo_set_contact_hint(const void* dist, const void* pos, const void* frame, int32_t* tie_pairs) {
+  g_hint_dist = dist; g_hint_pos = pos; g_hint_frame = frame; g_tie_pairs = tie_pairs;
+}
+
 #define REAL double
 #define SFX _f64
 #include "mjoracle_impl.h"

@@ -88,6 +88,7 @@ static void FN(step_env)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(MjoWork) * 
   for (int i = 0; i < nv; i++) { REAL x = w->qacc[i]; if (!isfinite(x) || R_FABS(x) > (REAL)mjMAXVAL) w->qacc[i] = 0; }
   REAL time0 = w->time[0];
   FN(forward_env)(M, w, MJH_STAGE_ALL, flags, 1);
+  w->hint_dist = NULL; /* the returned contact leaves are stage 0's: later RK4 stages resolve ties naturally */
   if (m->integrator == INT_EULER) { /* _euler :313-328 */
     const REAL* qacc = w->qacc;
     if (!(m->disableflags & DSBL_EULERDAMP)) {
@@ -161,12 +162,17 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       memcpy(w.in_subtree_com, w.subtree_com, sizeof(REAL) * 3 * m->nbody);
       w.knife = 0;
       w.knife_policy = knife_policy;
+      w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0;
+      w.hint_dist = g_hint_dist ? (const REAL*)g_hint_dist + e * m->ncon : NULL;
+      w.hint_pos = g_hint_pos ? (const REAL*)g_hint_pos + e * m->ncon * 3 : NULL;
+      w.hint_frame = g_hint_frame ? (const REAL*)g_hint_frame + e * m->ncon * 9 : NULL;
       if (do_step) FN(step_env)(&M, &w, &w0, flags);
       else FN(forward_env)(&M, &w, stages, flags, 1);
 #define X(n) { int c = FN(field_count)(m, #n); if (out->n && c) memcpy((REAL*)out->n + e * c, w.n, sizeof(REAL) * c); }
       MJH_DATA_REALS(X)
 #undef X
       if (knife) knife[e] = w.knife;
+      if (g_tie_pairs) g_tie_pairs[e] = w.tie_pairs;
       if (out->contact_dim) for (int c = 0; c < m->ncon; c++) out->contact_dim[e * m->ncon + c] = m->con_dim[c];
       if (out->contact_geom1) for (int c = 0; c < m->ncon; c++) out->contact_geom1[e * m->ncon + c] = m->con_geom1[c];
       if (out->contact_geom2) for (int c = 0; c < m->ncon; c++) out->contact_geom2[e * m->ncon + c] = m->con_geom2[c];

@@ -53,6 +53,8 @@
 #define DYN_FILTER 2
 #define DYN_FILTEREXACT 3
 #define INLINE_CHOL_MAX 16 /* math.py:84 */
+#define MJO_MAX_TIE 16
+#define MJO_MAX_TIE_RUNS 512
 /* constants the reference keeps in _CachedConst are float32 literals up-cast to the data dtype */
 #define MINVAL_CACHED ((float)1e-15)
 #endif
@@ -107,6 +109,13 @@ typedef struct FN(MjoWork) {
      tight solver-output tolerance (DESIGN.md "line-search knife edge"). */
   int knife;
   int knife_policy; /* <0: natural; j>=0: first j noise candidates read as exact zero, the (j+1)-th as non-zero */
+  /* index selections (argmax / argmin) of the convex narrow phase whose two best candidates differ by rounding noise
+     only: the reference's pick is implementation-defined there.  Each such selection is an "event"; tie_digit[e]
+     chooses the e-th event's candidate (0 = the natural pick).  collision() enumerates the digit combinations of a
+     pair and keeps the outcome closest to the caller's contact hint (DESIGN.md "narrow-phase ties"). */
+  int tie_on, tie_n, tie_digit[MJO_MAX_TIE], tie_count[MJO_MAX_TIE];
+  const REAL *hint_dist, *hint_pos, *hint_frame; /* this env's expected contact leaves or NULL */
+  int tie_pairs; /* pairs whose kept outcome is not the natural one */
 } FN(MjoWork);
 
 /* ---- small vector math (math.py) ------------------------------------------------------------ */
@@ -515,58 +524,557 @@ static void FN(closest_segment_to_segment)(const REAL* a0, const REAL* a1, const
   else { for (int i = 0; i < 3; i++) best_b[i] = new_b[i]; }
 }
 
+/* ---- convex narrow phase (collision_convex.py) -------------------------------------------------- */
+#ifndef MJO_CVX_COMMON_
+#define MJO_CVX_COMMON_
+#define MJO_MAXK 20              /* mesh.py:32 _MAX_HULL_FACE_VERTICES */
+#define MJO_MAXP (4 * MJO_MAXK) /* _clip output: 2 points per subject edge + 2 per clipping edge */
+#endif
+/* `1e-6 * (x == 0.0)`: bool tensor times Python float is float32 in torch; up-cast on use */
+#define EPS_F32 ((REAL)(float)1e-6)
+
+typedef struct FN(Cvx) {
+  int nvert, nface, nfv, nedge;
+  const REAL *vert, *norm;
+  const int *face, *edge;
+} FN(Cvx);
+static FN(Cvx) FN(cvx_of)(const FN(MjoModel) * M, int geom) {
+  const mjhModelDesc* m = M->d;
+  int c = m->geom_convexid[geom];
+  FN(Cvx) r;
+  r.nvert = m->convex_nvert[c]; r.nface = m->convex_nface[c]; r.nfv = m->convex_nfv[c]; r.nedge = m->convex_nedge[c];
+  r.vert = M->convex_vert + 3 * m->convex_vertadr[c];
+  r.norm = M->convex_facenormal + 3 * m->convex_normadr[c];
+  r.face = m->convex_face + m->convex_faceadr[c];
+  r.edge = m->convex_edge + 2 * m->convex_edgeadr[c];
+  return r;
+}
+/* vertex id k of face f when faces are padded to K >= nfv by repeating the last id (F.pad replicate, :810-816) */
+static inline int FN(cvx_fv)(const FN(Cvx) * c, int f, int k) { return c->face[f * c->nfv + (k < c->nfv ? k : c->nfv - 1)]; }
+static inline void FN(mat_t_vec)(const REAL* R, const REAL* v, REAL* o) { /* (mat.T * v).sum(-1) */
+  for (int i = 0; i < 3; i++) o[i] = R[0 + i] * v[0] + R[3 + i] * v[1] + R[6 + i] * v[2];
+}
+static inline void FN(mat_vec)(const REAL* R, const REAL* v, REAL* o) { /* (mat * v).sum(-1) == (v[:,None] * mat.T).sum(-2) */
+  for (int i = 0; i < 3; i++) o[i] = R[3 * i] * v[0] + R[3 * i + 1] * v[1] + R[3 * i + 2] * v[2];
+}
+static int FN(argmax_)(const REAL* x, int n) { int b = 0; for (int i = 1; i < n; i++) if (x[i] > x[b]) b = i; return b; }
+static int FN(argmin_)(const REAL* x, int n) { int b = 0; for (int i = 1; i < n; i++) if (x[i] < x[b]) b = i; return b; }
+#undef TIE_EPS
+#ifdef REAL_IS_FLOAT
+#define TIE_EPS ((REAL)2e-5)
+#else
+#define TIE_EPS ((REAL)1e-11)
+#endif
+/* argmax (sgn = +1) / argmin (sgn = -1) with tie events.  `scale`: magnitude of the terms the scores were summed from;
+   `key` (optional, n x 3): candidates with bit-identical key rows are the same outcome and count once. */
+static int FN(pick)(FN(MjoWork) * w, const REAL* x, int n, int sgn, REAL scale, const REAL* key, int keymod) {
+  int b = sgn > 0 ? FN(argmax_)(x, n) : FN(argmin_)(x, n);
+  if (!w || !w->tie_on) return b;
+  if (R_FABS(x[b]) >= (REAL)1e5) return b; /* best is a masked-out sentinel (-1e6, +-1e12): nothing is in contact */
+  REAL tol = TIE_EPS * scale;
+  int cand[64], nc = 0;
+  cand[nc++] = b;
+  for (int i = 0; i < n && nc < 64; i++) {
+    if (i == b || !(R_FABS(x[i] - x[b]) <= tol)) continue;
+    int dup = 0;
+    if (key) for (int c = 0; c < nc && !dup; c++) {
+      const REAL *ka = key + 3 * (cand[c] % keymod), *kb = key + 3 * (i % keymod);
+      dup = ka[0] == kb[0] && ka[1] == kb[1] && ka[2] == kb[2];
+    }
+    if (!dup) cand[nc++] = i;
+  }
+  if (nc == 1) return b;
+  int e = w->tie_n++;
+  if (e >= MJO_MAX_TIE) return b;
+  w->tie_count[e] = nc;
+  int d = w->tie_digit[e];
+  return cand[d < nc ? d : 0];
+}
+
+static void FN(closest_segment_point_plane)(const REAL* a, const REAL* b, const REAL* p0, const REAL* n, REAL* o) { /* :39-63 */
+  REAL ba[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  REAL d = FN(dot3)(p0, n);
+  REAL denom = FN(dot3)(n, ba);
+  REAL t = (d - FN(dot3)(n, a)) / (denom + (denom == 0 ? EPS_F32 : (REAL)0));
+  t = t < 0 ? 0 : (t > 1 ? 1 : t);
+  for (int i = 0; i < 3; i++) o[i] = a[i] + t * ba[i];
+}
+static void FN(project_pt_onto_plane)(const REAL* pt, const REAL* plane_pt, const REAL* n, REAL* o) { /* :238-241 */
+  REAL d[3] = {pt[0] - plane_pt[0], pt[1] - plane_pt[1], pt[2] - plane_pt[2]};
+  REAL dist = FN(dot3)(d, n);
+  for (int i = 0; i < 3; i++) o[i] = pt[i] - dist * n[i];
+}
+/* _manifold_points :183-235 (hard selection branch) */
+static void FN(manifold_points)(FN(MjoWork) * w, const REAL (*poly)[3], const unsigned char* mask, int n, const REAL* norm, int* out) {
+  REAL dm[MJO_MAXP > 64 ? MJO_MAXP : 64], sc[2 * (MJO_MAXP > 64 ? MJO_MAXP : 64)];
+  REAL* dmask = dm; REAL* score = sc;
+  REAL *hd = NULL, *hs = NULL;
+  if (n > (MJO_MAXP > 64 ? MJO_MAXP : 64)) { hd = (REAL*)malloc(sizeof(REAL) * n); hs = (REAL*)malloc(sizeof(REAL) * 2 * n); dmask = hd; score = hs; }
+  for (int i = 0; i < n; i++) dmask[i] = mask[i] ? (REAL)0 : (REAL)-1e6;
+  int ai = FN(argmax_)(dmask, n);
+  const REAL* a = poly[ai];
+  REAL scale = 0;
+  for (int i = 0; i < n; i++) {
+    REAL e0 = a[0] - poly[i][0], e1 = a[1] - poly[i][1], e2 = a[2] - poly[i][2];
+    score[i] = (e0 * e0 + e1 * e1 + e2 * e2) + dmask[i];
+    if (mask[i] && score[i] > scale) scale = score[i];
+  }
+  int bi = FN(pick)(w, score, n, +1, scale, &poly[0][0], n);
+  const REAL* b = poly[bi];
+  REAL amb[3] = {a[0] - b[0], a[1] - b[1], a[2] - b[2]}, ab[3];
+  FN(cross3)(norm, amb, ab);
+  scale = 0;
+  for (int i = 0; i < n; i++) {
+    REAL ap[3] = {a[0] - poly[i][0], a[1] - poly[i][1], a[2] - poly[i][2]};
+    score[i] = R_FABS(FN(dot3)(ap, ab)) + dmask[i];
+    REAL mag = R_FABS(ap[0] * ab[0]) + R_FABS(ap[1] * ab[1]) + R_FABS(ap[2] * ab[2]);
+    if (mask[i] && mag > scale) scale = mag;
+  }
+  int ci = FN(pick)(w, score, n, +1, scale, &poly[0][0], n);
+  const REAL* c = poly[ci];
+  REAL amc[3] = {a[0] - c[0], a[1] - c[1], a[2] - c[2]}, bmc[3] = {b[0] - c[0], b[1] - c[1], b[2] - c[2]}, ac[3], bc[3];
+  FN(cross3)(norm, amc, ac);
+  FN(cross3)(norm, bmc, bc);
+  scale = 0;
+  for (int i = 0; i < n; i++) {
+    REAL ap[3] = {a[0] - poly[i][0], a[1] - poly[i][1], a[2] - poly[i][2]};
+    REAL bp[3] = {b[0] - poly[i][0], b[1] - poly[i][1], b[2] - poly[i][2]};
+    score[i] = R_FABS(FN(dot3)(bp, bc)) + dmask[i];
+    score[n + i] = R_FABS(FN(dot3)(ap, ac)) + dmask[i];
+    REAL m1 = R_FABS(bp[0] * bc[0]) + R_FABS(bp[1] * bc[1]) + R_FABS(bp[2] * bc[2]);
+    REAL m2 = R_FABS(ap[0] * ac[0]) + R_FABS(ap[1] * ac[1]) + R_FABS(ap[2] * ac[2]);
+    if (mask[i] && m1 > scale) scale = m1;
+    if (mask[i] && m2 > scale) scale = m2;
+  }
+  int di = FN(pick)(w, score, 2 * n, +1, scale, &poly[0][0], n) % n;
+  out[0] = ai; out[1] = bi; out[2] = ci; out[3] = di;
+  free(hd); free(hs);
+}
+/* _clip_edge_to_planes :265-327; returns the mask */
+static int FN(clip_edge_to_planes)(const REAL* p0, const REAL* p1, const REAL (*plane_pts)[3], const REAL (*plane_n)[3], int K, REAL* o0, REAL* o1) {
+  unsigned char f0[MJO_MAXK], f1[MJO_MAXK];
+  REAL cand[MJO_MAXK][3], d0[MJO_MAXK], d1[MJO_MAXK];
+  int any_both = 0;
+  REAL p10[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]}, p01[3] = {p0[0] - p1[0], p0[1] - p1[1], p0[2] - p1[2]};
+  for (int k = 0; k < K; k++) {
+    REAL e0[3] = {p0[0] - plane_pts[k][0], p0[1] - plane_pts[k][1], p0[2] - plane_pts[k][2]};
+    REAL e1[3] = {p1[0] - plane_pts[k][0], p1[1] - plane_pts[k][1], p1[2] - plane_pts[k][2]};
+    f0[k] = FN(dot3)(e0, plane_n[k]) > (REAL)1e-6;
+    f1[k] = FN(dot3)(e1, plane_n[k]) > (REAL)1e-6;
+    any_both |= (f0[k] && f1[k]);
+    FN(closest_segment_point_plane)(p0, p1, plane_pts[k], plane_n[k], cand[k]);
+    REAL q0[3], q1[3];
+    for (int i = 0; i < 3; i++) { q0[i] = (f0[k] ? cand[k][i] : p0[i]) - p0[i]; q1[i] = (f1[k] ? cand[k][i] : p1[i]) - p1[i]; }
+    d0[k] = FN(dot3)(q0, p10);
+    d1[k] = FN(dot3)(q1, p01);
+  }
+  int i0 = FN(argmax_)(d0, K), i1 = FN(argmax_)(d1, K);
+  REAL n0[3], n1[3];
+  for (int i = 0; i < 3; i++) { n0[i] = f0[i0] ? cand[i0][i] : p0[i]; n1[i] = f1[i1] ? cand[i1][i] : p1[i]; }
+  int mask = !any_both;
+  for (int i = 0; i < 3; i++) { o0[i] = mask ? n0[i] : p0[i]; o1[i] = mask ? n1[i] : p1[i]; }
+  REAL dd[3] = {o0[0] - o1[0], o0[1] - o1[1], o0[2] - o1[2]};
+  if (FN(dot3)(p01, dd) < 0) mask = 0;
+  return mask;
+}
+/* _create_contact_manifold :395-449 with _clip :330-392 inlined.  Faces are K-gons (padded). */
+static void FN(create_contact_manifold)(FN(MjoWork) * w, const REAL (*clip_poly)[3], const REAL (*subj_poly)[3], int K, const REAL* clip_n, const REAL* subj_n,
+                                        const REAL* sep_axis, REAL* dist, REAL (*pos)[3], REAL* normal) {
+  REAL cp0[MJO_MAXK][3], cpn[MJO_MAXK][3], sp0[MJO_MAXK][3], spn[MJO_MAXK][3];
+  REAL inc[MJO_MAXP][3], ref[MJO_MAXP][3];
+  unsigned char mask[MJO_MAXP];
+  for (int k = 0; k < K; k++) {
+    int km = (k + K - 1) % K;
+    REAL e[3];
+    for (int i = 0; i < 3; i++) { cp0[k][i] = clip_poly[km][i]; e[i] = clip_poly[k][i] - clip_poly[km][i]; }
+    FN(cross3)(e, clip_n, cpn[k]);
+    for (int i = 0; i < 3; i++) { sp0[k][i] = subj_poly[km][i]; e[i] = subj_poly[k][i] - subj_poly[km][i]; }
+    FN(cross3)(e, subj_n, spn[k]);
+  }
+  /* subject edges against the clipping polygon's side planes */
+  for (int k = 0; k < K; k++) {
+    int mk = FN(clip_edge_to_planes)(sp0[k], subj_poly[k], cp0, cpn, K, inc[2 * k], inc[2 * k + 1]);
+    mask[2 * k] = mask[2 * k + 1] = (unsigned char)mk;
+  }
+  /* clipping polygon projected onto the subject plane along the clipping normal (:249-257) */
+  REAL d = FN(dot3)(subj_poly[0], subj_n);
+  REAL denom = FN(dot3)(clip_n, subj_n);
+  REAL den = denom + (denom == 0 ? EPS_F32 : (REAL)0);
+  REAL c0s[MJO_MAXK][3], c1s[MJO_MAXK][3];
+  for (int k = 0; k < K; k++) {
+    REAL t0 = (d - FN(dot3)(cp0[k], subj_n)) / den, t1 = (d - FN(dot3)(clip_poly[k], subj_n)) / den;
+    for (int i = 0; i < 3; i++) { c0s[k][i] = cp0[k][i] + t0 * clip_n[i]; c1s[k][i] = clip_poly[k][i] + t1 * clip_n[i]; }
+  }
+  for (int k = 0; k < K; k++) {
+    int mk = FN(clip_edge_to_planes)(c0s[k], c1s[k], sp0, spn, K, inc[2 * K + 2 * k], inc[2 * K + 2 * k + 1]);
+    mask[2 * K + 2 * k] = mask[2 * K + 2 * k + 1] = (unsigned char)mk;
+  }
+  int P = 4 * K;
+  REAL nn[3] = {clip_n[0], clip_n[1], clip_n[2]}, neg[3] = {-clip_n[0], -clip_n[1], -clip_n[2]};
+  FN(normalize_n)(nn, 3);
+  for (int p = 0; p < P; p++) {
+    FN(project_pt_onto_plane)(inc[p], clip_poly[0], nn, ref[p]);
+    REAL e[3] = {inc[p][0] - clip_poly[0][0], inc[p][1] - clip_poly[0][1], inc[p][2] - clip_poly[0][2]};
+    mask[p] = mask[p] && (FN(dot3)(e, neg) > (REAL)1e-6);
+  }
+  int best[4];
+  FN(manifold_points)(w, (const REAL(*)[3])ref, mask, P, clip_n, best);
+  for (int q = 0; q < 4; q++) {
+    int b = best[q];
+    REAL pd[3] = {inc[b][0] - ref[b][0], inc[b][1] - ref[b][1], inc[b][2] - ref[b][2]};
+    REAL pen = FN(dot3)(pd, neg);
+    dist[q] = mask[b] ? -pen : (REAL)1;
+    for (int i = 0; i < 3; i++) pos[q][i] = ref[b][i];
+  }
+  for (int i = 0; i < 3; i++) normal[i] = -sep_axis[i];
+}
+
+/* plane_convex :604-623 */
+static void FN(plane_convex_)(FN(MjoWork) * w, const REAL* ppos, const REAL* pmat, const REAL* cpos, const REAL* cmat, const FN(Cvx) * cv, REAL* dist, REAL (*pos)[3], REAL (*frame)[9]) {
+  REAL rel[3] = {ppos[0] - cpos[0], ppos[1] - cpos[1], ppos[2] - cpos[2]}, plane_pos[3], nw[3] = {pmat[2], pmat[5], pmat[8]}, n[3];
+  FN(mat_t_vec)(cmat, rel, plane_pos);
+  FN(mat_t_vec)(cmat, nw, n);
+  int V = cv->nvert;
+  REAL* support = (REAL*)malloc(sizeof(REAL) * V);
+  unsigned char* mask = (unsigned char*)malloc(V);
+  for (int v = 0; v < V; v++) {
+    REAL e[3] = {plane_pos[0] - cv->vert[3 * v], plane_pos[1] - cv->vert[3 * v + 1], plane_pos[2] - cv->vert[3 * v + 2]};
+    support[v] = FN(dot3)(e, n);
+    mask[v] = support[v] > 0;
+  }
+  int idx[4];
+  FN(manifold_points)(w, (const REAL(*)[3])cv->vert, mask, V, n, idx);
+  for (int q = 0; q < 4; q++) {
+    REAL r[3];
+    FN(mat_vec)(cmat, cv->vert + 3 * idx[q], r);
+    for (int i = 0; i < 3; i++) pos[q][i] = cpos[i] + r[i];
+    FN(make_frame)(nw, frame[q]);
+    int cnt = 0;
+    for (int j = 0; j <= q; j++) cnt += idx[j] == idx[q];
+    dist[q] = cnt == 1 ? -support[idx[q]] : (REAL)1;
+  }
+  free(support); free(mask);
+}
+
+/* face of the convex with the largest negative support (:644-657, :732-744) */
+static int FN(best_face_)(FN(MjoWork) * w, REAL* support, int F, REAL scale) {
+  for (int f = 0; f < F; f++) {
+    if (support[f] < 0 && -support[f] > scale) scale = -support[f];
+    if (support[f] >= 0) support[f] = (REAL)-1e12;
+  }
+  return FN(pick)(w, support, F, +1, scale, NULL, 1);
+}
+
+/* sphere_convex :626-699 */
+static void FN(sphere_convex_)(FN(MjoWork) * w, const REAL* spos, REAL r, const REAL* cpos, const REAL* cmat, const FN(Cvx) * cv, REAL* dist, REAL* pos, REAL* frame) {
+  REAL rel[3] = {spos[0] - cpos[0], spos[1] - cpos[1], spos[2] - cpos[2]}, sp[3];
+  FN(mat_t_vec)(cmat, rel, sp);
+  int F = cv->nface, K = cv->nfv;
+  REAL* support = (REAL*)malloc(sizeof(REAL) * F);
+  for (int f = 0; f < F; f++) {
+    const REAL *nf = cv->norm + 3 * f, *v0 = cv->vert + 3 * FN(cvx_fv)(cv, f, 0);
+    REAL e[3];
+    for (int i = 0; i < 3; i++) e[i] = (sp[i] - nf[i] * r) - v0[i];
+    support[f] = FN(dot3)(e, nf);
+  }
+  int bf = FN(best_face_)(w, support, F, r);
+  free(support);
+  const REAL* normal = cv->norm + 3 * bf;
+  REAL face[MJO_MAXK][3] = {{0}};
+  for (int k = 0; k < K; k++) for (int i = 0; i < 3; i++) face[k][i] = cv->vert[3 * FN(cvx_fv)(cv, bf, k) + i];
+  REAL pt[3];
+  FN(project_pt_onto_plane)(sp, face[0], normal, pt);
+  REAL ed[MJO_MAXK], edm[MJO_MAXK];
+  int inside = 1;
+  for (int k = 0; k < K; k++) {
+    int km = (k + K - 1) % K;
+    REAL e[3] = {face[k][0] - face[km][0], face[k][1] - face[km][1], face[k][2] - face[km][2]}, en[3];
+    FN(cross3)(e, normal, en);
+    REAL q[3] = {pt[0] - face[km][0], pt[1] - face[km][1], pt[2] - face[km][2]};
+    ed[k] = FN(dot3)(q, en);
+    if (!(ed[k] <= 0)) inside = 0;
+    int degenerate = en[0] == 0 && en[1] == 0 && en[2] == 0;
+    edm[k] = (degenerate || ed[k] < 0) ? (REAL)1e12 : ed[k];
+  }
+  REAL escale = 0;
+  for (int k = 0; k < K; k++) if (edm[k] < (REAL)1e11 && edm[k] > escale) escale = edm[k];
+  int ei = FN(pick)(w, edm, K, -1, escale + r * r, NULL, 1);
+  if (!inside) {
+    REAL ept[3];
+    FN(closest_segment_point)(face[(ei + K - 1) % K], face[ei], pt, ept);
+    for (int i = 0; i < 3; i++) pt[i] = ept[i];
+  }
+  REAL n[3] = {pt[0] - sp[0], pt[1] - sp[1], pt[2] - sp[2]};
+  REAL d = FN(normalize_n)(n, 3);
+  REAL lp[3], nw[3], pw[3];
+  for (int i = 0; i < 3; i++) { REAL spt = sp[i] + n[i] * r; lp[i] = (pt[i] + spt) * (REAL)0.5; }
+  *dist = d - r;
+  FN(mat_vec)(cmat, n, nw);
+  FN(mat_vec)(cmat, lp, pw);
+  for (int i = 0; i < 3; i++) pos[i] = pw[i] + cpos[i];
+  FN(make_frame)(nw, frame);
+}
+
+/* capsule_convex :702-802 */
+static void FN(capsule_convex_)(FN(MjoWork) * w, const REAL* kpos, const REAL* kmat, REAL r, REAL halflen, const REAL* cpos, const REAL* cmat, const FN(Cvx) * cv,
+                                REAL* dist, REAL (*pos)[3], REAL (*frame)[9]) {
+  REAL rel[3] = {kpos[0] - cpos[0], kpos[1] - cpos[1], kpos[2] - cpos[2]}, cp[3], axw[3] = {kmat[2], kmat[5], kmat[8]}, axis[3];
+  FN(mat_t_vec)(cmat, rel, cp);
+  FN(mat_t_vec)(cmat, axw, axis);
+  REAL pts[2][3];
+  for (int i = 0; i < 3; i++) { REAL sg = axis[i] * halflen; pts[0][i] = cp[i] - sg; pts[1][i] = cp[i] + sg; }
+  int F = cv->nface, K = cv->nfv;
+  REAL* support = (REAL*)malloc(sizeof(REAL) * F);
+  int has_support = 1;
+  for (int f = 0; f < F; f++) {
+    const REAL *nf = cv->norm + 3 * f, *v0 = cv->vert + 3 * FN(cvx_fv)(cv, f, 0);
+    REAL s2[2];
+    for (int q = 0; q < 2; q++) {
+      REAL e[3];
+      for (int i = 0; i < 3; i++) e[i] = (pts[q][i] - nf[i] * r) - v0[i];
+      s2[q] = FN(dot3)(e, nf);
+    }
+    support[f] = s2[1] < s2[0] ? s2[1] : s2[0];
+    if (!(support[f] < 0)) has_support = 0;
+  }
+  int bf = FN(best_face_)(w, support, F, r + halflen);
+  free(support);
+  const REAL* normal = cv->norm + 3 * bf;
+  REAL face[MJO_MAXK][3], ep0[MJO_MAXK][3], en[MJO_MAXK][3];
+  for (int k = 0; k < K; k++) for (int i = 0; i < 3; i++) face[k][i] = cv->vert[3 * FN(cvx_fv)(cv, bf, k) + i];
+  for (int k = 0; k < K; k++) {
+    int km = (k + K - 1) % K;
+    REAL e[3];
+    for (int i = 0; i < 3; i++) { ep0[k][i] = face[km][i]; e[i] = face[k][i] - face[km][i]; }
+    FN(cross3)(e, normal, en[k]);
+  }
+  REAL cl[2][3];
+  int mask = FN(clip_edge_to_planes)(pts[0], pts[1], (const REAL(*)[3])ep0, (const REAL(*)[3])en, K, cl[0], cl[1]);
+  REAL lpos[2][3], lnorm[2][3], pen[2];
+  for (int q = 0; q < 2; q++) {
+    REAL fp[3];
+    for (int i = 0; i < 3; i++) cl[q][i] = cl[q][i] - normal[i] * r;
+    FN(project_pt_onto_plane)(cl[q], face[0], normal, fp);
+    REAL e[3];
+    for (int i = 0; i < 3; i++) { lpos[q][i] = (cl[q][i] + fp[i]) * (REAL)0.5; lnorm[q][i] = normal[i]; e[i] = fp[i] - cl[q][i]; }
+    pen[q] = (mask && has_support) ? FN(dot3)(e, normal) : (REAL)-1;
+  }
+  /* potential edge contact */
+  REAL ed[MJO_MAXK], ecl[MJO_MAXK][3], ccl[MJO_MAXK][3];
+  for (int k = 0; k < K; k++) {
+    FN(closest_segment_to_segment)(ep0[k], face[k], pts[0], pts[1], ecl[k], ccl[k]);
+    REAL e0 = ecl[k][0] - ccl[k][0], e1 = ecl[k][1] - ccl[k][1], e2 = ecl[k][2] - ccl[k][2];
+    ed[k] = e0 * e0 + e1 * e1 + e2 * e2;
+  }
+  REAL escale = 0;
+  for (int k = 0; k < K; k++) if (ed[k] > escale) escale = ed[k];
+  int ei = FN(pick)(w, ed, K, -1, escale, NULL, 1);
+  REAL eax[3] = {ccl[ei][0] - ecl[ei][0], ccl[ei][1] - ecl[ei][1], ccl[ei][2] - ecl[ei][2]};
+  REAL edist = FN(normalize_n)(eax, 3);
+  REAL epen = r - edist;
+  if (epen > 0) {
+    for (int i = 0; i < 3; i++) { lpos[0][i] = (ecl[ei][i] + (ccl[ei][i] - eax[i] * r)) * (REAL)0.5; lnorm[0][i] = eax[i]; }
+    pen[0] = epen;
+  }
+  for (int q = 0; q < 2; q++) {
+    REAL nl[3] = {-lnorm[q][0], -lnorm[q][1], -lnorm[q][2]}, pw[3], nw[3];
+    FN(mat_vec)(cmat, lpos[q], pw);
+    FN(mat_vec)(cmat, nl, nw);
+    for (int i = 0; i < 3; i++) pos[q][i] = cpos[i] + pw[i];
+    dist[q] = -pen[q];
+    FN(make_frame)(nw, frame[q]);
+  }
+}
+
+/* separating axis number a of _sat_hull_hull (:495-503): normals of hull 1, of hull 2, then normalised edge x edge */
+static void FN(sat_axis)(int a, const FN(Cvx) * cv1, const FN(Cvx) * cv2, const REAL (*v1)[3], const REAL (*n1)[3], REAL* axis) {
+  int F1 = cv1->nface, F2 = cv2->nface, E1 = cv1->nedge;
+  const REAL(*v2)[3] = (const REAL(*)[3])cv2->vert;
+  if (a < F1) { for (int i = 0; i < 3; i++) axis[i] = n1[a][i]; return; }
+  if (a < F1 + F2) { for (int i = 0; i < 3; i++) axis[i] = cv2->norm[3 * (a - F1) + i]; return; }
+  int e = a - F1 - F2, i1 = e % E1, j2 = e / E1;
+  const REAL *a0 = v1[cv1->edge[2 * i1]], *a1 = v1[cv1->edge[2 * i1 + 1]], *b0 = v2[cv2->edge[2 * j2]], *b1 = v2[cv2->edge[2 * j2 + 1]];
+  REAL da[3] = {a0[0] - a1[0], a0[1] - a1[1], a0[2] - a1[2]}, db[3] = {b0[0] - b1[0], b0[1] - b1[1], b0[2] - b1[2]};
+  FN(cross3)(da, db, axis);
+  FN(normalize_n)(axis, 3);
+}
+/* convex_convex :805-856 with _sat_hull_hull :464-601 */
+static void FN(convex_convex_)(FN(MjoWork) * w, const REAL* pos1, const REAL* mat1, const FN(Cvx) * cv1, const REAL* pos2, const REAL* mat2, const FN(Cvx) * cv2,
+                               REAL* dist, REAL (*pos)[3], REAL (*frame)[9]) {
+  int K = cv1->nfv > cv2->nfv ? cv1->nfv : cv2->nfv;
+  int swapped = cv1->nvert > cv2->nvert;
+  if (swapped) { const REAL* t; const FN(Cvx) * c; t = pos1; pos1 = pos2; pos2 = t; t = mat1; mat1 = mat2; mat2 = t; c = cv1; cv1 = cv2; cv2 = c; }
+  int V1 = cv1->nvert, V2 = cv2->nvert, F1 = cv1->nface, F2 = cv2->nface, E1 = cv1->nedge, E2 = cv2->nedge;
+  REAL rel[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]}, tlp[3], tlm[9];
+  FN(mat_t_vec)(mat2, rel, tlp);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) tlm[3 * i + j] = mat2[0 + i] * mat1[0 + j] + mat2[3 + i] * mat1[3 + j] + mat2[6 + i] * mat1[6 + j];
+  REAL(*v1)[3] = (REAL(*)[3])malloc(sizeof(REAL) * 3 * V1);
+  REAL(*n1)[3] = (REAL(*)[3])malloc(sizeof(REAL) * 3 * F1);
+  for (int v = 0; v < V1; v++) { REAL t[3]; FN(mat_vec)(tlm, cv1->vert + 3 * v, t); for (int i = 0; i < 3; i++) v1[v][i] = tlp[i] + t[i]; }
+  for (int f = 0; f < F1; f++) FN(mat_vec)(tlm, cv1->norm + 3 * f, n1[f]);
+  const REAL(*v2)[3] = (const REAL(*)[3])cv2->vert;
+  const REAL(*n2)[3] = (const REAL(*)[3])cv2->norm;
+  /* separating axes: face normals of 1, of 2, then edge x edge (index j * E1 + i) */
+  int NA = F1 + F2 + E1 * E2;
+  REAL* sup = (REAL*)malloc(sizeof(REAL) * NA);
+  signed char* sgn = (signed char*)malloc(NA);
+  REAL sscale = 0;
+  for (int a = 0; a < NA; a++) {
+    REAL axis[3];
+    FN(sat_axis)(a, cv1, cv2, (const REAL(*)[3])v1, (const REAL(*)[3])n1, axis);
+    REAL amax = 0, amin = 0, bmax = 0, bmin = 0;
+    for (int v = 0; v < V1; v++) { REAL sv = FN(dot3)(axis, v1[v]); if (v == 0 || sv > amax) amax = sv; if (v == 0 || sv < amin) amin = sv; }
+    for (int v = 0; v < V2; v++) { REAL sv = FN(dot3)(axis, v2[v]); if (v == 0 || sv > bmax) bmax = sv; if (v == 0 || sv < bmin) bmin = sv; }
+    REAL d1 = amax - bmin, d2 = bmax - amin;
+    sgn[a] = d1 > d2 ? -1 : 1;
+    REAL d = d1 < d2 ? d1 : d2;   /* torch.minimum */
+    if (axis[0] == 0 && axis[1] == 0 && axis[2] == 0) d = (REAL)1e6;
+    else { REAL mg = R_FABS(amax) + R_FABS(amin) + R_FABS(bmax) + R_FABS(bmin); if (mg > sscale) sscale = mg; }
+    sup[a] = d;
+  }
+  int best = FN(pick)(w, sup, NA, -1, sscale, NULL, 1);
+  int best_sign = sgn[best];
+  REAL best_axis[3];
+  FN(sat_axis)(best, cv1, cv2, (const REAL(*)[3])v1, (const REAL(*)[3])n1, best_axis);
+  free(sup); free(sgn);
+  int is_edge = best >= F1 + F2;
+  REAL* fa = (REAL*)malloc(sizeof(REAL) * (F1 + F2));
+  REAL* fb = fa + F1;
+  for (int f = 0; f < F1; f++) fa[f] = FN(dot3)(best_axis, n1[f]);
+  for (int f = 0; f < F2; f++) fb[f] = FN(dot3)(best_axis, n2[f]);
+  int a_max = FN(pick)(w, fa, F1, +1, (REAL)1, NULL, 1), b_max = FN(pick)(w, fb, F2, +1, (REAL)1, NULL, 1);
+  int a_min = FN(pick)(w, fa, F1, -1, (REAL)1, NULL, 1), b_min = FN(pick)(w, fb, F2, -1, (REAL)1, NULL, 1);
+  free(fa);
+  REAL ref_face[MJO_MAXK][3], inc_face[MJO_MAXK][3], ref_n[3], inc_n[3], sep[3];
+  for (int k = 0; k < K; k++) for (int i = 0; i < 3; i++) {
+    ref_face[k][i] = best_sign > 0 ? v1[FN(cvx_fv)(cv1, a_max, k)][i] : v2[FN(cvx_fv)(cv2, b_max, k)][i];
+    inc_face[k][i] = best_sign > 0 ? v2[FN(cvx_fv)(cv2, b_min, k)][i] : v1[FN(cvx_fv)(cv1, a_min, k)][i];
+  }
+  for (int i = 0; i < 3; i++) {
+    ref_n[i] = best_sign > 0 ? n1[a_max][i] : n2[b_max][i];
+    inc_n[i] = best_sign > 0 ? n2[b_min][i] : n1[a_min][i];
+    sep[i] = (REAL)(-best_sign) * best_axis[i];
+  }
+  REAL ldist[4], lpos[4][3], lnormal[3];
+  FN(create_contact_manifold)(w, (const REAL(*)[3])ref_face, (const REAL(*)[3])inc_face, K, ref_n, inc_n, sep, ldist, lpos, lnormal);
+  if (is_edge) { /* :581-599 */
+    int idx = FN(pick)(w, ldist, 4, -1, (REAL)1, &lpos[0][0], 4);
+    REAL dd = ldist[idx], pp[3] = {lpos[idx][0], lpos[idx][1], lpos[idx][2]};
+    for (int q = 0; q < 4; q++) { ldist[q] = q == 0 ? dd : (REAL)1; for (int i = 0; i < 3; i++) lpos[q][i] = pp[i]; }
+  }
+  REAL nw[3];
+  FN(mat_vec)(mat2, lnormal, nw);
+  if (swapped) for (int i = 0; i < 3; i++) nw[i] = -nw[i];
+  for (int q = 0; q < 4; q++) {
+    REAL pw[3];
+    FN(mat_vec)(mat2, lpos[q], pw);
+    for (int i = 0; i < 3; i++) pos[q][i] = pos2[i] + pw[i];
+    dist[q] = ldist[q];
+    FN(make_frame)(nw, frame[q]);
+  }
+  free(v1); free(n1);
+}
+
+/* narrow phase of pair p (collision_driver.py:106-125 dispatch table) */
+static void FN(pair_contacts)(const FN(MjoModel) * M, FN(MjoWork) * w, int p, REAL* dist, REAL (*pos)[3], REAL (*frame)[9]) {
+  const mjhModelDesc* m = M->d;
+  int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], fn = m->pair_fn[p], k = m->pair_ncon[p];
+  const REAL *p1 = w->geom_xpos + 3 * g1, *m1 = w->geom_xmat + 9 * g1, *s1 = M->geom_size + 3 * g1;
+  const REAL *p2 = w->geom_xpos + 3 * g2, *m2 = w->geom_xmat + 9 * g2, *s2 = M->geom_size + 3 * g2;
+  if (fn == MJH_FN_PLANE_SPHERE) {
+    REAL n[3] = {m1[2], m1[5], m1[8]};
+    FN(plane_sphere_)(n, p1, p2, s2[0], &dist[0], pos[0]);
+    FN(make_frame)(n, frame[0]);
+  } else if (fn == MJH_FN_PLANE_CAPSULE) { /* collision_primitive.py:48-74 */
+    REAL n[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
+    REAL na = FN(dot3)(n, axis), b[3];
+    for (int i = 0; i < 3; i++) b[i] = axis[i] - n[i] * na;
+    REAL bn = FN(normalize_n)(b, 3);
+    if (bn < (REAL)0.5) {
+      b[0] = 0; b[1] = 0; b[2] = 0;
+      if ((REAL)-0.5 < n[1] && n[1] < (REAL)0.5) b[1] = 1; else b[2] = 1;
+    }
+    REAL c[3];
+    FN(cross3)(n, b, c);
+    REAL seg[3] = {axis[0] * s2[1], axis[1] * s2[1], axis[2] * s2[1]};
+    for (int q = 0; q < 2; q++) {
+      REAL sp[3];
+      for (int i = 0; i < 3; i++) sp[i] = p2[i] + (q == 0 ? seg[i] : -seg[i]);
+      FN(plane_sphere_)(n, p1, sp, s2[0], &dist[q], pos[q]);
+      for (int i = 0; i < 3; i++) { frame[q][i] = n[i]; frame[q][3 + i] = b[i]; frame[q][6 + i] = c[i]; }
+    }
+  } else if (fn == MJH_FN_SPHERE_SPHERE) {
+    REAL n[3];
+    FN(sphere_sphere_)(p1, s1[0], p2, s2[0], &dist[0], pos[0], n);
+    FN(make_frame)(n, frame[0]);
+  } else if (fn == MJH_FN_SPHERE_CAPSULE) { /* :195-201 */
+    REAL axis[3] = {m2[2], m2[5], m2[8]}, a[3], b[3], pt[3], n[3];
+    for (int i = 0; i < 3; i++) { REAL sg = axis[i] * s2[1]; a[i] = p2[i] - sg; b[i] = p2[i] + sg; }
+    FN(closest_segment_point)(a, b, p1, pt);
+    FN(sphere_sphere_)(p1, s1[0], pt, s2[0], &dist[0], pos[0], n);
+    FN(make_frame)(n, frame[0]);
+  } else if (fn == MJH_FN_CAPSULE_CAPSULE) { /* :204-221 */
+    REAL ax1[3] = {m1[2], m1[5], m1[8]}, ax2[3] = {m2[2], m2[5], m2[8]};
+    REAL a0[3], a1[3], b0[3], b1[3], pt1[3], pt2[3], n[3];
+    for (int i = 0; i < 3; i++) {
+      REAL sg1 = ax1[i] * s1[1], sg2 = ax2[i] * s2[1];
+      a0[i] = p1[i] - sg1; a1[i] = p1[i] + sg1; b0[i] = p2[i] - sg2; b1[i] = p2[i] + sg2;
+    }
+    FN(closest_segment_to_segment)(a0, a1, b0, b1, pt1, pt2);
+    FN(sphere_sphere_)(pt1, s1[0], pt2, s2[0], &dist[0], pos[0], n);
+    FN(make_frame)(n, frame[0]);
+  } else if (fn == MJH_FN_PLANE_CONVEX) {
+    FN(Cvx) c2 = FN(cvx_of)(M, g2);
+    FN(plane_convex_)(w, p1, m1, p2, m2, &c2, dist, pos, frame);
+  } else if (fn == MJH_FN_SPHERE_CONVEX) {
+    FN(Cvx) c2 = FN(cvx_of)(M, g2);
+    FN(sphere_convex_)(w, p1, s1[0], p2, m2, &c2, &dist[0], pos[0], frame[0]);
+  } else if (fn == MJH_FN_CAPSULE_CONVEX) {
+    FN(Cvx) c2 = FN(cvx_of)(M, g2);
+    FN(capsule_convex_)(w, p1, m1, s1[0], s1[1], p2, m2, &c2, dist, pos, frame);
+  } else if (fn == MJH_FN_CONVEX_CONVEX) {
+    FN(Cvx) c1 = FN(cvx_of)(M, g1), c2 = FN(cvx_of)(M, g2);
+    FN(convex_convex_)(w, p1, m1, &c1, p2, m2, &c2, dist, pos, frame);
+  } else {
+    for (int q = 0; q < k; q++) { dist[q] = 1; for (int i = 0; i < 3; i++) pos[q][i] = 0; for (int i = 0; i < 9; i++) frame[q][i] = 0; }
+  }
+}
+
 static void FN(collision)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* collision_driver.py:800-875 */
   const mjhModelDesc* m = M->d;
   for (int p = 0; p < m->npair; p++) {
-    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], fn = m->pair_fn[p];
-    const REAL *p1 = w->geom_xpos + 3 * g1, *m1 = w->geom_xmat + 9 * g1, *s1 = M->geom_size + 3 * g1;
-    const REAL *p2 = w->geom_xpos + 3 * g2, *m2 = w->geom_xmat + 9 * g2, *s2 = M->geom_size + 3 * g2;
     REAL dist[MJH_MAX_PAIR_CONTACTS], pos[MJH_MAX_PAIR_CONTACTS][3], frame[MJH_MAX_PAIR_CONTACTS][9];
     int k = m->pair_ncon[p];
-    if (fn == MJH_FN_PLANE_SPHERE) {
-      REAL n[3] = {m1[2], m1[5], m1[8]};
-      FN(plane_sphere_)(n, p1, p2, s2[0], &dist[0], pos[0]);
-      FN(make_frame)(n, frame[0]);
-    } else if (fn == MJH_FN_PLANE_CAPSULE) { /* collision_primitive.py:48-74 */
-      REAL n[3] = {m1[2], m1[5], m1[8]}, axis[3] = {m2[2], m2[5], m2[8]};
-      REAL na = FN(dot3)(n, axis), b[3];
-      for (int i = 0; i < 3; i++) b[i] = axis[i] - n[i] * na;
-      REAL bn = FN(normalize_n)(b, 3);
-      if (bn < (REAL)0.5) {
-        b[0] = 0; b[1] = 0; b[2] = 0;
-        if ((REAL)-0.5 < n[1] && n[1] < (REAL)0.5) b[1] = 1; else b[2] = 1;
-      }
-      REAL c[3];
-      FN(cross3)(n, b, c);
-      REAL seg[3] = {axis[0] * s2[1], axis[1] * s2[1], axis[2] * s2[1]};
-      for (int q = 0; q < 2; q++) {
-        REAL sp[3];
-        for (int i = 0; i < 3; i++) sp[i] = p2[i] + (q == 0 ? seg[i] : -seg[i]);
-        FN(plane_sphere_)(n, p1, sp, s2[0], &dist[q], pos[q]);
-        for (int i = 0; i < 3; i++) { frame[q][i] = n[i]; frame[q][3 + i] = b[i]; frame[q][6 + i] = c[i]; }
-      }
-    } else if (fn == MJH_FN_SPHERE_SPHERE) {
-      REAL n[3];
-      FN(sphere_sphere_)(p1, s1[0], p2, s2[0], &dist[0], pos[0], n);
-      FN(make_frame)(n, frame[0]);
-    } else if (fn == MJH_FN_SPHERE_CAPSULE) { /* :195-201 */
-      REAL axis[3] = {m2[2], m2[5], m2[8]}, a[3], b[3], pt[3], n[3];
-      for (int i = 0; i < 3; i++) { REAL sg = axis[i] * s2[1]; a[i] = p2[i] - sg; b[i] = p2[i] + sg; }
-      FN(closest_segment_point)(a, b, p1, pt);
-      FN(sphere_sphere_)(p1, s1[0], pt, s2[0], &dist[0], pos[0], n);
-      FN(make_frame)(n, frame[0]);
-    } else if (fn == MJH_FN_CAPSULE_CAPSULE) { /* :204-221 */
-      REAL ax1[3] = {m1[2], m1[5], m1[8]}, ax2[3] = {m2[2], m2[5], m2[8]};
-      REAL a0[3], a1[3], b0[3], b1[3], pt1[3], pt2[3], n[3];
-      for (int i = 0; i < 3; i++) {
-        REAL sg1 = ax1[i] * s1[1], sg2 = ax2[i] * s2[1];
-        a0[i] = p1[i] - sg1; a1[i] = p1[i] + sg1; b0[i] = p2[i] - sg2; b1[i] = p2[i] + sg2;
-      }
-      FN(closest_segment_to_segment)(a0, a1, b0, b1, pt1, pt2);
-      FN(sphere_sphere_)(pt1, s1[0], pt2, s2[0], &dist[0], pos[0], n);
-      FN(make_frame)(n, frame[0]);
+    const int* dst = m->pair_dst + p * MJH_MAX_PAIR_CONTACTS;
+    if (w->hint_dist && m->pair_fn[p] >= MJH_FN_PLANE_CONVEX) {
+      /* enumerate the pair's tie events; keep the outcome closest to the hint (the natural one on equality) */
+      REAL bd[MJH_MAX_PAIR_CONTACTS], bp[MJH_MAX_PAIR_CONTACTS][3], bf[MJH_MAX_PAIR_CONTACTS][9], best_err = 0;
+      int runs = 0, natural = 1;
+      w->tie_on = 1;
+      memset(w->tie_digit, 0, sizeof(w->tie_digit));
+      do {
+        w->tie_n = 0;
+        FN(pair_contacts)(M, w, p, dist, pos, frame);
+        REAL err = 0;
+        for (int q = 0; q < k; q++) {
+          int c = dst[q];
+          REAL e = R_FABS(dist[q] - w->hint_dist[c]);
+          if (e > err) err = e;
+          for (int i = 0; i < 3; i++) { e = R_FABS(pos[q][i] - w->hint_pos[3 * c + i]); if (e > err) err = e; }
+          for (int i = 0; i < 9; i++) { e = R_FABS(frame[q][i] - w->hint_frame[9 * c + i]); if (e > err) err = e; }
+        }
+        if (runs == 0 || err < best_err) { best_err = err; natural = runs == 0; memcpy(bd, dist, sizeof(bd)); memcpy(bp, pos, sizeof(bp)); memcpy(bf, frame, sizeof(bf)); }
+        runs++;
+        int e = (w->tie_n < MJO_MAX_TIE ? w->tie_n : MJO_MAX_TIE) - 1;
+        while (e >= 0 && w->tie_digit[e] + 1 >= w->tie_count[e]) { w->tie_digit[e] = 0; e--; }
+        if (e < 0) break;
+        w->tie_digit[e]++;
+      } while (runs < MJO_MAX_TIE_RUNS);
+      w->tie_on = 0;
+      if (!natural) w->tie_pairs++;
+      memcpy(dist, bd, sizeof(bd)); memcpy(pos, bp, sizeof(bp)); memcpy(frame, bf, sizeof(bf));
     } else {
-      for (int q = 0; q < k; q++) { dist[q] = 1; for (int i = 0; i < 3; i++) pos[q][i] = 0; for (int i = 0; i < 9; i++) frame[q][i] = 0; }
+      FN(pair_contacts)(M, w, p, dist, pos, frame);
     }
     for (int q = 0; q < k; q++) {
       int c = m->pair_dst[p * MJH_MAX_PAIR_CONTACTS + q];

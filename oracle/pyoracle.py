@@ -36,6 +36,8 @@ def lib():
         _lib.mjo_step.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         _lib.mjo_forward.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         _lib.mjo_max_threads.restype = ctypes.c_int
+        _lib.mjo_set_contact_hint.argtypes = [ctypes.c_void_p] * 4
+        _lib.mjo_set_contact_hint.restype = None
     return _lib
 
 
@@ -58,11 +60,15 @@ def _ptrs(arrs):
     return p
 
 
-def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1):
+def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1, contact_hint=None, tie_pairs=None):
     """Runs the oracle on a (possibly batched) CPU Data; returns {leaf: numpy array} of outputs.
 
     ``knife``: optional int32 array [B]; receives per env the number of line-search candidates whose
     derivative was rounding noise (the reference's result is implementation-defined on such steps).
+    ``contact_hint``: optional {"contact_dist", "contact_pos", "contact_frame"} arrays (the outputs under test): where
+    an index selection of the convex narrow phase is decided by rounding noise, the oracle keeps the admissible
+    outcome closest to the hint (natural pick on equality); ``tie_pairs`` (int32 [B]) receives how many geom pairs
+    per env ended on a non-natural outcome.
     ``knife_policy``: -1 natural rounding; j >= 0 forces the first j such candidates to read as an exact
     zero (rejected by both bracket tests, solver.py:440-449) and the next one as non-zero (accepted)."""
     dtype = d.qpos.dtype
@@ -74,13 +80,26 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
     pin, pout = _ptrs(inp), _ptrs(out)
     flags = 1 if fixed_iterations else 0
     dt = 0 if dtype == torch.float64 else 1
+    hint = None
+    if contact_hint is not None and inp["contact_dist"].size:
+        npdt = inp["contact_dist"].dtype
+        hint = [np.array(np.asarray(contact_hint[k]).reshape(inp[k].shape), dtype=npdt, order="C", copy=True) for k in ("contact_dist", "contact_pos", "contact_frame")]
+        lib().mjo_set_contact_hint(hint[0].ctypes.data, hint[1].ctypes.data, hint[2].ctypes.data, tie_pairs.ctypes.data if tie_pairs is not None else None)
+    try:
+        rc = _call(step, desc, pin, pout, B, dt, stages, flags, nthreads, knife, knife_policy)
+    finally:
+        lib().mjo_set_contact_hint(None, None, None, None)
+    if rc != 0:
+        raise RuntimeError(f"oracle failed: {rc}")
+    return out
+
+
+def _call(step, desc, pin, pout, B, dt, stages, flags, nthreads, knife, knife_policy):
     if step:
         rc = lib().mjo_step(ctypes.byref(desc), ctypes.byref(pin), ctypes.byref(pout), B, dt, flags, nthreads, knife.ctypes.data if knife is not None else None, knife_policy)
     else:
         rc = lib().mjo_forward(ctypes.byref(desc), ctypes.byref(pin), ctypes.byref(pout), B, dt, stages, flags, nthreads, knife.ctypes.data if knife is not None else None, knife_policy)
-    if rc != 0:
-        raise RuntimeError(f"oracle failed: {rc}")
-    return out
+    return rc
 
 
 def apply(d, out):
@@ -88,6 +107,10 @@ def apply(d, out):
     top, con = {}, {}
     for n, a in out.items():
         t = torch.from_numpy(a)
+        if t.is_floating_point():
+            # recorded reference leaves can carry their own dtype (qfrc_actuator is float32 zeros when nu == 0,
+            # forward.py:117-121): the ABI keeps every real leaf in the Data dtype
+            t = t.to(d.qpos.dtype)
         path = native.DATA_PATH[n]
         if len(path) == 2:
             con[path[1]] = t

@@ -85,13 +85,24 @@ SOLVER_LEAVES = ["qacc", "qacc_warmstart", "efc_force", "qfrc_constraint", "qpos
 MAX_KNIFE_POLICIES = 14
 
 
-def oracle_alternatives(model, d, step=True, **kw):
+HINT_LEAVES = ("contact_dist", "contact_pos", "contact_frame")
+
+
+def oracle_alternatives(model, d, step=True, hint=None, **kw):
     """Oracle outputs under every admissible rounding outcome of the line search's noise candidates.
 
     The reference accepts a line-search candidate whose derivative is +-1e-13 but rejects one whose
     derivative rounds to exactly 0.0 (solver.py:440-449); which of the two happens is decided by the
-    summation order of the implementation.  Returns [natural, policy 0, policy 1, ...]."""
+    summation order of the implementation.  Returns [natural, policy 0, policy 1, ...].
+
+    ``hint``: the outputs under test ({leaf: array}); forwarded as the oracle's contact hint so that index
+    selections of the convex narrow phase that rounding noise decides (argmax over exactly symmetric or
+    degenerate candidates, collision_convex.py:218-234, :532, :589) resolve to the admissible outcome the
+    outputs show (pyoracle.run)."""
     import pyoracle
+
+    if hint is not None and model.constraint_sizes_py[3] > 0 and any(c is not None for c in model.tables.convex):
+        kw["contact_hint"] = {k: hint[k] for k in HINT_LEAVES}
 
     B = int(np.prod(d.qpos.shape[:-1])) if d.qpos.ndim > 1 else 1
     knife = np.zeros(B, dtype=np.int32)
@@ -118,7 +129,7 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
     * solver-dependent leaves, per environment: must agree with the oracle under ONE admissible rounding
       outcome of the line search's noise candidates (oracle_alternatives).  Returns the fraction of
       environments that needed a non-natural branch."""
-    alts = oracle_alternatives(model, d_cpu, step=step, **kw)
+    alts = oracle_alternatives(model, d_cpu, step=step, hint=got, **kw)
     nat = alts[0]
     assert_leaves_close(lambda n: got[n], lambda n: nat[n], tol_pre, names=PRE_SOLVER, what=what)
     assert_ints_equal(lambda n: got[n], lambda n: nat[n], what=what)

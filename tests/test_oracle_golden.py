@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import pyoracle
-from _util import (SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+from _util import (HINT_LEAVES, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, oracle_alternatives, rel_err)
 
 # float64: the oracle follows the reference's operation order, differences are summation order in
@@ -30,7 +30,7 @@ def test_oracle_matches_reference_golden(case, oracle_lib):
         for s in range(g.nsteps):
             want = lambda n: g.expected(env, s, n)
             what = f"{case} env{env} step{s}"
-            alts = oracle_alternatives(g.model, d)
+            alts = oracle_alternatives(g.model, d, hint={n: want(n) for n in HINT_LEAVES})
             assert_leaves_close(lambda n: alts[0][n], want, tol, names=PRE_SOLVER, what=what)
             assert_ints_equal(lambda n: alts[0][n], want, what=what)
             errs = [max(rel_err(o[n], want(n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for o in alts]
@@ -53,3 +53,24 @@ def test_oracle_batched_equals_sequential(case, oracle_lib):
         out1 = pyoracle.run(g.model, g.input_data(env), step=True)
         for n in REAL_LEAVES + INT_LEAVES:
             assert np.array_equal(outb[n][env], out1[n]), n
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN_CASES if c.startswith(("mesh_contact", "convex_"))])
+def test_convex_tables_match_reference(case):
+    """device_put's box / mesh tables (mujoco_torch_amd/convex.py) == the ones the reference's mesh.get derived
+    (vertex order, polygon start vertex, face order, edge order: all of them steer index tie-breaks downstream)."""
+    g = Golden(case)
+    T = g.model.tables.convex
+    seen = 0
+    for geom, t in enumerate(T):
+        if t is None:
+            assert f"convex/{geom}/face" not in g.z
+            continue
+        seen += 1
+        assert np.array_equal(g.z[f"convex/{geom}/face"], t["face"])
+        assert np.array_equal(g.z[f"convex/{geom}/edge"], t["edge"])
+        want_dt = g.z[f"convex/{geom}/vert"].dtype
+        assert np.array_equal(g.z[f"convex/{geom}/vert"], t["vert"].astype(want_dt))
+        assert np.array_equal(g.z[f"convex/{geom}/facenormal"], t["facenormal"].astype(want_dt))
+        assert g.model.geom_convex_vert[geom].dtype == g.dtype
+    assert seen > 0
