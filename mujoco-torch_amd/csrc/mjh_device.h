@@ -104,6 +104,8 @@ struct DevModel {
   const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
+  const int* cvx_pairs;                    // ncvxpair: indices (into pair_*) of the pairs with a convex pair function
+  int ncvxpair;
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------------

@@ -702,9 +702,15 @@ struct Env {
     const int l = lane_id();
     row_load(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
     row_load(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
+    if (M.ncvxpair > 0) {  // box / mesh pairs were narrow-phased by mjh_convex_kernel (mjh_convex.h) into their contact slots
+      row_load(S.con_dist(), out.contact_dist, M.ncon, e);
+      row_load(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
+      row_load(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
+    }
     wave_sync();
     for (int p = l; p < M.npair; p += MJH_WAVE) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
+      if (fn >= MJH_FN_PLANE_CONVEX) continue;
       const REAL *p1 = S.geom_xpos() + 3 * g1, *m1 = S.geom_xmat() + 9 * g1, *s1 = M.geom_size + 3 * g1;
       const REAL *p2 = S.geom_xpos() + 3 * g2, *m2 = S.geom_xmat() + 9 * g2, *s2 = M.geom_size + 3 * g2;
       REAL dist[2], pos[2][3], frame[9];

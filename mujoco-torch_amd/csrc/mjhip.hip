@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "mjh_kernels.h"
+#include "mjh_convex.h"
 
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
@@ -27,6 +28,7 @@ struct mjhModel {
   size_t blob_bytes;
   LdsOff off[MJH_NPHASE];
   int lds_bytes[MJH_NPHASE];
+  int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of RK4 workspace (0 for Euler)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
@@ -71,6 +73,13 @@ std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
 const char* const kStageLeaves[] = {
     "qpos", "qvel", "act", "qacc_warmstart", "qacc", "act_dot", "xipos", "geom_xpos", "geom_xmat", "subtree_com", "cdof",
     "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint"};
+// ... plus, for models with convex pairs, the contact leaves the convex kernel hands to the constraint phase
+const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
+bool is_stage_leaf(const char* name, bool has_convex) {
+  for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
+  if (has_convex) for (const char* s : kConvexStageLeaves) if (!strcmp(s, name)) return true;
+  return false;
+}
 
 template <typename REAL>
 int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
@@ -150,8 +159,29 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
   M.max_depth = max_depth;
-  for (int p = 0; p < d->npair; p++)
-    if (d->pair_fn[p] > MJH_FN_CAPSULE_CAPSULE) return fail(-38, "convex (box/mesh) pair functions are not built yet");
+  // convex pairs and the LDS scratch their wave needs (layout in mjh_convex.h)
+  std::vector<int> cvx_pairs;
+  int cvx_reals = 0;
+  for (int p = 0; p < d->npair; p++) {
+    const int fn = d->pair_fn[p];
+    if (fn < MJH_FN_PLANE_CONVEX) continue;
+    if (fn > MJH_FN_CONVEX_CONVEX) return fail(-38, "pair function not implemented");
+    const int c2 = d->geom_convexid[d->pair_geom2[p]], c1 = d->geom_convexid[d->pair_geom1[p]];
+    if (c2 < 0 || c2 >= d->nconvex || (fn == MJH_FN_CONVEX_CONVEX && (c1 < 0 || c1 >= d->nconvex))) return fail(-22, "convex pair without convex tables");
+    int need = 0;
+    if (fn == MJH_FN_PLANE_CONVEX) need = 5 * d->convex_nvert[c2];
+    else if (fn == MJH_FN_CAPSULE_CONVEX) need = 6 * d->convex_nfv[c2];
+    else if (fn == MJH_FN_CONVEX_CONVEX) {
+      const int K = d->convex_nfv[c1] > d->convex_nfv[c2] ? d->convex_nfv[c1] : d->convex_nfv[c2];
+      need = 3 * (d->convex_nvert[c1] + d->convex_nface[c1] + d->convex_nvert[c2] + d->convex_nface[c2]) + 43 * K;
+    }
+    if (need > cvx_reals) cvx_reals = need;
+    cvx_pairs.push_back(p);
+  }
+  fix.push_back({(const void**)&M.cvx_pairs, bb.add(cvx_pairs.data(), sizeof(int) * cvx_pairs.size())});
+  M.ncvxpair = (int)cvx_pairs.size();
+  out->cvx_lds_bytes = (cvx_reals + 8) * (int)sizeof(REAL);
+  if (out->cvx_lds_bytes > 64 * 1024) return fail(-12, "convex hull too large for the pair kernel's LDS scratch");
 
   for (int p = 0; p < MJH_NPHASE; p++) {
     out->lds_bytes[p] = lds_carve(M, 1 << p, out->off[p]) * (int)sizeof(REAL);
@@ -166,8 +196,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
     };
     for (size_t i = 0; i < out->leaf_count.size(); i++)
-      for (const char* s : kStageLeaves)
-        if (!strcmp(s, names[i])) out->work_reals += out->leaf_count[i];
+      if (is_stage_leaf(names[i], M.ncvxpair > 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
 
@@ -180,6 +209,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #define SET_ATTR(P) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[P]));
   SET_ATTR(0) SET_ATTR(1) SET_ATTR(2) SET_ATTR(3) SET_ATTR(4)
 #undef SET_ATTR
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   return 0;
 }
 
@@ -198,6 +228,12 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
   if ((st & 0x7f) && (rc = launch_phase<REAL, 0>(m, a, stream))) return rc;
+  if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
+    const int64_t items = a.B * a.M.ncvxpair;
+    const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
+    hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
   if ((st & 0x70) && (rc = launch_phase<REAL, 3>(m, a, stream))) return rc;
@@ -221,6 +257,8 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
   a.warm_src = a.in.qacc_warmstart;
   a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
+  if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(a.fin.contact_dist && a.fin.contact_pos && a.fin.contact_frame && a.fin.geom_xpos && a.fin.geom_xmat))
+    return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
   if (!do_step || M.integrator == INT_EULER) return forward_pass<REAL>(m, a, s);
 
@@ -237,8 +275,7 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
 #undef X
     };
     for (size_t i = 0; i < m->leaf_count.size(); i++)
-      for (const char* nm : kStageLeaves)
-        if (!strcmp(nm, names[i])) { slots[i] = w; w += m->leaf_count[i] * B; }
+      if (is_stage_leaf(names[i], M.ncvxpair > 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
   }
   a.W.qvel0 = w; w += (int64_t)M.nv * B;
   a.W.kqvel = w; w += (int64_t)M.nv * B;

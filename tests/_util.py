@@ -101,7 +101,7 @@ def oracle_alternatives(model, d, step=True, hint=None, **kw):
     outputs show (pyoracle.run)."""
     import pyoracle
 
-    if hint is not None and model.constraint_sizes_py[3] > 0 and any(c is not None for c in model.tables.convex):
+    if hint is not None and model.constraint_sizes_py[3] > 0 and any(p[0] >= 5 for p in model.tables.pairs):
         kw["contact_hint"] = {k: hint[k] for k in HINT_LEAVES}
 
     B = int(np.prod(d.qpos.shape[:-1])) if d.qpos.ndim > 1 else 1

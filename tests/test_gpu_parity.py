@@ -27,17 +27,23 @@ def test_step_matches_reference_golden(case, oracle_lib):
     g = Golden(case)
     mdev = g.model.to("cuda")
     d = g.input_data()  # all envs batched
+    tol_pre, tol_sol = TOL_PRE[g.dtype], TOL_SOL[g.dtype]
+    via_oracle = 0
     for s in range(g.nsteps):
         out = gpu_out_to_numpy(mt.step(mdev, d.to("cuda")))
         want = lambda n: np.stack([g.expected(e, s, n) for e in range(g.nenv)])
         what = f"{case} step{s}"
-        assert_leaves_close(lambda n: out[n], want, TOL_PRE[g.dtype], names=PRE_SOLVER, what=what)
         assert_ints_equal(lambda n: out[n], want, what=what)
         for e in range(g.nenv):
+            err_pre = max(rel_err(out[n][e], g.expected(e, s, n)) for n in PRE_SOLVER)
             err_gold = max(rel_err(out[n][e], g.expected(e, s, n), SOLVER_FLOOR) for n in SOLVER_LEAVES)
-            if err_gold > TOL_SOL[g.dtype]:
-                check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, TOL_PRE[g.dtype], TOL_SOL[g.dtype], what=f"{what} env{e}")
+            if err_pre > tol_pre or err_gold > tol_sol:
+                # not the branch the reference's rounding took: it must still be an admissible outcome of the same
+                # algorithm (line-search noise candidates, narrow-phase index ties), which the oracle verifies
+                via_oracle += 1
+                check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, tol_pre, tol_sol, what=f"{what} env{e}")
         d = pyoracle.apply(d, {n: want(n) for n in REAL_LEAVES + INT_LEAVES})
+    print(f"{case}: {via_oracle}/{g.nsteps * g.nenv} env-steps verified through an admissible oracle branch instead of the golden one")
 
 
 @pytest.mark.parametrize("xml,overrides,dtype,B", [
@@ -46,20 +52,35 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 128),
     ("ant", {}, torch.float64, 64),
     ("cartpole", {}, torch.float64, 64),
+    ("mesh_contact", {}, torch.float32, 256),   # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
+    ("mesh_contact", {}, torch.float64, 64),
+    ("mesh_contact", {"solver": 1, "cone": 1, "_tol_sol": 1e-5}, torch.float64, 32),  # CG on 72 ill-conditioned rows: the iterates of 100 iterations amplify rounding
+    ("convex_meshes", {}, torch.float64, 32),
+    ("convex_primitives", {}, torch.float64, 32),
+    ("convex_primitives", {}, torch.float32, 32),
 ])
 def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_lib):
     """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs."""
+    overrides = dict(overrides)
+    tol_sol = overrides.pop("_tol_sol", TOL_SOL[dtype])
     mx = load_model(xml, overrides, dtype)
     rng = np.random.RandomState(42)
     d = mt.make_data(mx).expand(B).clone()
     d = d.replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(B, mx.nu)))
+    if any(p[0] >= 5 for p in mx.tables.pairs):  # convex pairs: free bodies resting on each other, jitter the poses too
+        q = d.qpos.clone()
+        for j in range(mx.njnt):
+            a = int(mx.jnt_qposadr[j])
+            q[:, a : a + 3] += torch.tensor(0.01 * rng.randn(B, 3))
+            q[:, a + 3 : a + 7] += torch.tensor(0.03 * rng.randn(B, 4))
+        d = d.replace(qpos=q, qvel=torch.tensor(0.2 * rng.randn(B, mx.nv)))
     if dtype != torch.float64:
         d = d.to(dtype)
     mdev = mx.to("cuda")
     dg = d.to("cuda")
     for s in range(3):
         og = mt.step(mdev, dg)
-        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], TOL_SOL[dtype], what=f"{xml} step{s}", nthreads=4)
+        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4)
         print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural line-search branch, worst solver rel err {worst:.2e}")
         dg = og
 
