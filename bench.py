@@ -33,6 +33,9 @@ WORKLOADS = {
     # configs[2]: ant.xml, RK4 + Newton, elliptic, float32
     "ant": dict(xml="ant", overrides={"integrator": 1, "solver": 2, "cone": 1}, dtype=torch.float32, batch=16384,
                 name="ant.xml batch=16384/GPU RK4+Newton elliptic float32"),
+    # configs[4]: plane + free box + free dodecahedron mesh, condim 6, Newton, float32
+    "mesh": dict(xml="mesh_contact", overrides={}, dtype=torch.float32, batch=8192,
+                 name="mesh_contact.xml (plane + box + dodecahedron mesh, condim 6) batch=8192/GPU Euler+Newton float32"),
     "cartpole": dict(xml="cartpole", overrides={}, dtype=torch.float64, batch=4096, name="cartpole.xml Euler float64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
@@ -159,7 +162,7 @@ def main():
                        "lds_bytes_per_env_by_phase": native.get_native_model(mdev, device, dtype).lds_bytes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_per_step": alg * B,
-                         "kernel": "mjh_phase_kernel<REAL,0..4>: the five phase launches of one step (HIP events on the launch stream)",
+                         "kernel": "mjh_phase_kernel<REAL,0..4> (+ mjh_convex_kernel for box/mesh pairs): the launches of one step (HIP events on the launch stream)",
                          "kernel_ms": kernel_ms},
         }
         if not args.no_cpu_baseline and world == 1:
