@@ -54,12 +54,19 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(cdof_dot, 6 * m.nv, PH_VEL) X(cvel, 6 * m.nbody, PH_VEL) X(cacc, 6 * m.nbody, PH_VEL)                      \
   X(cfrc, 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
   X(sub_pos, 3 * m.nbody, PH_KIN)                                                                              \
-  X(qM, m.nv * m.nv, PH_CRB | PH_SOL) X(qLD, m.nv * m.nv, PH_CRB | PH_VEL | PH_SOL)                            \
-  X(qLD_inv, m.nv, PH_VEL | PH_SOL) X(HL_inv, m.nv, PH_SOL)                                                    \
-  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)               \
+  X(qMp, m.nv * (m.nv + 1) / 2, PH_CRB) /* lower triangle, packed rows */                                      \
+  X(qLD, m.nv * m.nv, PH_VEL) /* PH_CRB: aliased over the dead arrays when the factor is written, see lds_carve */ \
+  X(qLDp, m.nv * (m.nv + 1) / 2, PH_SOL) /* lower triangle, packed rows */                                      \
+  X(qMs, m.sol_qm_lds ? m.nv * m.nv : 0, PH_SOL) /* only when the solver iterates enough to amortise the copy */ \
+  X(qLD_inv, m.nv, PH_VEL | PH_SOL)                                                                            \
+  X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL)                 \
+  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
-  X(efc_J, m.nefc * m.nv, PH_CON | PH_SOL) X(efc_D, m.nefc, PH_CON | PH_SOL)                                   \
+  X(efc_J, m.nefc * m.nv, PH_CON) X(efc_D, m.nefc, PH_CON | PH_SOL)                                            \
+  X(efc_Jc, (m.nefc - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
+  X(efc_Jl, m.nl, PH_SOL) /* the single non-zero of each joint-limit row (column lim_dof[r]) */                \
+  X(i_lim_dof, m.nl, PH_SOL) X(i_dof_limrow, m.nl ? m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_CON | PH_SOL)                                                                         \
   X(efc_pos, m.nefc, PH_CON) X(efc_pos_norm, m.nefc, PH_CON) X(efc_invweight, m.nefc, PH_CON)                  \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
@@ -104,6 +111,9 @@ struct DevModel {
   const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
+  const int* dof_limrow;                   // nv: the joint-limit row whose non-zero sits in column d, or -1
+  const int* lim_dof;                      // nl: dof of limit row r (the only non-zero column of its Jacobian row)
+  int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
   const int* cvx_pairs;                    // ncvxpair: indices (into pair_*) of the pairs with a convex pair function
   int ncvxpair;
 };

@@ -34,6 +34,13 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
 #define X(n, c, p) o.n = off; if ((p) & phase_bit) off += (((c) + 1) & ~1);
   MJH_LDS_ARRAYS(X, m)
 #undef X
+  if (phase_bit == PH_CRB) {
+    // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
+    // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
+    const int nn = ((m.nv * m.nv + 1) & ~1);
+    if (m.nv <= 32) { o.qLD = 0; if (off < nn) off = nn; }
+    else { o.qLD = off; off += nn; }
+  }
   return off;
 }
 
@@ -133,12 +140,25 @@ __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t 
 // the order k = 0, 1, ... -- the subtraction order of the reference's unrolled loop -- but the updates of one
 // column are independent, so their LDS traffic pipelines instead of forming one long dependent chain.
 // =====================================================================================================================
-template <typename REAL>
+// element (i, k), k <= i, of a lower-triangular factor stored as a full n x n matrix or as packed rows
+template <bool PACKED>
+__device__ __forceinline__ int tri_at(int i, int k, int n) { return PACKED ? (i * (i + 1)) / 2 + k : i * n + k; }
+
+// inverse of the packed index: w = i (i + 1) / 2 + j, 0 <= j <= i
+__device__ __forceinline__ void tri_unpack(int w, int& i, int& j) {
+  int r = (int)((__builtin_sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+  if ((r * (r + 1)) / 2 > w) r--;
+  if (((r + 1) * (r + 2)) / 2 <= w) r++;
+  i = r;
+  j = w - (r * (r + 1)) / 2;
+}
+
+template <bool APACKED, typename REAL>
 __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
   const int i = lane_id();
   for (int w = i; w < n * n; w += MJH_WAVE) {
     const int r = w / n, c = w - n * r;
-    L[w] = (c <= r) ? A[w] : (REAL)0;
+    L[w] = (c <= r) ? A[tri_at<APACKED>(r, c, n)] : (REAL)0;
   }
   wave_sync();
   const bool big = n > INLINE_CHOL_MAX;
@@ -173,20 +193,18 @@ __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
   }
 }
 
-template <typename REAL, int MAXREG>
-__device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n);
 
 // reciprocal diagonal of a Cholesky factor (one lane per row); consumed by chol_solve
-template <typename REAL>
+template <bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_inv_diag(const REAL* L, REAL* inv, int n) {
-  for (int k = lane_id(); k < n; k += MJH_WAVE) inv[k] = 1 / L[k * n + k];
+  for (int k = lane_id(); k < n; k += MJH_WAVE) inv[k] = 1 / L[tri_at<PACKED>(k, k, n)];
 }
 
 // x = (L L^T)^-1 b  (math.small_cholesky_solve :132-168).  Column-oriented substitution: lane i carries its
 // running right-hand side; the value solved at step k is broadcast.  Per element the operation order equals
 // the reference's row loops (k ascending forward, descending backward); the divisions by L[k][k] are
 // multiplications by the precomputed reciprocal (<= 1 ulp per step off the reference's quotient).
-template <typename REAL>
+template <bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
   const int i = lane_id();
   REAL s = (i < n) ? b[i] : (REAL)0;
@@ -195,7 +213,7 @@ __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, c
   for (int k0 = 0; k0 < n; k0 += 8) {
     REAL r[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) r[t] = (i > k0 + t && i < n && k0 + t < n) ? L[i * n + k0 + t] : (REAL)0;
+    for (int t = 0; t < 8; t++) r[t] = (i > k0 + t && i < n && k0 + t < n) ? L[tri_at<PACKED>(i, k0 + t, n)] : (REAL)0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
       const int k = k0 + t;
@@ -209,7 +227,7 @@ __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, c
   for (int k1 = n - 1; k1 >= 0; k1 -= 8) {
     REAL r[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) r[t] = (k1 - t >= 0 && i < k1 - t) ? L[(k1 - t) * n + i] : (REAL)0;
+    for (int t = 0; t < 8; t++) r[t] = (k1 - t >= 0 && i < k1 - t) ? L[tri_at<PACKED>(k1 - t, i, n)] : (REAL)0;
 #pragma unroll
     for (int t = 0; t < 8; t++) {
       const int k = k1 - t;
@@ -238,15 +256,15 @@ struct TriReg {
   REAL inv;        // 1 / L[i][i]
 };
 
-template <typename REAL, int NMAX>
+template <bool PACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void tri_load(TriReg<REAL, NMAX>& T, const REAL* L, int n) {
   const int i = lane_id();
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
-    T.row[k] = (k < n && i < n && k <= i) ? L[i * n + k] : (REAL)0;
-    T.col[k] = (k < n && i < n && k >= i) ? L[k * n + i] : (REAL)0;
+    T.row[k] = (k < n && i < n && k <= i) ? L[tri_at<PACKED>(i, k, n)] : (REAL)0;
+    T.col[k] = (k < n && i < n && k >= i) ? L[tri_at<PACKED>(k, i, n)] : (REAL)0;
   }
-  T.inv = (i < n) ? 1 / L[i * n + i] : (REAL)0;
+  T.inv = (i < n) ? 1 / L[tri_at<PACKED>(i, i, n)] : (REAL)0;
 }
 
 // x = (L L^T)^-1 b with b, x distributed one element per lane
@@ -274,12 +292,13 @@ __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, 
 }
 
 // Cholesky of the symmetric matrix A (LDS, n x n) into L (LDS, lower triangle, zeros above)
-template <typename REAL, int NMAX>
+template <bool APACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
   const int i = lane_id();
   REAL row[NMAX];
 #pragma unroll
-  for (int k = 0; k < NMAX; k++) row[k] = (k < n && i < n && k <= i) ? A[i * n + k] : (REAL)0;
+  for (int k = 0; k < NMAX; k++) row[k] = (k < n && i < n && k <= i) ? A[tri_at<APACKED>(i, k, n)] : (REAL)0;
+  wave_sync();  // L may alias A (and anything else that is dead by now): every lane has its row in registers
   const bool big = n > INLINE_CHOL_MAX;
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
@@ -304,30 +323,31 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
   wave_sync();
 }
 
-template <typename REAL, int NMAX>
+template <bool PACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_solve_reg(const REAL* L, const REAL* b, REAL* x, int n) {
   TriReg<REAL, NMAX> T;
-  tri_load(T, L, n);
+  tri_load<PACKED>(T, L, n);
   const int i = lane_id();
   const REAL xi = tri_solve(T, (i < n) ? b[i] : (REAL)0, n);
   if (i < n) x[i] = xi;
   wave_sync();
 }
-template <typename REAL>
+template <bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_solve(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
   // register variants only up to 16: at 32 the two register triangles push the solver phases to 256 VGPRs
   // (one wave per SIMD), which costs more than the substitution saves
-  if (n <= 8) chol_solve_reg<REAL, 8>(L, b, x, n);
-  else if (n <= 16) chol_solve_reg<REAL, 16>(L, b, x, n);
-  else chol_solve_lds(L, inv, b, x, n);
+  if (n <= 8) chol_solve_reg<PACKED, REAL, 8>(L, b, x, n);
+  else if (n <= 16) chol_solve_reg<PACKED, REAL, 16>(L, b, x, n);
+  else chol_solve_lds<PACKED>(L, inv, b, x, n);
 }
 
-template <typename REAL, int MAXREG = 32>
+// A: symmetric matrix, full n x n or (APACKED) packed lower rows; L: full n x n, may alias A when n <= 32
+template <typename REAL, int MAXREG, bool APACKED>
 __device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n) {
-  if (n <= 8) chol_factor_reg<REAL, 8>(A, L, n);
-  else if (n <= 16) chol_factor_reg<REAL, 16>(A, L, n);
-  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<REAL, 32>(A, L, n);
-  else chol_factor_lds(A, L, n);
+  if (n <= 8) chol_factor_reg<APACKED, REAL, 8>(A, L, n);
+  else if (n <= 16) chol_factor_reg<APACKED, REAL, 16>(A, L, n);
+  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<APACKED, REAL, 32>(A, L, n);
+  else chol_factor_lds<APACKED>(A, L, n);
 }
 
 // sum_k a[k * sa] * b[k * sb] accumulated in index order (the reference's reduction order for its explicit
@@ -632,13 +652,14 @@ struct Env {
         for (int k = 0; k < 6; k++) s += S.crb_cdof()[6 * hi + k] * S.cdof()[6 * lo + k];
         if (i == j) s = s + M.dof_armature[i];
       }
-      S.qM()[w] = s;
+      if (out.qM) out.qM[e * nv * nv + w] = s;                       // (i, j) and (j, i) evaluate the same expression: exactly symmetric
+      if (j <= i) S.qMp()[tri_at<true>(i, j, nv)] = s;
     }
-    wave_sync();
     STAMP(14);
-    put(out.crb, S.crb(), 10 * nb); put(out.qM, S.qM(), nv * nv);
+    put(out.crb, S.crb(), 10 * nb);
+    wave_sync();
     STAMP(15);
-    chol_factor<REAL, 32>(S.qM(), S.qLD(), nv);
+    chol_factor<REAL, 32, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve)
     STAMP(16);
     put(out.qLD, S.qLD(), nv * nv);
     STAMP(17);
@@ -956,7 +977,7 @@ struct Env {
     row_load(S.xipos(), out.xipos, 3 * nb, e);
     row_load(S.qLD(), out.qLD, nv * nv, e);
     wave_sync();
-    chol_inv_diag(S.qLD(), S.qLD_inv(), nv);
+    chol_inv_diag<false>(S.qLD(), S.qLD_inv(), nv);
     wave_sync();
     STAMP(31);
     for (int i = l; i < nu; i += MJH_WAVE) {
@@ -1160,7 +1181,7 @@ struct Env {
     }
     wave_sync();
     STAMP(41);
-    chol_solve(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    chol_solve<false>(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
     if (!off) put(out.actuator_force, S.act_force(), nu);
     put(out.act_dot, S.act_dot(), M.na);
     put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv); put(out.qacc_smooth, S.qacc_smooth(), nv);
@@ -1171,14 +1192,39 @@ struct Env {
   struct LSPoint { REAL alpha, cost, d0, d1; };
   struct Ctx { REAL gauss, cost, prev_cost; int niter; };
 
-  __device__ __forceinline__ void mul_M(const REAL* v, REAL* o) {  // (dense_M * v).sum(-1)
+  __device__ __forceinline__ int* lim_dof_lds() const { return reinterpret_cast<int*>(S.i_lim_dof()); }
+  __device__ __forceinline__ int* dof_limrow_lds() const { return reinterpret_cast<int*>(S.i_dof_limrow()); }
+
+  // (dense_M * v).sum(-1).  qM stays in global memory (L2-resident: the CRB phase just wrote it): it is exactly
+  // symmetric, so row i is read as column i -- lane i takes element i of every row, a coalesced load per term --
+  // and the terms are still accumulated in column order.
+  __device__ __forceinline__ void mul_M(const REAL* v, REAL* o) {
     const int nv = M.nv;
-    for (int i = lane_id(); i < nv; i += MJH_WAVE) o[i] = dot_seq(S.qM() + i * nv, 1, v, 1, nv);
+    if (M.sol_qm_lds) {
+      for (int i = lane_id(); i < nv; i += MJH_WAVE) o[i] = dot_seq(S.qMs() + i * nv, 1, v, 1, nv);
+      return;
+    }
+    const REAL* g = out.qM + e * nv * nv;
+    for (int i = lane_id(); i < nv; i += MJH_WAVE) {
+      REAL s = 0;
+      int k = 0;
+      for (; k + 8 <= nv; k += 8) {
+        REAL a[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[t] = g[(k + t) * nv + i];
+#pragma unroll
+        for (int t = 0; t < 8; t++) s += a[t] * v[k + t];
+      }
+      for (; k < nv; k++) s += g[k * nv + i] * v[k];
+      o[i] = s;
+    }
   }
-  __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {  // efc_J @ v  (- sub)
-    const int nv = M.nv;
+  // efc_J @ v (- sub).  A joint-limit row has one non-zero (column lim_dof[r]); the zeros of the dense product add
+  // exact zeros, so the single term is the same value.
+  __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {
+    const int nv = M.nv, nl = M.nl;
     for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
-      const REAL s = dot_seq(S.efc_J() + r * nv, 1, v, 1, nv);
+      const REAL s = r < nl ? S.efc_Jl()[r] * v[lim_dof_lds()[r]] : dot_seq(S.efc_Jc() + (r - nl) * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
     }
   }
@@ -1200,7 +1246,12 @@ struct Env {
     wave_sync();
     {  // qfrc = J^T force, rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
-      for (int base = 0; base < nefc; base += MJH_WAVE) {
+      const int nl = M.nl;
+      if (nl > 0 && l < nv) {  // the joint-limit rows come first; at most one of them has a non-zero in column l
+        const int lr = dof_limrow_lds()[l];
+        if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
+      }
+      for (int base = nl; base < nefc; base += MJH_WAVE) {
         const int r = base + l;
         const REAL f = (r < nefc) ? S.s_force()[r] : (REAL)0;
         unsigned long long mask = __ballot(f != 0);
@@ -1208,7 +1259,7 @@ struct Env {
           const int bit = __ffsll((long long)mask) - 1;
           mask &= mask - 1;
           const REAL fr = read_lane(f, bit);
-          if (l < nv) s += S.efc_J()[(base + bit) * nv + l] * fr;
+          if (l < nv) s += S.efc_Jc()[(base - nl + bit) * nv + l] * fr;
         }
       }
       if (l < nv) S.s_qfrc()[l] = s;
@@ -1225,47 +1276,37 @@ struct Env {
     for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
     wave_sync();
     if (M.solver == SOL_CG) {
-      chol_solve(S.qLD(), S.qLD_inv(), S.s_grad(), S.s_Mgrad(), nv);
+      chol_solve<true>(S.qLDp(), S.qLD_inv(), S.s_grad(), S.s_Mgrad(), nv);
     } else {
       // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
-      for (int w0 = 0; w0 < nv * nv; w0 += MJH_WAVE) {
+      // only the lower triangle is ever read by the factorisation: one lane per packed entry (i, j <= i)
+      const int np = (nv * (nv + 1)) / 2, nl = M.nl;
+      for (int w0 = 0; w0 < np; w0 += MJH_WAVE) {
         const int w = w0 + l;
-        const int i = (w < nv * nv) ? w / nv : 0, j = (w < nv * nv) ? w - nv * i : 0;
+        int i, j;
+        tri_unpack(w < np ? w : 0, i, j);
         REAL s = 0;
-        for (int base = 0; base < nefc; base += MJH_WAVE) {
+        if (nl > 0 && i == j) {  // a joint-limit row only touches its own diagonal entry, and it precedes the contact rows
+          const int lr = dof_limrow_lds()[i];
+          if (lr >= 0 && S.s_Jaref()[lr] < 0) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+        }
+        for (int base = nl; base < nefc; base += MJH_WAVE) {
           const int r = base + l;
           unsigned long long mask = __ballot(r < nefc && S.s_Jaref()[r] < 0);
           while (mask) {
             const int row = base + __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            s += (S.efc_J()[row * nv + i] * S.efc_D()[row] * (REAL)1) * S.efc_J()[row * nv + j];
+            const REAL* jr = S.efc_Jc() + (row - nl) * nv;
+            s += (jr[i] * S.efc_D()[row] * (REAL)1) * jr[j];
           }
         }
-        if (w < nv * nv) S.H()[w] = S.qM()[w] + s;
+        if (w < np) S.H()[w] = (M.sol_qm_lds ? S.qMs()[i * nv + j] : out.qM[e * nv * nv + i * nv + j]) + s;
       }
       wave_sync();
-      chol_factor<REAL, 16>(S.H(), S.HL(), nv);
-      chol_inv_diag(S.HL(), S.HL_inv(), nv);
+      chol_factor<REAL, 16, true>(S.H(), S.HL(), nv);
+      chol_inv_diag<false>(S.HL(), S.HL_inv(), nv);
       wave_sync();
-      chol_solve(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
-    }
-  }
-
-  __device__ __forceinline__ void create_context(Ctx& c, const REAL* qacc, bool grad_flag) {  // :293-318
-    const int l = lane_id();
-    const int nv = M.nv;
-    for (int d = l; d < nv; d += MJH_WAVE) S.s_qacc()[d] = qacc[d];
-    wave_sync();
-    mul_J(S.s_qacc(), S.s_Jaref(), S.efc_aref());
-    mul_M(S.s_qacc(), S.s_Ma());
-    c.gauss = 0; c.cost = (REAL)INFINITY; c.prev_cost = 0; c.niter = 0;
-    for (int d = l; d < nv; d += MJH_WAVE) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
-    wave_sync();
-    update_constraint(c);
-    if (grad_flag) {
-      update_gradient();
-      for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
-      wave_sync();
+      chol_solve<false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
     }
   }
 
@@ -1364,69 +1405,112 @@ struct Env {
     const int nv = M.nv, nefc = M.nefc;
     row_load(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
     row_load(S.qacc_smooth(), out.qacc_smooth, nv, e);
-    row_load(S.qM(), out.qM, nv * nv, e);
+    if (M.sol_qm_lds) row_load(S.qMs(), out.qM, nv * nv, e);
     if (nefc > 0) {
-      row_load(S.qLD(), out.qLD, nv * nv, e);
-      row_load(S.efc_J(), out.efc_J, nefc * nv, e);
+      const int l = lane_id(), nl = M.nl;
+      const REAL* gL = out.qLD + e * nv * nv;
+      for (int w = l; w < nv * nv; w += MJH_WAVE) {  // lower triangle of the factor, packed rows
+        const int i = w / nv, k = w - nv * i;
+        if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
+      }
+      const REAL* gJ = out.efc_J + e * nefc * nv;
+      for (int r = l; r < nl; r += MJH_WAVE) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
+      if (nl > 0) for (int d = l; d < nv; d += MJH_WAVE) dof_limrow_lds()[d] = M.dof_limrow[d];
+      {
+        const int n = (nefc - nl) * nv;
+        const REAL* src = gJ + nl * nv;
+        int i = l;
+        for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
+          const REAL a = src[i], b = src[i + MJH_WAVE], c = src[i + 2 * MJH_WAVE], d = src[i + 3 * MJH_WAVE];
+          S.efc_Jc()[i] = a; S.efc_Jc()[i + MJH_WAVE] = b; S.efc_Jc()[i + 2 * MJH_WAVE] = c; S.efc_Jc()[i + 3 * MJH_WAVE] = d;
+        }
+        for (; i < n; i += MJH_WAVE) S.efc_Jc()[i] = src[i];
+      }
       row_load(S.efc_D(), out.efc_D, nefc, e);
       row_load(S.efc_aref(), out.efc_aref, nefc, e);
       row_load(S.qacc_warm(), KA.warm_src, nv, e);
     }
     wave_sync();
-    if (nefc > 0) chol_inv_diag(S.qLD(), S.qLD_inv(), nv);
+    if (nefc > 0) chol_inv_diag<true>(S.qLDp(), S.qLD_inv(), nv);
     wave_sync();
   }
 
+  // solver.solve :244-553 as ONE loop whose body contains each heavy routine exactly once (line search, constraint
+  // update, gradient): the kernel is fully inlined, so every extra call site would be another copy of the routine and
+  // the iteration loop would no longer fit the instruction cache.  Steps, in order:
+  //   P_SMOOTH : context of qacc_smooth (cost only)                       } warm start enabled only (:526-531)
+  //   P_WARM   : context of qacc_warmstart (cost only); pick the cheaper  }
+  //   P_START  : the chosen context with gradient and search direction (:293-318).  When the warm start won, its
+  //              context is still in place and only the gradient is added.
+  //   P_ITER   : cond :501-508, then body :509-524 (line search, constraint update, gradient, new direction)
   __device__ __forceinline__ void solve() {
     const int l = lane_id();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
+    enum { P_SMOOTH = 0, P_WARM = 1, P_START = 2, P_ITER = 3 };
     Ctx c;
+    c.gauss = 0; c.cost = 0; c.prev_cost = 0; c.niter = 0;
     bool use_warm = false;
-    if (!(M.disableflags & DSBL_WARMSTART)) {  // :526-531
-      create_context(c, S.qacc_warm(), false);
-      const REAL warm_cost = c.cost;
-      create_context(c, S.qacc_smooth(), false);
-      use_warm = warm_cost < c.cost;
-    }
-    for (int d = l; d < nv; d += MJH_WAVE) S.tmp_nv()[d] = use_warm ? S.qacc_warm()[d] : S.qacc_smooth()[d];
-    wave_sync();
-    STAMP(54);
-    create_context(c, S.tmp_nv(), true);
-    STAMP(55);
-    for (int it = 0;; it++) {
-      if (M.iterations == 1) { if (it >= 1) break; }
-      else if (fixed) { if (it >= M.iterations) break; }
-      else {  // cond :501-508
-        REAL gg = 0;
-        for (int d = l; d < nv; d += MJH_WAVE) gg += S.s_grad()[d] * S.s_grad()[d];
-        gg = wave_sum(gg);
-        const REAL improvement = (c.prev_cost - c.cost) / scale;
-        const REAL gradient = r_sqrt<REAL>(gg) / scale;
-        bool done = c.niter >= M.iterations;
-        done |= improvement < (REAL)M.tolerance;
-        done |= gradient < (REAL)M.tolerance;
-        if (done) break;
+    REAL smooth_cost = 0;
+    int ph = (M.disableflags & DSBL_WARMSTART) ? P_START : P_SMOOTH;
+    int it = 0;
+    for (;;) {
+      bool do_init, do_grad, do_ls;
+      const REAL* src = S.qacc_smooth();
+      if (ph == P_SMOOTH) { do_init = true; do_grad = false; do_ls = false; }
+      else if (ph == P_WARM) { do_init = true; do_grad = false; do_ls = false; src = S.qacc_warm(); }
+      else if (ph == P_START) { do_init = !use_warm; do_grad = true; do_ls = false; }
+      else {
+        if (M.iterations == 1) { if (it >= 1) break; }
+        else if (fixed) { if (it >= M.iterations) break; }
+        else {  // cond :501-508
+          REAL gg = 0;
+          for (int d = l; d < nv; d += MJH_WAVE) gg += S.s_grad()[d] * S.s_grad()[d];
+          gg = wave_sum(gg);
+          const REAL improvement = (c.prev_cost - c.cost) / scale;
+          const REAL gradient = r_sqrt<REAL>(gg) / scale;
+          bool done = c.niter >= M.iterations;
+          done |= improvement < (REAL)M.tolerance;
+          done |= gradient < (REAL)M.tolerance;
+          if (done) break;
+        }
+        do_init = false; do_grad = true; do_ls = true;
       }
-      linesearch(c);
-      STAMP(60);
-      for (int d = l; d < nv; d += MJH_WAVE) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
-      wave_sync();
-      update_constraint(c);
-      update_gradient();
-      if (M.solver == SOL_NEWTON) {
-        for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
-      } else {  // Polak-Ribiere :519-523
-        REAL num = 0, den = 0;
-        for (int d = l; d < nv; d += MJH_WAVE) { num += S.s_grad()[d] * (S.s_Mgrad()[d] - S.s_pMgrad()[d]); den += S.s_pgrad()[d] * S.s_pMgrad()[d]; }
-        num = wave_sum(num); den = wave_sum(den);
-        REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
-        beta = beta > 0 ? beta : (REAL)0;
-        for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d] + beta * S.s_search()[d];
+      if (do_ls) {
+        linesearch(c);
+        STAMP(60);
+        for (int d = l; d < nv; d += MJH_WAVE) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
+        wave_sync();
       }
-      wave_sync();
-      c.niter++;
+      if (do_init) {  // _Context.create :293-318
+        for (int d = l; d < nv; d += MJH_WAVE) S.s_qacc()[d] = src[d];
+        wave_sync();
+        mul_J(S.s_qacc(), S.s_Jaref(), S.efc_aref());
+        mul_M(S.s_qacc(), S.s_Ma());
+        c.gauss = 0; c.cost = (REAL)INFINITY; c.prev_cost = 0; c.niter = 0;
+        for (int d = l; d < nv; d += MJH_WAVE) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
+        wave_sync();
+      }
+      if (do_ls || do_init) update_constraint(c);
+      if (do_grad) {
+        update_gradient();
+        if (ph == P_START || M.solver == SOL_NEWTON) {
+          for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
+        } else {  // Polak-Ribiere :519-523
+          REAL num = 0, den = 0;
+          for (int d = l; d < nv; d += MJH_WAVE) { num += S.s_grad()[d] * (S.s_Mgrad()[d] - S.s_pMgrad()[d]); den += S.s_pgrad()[d] * S.s_pMgrad()[d]; }
+          num = wave_sum(num); den = wave_sum(den);
+          REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+          beta = beta > 0 ? beta : (REAL)0;
+          for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d] + beta * S.s_search()[d];
+        }
+        wave_sync();
+      }
+      if (ph == P_SMOOTH) { smooth_cost = c.cost; ph = P_WARM; }
+      else if (ph == P_WARM) { use_warm = __builtin_amdgcn_readfirstlane((int)(c.cost < smooth_cost)) != 0; ph = P_START; STAMP(54); }  // wave-uniform by construction: keep the step flags scalar
+      else if (ph == P_START) { ph = P_ITER; STAMP(55); }
+      else { c.niter++; it++; }
     }
     for (int d = l; d < nv; d += MJH_WAVE) { S.qacc()[d] = S.s_qacc()[d]; S.qacc_warm()[d] = S.s_qacc()[d]; S.qfrc_constraint()[d] = S.s_qfrc()[d]; }
     wave_sync();
@@ -1538,16 +1622,18 @@ struct Env {
     if (rk < 0) {  // Euler
       const REAL* qacc = S.qacc();
       if (!(M.disableflags & DSBL_EULERDAMP)) {
-        for (int w = l; w < nv * nv; w += MJH_WAVE) {
-          const int i = w / nv, j = w - nv * i;
-          S.H()[w] = (i == j) ? S.qM()[w] + M.timestep * M.dof_damping[i] : S.qM()[w];
+        for (int w = l; w < (nv * (nv + 1)) / 2; w += MJH_WAVE) {
+          int i, j;
+          tri_unpack(w, i, j);
+          const REAL mw = out.qM[e * nv * nv + i * nv + j];
+          S.H()[w] = (i == j) ? mw + M.timestep * M.dof_damping[i] : mw;
         }
         for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
-        chol_factor<REAL, 16>(S.H(), S.HL(), nv);
-        chol_inv_diag(S.HL(), S.HL_inv(), nv);
+        chol_factor<REAL, 16, true>(S.H(), S.HL(), nv);
+        chol_inv_diag<false>(S.HL(), S.HL_inv(), nv);
         wave_sync();
-        chol_solve(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+        chol_solve<false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
         qacc = S.s_Mgrad();
       }
       advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);

@@ -158,7 +158,17 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.body_dofmask, bb.add(body_dofmask.data(), sizeof(unsigned long long) * nb)});
   fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
+  std::vector<int> lim_dof((size_t)d->nl, 0);
+  for (int r = 0; r < d->nl; r++) lim_dof[r] = d->jnt_dofadr[d->lim_jnt[r]];
+  fix.push_back({(const void**)&M.lim_dof, bb.add(lim_dof.data(), sizeof(int) * lim_dof.size())});
+  std::vector<int> dof_limrow((size_t)nv, -1);
+  for (int r = 0; r < d->nl; r++) {
+    if (dof_limrow[lim_dof[r]] >= 0) return fail(-22, "two joint-limit rows on one dof");
+    dof_limrow[lim_dof[r]] = r;
+  }
+  fix.push_back({(const void**)&M.dof_limrow, bb.add(dof_limrow.data(), sizeof(int) * dof_limrow.size())});
   M.max_depth = max_depth;
+  M.sol_qm_lds = (d->nefc > 0 && d->iterations > 4) ? 1 : 0;  // one pass over qM per solver iteration: from LDS when there are many
   // convex pairs and the LDS scratch their wave needs (layout in mjh_convex.h)
   std::vector<int> cvx_pairs;
   int cvx_reals = 0;
@@ -257,6 +267,7 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
   a.warm_src = a.in.qacc_warmstart;
   a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
+  if ((a.stages & 0x40) && !(a.fin.qM && a.fin.qLD)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
   if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(a.fin.contact_dist && a.fin.contact_pos && a.fin.contact_frame && a.fin.geom_xpos && a.fin.geom_xmat))
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
