@@ -167,6 +167,15 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 
+// ---- sub-wave helpers: W lanes (64 or 32) serve one environment, 64 / W environments share a wavefront ----------------
+template <int W> __device__ __forceinline__ int sub_lane() { return (W == MJH_WAVE) ? (int)threadIdx.x : (int)(threadIdx.x & (W - 1)); }
+// value of lane k OF THIS ENVIRONMENT's lane group (k uniform): v_readlane for a whole wave, a bpermute otherwise
+template <int W, typename T>
+__device__ __forceinline__ T sub_read(T v, int k) {
+  if (W == MJH_WAVE) return read_lane(v, k);
+  return __shfl(v, (int)(threadIdx.x & ~(W - 1)) + k, MJH_WAVE);
+}
+
 // ---- small-vector math, reference math.py ------------------------------------------------------------------
 template <typename R> __device__ __forceinline__ R r_sqrt(R x);
 template <> __device__ __forceinline__ double r_sqrt<double>(double x) { return sqrt(x); }

@@ -77,6 +77,8 @@ struct KArgs {
   DevData<REAL> fin;   // the returned Data (final advance)
   RkWork<REAL> W;
   int64_t B;
+  int64_t env_begin, env_count;  // environments of THIS launch (a packed launch covers an even count, a second one the odd tail)
+  int lds_reals;                 // REALs between the arenas of the environments sharing a wavefront
   int flags;
   int stages;          // MJH_STAGE_* prefix mask
   int do_step;
@@ -102,7 +104,7 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
     __builtin_amdgcn_sched_barrier(0);                                                               \
     unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
-    if (KA.stamps && lane_id() == 0) KA.stamps[e * 128 + (slot)] = t_;                               \
+    if (KA.stamps && lane() == 0) KA.stamps[e * 128 + (slot)] = t_;                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
   } while (0)
 #else
@@ -111,27 +113,27 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
 // Four independent transfers are issued per trip so one HBM/L2 (or LDS) round trip covers 256 elements.
-template <typename REAL>
+template <int W, typename REAL>
 __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t env) {
   if (!g) return;
   REAL* dst = g + env * n;
-  int i = lane_id();
-  for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
-    const REAL a = l[i], b = l[i + MJH_WAVE], c = l[i + 2 * MJH_WAVE], d = l[i + 3 * MJH_WAVE];
-    dst[i] = a; dst[i + MJH_WAVE] = b; dst[i + 2 * MJH_WAVE] = c; dst[i + 3 * MJH_WAVE] = d;
+  int i = sub_lane<W>();
+  for (; i + 3 * W < n; i += 4 * W) {
+    const REAL a = l[i], b = l[i + W], c = l[i + 2 * W], d = l[i + 3 * W];
+    dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = c; dst[i + 3 * W] = d;
   }
-  for (; i < n; i += MJH_WAVE) dst[i] = l[i];
+  for (; i < n; i += W) dst[i] = l[i];
 }
-template <typename REAL>
+template <int W, typename REAL>
 __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
-  if (!g) { for (int i = lane_id(); i < n; i += MJH_WAVE) l[i] = 0; return; }
+  if (!g) { for (int i = sub_lane<W>(); i < n; i += W) l[i] = 0; return; }
   const REAL* src = g + env * n;
-  int i = lane_id();
-  for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
-    const REAL a = src[i], b = src[i + MJH_WAVE], c = src[i + 2 * MJH_WAVE], d = src[i + 3 * MJH_WAVE];
-    l[i] = a; l[i + MJH_WAVE] = b; l[i + 2 * MJH_WAVE] = c; l[i + 3 * MJH_WAVE] = d;
+  int i = sub_lane<W>();
+  for (; i + 3 * W < n; i += 4 * W) {
+    const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
+    l[i] = a; l[i + W] = b; l[i + 2 * W] = c; l[i + 3 * W] = d;
   }
-  for (; i < n; i += MJH_WAVE) l[i] = src[i];
+  for (; i < n; i += W) l[i] = src[i];
 }
 
 // =====================================================================================================================
@@ -153,10 +155,10 @@ __device__ __forceinline__ void tri_unpack(int w, int& i, int& j) {
   j = w - (r * (r + 1)) / 2;
 }
 
-template <bool APACKED, typename REAL>
+template <int W, bool APACKED, typename REAL>
 __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
-  const int i = lane_id();
-  for (int w = i; w < n * n; w += MJH_WAVE) {
+  const int i = sub_lane<W>();
+  for (int w = i; w < n * n; w += W) {
     const int r = w / n, c = w - n * r;
     L[w] = (c <= r) ? A[tri_at<APACKED>(r, c, n)] : (REAL)0;
   }
@@ -176,8 +178,8 @@ __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
       const int m = n - j - 1;
       const float inv_m = 1.0f / (float)(m > 0 ? m : 1);
       const int total = m * m;
-      for (int t0 = 0; t0 < total; t0 += 2 * MJH_WAVE) {
-        const int ta = t0 + i, tb = t0 + MJH_WAVE + i;
+      for (int t0 = 0; t0 < total; t0 += 2 * W) {
+        const int ta = t0 + i, tb = t0 + W + i;
         const int ra = (int)(((float)ta + 0.5f) * inv_m), rb = (int)(((float)tb + 0.5f) * inv_m);
         const int ca = ta - ra * m, cb = tb - rb * m;
         const bool oka = ta < total && ca <= ra, okb = tb < total && cb <= rb;
@@ -195,18 +197,18 @@ __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
 
 
 // reciprocal diagonal of a Cholesky factor (one lane per row); consumed by chol_solve
-template <bool PACKED, typename REAL>
+template <int W, bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_inv_diag(const REAL* L, REAL* inv, int n) {
-  for (int k = lane_id(); k < n; k += MJH_WAVE) inv[k] = 1 / L[tri_at<PACKED>(k, k, n)];
+  for (int k = sub_lane<W>(); k < n; k += W) inv[k] = 1 / L[tri_at<PACKED>(k, k, n)];
 }
 
 // x = (L L^T)^-1 b  (math.small_cholesky_solve :132-168).  Column-oriented substitution: lane i carries its
 // running right-hand side; the value solved at step k is broadcast.  Per element the operation order equals
 // the reference's row loops (k ascending forward, descending backward); the divisions by L[k][k] are
 // multiplications by the precomputed reciprocal (<= 1 ulp per step off the reference's quotient).
-template <bool PACKED, typename REAL>
+template <int W, bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
-  const int i = lane_id();
+  const int i = sub_lane<W>();
   REAL s = (i < n) ? b[i] : (REAL)0;
   const REAL myinv = (i < n) ? inv[i] : (REAL)0;
   // forward: eight columns of this lane's row are fetched at once, then consumed by eight dependent steps
@@ -218,7 +220,7 @@ __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, c
     for (int t = 0; t < 8; t++) {
       const int k = k0 + t;
       if (k < n) {
-        const REAL yk = read_lane(s * myinv, k);
+        const REAL yk = sub_read<W>(s * myinv, k);
         if (i == k) s = yk;
         else if (i > k && i < n) s = s - r[t] * yk;
       }
@@ -232,7 +234,7 @@ __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, c
     for (int t = 0; t < 8; t++) {
       const int k = k1 - t;
       if (k >= 0) {
-        const REAL xk = read_lane(s * myinv, k);
+        const REAL xk = sub_read<W>(s * myinv, k);
         if (i == k) s = xk;
         else if (i < k) s = s - r[t] * xk;
       }
@@ -256,9 +258,9 @@ struct TriReg {
   REAL inv;        // 1 / L[i][i]
 };
 
-template <bool PACKED, typename REAL, int NMAX>
+template <int W, bool PACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void tri_load(TriReg<REAL, NMAX>& T, const REAL* L, int n) {
-  const int i = lane_id();
+  const int i = sub_lane<W>();
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
     T.row[k] = (k < n && i < n && k <= i) ? L[tri_at<PACKED>(i, k, n)] : (REAL)0;
@@ -268,14 +270,14 @@ __device__ __forceinline__ void tri_load(TriReg<REAL, NMAX>& T, const REAL* L, i
 }
 
 // x = (L L^T)^-1 b with b, x distributed one element per lane
-template <typename REAL, int NMAX>
+template <int W, typename REAL, int NMAX>
 __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, int n) {
-  const int i = lane_id();
+  const int i = sub_lane<W>();
   REAL s = (i < n) ? bi : (REAL)0;
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
     if (k < n) {
-      const REAL yk = read_lane(s * T.inv, k);
+      const REAL yk = sub_read<W>(s * T.inv, k);
       if (i == k) s = yk;
       else if (i > k && i < n) s = s - T.row[k] * yk;
     }
@@ -283,7 +285,7 @@ __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, 
 #pragma unroll
   for (int k = NMAX - 1; k >= 0; k--) {
     if (k < n) {
-      const REAL xk = read_lane(s * T.inv, k);
+      const REAL xk = sub_read<W>(s * T.inv, k);
       if (i == k) s = xk;
       else if (i < k) s = s - T.col[k] * xk;
     }
@@ -292,9 +294,9 @@ __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, 
 }
 
 // Cholesky of the symmetric matrix A (LDS, n x n) into L (LDS, lower triangle, zeros above)
-template <bool APACKED, typename REAL, int NMAX>
+template <int W, bool APACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
-  const int i = lane_id();
+  const int i = sub_lane<W>();
   REAL row[NMAX];
 #pragma unroll
   for (int k = 0; k < NMAX; k++) row[k] = (k < n && i < n && k <= i) ? A[tri_at<APACKED>(i, k, n)] : (REAL)0;
@@ -303,7 +305,7 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
     if (j < n) {
-      REAL s = read_lane(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
+      REAL s = sub_read<W>(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
       if (big) s = s + (REAL)1e-10;                  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
       const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
       const REAL lij = (i == j) ? d : row[j] / d;    // lanes i < j hold zeros: harmless
@@ -311,7 +313,7 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
 #pragma unroll
       for (int k = j + 1; k < NMAX; k++) {
         if (k < n) {
-          const REAL lkj = read_lane(lij, k);        // L[k][j]
+          const REAL lkj = sub_read<W>(lij, k);        // L[k][j]
           row[k] = row[k] - lij * lkj;               // only k <= i is ever read back
         }
       }
@@ -323,31 +325,31 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
   wave_sync();
 }
 
-template <bool PACKED, typename REAL, int NMAX>
+template <int W, bool PACKED, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_solve_reg(const REAL* L, const REAL* b, REAL* x, int n) {
   TriReg<REAL, NMAX> T;
-  tri_load<PACKED>(T, L, n);
-  const int i = lane_id();
-  const REAL xi = tri_solve(T, (i < n) ? b[i] : (REAL)0, n);
+  tri_load<W, PACKED>(T, L, n);
+  const int i = sub_lane<W>();
+  const REAL xi = tri_solve<W>(T, (i < n) ? b[i] : (REAL)0, n);
   if (i < n) x[i] = xi;
   wave_sync();
 }
-template <bool PACKED, typename REAL>
+template <int W, bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_solve(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
   // register variants only up to 16: at 32 the two register triangles push the solver phases to 256 VGPRs
   // (one wave per SIMD), which costs more than the substitution saves
-  if (n <= 8) chol_solve_reg<PACKED, REAL, 8>(L, b, x, n);
-  else if (n <= 16) chol_solve_reg<PACKED, REAL, 16>(L, b, x, n);
-  else chol_solve_lds<PACKED>(L, inv, b, x, n);
+  if (n <= 8) chol_solve_reg<W, PACKED, REAL, 8>(L, b, x, n);
+  else if (n <= 16) chol_solve_reg<W, PACKED, REAL, 16>(L, b, x, n);
+  else chol_solve_lds<W, PACKED>(L, inv, b, x, n);
 }
 
 // A: symmetric matrix, full n x n or (APACKED) packed lower rows; L: full n x n, may alias A when n <= 32
-template <typename REAL, int MAXREG, bool APACKED>
+template <int W, typename REAL, int MAXREG, bool APACKED>
 __device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n) {
-  if (n <= 8) chol_factor_reg<APACKED, REAL, 8>(A, L, n);
-  else if (n <= 16) chol_factor_reg<APACKED, REAL, 16>(A, L, n);
-  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<APACKED, REAL, 32>(A, L, n);
-  else chol_factor_lds<APACKED>(A, L, n);
+  if (n <= 8) chol_factor_reg<W, APACKED, REAL, 8>(A, L, n);
+  else if (n <= 16) chol_factor_reg<W, APACKED, REAL, 16>(A, L, n);
+  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<W, APACKED, REAL, 32>(A, L, n);
+  else chol_factor_lds<W, APACKED>(A, L, n);
 }
 
 // sum_k a[k * sa] * b[k * sb] accumulated in index order (the reference's reduction order for its explicit
@@ -366,8 +368,9 @@ __device__ __forceinline__ REAL dot_seq(const REAL* a, int sa, const REAL* b, in
 }
 
 // =====================================================================================================================
-template <typename REAL>
+template <typename REAL, int W = 64>
 struct Env {
+  __device__ __forceinline__ static int lane() { return sub_lane<W>(); }
   LdsView<REAL> S;
   int64_t e;      // environment index
   int flags;
@@ -376,7 +379,7 @@ struct Env {
 
   // every phase streams the leaves it produces to the Data being computed (`out` == KArgs::cur)
   template <typename T>
-  __device__ __forceinline__ void put(T* g, const REAL* l, int n) { row_store(g, l, n, e); }
+  __device__ __forceinline__ void put(T* g, const REAL* l, int n) { row_store<W>(g, l, n, e); }
 
   // ---- state loads (+ _check_state, forward.py:44-59, on the caller's state) ------------------------------------------------
   __device__ __forceinline__ REAL checked(REAL x, REAL fallback) const {
@@ -387,23 +390,23 @@ struct Env {
     const bool from_in = raw && !KA.state_from_cur;
     const REAL* src = (raw ? (KA.state_from_cur ? KA.cur.qpos : in.qpos) : KA.cur.qpos) + e * M.nq;
     const bool check = from_in && KA.do_step;
-    for (int i = lane_id(); i < M.nq; i += MJH_WAVE) S.qpos()[i] = check ? checked(src[i], M.qpos0[i]) : src[i];
+    for (int i = lane(); i < M.nq; i += W) S.qpos()[i] = check ? checked(src[i], M.qpos0[i]) : src[i];
   }
   __device__ __forceinline__ void load_qvel() {
     const bool from_in = !KA.state_from_cur;
     const REAL* src = (from_in ? in.qvel : KA.cur.qvel) + e * M.nv;
     const bool check = from_in && KA.do_step;
-    for (int i = lane_id(); i < M.nv; i += MJH_WAVE) S.qvel()[i] = check ? checked(src[i], (REAL)0) : src[i];
+    for (int i = lane(); i < M.nv; i += W) S.qvel()[i] = check ? checked(src[i], (REAL)0) : src[i];
   }
   __device__ __forceinline__ void load_act() {
     const REAL* src = KA.state_from_cur ? KA.cur.act : in.act;
-    row_load(S.act(), src, M.na, e);
+    row_load<W>(S.act(), src, M.na, e);
   }
 
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
   __device__ __forceinline__ void kinematics(bool with_cams) {
-    const int l = lane_id();
-    for (int b = l; b < M.nbody; b += MJH_WAVE) {
+    const int l = lane();
+    for (int b = l; b < M.nbody; b += W) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
       const int depth = M.body_depth[b];
@@ -474,7 +477,7 @@ struct Env {
     wave_sync();
     STAMP(2);
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
-    for (int j = l; j < M.njnt; j += MJH_WAVE) {
+    for (int j = l; j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
       if (t == JNT_FREE || t == JNT_BALL) {
         const int o = (t == JNT_FREE) ? qa + 3 : qa;
@@ -484,7 +487,7 @@ struct Env {
         for (int i = 0; i < 4; i++) S.qpos()[o + i] = q[i];
       }
     }
-    for (int g = l; g < M.ngeom; g += MJH_WAVE) {
+    for (int g = l; g < M.ngeom; g += W) {
       const int b = M.geom_bodyid[g];
       REAL p[3], mat[9];
       local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.geom_pos + 3 * g, M.geom_quat + 4 * g, p, mat);
@@ -492,7 +495,7 @@ struct Env {
       if (out.geom_xmat) for (int i = 0; i < 9; i++) out.geom_xmat[(e * M.ngeom + g) * 9 + i] = mat[i];
     }
     {
-      for (int s = l; s < M.nsite; s += MJH_WAVE) {
+      for (int s = l; s < M.nsite; s += W) {
         const int b = M.site_bodyid[s];
         REAL p[3], mat[9];
         local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.site_pos + 3 * s, M.site_quat + 4 * s, p, mat);
@@ -500,7 +503,7 @@ struct Env {
         if (out.site_xmat) for (int i = 0; i < 9; i++) out.site_xmat[(e * M.nsite + s) * 9 + i] = mat[i];
       }
       if (with_cams) {
-        for (int c = l; c < M.ncam; c += MJH_WAVE) {  // smooth.py:139-198
+        for (int c = l; c < M.ncam; c += W) {  // smooth.py:139-198
           const int b = M.cam_bodyid[c], mode = M.cam_mode[c], tgt = M.cam_targetbodyid[c];
           REAL cp[3], cm[9];
           local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.cam_pos + 3 * c, M.cam_quat + 4 * c, cp, cm);
@@ -527,7 +530,7 @@ struct Env {
           if (out.cam_xpos) for (int i = 0; i < 3; i++) out.cam_xpos[(e * M.ncam + c) * 3 + i] = cp[i];
           if (out.cam_xmat) for (int i = 0; i < 9; i++) out.cam_xmat[(e * M.ncam + c) * 9 + i] = cm[i];
         }
-        for (int q = l; q < M.nlight; q += MJH_WAVE) {  // :200-204
+        for (int q = l; q < M.nlight; q += W) {  // :200-204
           const int b = M.light_bodyid[q];
           REAL r[3], dir[3];
           rotate(M.light_pos + 3 * q, S.xquat() + 4 * b, r);
@@ -548,10 +551,10 @@ struct Env {
 
   // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void com_pos() {
-    const int l = lane_id();
+    const int l = lane();
     const int nb = M.nbody;
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
-    for (int w = l; w < nb * 4; w += MJH_WAVE) {
+    for (int w = l; w < nb * 4; w += W) {
       const int b = w >> 2, k = w & 3;
       const int end = M.body_subtree_end[b];
       REAL acc = 0;
@@ -559,7 +562,7 @@ struct Env {
       if (k < 3) S.sub_pos()[3 * b + k] = acc; else S.sub_mass()[b] = acc;
     }
     wave_sync();
-    for (int w = l; w < nb * 3; w += MJH_WAVE) {
+    for (int w = l; w < nb * 3; w += W) {
       const int b = w / 3;
       const REAL ms = S.sub_mass()[b];
       const REAL den = ms > (REAL)MINVAL_CACHED ? ms : (REAL)MINVAL_CACHED;
@@ -567,7 +570,7 @@ struct Env {
     }
     wave_sync();
     STAMP(5);
-    for (int b = l; b < nb; b += MJH_WAVE) {  // inert_com :236-243
+    for (int b = l; b < nb; b += W) {  // inert_com :236-243
       const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
       const REAL off[3] = {S.xipos()[3 * b] - rc[0], S.xipos()[3 * b + 1] - rc[1], S.xipos()[3 * b + 2] - rc[2]};
       const REAL mass = M.body_mass[b];
@@ -590,7 +593,7 @@ struct Env {
       ci[0] = I[0][0]; ci[1] = I[1][1]; ci[2] = I[2][2]; ci[3] = I[0][1]; ci[4] = I[0][2]; ci[5] = I[1][2];
       ci[6] = off[0] * mass; ci[7] = off[1] * mass; ci[8] = off[2] * mass; ci[9] = mass;
     }
-    for (int j = l; j < M.njnt; j += MJH_WAVE) {  // cdof_fn :250-273
+    for (int j = l; j < M.njnt; j += W) {  // cdof_fn :250-273
       const int b = M.jnt_bodyid[j], t = M.jnt_type[j];
       int d = M.jnt_dofadr[j];
       const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
@@ -622,14 +625,14 @@ struct Env {
 
   // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
   __device__ __forceinline__ void crb_factor() {
-    const int l = lane_id();
+    const int l = lane();
     const int nb = M.nbody, nv = M.nv;
     STAMP(10);
-    row_load(S.cinert(), out.cinert, 10 * nb, e);
-    row_load(S.cdof(), out.cdof, 6 * nv, e);
+    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);
+    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
     wave_sync();
     STAMP(11);
-    for (int w = l; w < nb * 10; w += MJH_WAVE) {
+    for (int w = l; w < nb * 10; w += W) {
       const int b = w / 10, k = w - 10 * b;
       REAL acc = 0;
       if (b > 0) {
@@ -640,10 +643,10 @@ struct Env {
     }
     wave_sync();
     STAMP(12);
-    for (int d = l; d < nv; d += MJH_WAVE) inert_mul(S.crb() + 10 * M.dof_bodyid[d], S.cdof() + 6 * d, S.crb_cdof() + 6 * d);
+    for (int d = l; d < nv; d += W) inert_mul(S.crb() + 10 * M.dof_bodyid[d], S.cdof() + 6 * d, S.crb_cdof() + 6 * d);
     wave_sync();
     STAMP(13);
-    for (int w = l; w < nv * nv; w += MJH_WAVE) {
+    for (int w = l; w < nv * nv; w += W) {
       const int i = w / nv, j = w - nv * i;
       const int hi = i > j ? i : j, lo = i > j ? j : i;
       REAL s = 0;
@@ -659,7 +662,7 @@ struct Env {
     put(out.crb, S.crb(), 10 * nb);
     wave_sync();
     STAMP(15);
-    chol_factor<REAL, 32, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve)
+    chol_factor<W, REAL, 32, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve)
     STAMP(16);
     put(out.qLD, S.qLD(), nv * nv);
     STAMP(17);
@@ -720,16 +723,16 @@ struct Env {
   }
 
   __device__ __forceinline__ void collision() {
-    const int l = lane_id();
-    row_load(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
-    row_load(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
+    const int l = lane();
+    row_load<W>(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
+    row_load<W>(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
     if (M.ncvxpair > 0) {  // box / mesh pairs were narrow-phased by mjh_convex_kernel (mjh_convex.h) into their contact slots
-      row_load(S.con_dist(), out.contact_dist, M.ncon, e);
-      row_load(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
-      row_load(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
+      row_load<W>(S.con_dist(), out.contact_dist, M.ncon, e);
+      row_load<W>(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
+      row_load<W>(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
     }
     wave_sync();
-    for (int p = l; p < M.npair; p += MJH_WAVE) {
+    for (int p = l; p < M.npair; p += W) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
       if (fn >= MJH_FN_PLANE_CONVEX) continue;
       const REAL *p1 = S.geom_xpos() + 3 * g1, *m1 = S.geom_xmat() + 9 * g1, *s1 = M.geom_size + 3 * g1;
@@ -804,12 +807,12 @@ struct Env {
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
-      row_store(out.contact_includemargin, M.con_includemargin, nc, e);
-      row_store(out.contact_friction, M.con_friction, 5 * nc, e);
-      row_store(out.contact_solref, M.con_solref, 2 * nc, e);
-      row_store(out.contact_solreffriction, M.con_solreffriction, 2 * nc, e);
-      row_store(out.contact_solimp, M.con_solimp, 5 * nc, e);
-      for (int c = l; c < nc; c += MJH_WAVE) {
+      row_store<W>(out.contact_includemargin, M.con_includemargin, nc, e);
+      row_store<W>(out.contact_friction, M.con_friction, 5 * nc, e);
+      row_store<W>(out.contact_solref, M.con_solref, 2 * nc, e);
+      row_store<W>(out.contact_solreffriction, M.con_solreffriction, 2 * nc, e);
+      row_store<W>(out.contact_solimp, M.con_solimp, 5 * nc, e);
+      for (int c = l; c < nc; c += W) {
         if (out.contact_dim) out.contact_dim[e * nc + c] = M.con_dim[c];
         if (out.contact_geom1) out.contact_geom1[e * nc + c] = M.con_geom1[c];
         if (out.contact_geom2) out.contact_geom2[e * nc + c] = M.con_geom2[c];
@@ -860,16 +863,16 @@ struct Env {
   }
 
   __device__ __forceinline__ void make_constraint() {
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nefc = M.nefc, nl = M.nl;
     if (nefc == 0) return;
     load_qpos(false); load_qvel();
-    row_load(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
-    row_load(S.cdof(), out.cdof, 6 * nv, e);
-    for (int w = l; w < nl * nv; w += MJH_WAVE) S.efc_J()[w] = 0;
+    row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
+    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
+    for (int w = l; w < nl * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
-    for (int r = l; r < nl; r += MJH_WAVE) {  // _instantiate_limit_slide_hinge :338-372
+    for (int r = l; r < nl; r += W) {  // _instantiate_limit_slide_hinge :338-372
       const int j = M.lim_jnt[r], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = S.qpos()[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
@@ -883,7 +886,7 @@ struct Env {
     }
     const bool elliptic = M.cone == CONE_ELLIPTIC;
     // contact rows: one lane per (contact, dof) column entry; all rows of the contact for that dof
-    for (int w = l; w < M.ncon * nv; w += MJH_WAVE) {
+    for (int w = l; w < M.ncon * nv; w += W) {
       const int c = w / nv, d = w - nv * c;
       const int dim = M.con_dim[c], row0 = M.con_efc_address[c];
       const int b1 = M.geom_bodyid[M.con_geom1[c]], b2 = M.geom_bodyid[M.con_geom2[c]];
@@ -934,7 +937,7 @@ struct Env {
     }
     wave_sync();
     STAMP(25);
-    for (int r = l; r < nefc; r += MJH_WAVE) {  // :683-693
+    for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
       if (r < nl) {
         const int j = M.lim_jnt[r];
@@ -963,37 +966,37 @@ struct Env {
     STAMP(26);
     put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
     STAMP(27);
-    if (out.efc_frictionloss) for (int r = l; r < nefc; r += MJH_WAVE) out.efc_frictionloss[e * nefc + r] = 0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = 0;
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
   __device__ __forceinline__ void velocity() {
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     load_qpos(false); load_qvel(); load_act();
-    row_load(S.cdof(), out.cdof, 6 * nv, e);
-    row_load(S.cinert(), out.cinert, 10 * nb, e);
-    row_load(S.subtree_com(), out.subtree_com, 3 * nb, e);
-    row_load(S.xipos(), out.xipos, 3 * nb, e);
-    row_load(S.qLD(), out.qLD, nv * nv, e);
+    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
+    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);
+    row_load<W>(S.subtree_com(), out.subtree_com, 3 * nb, e);
+    row_load<W>(S.xipos(), out.xipos, 3 * nb, e);
+    row_load<W>(S.qLD(), out.qLD, nv * nv, e);
     wave_sync();
-    chol_inv_diag<false>(S.qLD(), S.qLD_inv(), nv);
+    chol_inv_diag<W, false>(S.qLD(), S.qLD_inv(), nv);
     wave_sync();
     STAMP(31);
-    for (int i = l; i < nu; i += MJH_WAVE) {
+    for (int i = l; i < nu; i += W) {
       const REAL gear = M.act_gear[6 * i];
       S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
       S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
     }
     if (out.actuator_moment) {
-      for (int w = l; w < nu * nv; w += MJH_WAVE) {
+      for (int w = l; w < nu * nv; w += W) {
         const int i = w / nv, d = w - nv * i;
         out.actuator_moment[e * nu * nv + w] = (d == M.act_dofadr[i]) ? M.act_gear[6 * i] : (REAL)0;
       }
     }
     STAMP(32);
     // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
-    for (int b = l; b < nb; b += MJH_WAVE) {
+    for (int b = l; b < nb; b += W) {
       REAL cvel[6] = {0, 0, 0, 0, 0, 0};
       const int depth = M.body_depth[b];
       for (int kk = 0; kk < depth; kk++) {
@@ -1036,9 +1039,9 @@ struct Env {
     STAMP(33);
     // passive forces
     if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
-      for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = 0;
+      for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = 0;
     } else {
-      for (int j = l; j < M.njnt; j += MJH_WAVE) {
+      for (int j = l; j < M.njnt; j += W) {
         const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
         const REAL k = M.jnt_stiffness[j];
         if (t == JNT_FREE) {
@@ -1055,12 +1058,12 @@ struct Env {
         }
       }
       wave_sync();
-      for (int d = l; d < nv; d += MJH_WAVE) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
+      for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
     }
     wave_sync();
     STAMP(35);
     // rne: cacc along the ancestor chain (needs cdof_dot of ancestors: written above, visible after the sync)
-    for (int b = l; b < nb; b += MJH_WAVE) {
+    for (int b = l; b < nb; b += W) {
       REAL cacc[6];
       const bool nograv = M.disableflags & DSBL_GRAVITY;
 #pragma unroll
@@ -1087,7 +1090,7 @@ struct Env {
     }
     wave_sync();
     STAMP(36);
-    for (int w = l; w < nb * 6; w += MJH_WAVE) {  // subtree sums of the body forces
+    for (int w = l; w < nb * 6; w += W) {  // subtree sums of the body forces
       const int b = w / 6, k = w - 6 * b;
       const int end = M.body_subtree_end[b];
       REAL acc = 0;
@@ -1096,7 +1099,7 @@ struct Env {
     }
     wave_sync();
     STAMP(37);
-    for (int d = l; d < nv; d += MJH_WAVE) {
+    for (int d = l; d < nv; d += W) {
       REAL s = 0;
       const REAL* cf = S.cfrc() + 6 * M.dof_bodyid[d];
 #pragma unroll
@@ -1113,13 +1116,13 @@ struct Env {
 
   // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
   __device__ __forceinline__ void actuation() {
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nu = M.nu;
     const bool off = (nu == 0) || (M.disableflags & DSBL_ACTUATION);
     if (off) {
-      for (int i = l; i < M.na; i += MJH_WAVE) S.act_dot()[i] = 0;
+      for (int i = l; i < M.na; i += W) S.act_dot()[i] = 0;
     } else {
-      for (int i = l; i < nu; i += MJH_WAVE) {
+      for (int i = l; i < nu; i += W) {
         REAL ctrl = in.ctrl ? in.ctrl[e * nu + i] : (REAL)0;
         if (!(M.disableflags & DSBL_CLAMPCTRL) && M.act_ctrllimited[i]) {
           const REAL lo = M.act_ctrlrange[2 * i], hi = M.act_ctrlrange[2 * i + 1];
@@ -1154,7 +1157,7 @@ struct Env {
     }
     wave_sync();
     STAMP(40);
-    for (int d = l; d < nv; d += MJH_WAVE) {
+    for (int d = l; d < nv; d += W) {
       REAL s = 0;
       if (!off) {
         for (int i = 0; i < nu; i++) if (M.act_dofadr[i] == d) s += M.act_gear[6 * i] * S.act_force()[i];
@@ -1181,7 +1184,7 @@ struct Env {
     }
     wave_sync();
     STAMP(41);
-    chol_solve<false>(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    chol_solve<W, false>(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
     if (!off) put(out.actuator_force, S.act_force(), nu);
     put(out.act_dot, S.act_dot(), M.na);
     put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv); put(out.qacc_smooth, S.qacc_smooth(), nv);
@@ -1201,11 +1204,11 @@ struct Env {
   __device__ __forceinline__ void mul_M(const REAL* v, REAL* o) {
     const int nv = M.nv;
     if (M.sol_qm_lds) {
-      for (int i = lane_id(); i < nv; i += MJH_WAVE) o[i] = dot_seq(S.qMs() + i * nv, 1, v, 1, nv);
+      for (int i = lane(); i < nv; i += W) o[i] = dot_seq(S.qMs() + i * nv, 1, v, 1, nv);
       return;
     }
     const REAL* g = out.qM + e * nv * nv;
-    for (int i = lane_id(); i < nv; i += MJH_WAVE) {
+    for (int i = lane(); i < nv; i += W) {
       REAL s = 0;
       int k = 0;
       for (; k + 8 <= nv; k += 8) {
@@ -1223,24 +1226,24 @@ struct Env {
   // exact zeros, so the single term is the same value.
   __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {
     const int nv = M.nv, nl = M.nl;
-    for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
+    for (int r = lane(); r < M.nefc; r += W) {
       const REAL s = r < nl ? S.efc_Jl()[r] * v[lim_dof_lds()[r]] : dot_seq(S.efc_Jc() + (r - nl) * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
     }
   }
 
   __device__ __forceinline__ void update_constraint(Ctx& c) {  // :320-357
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
     REAL part = 0;
-    for (int r = l; r < nefc; r += MJH_WAVE) {
+    for (int r = l; r < nefc; r += W) {
       const REAL ja = S.s_Jaref()[r];
       const REAL active = (REAL)(ja < 0);
       S.s_force()[r] = S.efc_D()[r] * -ja * active + 0;
       part += S.efc_D()[r] * ja * ja * active;
     }
     REAL gpart = 0;
-    for (int d = l; d < nv; d += MJH_WAVE) gpart += (S.s_Ma()[d] - S.qfrc_smooth()[d]) * (S.s_qacc()[d] - S.qacc_smooth()[d]);
+    for (int d = l; d < nv; d += W) gpart += (S.s_Ma()[d] - S.qfrc_smooth()[d]) * (S.s_qacc()[d] - S.qacc_smooth()[d]);
     const REAL csum = wave_sum(part);
     const REAL g = wave_sum(gpart);
     wave_sync();
@@ -1251,7 +1254,7 @@ struct Env {
         const int lr = dof_limrow_lds()[l];
         if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
       }
-      for (int base = nl; base < nefc; base += MJH_WAVE) {
+      for (int base = nl; base < nefc; base += W) {
         const int r = base + l;
         const REAL f = (r < nefc) ? S.s_force()[r] : (REAL)0;
         unsigned long long mask = __ballot(f != 0);
@@ -1271,17 +1274,17 @@ struct Env {
   }
 
   __device__ __forceinline__ void update_gradient() {  // :359-376
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
-    for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
+    for (int d = l; d < nv; d += W) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
     wave_sync();
     if (M.solver == SOL_CG) {
-      chol_solve<true>(S.qLDp(), S.qLD_inv(), S.s_grad(), S.s_Mgrad(), nv);
+      chol_solve<W, true>(S.qLDp(), S.qLD_inv(), S.s_grad(), S.s_Mgrad(), nv);
     } else {
       // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
       // only the lower triangle is ever read by the factorisation: one lane per packed entry (i, j <= i)
       const int np = (nv * (nv + 1)) / 2, nl = M.nl;
-      for (int w0 = 0; w0 < np; w0 += MJH_WAVE) {
+      for (int w0 = 0; w0 < np; w0 += W) {
         const int w = w0 + l;
         int i, j;
         tri_unpack(w < np ? w : 0, i, j);
@@ -1290,7 +1293,7 @@ struct Env {
           const int lr = dof_limrow_lds()[i];
           if (lr >= 0 && S.s_Jaref()[lr] < 0) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
         }
-        for (int base = nl; base < nefc; base += MJH_WAVE) {
+        for (int base = nl; base < nefc; base += W) {
           const int r = base + l;
           unsigned long long mask = __ballot(r < nefc && S.s_Jaref()[r] < 0);
           while (mask) {
@@ -1303,16 +1306,16 @@ struct Env {
         if (w < np) S.H()[w] = (M.sol_qm_lds ? S.qMs()[i * nv + j] : out.qM[e * nv * nv + i * nv + j]) + s;
       }
       wave_sync();
-      chol_factor<REAL, 16, true>(S.H(), S.HL(), nv);
-      chol_inv_diag<false>(S.HL(), S.HL_inv(), nv);
+      chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
+      chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
       wave_sync();
-      chol_solve<false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+      chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
     }
   }
 
   __device__ __forceinline__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
     REAL q0 = 0, q1 = 0, q2 = 0;
-    for (int r = lane_id(); r < M.nefc; r += MJH_WAVE) {
+    for (int r = lane(); r < M.nefc; r += W) {
       const REAL x = S.s_Jaref()[r] + alpha * S.s_jv()[r];
       const REAL a = (REAL)(x < 0);
       q0 += S.s_quad()[3 * r] * a;
@@ -1334,12 +1337,12 @@ struct Env {
   }
 
   __device__ __forceinline__ void linesearch(Ctx& c) {  // :378-497
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     REAL ss = 0;
     bool nz = false;
-    for (int d = l; d < nv; d += MJH_WAVE) { ss += S.s_search()[d] * S.s_search()[d]; nz = nz || (S.s_search()[d] != 0); }
+    for (int d = l; d < nv; d += W) { ss += S.s_search()[d] * S.s_search()[d]; nz = nz || (S.s_search()[d] != 0); }
     ss = wave_sum(ss);
     const REAL snorm = wave_any(nz) ? r_sqrt<REAL>(ss) : (REAL)0;
     const REAL smag = snorm * scale;
@@ -1349,10 +1352,10 @@ struct Env {
     wave_sync();
     STAMP(57);
     REAL a = 0, b = 0, cc = 0;
-    for (int d = l; d < nv; d += MJH_WAVE) { a += S.s_search()[d] * S.s_Ma()[d]; b += S.s_search()[d] * S.qfrc_smooth()[d]; cc += S.s_search()[d] * S.s_mv()[d]; }
+    for (int d = l; d < nv; d += W) { a += S.s_search()[d] * S.s_Ma()[d]; b += S.s_search()[d] * S.qfrc_smooth()[d]; cc += S.s_search()[d] * S.s_mv()[d]; }
     a = wave_sum(a); b = wave_sum(b); cc = wave_sum(cc);
     const REAL qg[3] = {c.gauss, a - b, (REAL)0.5 * cc};
-    for (int r = l; r < nefc; r += MJH_WAVE) {
+    for (int r = l; r < nefc; r += W) {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r], D = S.efc_D()[r];
       S.s_quad()[3 * r] = ((REAL)0.5 * ja * ja) * D;
       S.s_quad()[3 * r + 1] = (jv * ja) * D;
@@ -1392,46 +1395,46 @@ struct Env {
     }
     const REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
     const REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
-    for (int d = l; d < nv; d += MJH_WAVE) {
+    for (int d = l; d < nv; d += W) {
       S.s_qacc()[d] = S.s_qacc()[d] + improved * S.s_search()[d] * alpha;
       S.s_Ma()[d] = S.s_Ma()[d] + improved * S.s_mv()[d] * alpha;
     }
-    for (int r = l; r < nefc; r += MJH_WAVE) S.s_Jaref()[r] = S.s_Jaref()[r] + improved * S.s_jv()[r] * alpha;
+    for (int r = l; r < nefc; r += W) S.s_Jaref()[r] = S.s_Jaref()[r] + improved * S.s_jv()[r] * alpha;
     wave_sync();
     STAMP(59);
   }
 
   __device__ __forceinline__ void load_solver_inputs() {
     const int nv = M.nv, nefc = M.nefc;
-    row_load(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
-    row_load(S.qacc_smooth(), out.qacc_smooth, nv, e);
-    if (M.sol_qm_lds) row_load(S.qMs(), out.qM, nv * nv, e);
+    row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
+    row_load<W>(S.qacc_smooth(), out.qacc_smooth, nv, e);
+    if (M.sol_qm_lds) row_load<W>(S.qMs(), out.qM, nv * nv, e);
     if (nefc > 0) {
-      const int l = lane_id(), nl = M.nl;
+      const int l = lane(), nl = M.nl;
       const REAL* gL = out.qLD + e * nv * nv;
-      for (int w = l; w < nv * nv; w += MJH_WAVE) {  // lower triangle of the factor, packed rows
+      for (int w = l; w < nv * nv; w += W) {  // lower triangle of the factor, packed rows
         const int i = w / nv, k = w - nv * i;
         if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
       }
       const REAL* gJ = out.efc_J + e * nefc * nv;
-      for (int r = l; r < nl; r += MJH_WAVE) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
-      if (nl > 0) for (int d = l; d < nv; d += MJH_WAVE) dof_limrow_lds()[d] = M.dof_limrow[d];
+      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
+      if (nl > 0) for (int d = l; d < nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
       {
         const int n = (nefc - nl) * nv;
         const REAL* src = gJ + nl * nv;
         int i = l;
-        for (; i + 3 * MJH_WAVE < n; i += 4 * MJH_WAVE) {
-          const REAL a = src[i], b = src[i + MJH_WAVE], c = src[i + 2 * MJH_WAVE], d = src[i + 3 * MJH_WAVE];
-          S.efc_Jc()[i] = a; S.efc_Jc()[i + MJH_WAVE] = b; S.efc_Jc()[i + 2 * MJH_WAVE] = c; S.efc_Jc()[i + 3 * MJH_WAVE] = d;
+        for (; i + 3 * W < n; i += 4 * W) {
+          const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
+          S.efc_Jc()[i] = a; S.efc_Jc()[i + W] = b; S.efc_Jc()[i + 2 * W] = c; S.efc_Jc()[i + 3 * W] = d;
         }
-        for (; i < n; i += MJH_WAVE) S.efc_Jc()[i] = src[i];
+        for (; i < n; i += W) S.efc_Jc()[i] = src[i];
       }
-      row_load(S.efc_D(), out.efc_D, nefc, e);
-      row_load(S.efc_aref(), out.efc_aref, nefc, e);
-      row_load(S.qacc_warm(), KA.warm_src, nv, e);
+      row_load<W>(S.efc_D(), out.efc_D, nefc, e);
+      row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
+      row_load<W>(S.qacc_warm(), KA.warm_src, nv, e);
     }
     wave_sync();
-    if (nefc > 0) chol_inv_diag<true>(S.qLDp(), S.qLD_inv(), nv);
+    if (nefc > 0) chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
     wave_sync();
   }
 
@@ -1444,7 +1447,7 @@ struct Env {
   //              context is still in place and only the gradient is added.
   //   P_ITER   : cond :501-508, then body :509-524 (line search, constraint update, gradient, new direction)
   __device__ __forceinline__ void solve() {
-    const int l = lane_id();
+    const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
@@ -1466,7 +1469,7 @@ struct Env {
         else if (fixed) { if (it >= M.iterations) break; }
         else {  // cond :501-508
           REAL gg = 0;
-          for (int d = l; d < nv; d += MJH_WAVE) gg += S.s_grad()[d] * S.s_grad()[d];
+          for (int d = l; d < nv; d += W) gg += S.s_grad()[d] * S.s_grad()[d];
           gg = wave_sum(gg);
           const REAL improvement = (c.prev_cost - c.cost) / scale;
           const REAL gradient = r_sqrt<REAL>(gg) / scale;
@@ -1480,30 +1483,30 @@ struct Env {
       if (do_ls) {
         linesearch(c);
         STAMP(60);
-        for (int d = l; d < nv; d += MJH_WAVE) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
+        for (int d = l; d < nv; d += W) { S.s_pgrad()[d] = S.s_grad()[d]; S.s_pMgrad()[d] = S.s_Mgrad()[d]; }
         wave_sync();
       }
       if (do_init) {  // _Context.create :293-318
-        for (int d = l; d < nv; d += MJH_WAVE) S.s_qacc()[d] = src[d];
+        for (int d = l; d < nv; d += W) S.s_qacc()[d] = src[d];
         wave_sync();
         mul_J(S.s_qacc(), S.s_Jaref(), S.efc_aref());
         mul_M(S.s_qacc(), S.s_Ma());
         c.gauss = 0; c.cost = (REAL)INFINITY; c.prev_cost = 0; c.niter = 0;
-        for (int d = l; d < nv; d += MJH_WAVE) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
+        for (int d = l; d < nv; d += W) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
         wave_sync();
       }
       if (do_ls || do_init) update_constraint(c);
       if (do_grad) {
         update_gradient();
         if (ph == P_START || M.solver == SOL_NEWTON) {
-          for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d];
+          for (int d = l; d < nv; d += W) S.s_search()[d] = -S.s_Mgrad()[d];
         } else {  // Polak-Ribiere :519-523
           REAL num = 0, den = 0;
-          for (int d = l; d < nv; d += MJH_WAVE) { num += S.s_grad()[d] * (S.s_Mgrad()[d] - S.s_pMgrad()[d]); den += S.s_pgrad()[d] * S.s_pMgrad()[d]; }
+          for (int d = l; d < nv; d += W) { num += S.s_grad()[d] * (S.s_Mgrad()[d] - S.s_pMgrad()[d]); den += S.s_pgrad()[d] * S.s_pMgrad()[d]; }
           num = wave_sum(num); den = wave_sum(den);
           REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
           beta = beta > 0 ? beta : (REAL)0;
-          for (int d = l; d < nv; d += MJH_WAVE) S.s_search()[d] = -S.s_Mgrad()[d] + beta * S.s_search()[d];
+          for (int d = l; d < nv; d += W) S.s_search()[d] = -S.s_Mgrad()[d] + beta * S.s_search()[d];
         }
         wave_sync();
       }
@@ -1512,7 +1515,7 @@ struct Env {
       else if (ph == P_START) { ph = P_ITER; STAMP(55); }
       else { c.niter++; it++; }
     }
-    for (int d = l; d < nv; d += MJH_WAVE) { S.qacc()[d] = S.s_qacc()[d]; S.qacc_warm()[d] = S.s_qacc()[d]; S.qfrc_constraint()[d] = S.s_qfrc()[d]; }
+    for (int d = l; d < nv; d += W) { S.qacc()[d] = S.s_qacc()[d]; S.qacc_warm()[d] = S.s_qacc()[d]; S.qfrc_constraint()[d] = S.s_qfrc()[d]; }
     wave_sync();
     STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
@@ -1522,7 +1525,7 @@ struct Env {
 
   // ---- integrators (forward.py:231-370) ---------------------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void integrate_pos(const REAL* qpos, const REAL* qvel, REAL dt, REAL* o) {  // :231-252, one lane per joint
-    for (int j = lane_id(); j < M.njnt; j += MJH_WAVE) {
+    for (int j = lane(); j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       if (t == JNT_FREE) {
         for (int i = 0; i < 3; i++) o[qa + i] = qpos[qa + i] + dt * qvel[da + i];
@@ -1542,7 +1545,7 @@ struct Env {
   // act <- act + act_dot * dt (or exact filter), clamped (forward.py:267-294); one lane per actuator
   __device__ __forceinline__ void advance_act(const REAL* act0, const REAL* act_dot, REAL* dst) {
     const REAL dt = M.timestep;
-    for (int i = lane_id(); i < M.nu; i += MJH_WAVE) {
+    for (int i = lane(); i < M.nu; i += W) {
       const int dyn = M.act_dyntype[i];
       if (dyn == DYN_NONE) continue;
       const int a = M.act_actadr[i];
@@ -1565,16 +1568,16 @@ struct Env {
   // _advance :255-310 into the RETURNED Data (KArgs::out): qvel += qacc dt, qpos integrated with qvel_for_pos
   // (the new qvel when null), act, time.
   __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
-    const int l = lane_id();
+    const int l = lane();
     const REAL dt = M.timestep;
     const DevData<REAL>& fin = KA.fin;
     advance_act(act0, act_dot, fin.act);
-    for (int d = l; d < M.nv; d += MJH_WAVE) S.tmp_nv()[d] = qvel0[d] + qacc[d] * dt;
+    for (int d = l; d < M.nv; d += W) S.tmp_nv()[d] = qvel0[d] + qacc[d] * dt;
     wave_sync();
     integrate_pos(qpos0, qvel_for_pos ? qvel_for_pos : S.tmp_nv(), dt, S.tmp_nq());
     wave_sync();
-    row_store(fin.qpos, S.tmp_nq(), M.nq, e);
-    row_store(fin.qvel, S.tmp_nv(), M.nv, e);
+    row_store<W>(fin.qpos, S.tmp_nq(), M.nq, e);
+    row_store<W>(fin.qvel, S.tmp_nv(), M.nv, e);
     if (l == 0 && fin.time) fin.time[e] = time0 + dt;
   }
 
@@ -1601,15 +1604,15 @@ struct Env {
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.
   __device__ __forceinline__ void run_sol() {
-    const int l = lane_id();
+    const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
     STAMP(50);
     load_qpos(false); load_qvel(); load_act();
-    row_load(S.act_dot(), out.act_dot, na, e);
+    row_load<W>(S.act_dot(), out.act_dot, na, e);
     load_solver_inputs();
     STAMP(51);
     if (M.nefc == 0) {
-      for (int d = l; d < nv; d += MJH_WAVE) S.qacc()[d] = S.qacc_smooth()[d];
+      for (int d = l; d < nv; d += W) S.qacc()[d] = S.qacc_smooth()[d];
       wave_sync();
       put(out.qacc, S.qacc(), nv);
     } else {
@@ -1622,18 +1625,18 @@ struct Env {
     if (rk < 0) {  // Euler
       const REAL* qacc = S.qacc();
       if (!(M.disableflags & DSBL_EULERDAMP)) {
-        for (int w = l; w < (nv * (nv + 1)) / 2; w += MJH_WAVE) {
+        for (int w = l; w < (nv * (nv + 1)) / 2; w += W) {
           int i, j;
           tri_unpack(w, i, j);
           const REAL mw = out.qM[e * nv * nv + i * nv + j];
           S.H()[w] = (i == j) ? mw + M.timestep * M.dof_damping[i] : mw;
         }
-        for (int d = l; d < nv; d += MJH_WAVE) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
+        for (int d = l; d < nv; d += W) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
-        chol_factor<REAL, 16, true>(S.H(), S.HL(), nv);
-        chol_inv_diag<false>(S.HL(), S.HL_inv(), nv);
+        chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
+        chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
         wave_sync();
-        chol_solve<false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+        chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
         qacc = S.s_Mgrad();
       }
       advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
@@ -1642,42 +1645,42 @@ struct Env {
     // RK4: the tableau is a float32 literal tensor up-cast to the data dtype (forward.py:63-70, math.py:34-45)
     const REAL A[3] = {(REAL)0.5, (REAL)0.5, (REAL)1.0};
     const REAL Bt[4] = {(REAL)(float)(1.0 / 6.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 3.0), (REAL)(float)(1.0 / 6.0)};
-    const RkWork<REAL>& W = KA.W;
+    const RkWork<REAL>& RW = KA.W;
     const REAL b = Bt[rk];
     // this stage's state: S.qvel() is kqvel_s, S.qacc() / S.act_dot() are this pass's results
-    for (int i = l; i < nv; i += MJH_WAVE) {
+    for (int i = l; i < nv; i += W) {
       const REAL kq = S.qvel()[i], qa = S.qacc()[i];
-      if (rk == 0) { W.qvel0[e * nv + i] = kq; W.sum_qvel[e * nv + i] = b * kq; W.sum_qacc[e * nv + i] = b * qa; }
-      else { W.sum_qvel[e * nv + i] = W.sum_qvel[e * nv + i] + b * kq; W.sum_qacc[e * nv + i] = W.sum_qacc[e * nv + i] + b * qa; }
+      if (rk == 0) { RW.qvel0[e * nv + i] = kq; RW.sum_qvel[e * nv + i] = b * kq; RW.sum_qacc[e * nv + i] = b * qa; }
+      else { RW.sum_qvel[e * nv + i] = RW.sum_qvel[e * nv + i] + b * kq; RW.sum_qacc[e * nv + i] = RW.sum_qacc[e * nv + i] + b * qa; }
     }
-    for (int i = l; i < na; i += MJH_WAVE) {
+    for (int i = l; i < na; i += W) {
       const REAL ad = S.act_dot()[i];
-      if (rk == 0) { W.act0[e * na + i] = S.act()[i]; W.sum_actdot[e * na + i] = b * ad; }
-      else W.sum_actdot[e * na + i] = W.sum_actdot[e * na + i] + b * ad;
+      if (rk == 0) { RW.act0[e * na + i] = S.act()[i]; RW.sum_actdot[e * na + i] = b * ad; }
+      else RW.sum_actdot[e * na + i] = RW.sum_actdot[e * na + i] + b * ad;
     }
     // d_t0's state: the stage-0 normalised qpos lives in the returned Data until the final advance overwrites it
     const REAL* qpos0g = KA.fin.qpos + e * nq;
-    for (int i = l; i < nq; i += MJH_WAVE) S.tmp_nq()[i] = (rk == 0) ? S.qpos()[i] : qpos0g[i];
-    for (int i = l; i < nv; i += MJH_WAVE) S.s_pgrad()[i] = (rk == 0) ? S.qvel()[i] : W.qvel0[e * nv + i];  // qvel0
-    for (int i = l; i < na; i += MJH_WAVE) S.act()[i] = (rk == 0) ? S.act()[i] : W.act0[e * na + i];         // act0
+    for (int i = l; i < nq; i += W) S.tmp_nq()[i] = (rk == 0) ? S.qpos()[i] : qpos0g[i];
+    for (int i = l; i < nv; i += W) S.s_pgrad()[i] = (rk == 0) ? S.qvel()[i] : RW.qvel0[e * nv + i];  // qvel0
+    for (int i = l; i < na; i += W) S.act()[i] = (rk == 0) ? S.act()[i] : RW.act0[e * na + i];         // act0
     wave_sync();
     if (rk < 3) {  // state of the next stage (forward.py:356-362)
       const REAL a = A[rk];
-      for (int i = l; i < nv; i += MJH_WAVE) S.tmp_nv2()[i] = a * S.qvel()[i];
+      for (int i = l; i < nv; i += W) S.tmp_nv2()[i] = a * S.qvel()[i];
       wave_sync();
-      for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];  // qpos0 (integrate_pos output goes to tmp_nq)
+      for (int i = l; i < nq; i += W) S.qpos()[i] = S.tmp_nq()[i];  // qpos0 (integrate_pos output goes to tmp_nq)
       wave_sync();
       integrate_pos(S.qpos(), S.tmp_nv2(), dt, S.tmp_nq());
-      for (int i = l; i < na; i += MJH_WAVE) KA.nxt.act[e * na + i] = S.act()[i] + (a * S.act_dot()[i]) * dt;
-      for (int i = l; i < nv; i += MJH_WAVE) KA.nxt.qvel[e * nv + i] = S.s_pgrad()[i] + (a * S.qacc()[i]) * dt;
+      for (int i = l; i < na; i += W) KA.nxt.act[e * na + i] = S.act()[i] + (a * S.act_dot()[i]) * dt;
+      for (int i = l; i < nv; i += W) KA.nxt.qvel[e * nv + i] = S.s_pgrad()[i] + (a * S.qacc()[i]) * dt;
       wave_sync();
-      row_store(KA.nxt.qpos, S.tmp_nq(), nq, e);
+      row_store<W>(KA.nxt.qpos, S.tmp_nq(), nq, e);
       return;
     }
     // final _advance(d_t0, act_dot_sum, qacc_sum, qvel_sum)
-    for (int i = l; i < nv; i += MJH_WAVE) { S.s_mv()[i] = W.sum_qacc[e * nv + i]; S.tmp_nv2()[i] = W.sum_qvel[e * nv + i]; }
-    for (int i = l; i < na; i += MJH_WAVE) S.act_dot()[i] = W.sum_actdot[e * na + i];
-    for (int i = l; i < nq; i += MJH_WAVE) S.qpos()[i] = S.tmp_nq()[i];
+    for (int i = l; i < nv; i += W) { S.s_mv()[i] = RW.sum_qacc[e * nv + i]; S.tmp_nv2()[i] = RW.sum_qvel[e * nv + i]; }
+    for (int i = l; i < na; i += W) S.act_dot()[i] = RW.sum_actdot[e * na + i];
+    for (int i = l; i < nq; i += W) S.qpos()[i] = S.tmp_nq()[i];
     wave_sync();
     advance(S.qpos(), S.s_pgrad(), S.act(), time0, S.act_dot(), S.s_mv(), S.tmp_nv2());
   }
@@ -1691,13 +1694,15 @@ struct Env {
 
 // No minimum-waves launch bound: capping the allocator at 128 VGPRs (4 waves/SIMD) was measured 3-11 % slower
 // than letting it use ~180-230 VGPRs (2 waves/SIMD) because of scratch spills (profiles/r01/notes.md).
-template <typename REAL, int PHASE>
+template <typename REAL, int PHASE, int W>
 __global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  REAL* lds = reinterpret_cast<REAL*>(lds_raw);
   const KArgs<REAL>& K = kargs<REAL>();
-  for (int64_t env = blockIdx.x; env < K.B; env += gridDim.x) {
-    Env<REAL> E(lds, env, K.flags);
+  constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
+  const int sub = (W == MJH_WAVE) ? 0 : (int)(threadIdx.x / W);  // folded away for a whole-wave environment: everything stays scalar
+  REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
+  for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
+    Env<REAL, W> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
     if (PHASE == 0) E.run_kin();
     else if (PHASE == 1) E.run_crb();
     else if (PHASE == 2) E.run_con();

@@ -28,6 +28,7 @@ struct mjhModel {
   size_t blob_bytes;
   LdsOff off[MJH_NPHASE];
   int lds_bytes[MJH_NPHASE];
+  int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of RK4 workspace (0 for Euler)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
@@ -216,20 +217,45 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   for (auto& f : fix) *f.first = (const unsigned char*)dev + f.second;
   out->blob = dev;
   out->blob_bytes = bb.host.size();
-#define SET_ATTR(P) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[P]));
+#define SET_ATTR(P) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[P]));
   SET_ATTR(0) SET_ATTR(1) SET_ATTR(2) SET_ATTR(3) SET_ATTR(4)
 #undef SET_ATTR
+  // phases that are register-bound (not LDS-bound) run two environments per wavefront, 32 lanes each: the same
+  // VGPR budget then keeps twice as many environments in flight (mjh_kernels.h, Env<REAL, W>)
+  for (int p = 0; p < MJH_NPHASE; p++) out->pack2[p] = 0;
+#define SET_PACK(P)                                                                                                          \
+  if (2 * out->lds_bytes[P] <= 64 * 1024) {                                                                                  \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[P])); \
+    out->pack2[P] = 1;                                                                                                       \
+  }
+  SET_PACK(0)
+#undef SET_PACK
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   return 0;
 }
 
-template <typename REAL, int P>
-int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+template <typename REAL, int P, int W>
+int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
+  if (count <= 0) return 0;
+  constexpr int NSUB = MJH_WAVE / W;
   a.off = m->off[P];
-  const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->lds_bytes[P], stream, a);
+  a.env_begin = begin; a.env_count = count;
+  a.lds_reals = m->lds_bytes[P] / (int)sizeof(REAL);
+  const int64_t blocks = count / NSUB;
+  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
+  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * m->lds_bytes[P]), stream, a);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+template <typename REAL, int P>
+int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  if (P == 0 && m->pack2[P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
+    const int64_t even = a.B & ~(int64_t)1;
+    int rc = launch_range<REAL, P, (P == 0 ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
+    if (rc) return rc;
+    return launch_range<REAL, P, MJH_WAVE>(m, a, even, a.B - even, stream);
+  }
+  return launch_range<REAL, P, MJH_WAVE>(m, a, 0, a.B, stream);
 }
 
 // one forward pass = the phases selected by `stages`
