@@ -55,10 +55,10 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(cfrc, 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
   X(sub_pos, 3 * m.nbody, PH_KIN)                                                                              \
   X(qMp, m.nv * (m.nv + 1) / 2, PH_CRB) /* lower triangle, packed rows */                                      \
-  X(qLD, m.nv * m.nv, PH_VEL) /* PH_CRB: aliased over the dead arrays when the factor is written, see lds_carve */ \
+  X(qLD, m.nv * m.nv, 0) /* PH_CRB only, aliased over the dead arrays when the factor is written: see lds_carve */ \
   X(qLDp, m.nv * (m.nv + 1) / 2, PH_SOL) /* lower triangle, packed rows */                                      \
   X(qMs, m.sol_qm_lds ? m.nv * m.nv : 0, PH_SOL) /* only when the solver iterates enough to amortise the copy */ \
-  X(qLD_inv, m.nv, PH_VEL | PH_SOL)                                                                            \
+  X(qLD_inv, m.nv, PH_SOL)                                                                            \
   X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL)                 \
   X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
@@ -169,6 +169,14 @@ __device__ __forceinline__ int wave_any(int p) { return __any(p); }
 
 // ---- sub-wave helpers: W lanes (64 or 32) serve one environment, 64 / W environments share a wavefront ----------------
 template <int W> __device__ __forceinline__ int sub_lane() { return (W == MJH_WAVE) ? (int)threadIdx.x : (int)(threadIdx.x & (W - 1)); }
+// any() over the lanes of this environment
+template <int W>
+__device__ __forceinline__ bool sub_any(bool p) {
+  if (W == MJH_WAVE) return __any(p) != 0;
+  const unsigned long long m = __ballot(p);
+  const int sh = (int)(threadIdx.x & ~(W - 1));
+  return ((m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1))) != 0;
+}
 // value of lane k OF THIS ENVIRONMENT's lane group (k uniform): v_readlane for a whole wave, a bpermute otherwise
 template <int W, typename T>
 __device__ __forceinline__ T sub_read(T v, int k) {

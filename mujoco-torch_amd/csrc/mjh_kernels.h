@@ -978,9 +978,6 @@ struct Env {
     row_load<W>(S.cinert(), out.cinert, 10 * nb, e);
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * nb, e);
     row_load<W>(S.xipos(), out.xipos, 3 * nb, e);
-    row_load<W>(S.qLD(), out.qLD, nv * nv, e);
-    wave_sync();
-    chol_inv_diag<W, false>(S.qLD(), S.qLD_inv(), nv);
     wave_sync();
     STAMP(31);
     for (int i = l; i < nu; i += W) {
@@ -1157,6 +1154,14 @@ struct Env {
     }
     wave_sync();
     STAMP(40);
+    // xfrc_accumulate visits every body for every dof even when no force is applied (support.py:184-194).  With an
+    // all-zero xfrc_applied every term is an exact +-0 and the sum is +0: the body loop is skipped in that case.
+    bool any_xfrc = false;
+    if (in.xfrc_applied) {
+      bool nzf = false;
+      for (int i = l; i < 6 * M.nbody; i += W) nzf = nzf || (in.xfrc_applied[e * M.nbody * 6 + i] != 0);
+      any_xfrc = sub_any<W>(nzf);
+    }
     for (int d = l; d < nv; d += W) {
       REAL s = 0;
       if (!off) {
@@ -1170,7 +1175,7 @@ struct Env {
       S.qfrc_actuator()[d] = s;
       // xfrc_accumulate: sum over bodies of jacp^T f + jacr^T tau at the body's inertial origin
       REAL acc = 0;
-      if (in.xfrc_applied) {
+      if (any_xfrc) {
         for (int b = 0; b < M.nbody; b++) {
           const REAL* f = in.xfrc_applied + (e * M.nbody + b) * 6;
           REAL jp[3], jr[3];
@@ -1184,10 +1189,11 @@ struct Env {
     }
     wave_sync();
     STAMP(41);
-    chol_solve<W, false>(S.qLD(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    // qacc_smooth = M^-1 qfrc_smooth (forward.py:222-228) is the first thing the solver phase computes: the factor is
+    // resident there anyway, and without it this phase's arena is small enough for two environments per wavefront
     if (!off) put(out.actuator_force, S.act_force(), nu);
     put(out.act_dot, S.act_dot(), M.na);
-    put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv); put(out.qacc_smooth, S.qacc_smooth(), nv);
+    put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv);
     STAMP(42);
   }
 
@@ -1404,18 +1410,26 @@ struct Env {
     STAMP(59);
   }
 
+  // first half of the solver phase's inputs and _acceleration's solve (forward.py:222-228): qacc_smooth = M^-1 qfrc_smooth
+  __device__ __forceinline__ void load_factor_and_accelerate() {
+    const int l = lane(), nv = M.nv;
+    row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
+    const REAL* gL = out.qLD + e * nv * nv;
+    for (int w = l; w < nv * nv; w += W) {  // lower triangle of the factor, packed rows
+      const int i = w / nv, k = w - nv * i;
+      if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
+    }
+    wave_sync();
+    chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
+    wave_sync();
+    chol_solve<W, true>(S.qLDp(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    put(out.qacc_smooth, S.qacc_smooth(), nv);
+  }
   __device__ __forceinline__ void load_solver_inputs() {
     const int nv = M.nv, nefc = M.nefc;
-    row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
-    row_load<W>(S.qacc_smooth(), out.qacc_smooth, nv, e);
     if (M.sol_qm_lds) row_load<W>(S.qMs(), out.qM, nv * nv, e);
     if (nefc > 0) {
       const int l = lane(), nl = M.nl;
-      const REAL* gL = out.qLD + e * nv * nv;
-      for (int w = l; w < nv * nv; w += W) {  // lower triangle of the factor, packed rows
-        const int i = w / nv, k = w - nv * i;
-        if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
-      }
       const REAL* gJ = out.efc_J + e * nefc * nv;
       for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
       if (nl > 0) for (int d = l; d < nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
@@ -1433,8 +1447,6 @@ struct Env {
       row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
       row_load<W>(S.qacc_warm(), KA.warm_src, nv, e);
     }
-    wave_sync();
-    if (nefc > 0) chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
     wave_sync();
   }
 
@@ -1607,6 +1619,8 @@ struct Env {
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
     STAMP(50);
+    load_factor_and_accelerate();
+    if (!(KA.stages & 0x40)) return;  // forward() with a stage prefix that ends at _acceleration
     load_qpos(false); load_qvel(); load_act();
     row_load<W>(S.act_dot(), out.act_dot, na, e);
     load_solver_inputs();

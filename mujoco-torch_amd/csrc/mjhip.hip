@@ -228,7 +228,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[P])); \
     out->pack2[P] = 1;                                                                                                       \
   }
-  SET_PACK(0)
+  SET_PACK(0) SET_PACK(3)
 #undef SET_PACK
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   return 0;
@@ -249,9 +249,9 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  if (P == 0 && m->pack2[P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
+  if ((P == 0 || P == 3) && m->pack2[P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
     const int64_t even = a.B & ~(int64_t)1;
-    int rc = launch_range<REAL, P, (P == 0 ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
+    int rc = launch_range<REAL, P, ((P == 0 || P == 3) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
     if (rc) return rc;
     return launch_range<REAL, P, MJH_WAVE>(m, a, even, a.B - even, stream);
   }
@@ -273,7 +273,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
   if ((st & 0x70) && (rc = launch_phase<REAL, 3>(m, a, stream))) return rc;
-  if ((st & 0x40) && (rc = launch_phase<REAL, 4>(m, a, stream))) return rc;
+  if ((st & 0x60) && (rc = launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
 
@@ -293,7 +293,7 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
   a.warm_src = a.in.qacc_warmstart;
   a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
-  if ((a.stages & 0x40) && !(a.fin.qM && a.fin.qLD)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
+  if ((a.stages & 0x60) && !(a.fin.qM && a.fin.qLD && a.fin.qfrc_smooth)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
   if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(a.fin.contact_dist && a.fin.contact_pos && a.fin.contact_frame && a.fin.geom_xpos && a.fin.geom_xmat))
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
