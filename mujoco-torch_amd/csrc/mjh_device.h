@@ -111,6 +111,10 @@ struct DevModel {
   const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
+  const REAL* act_moment;                  // nu*nv: the (constant) moment matrix of joint transmissions (reference device.py:588-629)
+  const int* dof_act_adr;                  // nv+1: CSR of the actuators driving each dof, in actuator order
+  const int* dof_act_id;
+  float inv_nv;                            // 1 / nv for the index splits below
   const int* dof_limrow;                   // nv: the joint-limit row whose non-zero sits in column d, or -1
   const int* lim_dof;                      // nl: dof of limit row r (the only non-zero column of its Jacobian row)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
@@ -166,6 +170,14 @@ __device__ __forceinline__ T wave_sum(T v) {
 #endif
 }
 __device__ __forceinline__ int wave_any(int p) { return __any(p); }
+
+// w -> (w / n, w % n) for a wave-uniform runtime n without the ~30-instruction integer division: float estimate + fix-up
+__device__ __forceinline__ void split_index(int w, int n, float inv_n, int& q, int& r) {
+  q = (int)((float)w * inv_n);
+  r = w - q * n;
+  if (r < 0) { q--; r += n; }
+  if (r >= n) { q++; r -= n; }
+}
 
 // ---- sub-wave helpers: W lanes (64 or 32) serve one environment, 64 / W environments share a wavefront ----------------
 template <int W> __device__ __forceinline__ int sub_lane() { return (W == MJH_WAVE) ? (int)threadIdx.x : (int)(threadIdx.x & (W - 1)); }

@@ -274,21 +274,18 @@ template <int W, typename REAL, int NMAX>
 __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, int n) {
   const int i = sub_lane<W>();
   REAL s = (i < n) ? bi : (REAL)0;
+  // no k < n guards: lanes >= n carry s = 0 and inv = 0, rows / columns >= n are zero, so those steps change nothing
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
-    if (k < n) {
-      const REAL yk = sub_read<W>(s * T.inv, k);
-      if (i == k) s = yk;
-      else if (i > k && i < n) s = s - T.row[k] * yk;
-    }
+    const REAL yk = sub_read<W>(s * T.inv, k);
+    if (i == k) s = yk;
+    else if (i > k) s = s - T.row[k] * yk;
   }
 #pragma unroll
   for (int k = NMAX - 1; k >= 0; k--) {
-    if (k < n) {
-      const REAL xk = sub_read<W>(s * T.inv, k);
-      if (i == k) s = xk;
-      else if (i < k) s = s - T.col[k] * xk;
-    }
+    const REAL xk = sub_read<W>(s * T.inv, k);
+    if (i == k) s = xk;
+    else if (i < k) s = s - T.col[k] * xk;
   }
   return s;
 }
@@ -308,14 +305,12 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
       REAL s = sub_read<W>(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
       if (big) s = s + (REAL)1e-10;                  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
       const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
-      const REAL lij = (i == j) ? d : row[j] / d;    // lanes i < j hold zeros: harmless
+      const REAL lij = (i == j) ? d : ((i < n) ? row[j] / d : (REAL)0);  // lanes i < j hold zeros: harmless; lanes >= n stay zero
       row[j] = lij;
 #pragma unroll
-      for (int k = j + 1; k < NMAX; k++) {
-        if (k < n) {
-          const REAL lkj = sub_read<W>(lij, k);        // L[k][j]
-          row[k] = row[k] - lij * lkj;               // only k <= i is ever read back
-        }
+      for (int k = j + 1; k < NMAX; k++) {             // no k < n guard: lanes / columns >= n carry exact zeros, the update is a no-op there
+        const REAL lkj = sub_read<W>(lij, k);          // L[k][j]
+        row[k] = row[k] - lij * lkj;                   // only k <= i is ever read back
       }
     }
   }
@@ -554,11 +549,20 @@ struct Env {
     const int l = lane();
     const int nb = M.nbody;
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
+    // the per-body terms first (one global read of the mass per term, staged where cinert will be written later), so the
+    // subtree loops below run on LDS only
+    REAL* term = S.cinert();
+    for (int w = l; w < nb * 4; w += W) {
+      const int b = w >> 2, k = w & 3;
+      const REAL mass = M.body_mass[b];
+      term[w] = (k < 3) ? S.xipos()[3 * b + k] * mass : mass;
+    }
+    wave_sync();
     for (int w = l; w < nb * 4; w += W) {
       const int b = w >> 2, k = w & 3;
       const int end = M.body_subtree_end[b];
       REAL acc = 0;
-      for (int d = end - 1; d >= b; d--) acc += (k < 3) ? S.xipos()[3 * d + k] * M.body_mass[d] : M.body_mass[d];
+      for (int d = end - 1; d >= b; d--) acc += term[4 * d + k];
       if (k < 3) S.sub_pos()[3 * b + k] = acc; else S.sub_mass()[b] = acc;
     }
     wave_sync();
@@ -647,7 +651,8 @@ struct Env {
     wave_sync();
     STAMP(13);
     for (int w = l; w < nv * nv; w += W) {
-      const int i = w / nv, j = w - nv * i;
+      int i, j;
+      split_index(w, nv, M.inv_nv, i, j);
       const int hi = i > j ? i : j, lo = i > j ? j : i;
       REAL s = 0;
       if ((M.dof_ancmask[hi] >> lo) & 1ull) {
@@ -887,7 +892,8 @@ struct Env {
     const bool elliptic = M.cone == CONE_ELLIPTIC;
     // contact rows: one lane per (contact, dof) column entry; all rows of the contact for that dof
     for (int w = l; w < M.ncon * nv; w += W) {
-      const int c = w / nv, d = w - nv * c;
+      int c, d;
+      split_index(w, nv, M.inv_nv, c, d);
       const int dim = M.con_dim[c], row0 = M.con_efc_address[c];
       const int b1 = M.geom_bodyid[M.con_geom1[c]], b2 = M.geom_bodyid[M.con_geom2[c]];
       const REAL* fr = S.con_frame() + 9 * c;
@@ -985,12 +991,7 @@ struct Env {
       S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
       S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
     }
-    if (out.actuator_moment) {
-      for (int w = l; w < nu * nv; w += W) {
-        const int i = w / nv, d = w - nv * i;
-        out.actuator_moment[e * nu * nv + w] = (d == M.act_dofadr[i]) ? M.act_gear[6 * i] : (REAL)0;
-      }
-    }
+    row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // joint transmissions: a model constant (smooth.py:535-591)
     STAMP(32);
     // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
     for (int b = l; b < nb; b += W) {
@@ -1165,7 +1166,8 @@ struct Env {
     for (int d = l; d < nv; d += W) {
       REAL s = 0;
       if (!off) {
-        for (int i = 0; i < nu; i++) if (M.act_dofadr[i] == d) s += M.act_gear[6 * i] * S.act_force()[i];
+        // moment^T force: only the actuators on this dof have a non-zero moment entry (actuator order kept)
+        for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) { const int i = M.dof_act_id[q]; s += M.act_gear[6 * i] * S.act_force()[i]; }
         const int j = M.dof_jntid[d];
         if (M.jnt_actfrclimited[j]) {
           const REAL lo = M.jnt_actfrcrange[2 * j], hi = M.jnt_actfrcrange[2 * j + 1];
@@ -1416,7 +1418,8 @@ struct Env {
     row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
     const REAL* gL = out.qLD + e * nv * nv;
     for (int w = l; w < nv * nv; w += W) {  // lower triangle of the factor, packed rows
-      const int i = w / nv, k = w - nv * i;
+      int i, k;
+      split_index(w, nv, M.inv_nv, i, k);
       if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
     }
     wave_sync();

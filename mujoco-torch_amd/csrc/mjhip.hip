@@ -162,6 +162,20 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   std::vector<int> lim_dof((size_t)d->nl, 0);
   for (int r = 0; r < d->nl; r++) lim_dof[r] = d->jnt_dofadr[d->lim_jnt[r]];
   fix.push_back({(const void**)&M.lim_dof, bb.add(lim_dof.data(), sizeof(int) * lim_dof.size())});
+  {
+    std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
+    std::vector<int> adr((size_t)nv + 1, 0), ids;
+    for (int dd = 0; dd < nv; dd++) {
+      adr[dd] = (int)ids.size();
+      for (int i = 0; i < d->nu; i++) if (d->act_dofadr[i] == dd) ids.push_back(i);
+    }
+    adr[nv] = (int)ids.size();
+    for (int i = 0; i < d->nu; i++) moment[(size_t)i * nv + d->act_dofadr[i]] = (REAL)d->act_gear[6 * i];
+    fix.push_back({(const void**)&M.act_moment, bb.add(moment.data(), sizeof(REAL) * moment.size())});
+    fix.push_back({(const void**)&M.dof_act_adr, bb.add(adr.data(), sizeof(int) * adr.size())});
+    fix.push_back({(const void**)&M.dof_act_id, bb.add(ids.data(), sizeof(int) * ids.size())});
+    M.inv_nv = nv > 0 ? 1.0f / (float)nv : 0.0f;
+  }
   std::vector<int> dof_limrow((size_t)nv, -1);
   for (int r = 0; r < d->nl; r++) {
     if (dof_limrow[lim_dof[r]] >= 0) return fail(-22, "two joint-limit rows on one dof");
