@@ -1219,12 +1219,19 @@ struct Env {
     for (int i = lane(); i < nv; i += W) {
       REAL s = 0;
       int k = 0;
-      for (; k + 8 <= nv; k += 8) {
-        REAL a[8];
+      for (; k + 14 <= nv; k += 14) {  // 14 rows in flight per round trip (two trips cover the humanoid's 27)
+        REAL a[14];
 #pragma unroll
-        for (int t = 0; t < 8; t++) a[t] = g[(k + t) * nv + i];
+        for (int t = 0; t < 14; t++) a[t] = g[(k + t) * nv + i];
 #pragma unroll
-        for (int t = 0; t < 8; t++) s += a[t] * v[k + t];
+        for (int t = 0; t < 14; t++) s += a[t] * v[k + t];
+      }
+      for (; k + 4 <= nv; k += 4) {
+        REAL a[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) a[t] = g[(k + t) * nv + i];
+#pragma unroll
+        for (int t = 0; t < 4; t++) s += a[t] * v[k + t];
       }
       for (; k < nv; k++) s += g[k * nv + i] * v[k];
       o[i] = s;
@@ -1254,8 +1261,17 @@ struct Env {
     for (int d = l; d < nv; d += W) gpart += (S.s_Ma()[d] - S.qfrc_smooth()[d]) * (S.s_qacc()[d] - S.qacc_smooth()[d]);
     const REAL csum = wave_sum(part);
     const REAL g = wave_sum(gpart);
+    c.gauss = (REAL)0.5 * g;
+    c.prev_cost = c.cost;
+    c.cost = ((REAL)0.5 * csum + c.gauss) + 0;
     wave_sync();
-    {  // qfrc = J^T force, rows in index order; rows whose force is exactly zero add +-0 and are skipped
+  }
+  // second half of _update_constraint: qfrc_constraint = J^T efc_force.  Only needed once a context is iterated on or
+  // returned -- the cost-only contexts of the warm-start choice (:526-531) never read it.
+  __device__ __forceinline__ void constraint_qfrc() {
+    const int l = lane();
+    const int nv = M.nv, nefc = M.nefc;
+    {  // rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
       const int nl = M.nl;
       if (nl > 0 && l < nv) {  // the joint-limit rows come first; at most one of them has a non-zero in column l
@@ -1275,9 +1291,6 @@ struct Env {
       }
       if (l < nv) S.s_qfrc()[l] = s;
     }
-    c.gauss = (REAL)0.5 * g;
-    c.prev_cost = c.cost;
-    c.cost = ((REAL)0.5 * csum + c.gauss) + 0;
     wave_sync();
   }
 
@@ -1413,7 +1426,7 @@ struct Env {
   }
 
   // first half of the solver phase's inputs and _acceleration's solve (forward.py:222-228): qacc_smooth = M^-1 qfrc_smooth
-  __device__ __forceinline__ void load_factor_and_accelerate() {
+  __device__ __forceinline__ void load_factor_and_accelerate(bool solving) {
     const int l = lane(), nv = M.nv;
     row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
     const REAL* gL = out.qLD + e * nv * nv;
@@ -1421,6 +1434,11 @@ struct Env {
       int i, k;
       split_index(w, nv, M.inv_nv, i, k);
       if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
+    }
+    if (solving) {  // every other input of the phase is requested now too: one wait for all of them
+      load_qpos(false); load_qvel(); load_act();
+      row_load<W>(S.act_dot(), out.act_dot, M.na, e);
+      load_solver_inputs();
     }
     wave_sync();
     chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
@@ -1450,7 +1468,6 @@ struct Env {
       row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
       row_load<W>(S.qacc_warm(), KA.warm_src, nv, e);
     }
-    wave_sync();
   }
 
   // solver.solve :244-553 as ONE loop whose body contains each heavy routine exactly once (line search, constraint
@@ -1493,7 +1510,9 @@ struct Env {
           done |= gradient < (REAL)M.tolerance;
           if (done) break;
         }
-        do_init = false; do_grad = true; do_ls = true;
+        // the gradient (and the next search direction) of the last allowed iteration is never read: cond's
+        // `niter >= iterations` ends the loop whatever the gradient norm is
+        do_init = false; do_ls = true; do_grad = !(it + 1 >= M.iterations);
       }
       if (do_ls) {
         linesearch(c);
@@ -1511,6 +1530,7 @@ struct Env {
         wave_sync();
       }
       if (do_ls || do_init) update_constraint(c);
+      if (ph >= P_START) constraint_qfrc();
       if (do_grad) {
         update_gradient();
         if (ph == P_START || M.solver == SOL_NEWTON) {
@@ -1622,11 +1642,8 @@ struct Env {
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
     STAMP(50);
-    load_factor_and_accelerate();
+    load_factor_and_accelerate((KA.stages & 0x40) != 0);
     if (!(KA.stages & 0x40)) return;  // forward() with a stage prefix that ends at _acceleration
-    load_qpos(false); load_qvel(); load_act();
-    row_load<W>(S.act_dot(), out.act_dot, na, e);
-    load_solver_inputs();
     STAMP(51);
     if (M.nefc == 0) {
       for (int d = l; d < nv; d += W) S.qacc()[d] = S.qacc_smooth()[d];
