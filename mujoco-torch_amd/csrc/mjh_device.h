@@ -48,6 +48,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, 9 * m.nbody, PH_KIN)                      \
   X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
   X(xanchor, 3 * m.njnt, PH_KIN) X(xaxis, 3 * m.njnt, PH_KIN)                                                  \
+  X(jquat, 4 * m.njnt, PH_KIN) /* per-joint local rotation (or slide offset), computed before the chain walk */ \
   X(geom_xpos, 3 * m.ngeom, PH_CON) X(geom_xmat, 9 * m.ngeom, PH_CON)                                          \
   X(subtree_com, 3 * m.nbody, PH_KIN | PH_CON | PH_VEL) X(cinert, 10 * m.nbody, PH_KIN | PH_CRB | PH_VEL)      \
   X(crb, 10 * m.nbody, PH_CRB) X(cdof, 6 * m.nv, PH_KIN | PH_CRB | PH_CON | PH_VEL)                            \

@@ -401,57 +401,79 @@ struct Env {
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
   __device__ __forceinline__ void kinematics(bool with_cams) {
     const int l = lane();
+    // joint-local rotations first, one lane per joint: the trigonometry and the quaternion normalisations leave the
+    // serial ancestor walk below (same expressions, smooth.py:85-120)
+    for (int j = l; j < M.njnt; j += W) {
+      const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
+      REAL q[4] = {0, 0, 0, 0};
+      if (t == JNT_FREE || t == JNT_BALL) {
+        const int o = (t == JNT_FREE) ? qa + 3 : qa;
+#pragma unroll
+        for (int i = 0; i < 4; i++) q[i] = S.qpos()[o + i];
+        normalize_n<REAL, 4>(q);
+      } else if (t == JNT_HINGE) {
+        axis_angle_to_quat(M.jnt_axis + 3 * j, S.qpos()[qa] - M.qpos0[qa], q);
+      } else {
+        q[0] = S.qpos()[qa] - M.qpos0[qa];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) S.jquat()[4 * j + i] = q[i];
+    }
+    wave_sync();
     for (int b = l; b < M.nbody; b += W) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
-      const int depth = M.body_depth[b];
-      for (int k = 0; k < depth; k++) {
-        const int c = M.body_chain[b * M.max_depth + k];
+      const int depth = M.body_depth[b], md = M.max_depth;
+      // the constants of level k + 1 are requested while level k is computed: the chain ids depend on (b, k) only
+      int c_n = depth > 0 ? M.body_chain[b * md] : 0;
+      REAL bp_n[3] = {M.body_pos[3 * c_n], M.body_pos[3 * c_n + 1], M.body_pos[3 * c_n + 2]};
+      REAL bq_n[4] = {M.body_quat[4 * c_n], M.body_quat[4 * c_n + 1], M.body_quat[4 * c_n + 2], M.body_quat[4 * c_n + 3]};
+      int jn_n = M.body_jntnum[c_n], j0_n = M.body_jntadr[c_n];
+      for (int k = 0; k < md; k++) {  // uniform trip count, lanes past their depth idle
+        const int c = c_n, jn = jn_n, j0 = j0_n;
+        const REAL bp[3] = {bp_n[0], bp_n[1], bp_n[2]}, bq[4] = {bq_n[0], bq_n[1], bq_n[2], bq_n[3]};
+        if (k + 1 < md) {
+          c_n = (k + 1 < depth) ? M.body_chain[b * md + k + 1] : 0;
+#pragma unroll
+          for (int i = 0; i < 3; i++) bp_n[i] = M.body_pos[3 * c_n + i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) bq_n[i] = M.body_quat[4 * c_n + i];
+          jn_n = M.body_jntnum[c_n]; j0_n = M.body_jntadr[c_n];
+        }
+        if (k >= depth) continue;
         const bool own = (k == depth - 1);
         {
           REAL r[3];
-          rotate(M.body_pos + 3 * c, quat, r);
+          rotate(bp, quat, r);
 #pragma unroll
           for (int i = 0; i < 3; i++) pos[i] = pos[i] + r[i];
-          quat_mul(quat, M.body_quat + 4 * c, quat);
+          quat_mul(quat, bq, quat);
         }
-        const int jn = M.body_jntnum[c], j0 = M.body_jntadr[c];
         for (int jj = 0; jj < jn; jj++) {
           const int j = j0 + jj, t = M.jnt_type[j], qa = M.jnt_qposadr[j];
-          const REAL* jpos = M.jnt_pos + 3 * j;
-          const REAL* jaxis = M.jnt_axis + 3 * j;
+          const REAL jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+          const REAL jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
+          const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
           REAL anchor[3], axis[3];
           if (t == JNT_FREE) {
 #pragma unroll
             for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
             axis[0] = 0; axis[1] = 0; axis[2] = 1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) quat[i] = S.qpos()[qa + 3 + i];
-            normalize_n<REAL, 4>(quat);
+            for (int i = 0; i < 4; i++) quat[i] = ql[i];
           } else {
             REAL r[3];
             rotate(jpos, quat, r);
 #pragma unroll
             for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
             rotate(jaxis, quat, axis);
-            if (t == JNT_BALL) {
-              REAL ql[4];
-#pragma unroll
-              for (int i = 0; i < 4; i++) ql[i] = S.qpos()[qa + i];
-              normalize_n<REAL, 4>(ql);
-              quat_mul(quat, ql, quat);
-              rotate(jpos, quat, r);
-#pragma unroll
-              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
-            } else if (t == JNT_HINGE) {
-              REAL angle = S.qpos()[qa] - M.qpos0[qa], ql[4];
-              axis_angle_to_quat(jaxis, angle, ql);
+            if (t == JNT_BALL || t == JNT_HINGE) {
               quat_mul(quat, ql, quat);
               rotate(jpos, quat, r);
 #pragma unroll
               for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
             } else {
-              REAL dq = S.qpos()[qa] - M.qpos0[qa];
+              const REAL dq = ql[0];
 #pragma unroll
               for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
             }
@@ -476,10 +498,8 @@ struct Env {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
       if (t == JNT_FREE || t == JNT_BALL) {
         const int o = (t == JNT_FREE) ? qa + 3 : qa;
-        REAL q[4] = {S.qpos()[o], S.qpos()[o + 1], S.qpos()[o + 2], S.qpos()[o + 3]};
-        normalize_n<REAL, 4>(q);
 #pragma unroll
-        for (int i = 0; i < 4; i++) S.qpos()[o + i] = q[i];
+        for (int i = 0; i < 4; i++) S.qpos()[o + i] = S.jquat()[4 * j + i];
       }
     }
     for (int g = l; g < M.ngeom; g += W) {
