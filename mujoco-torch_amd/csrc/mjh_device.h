@@ -110,6 +110,9 @@ struct DevModel {
   const int* body_subtree_end; // nbody: one past the last body of b's subtree (bodies are in DFS order)
   const unsigned long long* body_dofmask;  // nbody: dofs whose body is an ancestor-or-self of b
   const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
+  const int* chain_dof;        // nbody*max_depth: dofadr | dofnum << 16 of the k-th body on the path world -> b
+  const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none
+  int max_jnt;
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
   const REAL* act_moment;                  // nu*nv: the (constant) moment matrix of joint transmissions (reference device.py:588-629)

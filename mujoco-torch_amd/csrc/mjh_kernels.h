@@ -1016,13 +1016,14 @@ struct Env {
     // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
     for (int b = l; b < nb; b += W) {
       REAL cvel[6] = {0, 0, 0, 0, 0, 0};
-      const int depth = M.body_depth[b];
-      for (int kk = 0; kk < depth; kk++) {
-        const int c = M.body_chain[b * M.max_depth + kk];
+      const int depth = M.body_depth[b], md = M.max_depth, mj = M.max_jnt;
+      for (int kk = 0; kk < md; kk++) {  // uniform trip counts; the joint list of every level comes from one flat table
+        if (kk >= depth) continue;      // (its addresses depend on (b, level) only, so the loads run ahead of the arithmetic)
         const bool own = (kk == depth - 1);
-        const int jn = M.body_jntnum[c], j0 = M.body_jntadr[c];
-        for (int jj = 0; jj < jn; jj++) {
-          const int j = j0 + jj, t = M.jnt_type[j], d = M.jnt_dofadr[j];
+        for (int jj = 0; jj < mj; jj++) {
+          const int pk = M.chain_jnt[(b * md + kk) * mj + jj];
+          if (pk == 0) continue;
+          const int t = (pk & 0xff) - 1, d = pk >> 8;
           if (t == JNT_FREE) {
             REAL s[6];
 #pragma unroll
@@ -1086,10 +1087,11 @@ struct Env {
       const bool nograv = M.disableflags & DSBL_GRAVITY;
 #pragma unroll
       for (int k = 0; k < 3; k++) { cacc[k] = 0; cacc[3 + k] = nograv ? (REAL)0 : -M.gravity[k]; }
-      const int depth = M.body_depth[b];
-      for (int kk = 0; kk < depth; kk++) {
-        const int c = M.body_chain[b * M.max_depth + kk];
-        const int d0 = M.body_dofadr[c], nd = M.body_dofnum[c];
+      const int depth = M.body_depth[b], md = M.max_depth;
+      for (int kk = 0; kk < md; kk++) {
+        if (kk >= depth) continue;
+        const int pk = M.chain_dof[b * md + kk];
+        const int d0 = pk & 0xffff, nd = pk >> 16;
         if (nd > 0) {
 #pragma unroll
           for (int k = 0; k < 6; k++) {

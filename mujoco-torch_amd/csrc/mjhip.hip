@@ -153,6 +153,23 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       row_con[row] = c;
     }
   }
+  {
+    int max_jnt = 1;
+    for (int b = 0; b < nb; b++) if (d->body_jntnum[b] > max_jnt) max_jnt = d->body_jntnum[b];
+    std::vector<int> chain_dof((size_t)nb * max_depth, 0), chain_jnt((size_t)nb * max_depth * max_jnt, 0);
+    for (int b = 1; b < nb; b++)
+      for (int k = 0; k < depth[b]; k++) {
+        const int c = chain[(size_t)b * max_depth + k];
+        chain_dof[(size_t)b * max_depth + k] = d->body_dofadr[c] < 0 ? 0 : (d->body_dofadr[c] | (d->body_dofnum[c] << 16));
+        for (int jj = 0; jj < d->body_jntnum[c]; jj++) {
+          const int j = d->body_jntadr[c] + jj;
+          chain_jnt[((size_t)b * max_depth + k) * max_jnt + jj] = (d->jnt_type[j] + 1) | (d->jnt_dofadr[j] << 8);
+        }
+      }
+    M.max_jnt = max_jnt;
+    fix.push_back({(const void**)&M.chain_dof, bb.add(chain_dof.data(), sizeof(int) * chain_dof.size())});
+    fix.push_back({(const void**)&M.chain_jnt, bb.add(chain_jnt.data(), sizeof(int) * chain_jnt.size())});
+  }
   fix.push_back({(const void**)&M.body_depth, bb.add(depth.data(), sizeof(int) * nb)});
   fix.push_back({(const void**)&M.body_chain, bb.add(chain.data(), sizeof(int) * chain.size())});
   fix.push_back({(const void**)&M.body_subtree_end, bb.add(sub_end.data(), sizeof(int) * nb)});
