@@ -1463,9 +1463,11 @@ struct Env {
       load_solver_inputs();
     }
     wave_sync();
+    STAMP(51);
     chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
     wave_sync();
     chol_solve<W, true>(S.qLDp(), S.qLD_inv(), S.qfrc_smooth(), S.qacc_smooth(), nv);
+    STAMP(52);
     put(out.qacc_smooth, S.qacc_smooth(), nv);
   }
   __device__ __forceinline__ void load_solver_inputs() {
@@ -1666,7 +1668,7 @@ struct Env {
     STAMP(50);
     load_factor_and_accelerate((KA.stages & 0x40) != 0);
     if (!(KA.stages & 0x40)) return;  // forward() with a stage prefix that ends at _acceleration
-    STAMP(51);
+    STAMP(53);
     if (M.nefc == 0) {
       for (int d = l; d < nv; d += W) S.qacc()[d] = S.qacc_smooth()[d];
       wave_sync();

@@ -34,7 +34,7 @@ names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, 
          10: "CRB start", 11: "loads", 12: "crb subtree sums", 13: "inert_mul", 14: "qM", 15: "stores", 16: "chol_factor", 17: "store qLD",
          19: "CON start", 20: "load geoms + narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
          30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
-         50: "SOL start", 51: "loads", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
+         50: "SOL start", 51: "all loads issued + waited", 52: "inv_diag + chol_solve (qacc_smooth)", 53: "store qacc_smooth", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
 last = {}
 for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 79)]:
     prev = None; tot = 0
