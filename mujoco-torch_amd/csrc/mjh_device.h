@@ -115,6 +115,9 @@ struct DevModel {
   int max_jnt;
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   int max_depth;
+  const int* qm_pair;                      // nqmpair: i << 8 | j (j <= i) of the inertia-matrix entries that can be non-zero
+  int nqmpair;
+  const int* qm_slot;                      // nv*nv: packed lower-triangle slot holding entry (i, j), -1 where qM is structurally zero
   const REAL* act_moment;                  // nu*nv: the (constant) moment matrix of joint transmissions (reference device.py:588-629)
   const int* dof_act_adr;                  // nv+1: CSR of the actuators driving each dof, in actuator order
   const int* dof_act_id;

@@ -343,6 +343,8 @@ template <int W, typename REAL, int MAXREG, bool APACKED>
 __device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n) {
   if (n <= 8) chol_factor_reg<W, APACKED, REAL, 8>(A, L, n);
   else if (n <= 16) chol_factor_reg<W, APACKED, REAL, 16>(A, L, n);
+  else if (MAXREG >= 32 && n <= 24) chol_factor_reg<W, APACKED, REAL, 24>(A, L, n);
+  else if (MAXREG >= 32 && n <= 28) chol_factor_reg<W, APACKED, REAL, 28>(A, L, n);
   else if (MAXREG >= 32 && n <= 32) chol_factor_reg<W, APACKED, REAL, 32>(A, L, n);
   else chol_factor_lds<W, APACKED>(A, L, n);
 }
@@ -670,18 +672,23 @@ struct Env {
     for (int d = l; d < nv; d += W) inert_mul(S.crb() + 10 * M.dof_bodyid[d], S.cdof() + 6 * d, S.crb_cdof() + 6 * d);
     wave_sync();
     STAMP(13);
-    for (int w = l; w < nv * nv; w += W) {
-      int i, j;
-      split_index(w, nv, M.inv_nv, i, j);
-      const int hi = i > j ? i : j, lo = i > j ? j : i;
+    // qM (support.make_m :50-80) is zero except for dof pairs on one ancestor path: one lane per structurally non-zero
+    // lower-triangle entry computes it into the packed copy, then the full symmetric row is written out through a
+    // slot table (each address stored exactly once, coalesced).
+    for (int w = l; w < (nv * (nv + 1)) / 2; w += W) S.qMp()[w] = 0;
+    wave_sync();
+    for (int w = l; w < M.nqmpair; w += W) {
+      const int pk = M.qm_pair[w], i = pk >> 8, j = pk & 0xff;  // j <= i, and j is an ancestor-or-self dof of i
       REAL s = 0;
-      if ((M.dof_ancmask[hi] >> lo) & 1ull) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) s += S.crb_cdof()[6 * hi + k] * S.cdof()[6 * lo + k];
-        if (i == j) s = s + M.dof_armature[i];
-      }
-      if (out.qM) out.qM[e * nv * nv + w] = s;                       // (i, j) and (j, i) evaluate the same expression: exactly symmetric
-      if (j <= i) S.qMp()[tri_at<true>(i, j, nv)] = s;
+      for (int k = 0; k < 6; k++) s += S.crb_cdof()[6 * i + k] * S.cdof()[6 * j + k];
+      if (i == j) s = s + M.dof_armature[i];
+      S.qMp()[tri_at<true>(i, j, nv)] = s;
+    }
+    wave_sync();
+    if (out.qM) {
+      REAL* gM = out.qM + e * nv * nv;
+      for (int w = l; w < nv * nv; w += W) { const int sl = M.qm_slot[w]; gM[w] = sl >= 0 ? S.qMp()[sl] : (REAL)0; }
     }
     STAMP(14);
     put(out.crb, S.crb(), 10 * nb);

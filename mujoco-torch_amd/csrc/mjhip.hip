@@ -143,6 +143,21 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       a = d->body_parentid[a];
     }
   }
+  {  // lower-triangle entries (i, j) of qM whose dofs are on one ancestor path (support.make_m :50-80 masks the rest to zero)
+    std::vector<int> pairs;
+    for (int i = 0; i < nv; i++)
+      for (int j = 0; j <= i; j++)
+        if ((dof_ancmask[i] >> j) & 1ull) pairs.push_back((i << 8) | j);
+    M.nqmpair = (int)pairs.size();
+    std::vector<int> slot((size_t)nv * nv, -1);
+    for (int pk : pairs) {
+      const int i = pk >> 8, j = pk & 0xff, sl = (i * (i + 1)) / 2 + j;
+      slot[(size_t)i * nv + j] = sl;
+      slot[(size_t)j * nv + i] = sl;
+    }
+    fix.push_back({(const void**)&M.qm_slot, bb.add(slot.data(), sizeof(int) * slot.size())});
+    fix.push_back({(const void**)&M.qm_pair, bb.add(pairs.data(), sizeof(int) * pairs.size())});
+  }
   std::vector<int> row_con((size_t)d->nefc, -1);
   for (int c = 0; c < d->ncon; c++) {
     int dim = d->con_dim[c];
