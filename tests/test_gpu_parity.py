@@ -154,3 +154,16 @@ def test_cpu_tensors_are_rejected_loudly():
     mx = load_model("cartpole")
     with pytest.raises(RuntimeError, match="HIP device"):
         mt.step(mx, mt.make_data(mx))
+
+
+@pytest.mark.parametrize("name", sorted(__import__("test_collision_kat").KATS))
+def test_collision_kat_gpu(name):
+    """The reference's collision known-answer scenes (tests/test_collision_kat.py) through the HIP path."""
+    import test_collision_kat as kat
+
+    def runner(mx, d):
+        out = mt.forward(mx.to("cuda"), d.to("cuda"), stages=kat.STAGES_COLLISION)
+        return {n: leaf(out, n).detach().cpu().numpy() for n in ("contact_dist", "contact_pos", "contact_frame")}
+
+    xml, check = kat.KATS[name]
+    check(*kat.collide(xml, runner))
