@@ -119,3 +119,37 @@ def test_hull_topology():
         for f, nf in zip(tab["face"], n):  # outward: the face centre is on the positive side of its normal
             assert np.dot(tab["vert"][f].mean(0) - centroid, nf) > 0
         assert len({tuple(e) for e in tab["edge"]}) == len(tab["edge"])
+
+
+# ---- dynamics known answers (reference test/smooth_test.py:181-208, test/forward_test.py:128-140) --------------------
+FREE_BODY = """<mujoco><option timestep="0.01"/><worldbody><body><joint type="free"/><geom size="0.1"/></body></worldbody></mujoco>"""
+
+
+def test_free_fall_one_step_oracle(oracle_lib):
+    """One 0.01 s semi-implicit Euler step of a free body: z = -9.81e-4; with gravity disabled nothing moves."""
+    from mujoco_torch_amd._enums import DisableBit
+
+    lite = mt.mjcf.from_xml_string(FREE_BODY)
+    mx = mt.device_put(lite)
+    out = pyoracle.run(mx, mt.make_data(mx), step=True)
+    np.testing.assert_array_almost_equal(out["qpos"], [0.0, 0.0, -9.81e-4, 1.0, 0.0, 0.0, 0.0], decimal=7)
+    lite.opt.disableflags = int(lite.opt.disableflags) | int(DisableBit.GRAVITY)
+    mx = mt.device_put(lite)
+    out = pyoracle.run(mx, mt.make_data(mx), step=True)
+    np.testing.assert_equal(out["qpos"], [0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])
+
+
+def test_euler_without_eulerdamp_oracle(oracle_lib):
+    """With EULERDAMP disabled the Euler update is exactly qvel + dt * qacc even when dofs are damped: a free body with
+    joint damping falls like an undamped one for its first step from rest (qacc = g, qvel = g dt)."""
+    from mujoco_torch_amd._enums import DisableBit
+
+    xml = FREE_BODY.replace('<joint type="free"/>', '<joint type="free" damping="3"/>')
+    lite = mt.mjcf.from_xml_string(xml)
+    lite.opt.disableflags = int(lite.opt.disableflags) | int(DisableBit.EULERDAMP)
+    mx = mt.device_put(lite)
+    d = mt.make_data(mx).replace(qvel=torch.tensor([0.0, 0.0, 1.0, 0.0, 0.0, 0.0], dtype=torch.float64))
+    out = pyoracle.run(mx, d, step=True)
+    # passive damping force -3 * 1 on a 4.19 kg sphere: qacc = -9.81 - 3 / m; explicit update, no implicit damping
+    mass = float(mx.body_mass[1])
+    np.testing.assert_allclose(out["qvel"][2], 1.0 + 0.01 * (-9.81 - 3.0 / mass), rtol=1e-12)
