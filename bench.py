@@ -96,9 +96,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks for a one-GPU box: MJH_BENCH_BACKEND=gloo + MJH_BENCH_SHARE_GPU=1 run every rank on cuda:0 (RCCL refuses
+    # two ranks on one device); the driver's multi-GPU runs use the defaults (RCCL, one GPU per rank)
+    backend = os.environ.get("MJH_BENCH_BACKEND", "nccl")
+    if os.environ.get("MJH_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -136,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time of one step (its phase kernels) on this stream
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final = bufs[cur]
