@@ -51,6 +51,13 @@ CASES = {
     "convex_meshes_f64": ("convex_meshes", {}, "float64", 4, 3, "convex"),
     "convex_primitives_f64": ("convex_primitives", {}, "float64", 4, 3, "convex"),
     "convex_primitives_f32": ("convex_primitives", {}, "float32", 3, 2, "convex"),
+    # the other bundled models of the reference (mujoco_torch/test_data/*.xml) that the path supports, as they are
+    "halfcheetah_f64": ("halfcheetah", {}, "float64", 2, 3, "generic"),
+    "hopper_f64": ("hopper", {}, "float64", 2, 3, "generic"),
+    "walker2d_f64": ("walker2d", {}, "float64", 2, 3, "generic"),
+    "walker2d_rk4_f32": ("walker2d", {"integrator": 1}, "float32", 2, 2, "generic"),
+    "satellite_large_f64": ("satellite_large", {}, "float64", 2, 3, "generic"),
+    "convex_bundled_f64": ("convex", {}, "float64", 2, 2, "generic"),
 }
 
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
@@ -82,6 +89,10 @@ def make_inputs(recipe, lite, env):
                 q[a + 3 : a + 7] += 0.03 * rng.randn(4)  # un-normalised on purpose
         out["qpos"] = q
         out["qvel"] = 0.2 * rng.randn(nv)
+    elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
+        out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
+        out["qvel"] = 0.3 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.5 * rng.randn(nu), -1, 1)
     elif recipe == "perturbed":
         q = lite.qpos0.copy()
         q[7:] += 0.4 * rng.randn(nq - 7)
