@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 1
+#define MJH_ABI_VERSION 2
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -113,6 +113,7 @@ extern "C" {
   X(act_actlimited)   /* nu */                                                                   \
   X(act_actadr)     /* nu */                                                                     \
   X(act_actnum)     /* nu */                                                                     \
+  X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
   X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
   X(pair_fn)        /* npair: MJH_FN_* */                                                        \
   X(pair_geom1)     /* npair */                                                                  \
@@ -156,6 +157,9 @@ extern "C" {
   X(dof_armature)   /* nv */                                                                     \
   X(dof_damping)    /* nv */                                                                     \
   X(dof_invweight0) /* nv */                                                                     \
+  X(dof_frictionloss) /* nv */                                                                   \
+  X(dof_solref)     /* nv*2 */                                                                   \
+  X(dof_solimp)     /* nv*5 */                                                                   \
   X(geom_pos)       /* ngeom*3 */                                                                \
   X(geom_quat)      /* ngeom*4 */                                                                \
   X(geom_size)      /* ngeom*3 */                                                                \

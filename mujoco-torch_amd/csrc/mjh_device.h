@@ -65,9 +65,10 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
   X(efc_J, m.nefc * m.nv, PH_CON) X(efc_D, m.nefc, PH_CON | PH_SOL)                                            \
-  X(efc_Jc, (m.nefc - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
-  X(efc_Jl, m.nl, PH_SOL) /* the single non-zero of each joint-limit row (column lim_dof[r]) */                \
-  X(i_lim_dof, m.nl, PH_SOL) X(i_dof_limrow, m.nl ? m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
+  X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
+  X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
+  X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
+  X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_CON | PH_SOL)                                                                         \
   X(efc_pos, m.nefc, PH_CON) X(efc_pos_norm, m.nefc, PH_CON) X(efc_invweight, m.nefc, PH_CON)                  \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
@@ -122,8 +123,8 @@ struct DevModel {
   const int* dof_act_adr;                  // nv+1: CSR of the actuators driving each dof, in actuator order
   const int* dof_act_id;
   float inv_nv;                            // 1 / nv for the index splits below
-  const int* dof_limrow;                   // nv: the joint-limit row whose non-zero sits in column d, or -1
-  const int* lim_dof;                      // nl: dof of limit row r (the only non-zero column of its Jacobian row)
+  const int* dof_limrow;                   // 2*nv: the (up to two: frictionloss, then joint limit) single-column rows of dof d, -1 = none
+  const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
   const int* cvx_pairs;                    // ncvxpair: indices (into pair_*) of the pairs with a convex pair function
   int ncvxpair;

@@ -896,16 +896,24 @@ struct Env {
 
   __device__ __forceinline__ void make_constraint() {
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc, nl = M.nl;
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf;
     if (nefc == 0) return;
     load_qpos(false); load_qvel();
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
     row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
-    for (int w = l; w < nl * nv; w += W) S.efc_J()[w] = 0;
+    for (int w = l; w < (nf + nl) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
-    for (int r = l; r < nl; r += W) {  // _instantiate_limit_slide_hinge :338-372
-      const int j = M.lim_jnt[r], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+    for (int r = l; r < nf; r += W) {  // _instantiate_friction :215-251 (dof rows)
+      const int da = M.fric_dof[r];
+      S.efc_J()[r * nv + da] = 1;
+      S.efc_pos()[r] = 0;
+      S.efc_pos_norm()[r] = 0;
+      S.efc_invweight()[r] = M.dof_invweight0[da];
+    }
+    for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
+      const int r = nf + r0;
+      const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = S.qpos()[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
       const REAL val = (REAL)(dist_min < dist_max) * 2 - 1;
@@ -972,8 +980,12 @@ struct Env {
     STAMP(25);
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
-      if (r < nl) {
-        const int j = M.lim_jnt[r];
+      if (r < nf) {
+        const int da = M.fric_dof[r];
+        solref[0] = M.dof_solref[2 * da]; solref[1] = M.dof_solref[2 * da + 1];
+        for (int i = 0; i < 5; i++) solimp[i] = M.dof_solimp[5 * da + i];
+      } else if (r < nf + nl) {
+        const int j = M.lim_jnt[r - nf];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
       } else {
@@ -999,7 +1011,7 @@ struct Env {
     STAMP(26);
     put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
     STAMP(27);
-    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = 0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = r < nf ? M.dof_frictionloss[M.fric_dof[r]] : (REAL)0;
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
@@ -1269,7 +1281,7 @@ struct Env {
   // efc_J @ v (- sub).  A joint-limit row has one non-zero (column lim_dof[r]); the zeros of the dense product add
   // exact zeros, so the single term is the same value.
   __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {
-    const int nv = M.nv, nl = M.nl;
+    const int nv = M.nv, nl = M.nf + M.nl;  // single-column rows (frictionloss, joint limits) come first
     for (int r = lane(); r < M.nefc; r += W) {
       const REAL s = r < nl ? S.efc_Jl()[r] * v[lim_dof_lds()[r]] : dot_seq(S.efc_Jc() + (r - nl) * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
@@ -1279,12 +1291,31 @@ struct Env {
   __device__ __forceinline__ void update_constraint(Ctx& c) {  // :320-357
     const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
-    REAL part = 0;
+    REAL part = 0, fneg = 0, fpos = 0;
+    const int nf = M.nf;
     for (int r = l; r < nefc; r += W) {
       const REAL ja = S.s_Jaref()[r];
-      const REAL active = (REAL)(ja < 0);
-      S.s_force()[r] = S.efc_D()[r] * -ja * active + 0;
+      bool act = (ja < 0);
+      REAL floss_force = 0;
+      if (nf > 0 && r < nf) {
+        act = true;  // frictionloss row: quadratic inside |Jaref| < R f, linear (saturated force) outside (solver.py:326-342)
+        const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+        const REAL rr = 1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL);
+        const bool lin_neg = (ja <= -rr * fl) && (fl > 0), lin_pos = (ja >= rr * fl) && (fl > 0);
+        act = act && !lin_neg && !lin_pos;
+        floss_force = lin_neg ? fl : (lin_pos ? -fl : (REAL)0);
+        fneg = (REAL)lin_neg * ((REAL)-0.5 * rr * fl * fl - fl * ja);
+        fpos = (REAL)lin_pos * ((REAL)-0.5 * rr * fl * fl + fl * ja);
+      }
+      const REAL active = (REAL)act;
+      S.s_force()[r] = S.efc_D()[r] * -ja * active + floss_force;
       part += S.efc_D()[r] * ja * ja * active;
+    }
+    REAL floss_cost = 0;
+    if (nf > 0) {  // the two frictionloss cost sums, rows in index order (nf <= nv <= 64: one row per lane)
+      REAL sn = 0, sp = 0;
+      for (int r = 0; r < nf; r++) { sn += read_lane(fneg, r); sp += read_lane(fpos, r); }
+      floss_cost = sn + sp;
     }
     REAL gpart = 0;
     for (int d = l; d < nv; d += W) gpart += (S.s_Ma()[d] - S.qfrc_smooth()[d]) * (S.s_qacc()[d] - S.qacc_smooth()[d]);
@@ -1292,8 +1323,16 @@ struct Env {
     const REAL g = wave_sum(gpart);
     c.gauss = (REAL)0.5 * g;
     c.prev_cost = c.cost;
-    c.cost = ((REAL)0.5 * csum + c.gauss) + 0;
+    c.cost = ((REAL)0.5 * csum + c.gauss) + floss_cost;
     wave_sync();
+  }
+  // whether row r (a single-column row: frictionloss first, then joint limits) is in the quadratic (active) set
+  __device__ __forceinline__ bool crow_active(int r) const {
+    const REAL ja = S.s_Jaref()[r];
+    if (r >= M.nf) return ja < 0;
+    const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+    const REAL rr = 1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL);
+    return !((ja <= -rr * fl) && (fl > 0)) && !((ja >= rr * fl) && (fl > 0));
   }
   // second half of _update_constraint: qfrc_constraint = J^T efc_force.  Only needed once a context is iterated on or
   // returned -- the cost-only contexts of the warm-start choice (:526-531) never read it.
@@ -1302,10 +1341,13 @@ struct Env {
     const int nv = M.nv, nefc = M.nefc;
     {  // rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
-      const int nl = M.nl;
-      if (nl > 0 && l < nv) {  // the joint-limit rows come first; at most one of them has a non-zero in column l
-        const int lr = dof_limrow_lds()[l];
-        if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
+      const int nl = M.nf + M.nl;
+      if (nl > 0 && l < nv) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch column l
+        const int nslot = M.nf > 0 ? 2 : 1;  // without frictionloss rows the second slot of every dof is empty
+        for (int q = 0; q < nslot; q++) {
+          const int lr = dof_limrow_lds()[2 * l + q];
+          if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
+        }
       }
       for (int base = nl; base < nefc; base += W) {
         const int r = base + l;
@@ -1333,15 +1375,18 @@ struct Env {
     } else {
       // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
       // only the lower triangle is ever read by the factorisation: one lane per packed entry (i, j <= i)
-      const int np = (nv * (nv + 1)) / 2, nl = M.nl;
+      const int np = (nv * (nv + 1)) / 2, nl = M.nf + M.nl;
       for (int w0 = 0; w0 < np; w0 += W) {
         const int w = w0 + l;
         int i, j;
         tri_unpack(w < np ? w : 0, i, j);
         REAL s = 0;
-        if (nl > 0 && i == j) {  // a joint-limit row only touches its own diagonal entry, and it precedes the contact rows
-          const int lr = dof_limrow_lds()[i];
-          if (lr >= 0 && S.s_Jaref()[lr] < 0) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+        if (nl > 0 && i == j) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
+          const int nslot = M.nf > 0 ? 2 : 1;
+          for (int q = 0; q < nslot; q++) {
+            const int lr = dof_limrow_lds()[2 * i + q];
+            if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+          }
         }
         for (int base = nl; base < nefc; base += W) {
           const int r = base + l;
@@ -1365,15 +1410,36 @@ struct Env {
 
   __device__ __forceinline__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
     REAL q0 = 0, q1 = 0, q2 = 0;
+    REAL f0n = 0, f0p = 0, f1n = 0, f1p = 0;
+    const int nf = M.nf;
     for (int r = lane(); r < M.nefc; r += W) {
-      const REAL x = S.s_Jaref()[r] + alpha * S.s_jv()[r];
-      const REAL a = (REAL)(x < 0);
+      const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
+      const REAL x = ja + alpha * jv;
+      bool act = (x < 0);
+      if (nf > 0 && r < nf) {  // frictionloss row (solver.py:404-416): active unless in a linear zone
+        act = true;
+        const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+        const REAL rf = (1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL)) * fl;
+        const bool ln = (x <= -rf) && (fl > 0), lp = (x >= rf) && (fl > 0);
+        f0n = (REAL)ln * fl * ((REAL)-0.5 * rf - ja);
+        f0p = (REAL)lp * fl * ((REAL)-0.5 * rf + ja);
+        f1n = (REAL)ln * (-fl * jv);
+        f1p = (REAL)lp * (fl * jv);
+        act = act && !ln && !lp;
+      }
+      const REAL a = (REAL)act;
       q0 += S.s_quad()[3 * r] * a;
       q1 += S.s_quad()[3 * r + 1] * a;
       q2 += S.s_quad()[3 * r + 2] * a;
     }
     q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
-    const REAL t0 = (qg[0] + q0) + 0, t1 = (qg[1] + q1) + 0, t2 = (qg[2] + q2) + 0;
+    REAL fa0 = 0, fa1 = 0;
+    if (nf > 0) {  // frictionloss adjustments, rows in index order (one row per lane)
+      REAL s0n = 0, s0p = 0, s1n = 0, s1p = 0;
+      for (int r = 0; r < nf; r++) { s0n += read_lane(f0n, r); s0p += read_lane(f0p, r); s1n += read_lane(f1n, r); s1p += read_lane(f1p, r); }
+      fa0 = s0n + s0p; fa1 = s1n + s1p;
+    }
+    const REAL t0 = (qg[0] + q0) + fa0, t1 = (qg[1] + q1) + fa1, t2 = (qg[2] + q2) + 0;
     LSPoint p;
     p.alpha = alpha;
     p.cost = alpha * alpha * t2 + alpha * t1 + t0;
@@ -1481,10 +1547,11 @@ struct Env {
     const int nv = M.nv, nefc = M.nefc;
     if (M.sol_qm_lds) row_load<W>(S.qMs(), out.qM, nv * nv, e);
     if (nefc > 0) {
-      const int l = lane(), nl = M.nl;
+      const int l = lane(), nl = M.nf + M.nl;
       const REAL* gJ = out.efc_J + e * nefc * nv;
       for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
-      if (nl > 0) for (int d = l; d < nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
+      for (int r = l; r < M.nf; r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
+      if (nl > 0) for (int d = l; d < 2 * nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
       {
         const int n = (nefc - nl) * nv;
         const REAL* src = gJ + nl * nv;

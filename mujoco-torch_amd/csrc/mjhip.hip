@@ -191,9 +191,6 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.body_dofmask, bb.add(body_dofmask.data(), sizeof(unsigned long long) * nb)});
   fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
-  std::vector<int> lim_dof((size_t)d->nl, 0);
-  for (int r = 0; r < d->nl; r++) lim_dof[r] = d->jnt_dofadr[d->lim_jnt[r]];
-  fix.push_back({(const void**)&M.lim_dof, bb.add(lim_dof.data(), sizeof(int) * lim_dof.size())});
   {
     std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
     std::vector<int> adr((size_t)nv + 1, 0), ids;
@@ -208,10 +205,18 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     fix.push_back({(const void**)&M.dof_act_id, bb.add(ids.data(), sizeof(int) * ids.size())});
     M.inv_nv = nv > 0 ? 1.0f / (float)nv : 0.0f;
   }
-  std::vector<int> dof_limrow((size_t)nv, -1);
-  for (int r = 0; r < d->nl; r++) {
-    if (dof_limrow[lim_dof[r]] >= 0) return fail(-22, "two joint-limit rows on one dof");
-    dof_limrow[lim_dof[r]] = r;
+  // single-column rows: dof-frictionloss rows (J = e_dof) first, then slide/hinge limit rows (J = +-e_dof or 0)
+  const int ncr = d->nf + d->nl;
+  std::vector<int> lim_dof((size_t)ncr, 0);
+  for (int r = 0; r < d->nf; r++) lim_dof[r] = d->fric_dof[r];
+  for (int r = 0; r < d->nl; r++) lim_dof[d->nf + r] = d->jnt_dofadr[d->lim_jnt[r]];
+  fix.push_back({(const void**)&M.lim_dof, bb.add(lim_dof.data(), sizeof(int) * lim_dof.size())});
+  std::vector<int> dof_limrow((size_t)2 * nv, -1);
+  for (int r = 0; r < ncr; r++) {
+    const int dd = lim_dof[r];
+    if (dof_limrow[2 * dd] < 0) dof_limrow[2 * dd] = r;
+    else if (dof_limrow[2 * dd + 1] < 0) dof_limrow[2 * dd + 1] = r;
+    else return fail(-22, "more than two single-column rows on one dof");
   }
   fix.push_back({(const void**)&M.dof_limrow, bb.add(dof_limrow.data(), sizeof(int) * dof_limrow.size())});
   M.max_depth = max_depth;
@@ -391,7 +396,7 @@ int mjh_model_create(const mjhModelDesc* desc, int dtype, mjhModel** out) {
   if (dtype != MJH_F64 && dtype != MJH_F32) return fail(-22, "dtype must be MJH_F64 or MJH_F32");
   if (desc->integrator != INT_EULER && desc->integrator != INT_RK4) return fail(-38, "integrator not implemented");
   if (desc->solver != SOL_CG && desc->solver != SOL_NEWTON) return fail(-38, "solver not implemented");
-  if (desc->ne || desc->nf) return fail(-38, "equality / frictionloss rows not implemented");
+  if (desc->ne) return fail(-38, "equality rows not implemented");
   mjhModel* m = new mjhModel();
   m->dtype = dtype;
   int rc = dtype == MJH_F64 ? build<double>(desc, m, m->m64) : build<float>(desc, m, m->m32);

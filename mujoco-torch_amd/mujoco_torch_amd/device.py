@@ -83,8 +83,6 @@ def _validate(m):
         raise NotImplementedError("equality constraints and tendons are 'next' items (SURVEY section 8f).")
     if int(m.nmocap):
         raise NotImplementedError("mocap bodies are not supported by the native stepper yet.")
-    if (np.asarray(m.dof_frictionloss) > 0).any() and not (int(opt.disableflags) & DisableBit.FRICTIONLOSS):
-        raise NotImplementedError("dof frictionloss rows are a 'next' item (SURVEY section 8f).")
     if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
         raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
     if np.any(np.asarray(_get(m, "body_gravcomp", lambda: np.zeros(int(m.nbody)))) != 0):
@@ -193,6 +191,11 @@ def _build_tables(m, dtype) -> StaticTables:
         for j in range(int(m.njnt)):
             if bool(np.asarray(m.jnt_limited)[j]) and int(jt[j]) in (int(JointType.SLIDE), int(JointType.HINGE)):
                 lim.append(j)
+    fric = []
+    if not (flags & (DisableBit.CONSTRAINT | DisableBit.FRICTIONLOSS)):
+        fric = [d for d in range(int(m.nv)) if float(np.asarray(m.dof_frictionloss)[d]) > 0]
+    T.fric_dof = np.array(fric, dtype=np.int32)
+    assert len(fric) == nf, (len(fric), nf)
     T.lim_jnt = np.array(lim, dtype=np.int32)
     assert len(lim) == nl, (len(lim), nl)
     return T

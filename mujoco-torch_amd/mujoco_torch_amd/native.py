@@ -112,7 +112,7 @@ def pack_model(m, dtype: torch.dtype):
         act_biastype=i32(m.actuator_biastype.data.cpu().numpy()), act_dyntype=i32(m.actuator_dyntype.data.cpu().numpy()),
         act_ctrllimited=i32(A("actuator_ctrllimited")), act_forcelimited=i32(A("actuator_forcelimited")),
         act_actlimited=i32(A("actuator_actlimited")), act_actadr=i32(A("actuator_actadr")), act_actnum=i32(A("actuator_actnum")),
-        lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
+        fric_dof=i32(T.fric_dof), lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
         pair_geom2=i32([p[2].geom2 for p in T.pairs]), pair_ncon=i32([p[1] for p in T.pairs]), pair_dst=i32(T.pair_dst),
         con_dim=i32(T.con_dim), con_geom1=i32(T.con_geom1), con_geom2=i32(T.con_geom2), con_efc_address=i32(T.con_efc_address),
         convex_nvert=i32([]), convex_nface=i32([]), convex_nfv=i32([]), convex_nedge=i32([]), convex_vertadr=i32([]),
@@ -143,7 +143,7 @@ def pack_model(m, dtype: torch.dtype):
         jnt_axis=f64(m.jnt_axis), jnt_stiffness=f64(m.jnt_stiffness), jnt_range=f64(m.jnt_range),
         jnt_margin=f64(m.jnt_margin), jnt_solref=f64(m.jnt_solref), jnt_solimp=f64(m.jnt_solimp),
         jnt_actfrcrange=f64(m.jnt_actfrcrange), dof_armature=f64(m.dof_armature), dof_damping=f64(m.dof_damping),
-        dof_invweight0=f64(m.dof_invweight0), geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
+        dof_invweight0=f64(m.dof_invweight0), dof_frictionloss=f64(m.dof_frictionloss), dof_solref=f64(m.dof_solref), dof_solimp=f64(m.dof_solimp), geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
         geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
         cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
         light_dir=f64(m.light_dir), act_gear=f64(m.actuator_gear) if nu else empty,
@@ -154,7 +154,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 1
+    desc.abi_version = 2
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

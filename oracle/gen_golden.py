@@ -58,6 +58,12 @@ CASES = {
     "walker2d_rk4_f32": ("walker2d", {"integrator": 1}, "float32", 2, 2, "generic"),
     "satellite_large_f64": ("satellite_large", {}, "float64", 2, 3, "generic"),
     "convex_bundled_f64": ("convex", {}, "float64", 2, 2, "generic"),
+    # dof frictionloss rows (constraint.py:215-251, solver.py:326-342, :404-416): the bundled single-hinge model and the ant
+    # with frictionloss on every joint, Newton and CG
+    "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
+    "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
+    "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
+    "ant_frictionloss_rk4_ell_f32": ("ant_frictionloss", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 2, 2, "bench_ctrl"),
 }
 
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
@@ -89,6 +95,9 @@ def make_inputs(recipe, lite, env):
                 q[a + 3 : a + 7] += 0.03 * rng.randn(4)  # un-normalised on purpose
         out["qpos"] = q
         out["qvel"] = 0.2 * rng.randn(nv)
+    elif recipe == "friction_hinge":  # stick (small torque), slip both ways (large torque): reference test/solver_test.py:77-108
+        out["qvel"] = np.array([0.0, 0.5, -0.5][env % 3]) * np.ones(nv)
+        out["qfrc_applied"] = np.array([0.5, 100.0, -100.0][env % 3]) * np.ones(nv)
     elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
         out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
         out["qvel"] = 0.3 * rng.randn(nv)

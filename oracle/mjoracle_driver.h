@@ -162,6 +162,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       memcpy(w.in_subtree_com, w.subtree_com, sizeof(REAL) * 3 * m->nbody);
       w.knife = 0;
       w.knife_policy = knife_policy;
+      w.nf = m->nf; w.ne_nf = m->ne + m->nf; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0;
       w.hint_dist = g_hint_dist ? (const REAL*)g_hint_dist + e * m->ncon : NULL;
       w.hint_pos = g_hint_pos ? (const REAL*)g_hint_pos + e * m->ncon * 3 : NULL;

@@ -107,6 +107,7 @@ typedef struct FN(MjoWork) {
      accepted depends on the sign / exact-zeroness of that noise (solver.py:440-463), so the
      reference's own result is implementation-defined on these steps; tests exempt them from the
      tight solver-output tolerance (DESIGN.md "line-search knife edge"). */
+  int nf, ne_nf; /* copies of the model's row counts for the line search's point function */
   int knife;
   int knife_policy; /* <0: natural; j>=0: first j noise candidates read as exact zero, the (j+1)-th as non-zero */
   /* index selections (argmax / argmin) of the convex narrow phase whose two best candidates differ by rounding noise
@@ -1140,6 +1141,17 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
   if (nefc == 0) return;
   for (int i = 0; i < nefc * nv; i++) w->efc_J[i] = 0;
   int row = 0;
+  for (int r = 0; r < nefc; r++) w->efc_frictionloss[r] = 0;
+  for (int f = 0; f < m->nf; f++, row++) { /* _instantiate_friction :215-251 (dof rows) */
+    int da = m->fric_dof[f];
+    w->efc_J[row * nv + da] = 1;
+    w->efc_pos[row] = 0;
+    w->efc_pos_norm[row] = 0;
+    w->efc_invweight[row] = M->dof_invweight0[da];
+    w->efc_frictionloss[row] = M->dof_frictionloss[da];
+    for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->dof_solref[2 * da + i];
+    for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->dof_solimp[5 * da + i];
+  }
   for (int l = 0; l < m->nl; l++, row++) { /* _instantiate_limit_slide_hinge :338-372 */
     int j = m->lim_jnt[l], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
     REAL q = w->qpos[qa];
@@ -1224,7 +1236,6 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
     for (int d = 0; d < nv; d++) jv += w->efc_J[r * nv + d] * w->qvel[d];
     w->efc_aref[r] = -b * jv - k * imp * w->efc_pos[r];
     w->efc_D[r] = 1 / rr;
-    w->efc_frictionloss[r] = 0;
   }
 }
 
@@ -1409,12 +1420,23 @@ typedef struct FN(SolveCtx) {
 static void FN(update_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx) * c) { /* :320-357 */
   const mjhModelDesc* m = M->d;
   int nv = m->nv, nefc = m->nefc;
-  REAL csum = 0;
+  REAL csum = 0, fneg = 0, fpos = 0;
+  int ne_nf = m->ne + m->nf;
   for (int r = 0; r < nefc; r++) {
     REAL ja = w->s_Jaref[r];
-    int active = ja < 0;
+    int active = (ja < 0) || (r < ne_nf);
+    REAL floss_force = 0;
+    if (m->nf > 0) { /* quadratic inside |Jaref| < R f, linear outside (solver.py:326-342) */
+      REAL fl = w->efc_frictionloss[r];
+      REAL rr = 1 / (w->efc_D[r] + (REAL)(w->efc_D[r] == 0) * (REAL)(float)mjMINVAL);
+      int lin_neg = (ja <= -rr * fl) && (fl > 0), lin_pos = (ja >= rr * fl) && (fl > 0);
+      active = active && !lin_neg && !lin_pos;
+      floss_force = lin_neg ? fl : (lin_pos ? -fl : (REAL)0);
+      fneg += (REAL)lin_neg * ((REAL)-0.5 * rr * fl * fl - fl * ja);
+      fpos += (REAL)lin_pos * ((REAL)-0.5 * rr * fl * fl + fl * ja);
+    }
     w->s_active[r] = (unsigned char)active;
-    w->s_force[r] = w->efc_D[r] * -ja * (REAL)active + 0;
+    w->s_force[r] = w->efc_D[r] * -ja * (REAL)active + floss_force;
     csum += w->efc_D[r] * ja * ja * (REAL)active;
   }
   for (int d = 0; d < nv; d++) {
@@ -1425,7 +1447,7 @@ static void FN(update_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(So
   REAL g = 0;
   for (int d = 0; d < nv; d++) g += (w->s_Ma[d] - w->qfrc_smooth[d]) * (w->s_qacc[d] - w->qacc_smooth[d]);
   c->gauss = (REAL)0.5 * g;
-  REAL cost = ((REAL)0.5 * csum + c->gauss) + 0;
+  REAL cost = ((REAL)0.5 * csum + c->gauss) + (fneg + fpos);
   c->prev_cost = c->cost;
   c->cost = cost;
 }
@@ -1473,14 +1495,27 @@ static void FN(create_context)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(Solve
 
 static FN(LSPoint) FN(ls_point)(const FN(MjoWork) * w, int nefc, const REAL* qg, REAL alpha) { /* point_fn :396-422 */
   REAL q0 = 0, q1 = 0, q2 = 0;
+  REAL f0n = 0, f0p = 0, f1n = 0, f1p = 0;
   for (int r = 0; r < nefc; r++) {
     REAL x = w->s_Jaref[r] + alpha * w->s_jv[r];
-    REAL a = (REAL)(x < 0);
+    int act = (x < 0) || (r < w->ne_nf);
+    if (w->nf > 0) {
+      REAL fl = w->efc_frictionloss[r];
+      REAL rr = 1 / (w->efc_D[r] + (REAL)(w->efc_D[r] == 0) * (REAL)(float)mjMINVAL);
+      REAL rf = rr * fl;
+      int ln = (x <= -rf) && (fl > 0), lp = (x >= rf) && (fl > 0);
+      f0n += (REAL)ln * fl * ((REAL)-0.5 * rf - w->s_Jaref[r]);
+      f0p += (REAL)lp * fl * ((REAL)-0.5 * rf + w->s_Jaref[r]);
+      f1n += (REAL)ln * (-fl * w->s_jv[r]);
+      f1p += (REAL)lp * (fl * w->s_jv[r]);
+      act = act && !ln && !lp;
+    }
+    REAL a = (REAL)act;
     q0 += w->s_quad[3 * r] * a;
     q1 += w->s_quad[3 * r + 1] * a;
     q2 += w->s_quad[3 * r + 2] * a;
   }
-  REAL t0 = (qg[0] + q0) + 0, t1 = (qg[1] + q1) + 0, t2 = (qg[2] + q2) + 0;
+  REAL t0 = (qg[0] + q0) + (f0n + f0p), t1 = (qg[1] + q1) + (f1n + f1p), t2 = (qg[2] + q2) + 0;
   FN(LSPoint) p;
   p.alpha = alpha;
   p.cost = alpha * alpha * t2 + alpha * t1 + t0;

@@ -30,7 +30,7 @@ def test_header_entry_points_exported(lib):
 
 def test_field_lists_match_header(lib):
     native.check_abi(lib)
-    assert lib.mjh_abi_version() == 1
+    assert lib.mjh_abi_version() == 2
 
 
 def test_struct_sizes_match_binding(lib):

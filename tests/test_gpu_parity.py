@@ -58,6 +58,10 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("convex_meshes", {}, torch.float64, 32),
     ("convex_primitives", {}, torch.float64, 32),
     ("convex_primitives", {}, torch.float32, 32),
+    ("ant_frictionloss", {}, torch.float64, 64),                                   # dof frictionloss rows, Newton
+    ("ant_frictionloss", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),      # ... CG (100 iterations on a piecewise-quadratic cost amplify rounding)
+    ("halfcheetah", {}, torch.float64, 64),
+    ("hopper", {"_tol_sol": 1e-6}, torch.float64, 64),
 ])
 def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_lib):
     """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs."""
