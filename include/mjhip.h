@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 2
+#define MJH_ABI_VERSION 3
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -69,6 +69,7 @@ extern "C" {
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
   X(ne) X(nf) X(nl) X(ncon) X(nefc) X(npair) X(nconvex)                                          \
+  X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
   X(integrator) X(solver) X(cone) X(disableflags) X(iterations) X(ls_iterations)
 
 /* double scalars */
@@ -113,6 +114,15 @@ extern "C" {
   X(act_actlimited)   /* nu */                                                                   \
   X(act_actadr)     /* nu */                                                                     \
   X(act_actnum)     /* nu */                                                                     \
+  X(sns_type)       /* nsensor: mjtSensor (accelerometer 1, velocimeter 2, gyro 3, rangefinder 7, jointpos 9, jointvel 10) */ \
+  X(sns_adr)        /* nsensor: first slot in sensordata */                                      \
+  X(sns_objid)      /* nsensor: site id (frame sensors, rangefinder) or qpos / dof address (jointpos / jointvel) */ \
+  X(sns_bodyid)     /* nsensor: body of the site */                                              \
+  X(sns_rootid)     /* nsensor: root body of that body */                                        \
+  X(sns_datatype)   /* nsensor: mjtDataType (0 real, 1 positive) for the cutoff rule */          \
+  X(sns_rfadr)      /* nsensor+1: rangefinders, range into rf_geom; geoms in the reference's evaluation order */ \
+  X(rf_geom)        /* geom ids a rangefinder ray is tested against (ray.py:292-325: site's own body excluded, invisible geoms dropped) */ \
+  X(slot_sensor)    /* nsensordata: sns_* index that produces the slot, -1 = the slot keeps the caller's value */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
   X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
   X(pair_fn)        /* npair: MJH_FN_* */                                                        \
@@ -157,6 +167,7 @@ extern "C" {
   X(dof_armature)   /* nv */                                                                     \
   X(dof_damping)    /* nv */                                                                     \
   X(dof_invweight0) /* nv */                                                                     \
+  X(sns_cutoff)     /* nsensor */                                                                \
   X(dof_frictionloss) /* nv */                                                                   \
   X(dof_solref)     /* nv*2 */                                                                   \
   X(dof_solimp)     /* nv*5 */                                                                   \
@@ -253,6 +264,7 @@ typedef struct mjhModelDesc {
   X(contact_solref)         /* ncon*2 */                                                         \
   X(contact_solreffriction) /* ncon*2 */                                                         \
   X(contact_solimp)         /* ncon*5 */                                                         \
+  X(sensordata)       /* nsensordata (sensor.py:56-440; written by forward passes that include the solver stage) */ \
   X(efc_J)            /* nefc*nv */                                                              \
   X(efc_frictionloss) /* nefc */                                                                 \
   X(efc_D)            /* nefc */                                                                 \

@@ -12,6 +12,7 @@
 
 #include "mjh_kernels.h"
 #include "mjh_convex.h"
+#include "mjh_sensor.h"
 
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
@@ -61,7 +62,7 @@ std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
   F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(actuator_length, nu)
   F(actuator_moment, nu * nv) F(qM, nv * nv) F(qLD, nv * nv) F(contact_dist, ncon) F(contact_pos, ncon * 3)
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
-  F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
+  F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
   F(efc_D, nefc) F(efc_aref, nefc) F(efc_force, nefc) F(actuator_velocity, nu) F(cvel, nb * 6) F(cdof_dot, nv * 6)
   F(qfrc_bias, nv) F(qfrc_passive, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
   F(qacc_smooth, nv) F(qfrc_constraint, nv)
@@ -324,6 +325,11 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
   if ((st & 0x70) && (rc = launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
+    const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
+    hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), 0, stream, a);
+    HIP_TRY(hipGetLastError());
+  }
   if ((st & 0x60) && (rc = launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }

@@ -31,6 +31,7 @@ from ._enums import (
     IntegratorType,
     JacobianType,
     JointType,
+    SensorType,
     SolverType,
     TrnType,
     SUPPORTED_CONDIM,
@@ -125,6 +126,50 @@ def _option(opt, dtype) -> Option:
     )
 
 
+_SNS_SITE = (int(SensorType.ACCELEROMETER), int(SensorType.VELOCIMETER), int(SensorType.GYRO), int(SensorType.RANGEFINDER))
+_SNS_SKIPPED = (int(SensorType.TOUCH),)  # the reference leaves these slots untouched too (sensor.py:420-423)
+_RAY_GEOM_ORDER = (GeomType.PLANE, GeomType.SPHERE, GeomType.CAPSULE, GeomType.ELLIPSOID, GeomType.CYLINDER, GeomType.BOX)  # ray.py:282-289
+
+
+def _sensor_tables(m) -> dict:
+    """Sensors the native stepper evaluates (reference sensor.py:56-440, device.py:381-585), flattened per sensor."""
+    ns, nsd = int(getattr(m, "nsensor", 0) or 0), int(getattr(m, "nsensordata", 0) or 0)
+    out = dict(type=[], adr=[], objid=[], bodyid=[], rootid=[], datatype=[], cutoff=[], rfadr=[0], rf_geom=[], slot=-np.ones(nsd, dtype=np.int32))
+    if ns == 0 or (int(m.opt.disableflags) & DisableBit.SENSOR):
+        return out
+    stype = np.asarray(m.sensor_type)
+    for i in range(ns):
+        t, oid = int(stype[i]), int(np.asarray(m.sensor_objid)[i])
+        if t in _SNS_SKIPPED:
+            continue
+        if t in _SNS_SITE:
+            body = int(np.asarray(m.site_bodyid)[oid])
+            obj, root = oid, int(np.asarray(m.body_rootid)[body])
+        elif t == int(SensorType.JOINTPOS):
+            obj, body, root = int(np.asarray(m.jnt_qposadr)[oid]), 0, 0
+        elif t == int(SensorType.JOINTVEL):
+            obj, body, root = int(np.asarray(m.jnt_dofadr)[oid]), 0, 0
+        else:
+            raise NotImplementedError(f"sensor type {SensorType(t).name} is not implemented by the native stepper.")
+        k = len(out["type"])
+        dim = int(np.asarray(m.sensor_dim)[i])
+        out["slot"][int(np.asarray(m.sensor_adr)[i]) : int(np.asarray(m.sensor_adr)[i]) + dim] = k
+        out["type"].append(t); out["adr"].append(int(np.asarray(m.sensor_adr)[i])); out["objid"].append(obj)
+        out["bodyid"].append(body); out["rootid"].append(root)
+        out["datatype"].append(int(np.asarray(m.sensor_datatype)[i])); out["cutoff"].append(float(np.asarray(m.sensor_cutoff)[i]))
+        if t == int(SensorType.RANGEFINDER):  # ray.precompute_ray_data(flg_static=True, bodyexclude=site body), type-major order
+            gtype, gbody = np.asarray(m.geom_type), np.asarray(m.geom_bodyid)
+            rgba = np.asarray(getattr(m, "geom_rgba", np.ones((int(m.ngeom), 4))))
+            matid = np.asarray(getattr(m, "geom_matid", -np.ones(int(m.ngeom), dtype=np.int32)))
+            for gt in _RAY_GEOM_ORDER:
+                for g in range(int(m.ngeom)):
+                    visible = (matid[g] != -1) or (rgba[g, 3] != 0)  # material alpha is not modelled by the MJCF subset
+                    if int(gtype[g]) == int(gt) and int(gbody[g]) != body and visible:
+                        out["rf_geom"].append(g)
+        out["rfadr"].append(len(out["rf_geom"]))
+    return out
+
+
 class StaticTables:
     """Everything about a model that is constant across steps and environments.
 
@@ -196,6 +241,7 @@ def _build_tables(m, dtype) -> StaticTables:
         fric = [d for d in range(int(m.nv)) if float(np.asarray(m.dof_frictionloss)[d]) > 0]
     T.fric_dof = np.array(fric, dtype=np.int32)
     assert len(fric) == nf, (len(fric), nf)
+    T.sensors = _sensor_tables(m)
     T.lim_jnt = np.array(lim, dtype=np.int32)
     assert len(lim) == nl, (len(lim), nl)
     return T

@@ -46,6 +46,8 @@ def _written_names(m: Model, step: bool):
         names += _WRITTEN_CONTACT
     if nefc > 0:
         names += _WRITTEN_EFC
+    if len(m.tables.sensors["type"]) > 0:
+        names += ["sensordata"]
     if step:
         names += _WRITTEN_STEP
     return names
@@ -85,6 +87,8 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
     B = int(math.prod(batch)) if batch else 1
     nm = native.get_native_model(m, device, dtype)
     names = _written_names(m, step)
+    if not step and not (stages & 0x40):
+        names = [n for n in names if n != "sensordata"]  # sensors belong to complete forward passes
     in_ptrs, keep_in = _fill_ptrs(d, _ALL_NAMES, dtype, device)
     if out is None:
         new = {}

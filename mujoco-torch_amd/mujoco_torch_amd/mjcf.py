@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import math
 import os
+import re
 import struct
 import xml.etree.ElementTree as ET
 from types import SimpleNamespace
@@ -1259,7 +1260,25 @@ class _Compiler:
         m.sensor_dim = np.array(dims, dtype=np.int32)
         m.sensor_adr = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32) if sens else np.zeros(0, dtype=np.int32)
         m.nsensordata = int(sum(dims))
-        m.sensor_objid = np.array([m.names_site.index(s.get("site")) if s.get("site") in m.names_site else -1 for s in sens], dtype=np.int32)
+        # object the sensor is attached to (mjtObj: 3 joint, 6 site), stage it needs (mjtStage: 1 pos, 2 vel, 3 acc) and
+        # its data type (mjtDataType: 0 real, 1 positive), as the MuJoCo compiler sets them per sensor type
+        objid, objtype, stage, dtype_ = [], [], [], []
+        for sn in sens:
+            t = sn.tag
+            if t in ("jointpos", "jointvel"):
+                objtype.append(3)
+                objid.append(m.names_jnt.index(sn.get("joint")))
+            else:
+                objtype.append(6)
+                objid.append(m.names_site.index(sn.get("site")))
+            stage.append({"touch": 3, "accelerometer": 3, "force": 3, "torque": 3, "velocimeter": 2, "gyro": 2, "jointvel": 2}.get(t, 1))
+            dtype_.append(1 if t == "touch" else 0)
+        m.sensor_objid = np.array(objid, dtype=np.int32)
+        m.sensor_objtype = np.array(objtype, dtype=np.int32)
+        m.sensor_needstage = np.array(stage, dtype=np.int32)
+        m.sensor_datatype = np.array(dtype_, dtype=np.int32)
+        m.sensor_reftype = np.zeros(len(sens), dtype=np.int32)
+        m.sensor_refid = -np.ones(len(sens), dtype=np.int32)
         m.sensor_cutoff = np.array([float(s.get("cutoff", 0.0)) for s in sens], dtype=np.float64)
 
     def _build_empty_sections(self, m):
@@ -1463,8 +1482,12 @@ def _set_const(m, stat_meaninertia=None):
 # --------------------------------------------------------------------------
 
 
+_XML_COMMENT = re.compile(r"<!--.*?-->", re.S)
+
+
 def from_xml_string(xml: str, base_dir: str = ".") -> MjModelLite:
-    return _Compiler(ET.fromstring(xml), base_dir).build()
+    # MuJoCo's parser tolerates "--" inside comments (ASCII tables in bundled models); expat does not: drop comments first
+    return _Compiler(ET.fromstring(_XML_COMMENT.sub("", xml)), base_dir).build()
 
 
 def from_xml_path(path: str) -> MjModelLite:

@@ -57,9 +57,14 @@ CASES = {
     "walker2d_f64": ("walker2d", {}, "float64", 2, 3, "generic"),
     "walker2d_rk4_f32": ("walker2d", {"integrator": 1}, "float32", 2, 2, "generic"),
     "satellite_large_f64": ("satellite_large", {}, "float64", 2, 3, "generic"),
+    "satellite_small_f64": ("satellite_small", {}, "float64", 2, 3, "generic"),
     "convex_bundled_f64": ("convex", {}, "float64", 2, 2, "generic"),
     # dof frictionloss rows (constraint.py:215-251, solver.py:326-342, :404-416): the bundled single-hinge model and the ant
     # with frictionloss on every joint, Newton and CG
+    # sensors on the step path (sensor.py:56-440, ray.py): velocimeter / gyro / accelerometer / rangefinders against every primitive
+    # geom type / joint sensors, with cutoffs
+    "sensor_rig_f64": ("sensor_rig", {}, "float64", 4, 3, "sensor_rig"),
+    "sensor_rig_rk4_f64": ("sensor_rig", {"integrator": 1}, "float64", 2, 2, "sensor_rig"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
@@ -95,6 +100,13 @@ def make_inputs(recipe, lite, env):
                 q[a + 3 : a + 7] += 0.03 * rng.randn(4)  # un-normalised on purpose
         out["qpos"] = q
         out["qvel"] = 0.2 * rng.randn(nv)
+    elif recipe == "sensor_rig":
+        q = lite.qpos0.copy()
+        q[:3] += 0.1 * rng.randn(3) * (env > 0)
+        q[3:7] += 0.2 * rng.randn(4) * (env > 0)
+        q[7:] += 0.3 * rng.randn(nq - 7)
+        out["qpos"] = q
+        out["qvel"] = 0.5 * rng.randn(nv)
     elif recipe == "friction_hinge":  # stick (small torque), slip both ways (large torque): reference test/solver_test.py:77-108
         out["qvel"] = np.array([0.0, 0.5, -0.5][env % 3]) * np.ones(nv)
         out["qfrc_applied"] = np.array([0.5, 100.0, -100.0][env % 3]) * np.ones(nv)
@@ -135,14 +147,16 @@ def main(only=None):
         for k, v in overrides.items():
             setattr(lite.opt, k, v)
         has_convex = any(int(t) in (6, 7) for t in lite.geom_type)
+        # float32 + rangefinder raises inside the reference (float64 ray tables, ray.py:317): record those cases sensor-less
+        keep_sensors = not (dtype != torch.float64 and any(int(t) == 7 for t in getattr(lite, "sensor_type", [])))
         if has_convex:
             # the reference's device_put(dtype=float32) leaves the convex tables in float64 and its step then fails on
             # mixed dtypes (constraint.py:475); Model.to(float32) is the route that works
-            mref = ref_harness.put_model(ref, lite)
+            mref = ref_harness.put_model(ref, lite, keep_sensors=keep_sensors)
             if dtype != torch.float64:
                 mref = mref.to(dtype)
         else:
-            mref = ref_harness.put_model(ref, lite, dtype=dtype if dtype != torch.float64 else None)
+            mref = ref_harness.put_model(ref, lite, dtype=dtype if dtype != torch.float64 else None, keep_sensors=keep_sensors)
         store = {}
         for g in range(lite.ngeom):  # the convex tables the reference derived (mesh.py:405-447, on oracle/ref_stubs/trimesh)
             if mref.geom_convex_face[g] is not None:
@@ -161,7 +175,7 @@ def main(only=None):
                 for n in names:
                     t = leaf(d, n)
                     store[f"out/{env}/{s}/{n}"] = t.numpy().copy()
-        meta = dict(xml=xml, overrides=overrides, dtype=dtype_s, nenv=nenv, nsteps=nsteps, recipe=recipe,
+        meta = dict(xml=xml, overrides=overrides, dtype=dtype_s, nenv=nenv, nsteps=nsteps, recipe=recipe, keep_sensors=keep_sensors,
                     constraint_sizes=list(mref.constraint_sizes_py), torch=torch.__version__)
         store["meta"] = np.array(json.dumps(meta))
         path = os.path.join(GOLD, case + ".npz")

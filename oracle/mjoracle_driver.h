@@ -13,7 +13,7 @@ static int FN(field_count)(const mjhModelDesc* m, const char* name) {
   F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(actuator_length, nu)
   F(actuator_moment, nu * nv) F(qM, nv * nv) F(qLD, nv * nv) F(contact_dist, ncon) F(contact_pos, ncon * 3)
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
-  F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
+  F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
   F(efc_D, nefc) F(efc_aref, nefc) F(efc_force, nefc) F(actuator_velocity, nu) F(cvel, nb * 6) F(cdof_dot, nv * 6)
   F(qfrc_bias, nv) F(qfrc_passive, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
   F(qacc_smooth, nv) F(qfrc_constraint, nv)

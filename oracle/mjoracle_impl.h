@@ -1658,6 +1658,145 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
 }
 
 /* ---- forward (forward.py:373-401) ----------------------------------------------------------------- */
+/* ---- sensors (sensor.py:56-440, ray.py:28-373) ------------------------------------------------------- */
+/* ray functions run in double whatever the Data dtype: the reference keeps the geom sizes of its ray tables in float64
+   (ray.py:317) and torch promotes; with float32 Data its own call raises on the mixed dot products, so float32 +
+   rangefinder is this build's choice: transform in the Data dtype, intersect in double, round the distance. */
+#ifndef MJO_RAY_COMMON_
+#define MJO_RAY_COMMON_
+static double mjo_safe_div(double num, double den) { return num / (den + (den == 0 ? (double)(float)mjMINVAL : 0.0)); }
+static void mjo_ray_quad(double a, double b, double c, double* x0, double* x1) { /* :28-40 */
+  double det = b * b - a * c, det2 = sqrt(det);
+  double r0 = mjo_safe_div(-b - det2, a), r1 = mjo_safe_div(-b + det2, a);
+  *x0 = ((det < mjMINVAL) || (r0 < 0)) ? INFINITY : r0;
+  *x1 = ((det < mjMINVAL) || (r1 < 0)) ? INFINITY : r1;
+}
+static double mjo_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double mjo_ray_geom(int type, const double* size, const double* pnt, const double* vec) {
+  if (type == 0) { /* plane :43-57 */
+    double x = -mjo_safe_div(pnt[2], vec[2]);
+    int valid = (vec[2] <= -mjMINVAL) && (x >= 0);
+    for (int i = 0; i < 2; i++) { double p = pnt[i] + x * vec[i]; valid = valid && ((size[i] <= 0) || (fabs(p) <= size[i])); }
+    return valid ? x : INFINITY;
+  }
+  if (type == 2) { /* sphere :60-69 */
+    double x0, x1;
+    mjo_ray_quad(mjo_dot3(vec, vec), mjo_dot3(vec, pnt), mjo_dot3(pnt, pnt) - size[0] * size[0], &x0, &x1);
+    return isinf(x0) ? x1 : x0;
+  }
+  if (type == 3) { /* capsule :72-106 */
+    double a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
+    double x0, x1;
+    mjo_ray_quad(a, b, c, &x0, &x1);
+    double x = isinf(x0) ? x1 : x0;
+    x = (fabs(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
+    for (int cap = 0; cap < 2; cap++) {
+      double dif[3] = {pnt[0], pnt[1], cap == 0 ? pnt[2] - size[1] : pnt[2] + size[1]};
+      mjo_ray_quad(mjo_dot3(vec, vec), mjo_dot3(vec, dif), mjo_dot3(dif, dif) - size[0] * size[0], &x0, &x1);
+      if (cap == 0) {
+        if ((pnt[2] + x0 * vec[2] >= size[1]) && (x0 < x)) x = x0;
+        if ((pnt[2] + x1 * vec[2] >= size[1]) && (x1 < x)) x = x1;
+      } else {
+        if ((pnt[2] + x0 * vec[2] <= -size[1]) && (x0 < x)) x = x0;
+        if ((pnt[2] + x1 * vec[2] <= -size[1]) && (x1 < x)) x = x1;
+      }
+    }
+    return x;
+  }
+  if (type == 4) { /* ellipsoid :109-129 */
+    double s[3], sv[3], sp[3];
+    for (int i = 0; i < 3; i++) { s[i] = mjo_safe_div(1, size[i] * size[i]); sv[i] = s[i] * vec[i]; sp[i] = s[i] * pnt[i]; }
+    double x0, x1;
+    mjo_ray_quad(mjo_dot3(sv, vec), mjo_dot3(sv, pnt), mjo_dot3(sp, pnt) - 1, &x0, &x1);
+    return isinf(x0) ? x1 : x0;
+  }
+  if (type == 5) { /* cylinder :235-268 */
+    double a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
+    double x0, x1;
+    mjo_ray_quad(a, b, c, &x0, &x1);
+    double x = isinf(x0) ? x1 : x0;
+    x = (fabs(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
+    for (int cap = 0; cap < 2; cap++) {
+      double t = mjo_safe_div((cap == 0 ? size[1] : -size[1]) - pnt[2], vec[2]);
+      double p0 = pnt[0] + t * vec[0], p1 = pnt[1] + t * vec[1];
+      if ((t >= 0) && (p0 * p0 + p1 * p1 <= size[0] * size[0]) && (t < x)) x = t;
+    }
+    return x;
+  }
+  if (type == 6) { /* box :132-161 */
+    static const int iface[6][2] = {{1, 2}, {0, 2}, {0, 1}, {1, 2}, {0, 2}, {0, 1}};
+    double best = INFINITY;
+    for (int f = 0; f < 6; f++) {
+      int ax = f % 3;
+      double x = f < 3 ? mjo_safe_div(size[ax] - pnt[ax], vec[ax]) : -mjo_safe_div(size[ax] + pnt[ax], vec[ax]);
+      double p0 = pnt[iface[f][0]] + x * vec[iface[f][0]], p1 = pnt[iface[f][1]] + x * vec[iface[f][1]];
+      int valid = (fabs(p0) <= size[iface[f][0]]) && (fabs(p1) <= size[iface[f][1]]) && (x >= 0);
+      if (valid && x < best) best = x;
+    }
+    return best;
+  }
+  return INFINITY;
+}
+#endif
+
+static REAL FN(sensor_cut)(REAL v, REAL cutoff, int datatype) { /* _apply_cutoff :41-53 */
+  if (!(cutoff > 0)) return v;
+  if (datatype == 0) return v < -cutoff ? -cutoff : (v > cutoff ? cutoff : v);
+  if (datatype == 1) return v < cutoff ? v : cutoff;
+  return v;
+}
+/* value of sensor s, component comp */
+static REAL FN(sensor_value)(const FN(MjoModel) * M, const FN(MjoWork) * w, int s, int comp) {
+  const mjhModelDesc* m = M->d;
+  int type = m->sns_type[s], obj = m->sns_objid[s], body = m->sns_bodyid[s], root = m->sns_rootid[s];
+  if (type == 9) return w->qpos[obj];  /* jointpos */
+  if (type == 10) return w->qvel[obj]; /* jointvel */
+  const REAL* rot = w->site_xmat + 9 * obj;
+  const REAL* pos = w->site_xpos + 3 * obj;
+  if (type == 7) { /* rangefinder: ray along the site's z axis (sensor.py:94-108, ray.py:327-372) */
+    REAL vec[3] = {rot[2], rot[5], rot[8]};
+    double best = INFINITY;
+    for (int q = m->sns_rfadr[s]; q < m->sns_rfadr[s + 1]; q++) {
+      int g = m->rf_geom[q];
+      const REAL *gm = w->geom_xmat + 9 * g, *gp = w->geom_xpos + 3 * g;
+      REAL d3[3] = {pos[0] - gp[0], pos[1] - gp[1], pos[2] - gp[2]}, lp[3], lv[3];
+      for (int i = 0; i < 3; i++) { lp[i] = gm[i] * d3[0] + gm[3 + i] * d3[1] + gm[6 + i] * d3[2]; lv[i] = gm[i] * vec[0] + gm[3 + i] * vec[1] + gm[6 + i] * vec[2]; }
+      double size[3] = {m->geom_size[3 * g], m->geom_size[3 * g + 1], m->geom_size[3 * g + 2]};
+      double dp[3] = {lp[0], lp[1], lp[2]}, dv[3] = {lv[0], lv[1], lv[2]};
+      double x = mjo_ray_geom(m->geom_type[g], size, dp, dv);
+      if (x < best) best = x;
+    }
+    return isinf(best) ? (REAL)-1 : (REAL)best;
+  }
+  const REAL* cvel = w->cvel + 6 * body;
+  const REAL* sc = w->subtree_com + 3 * root;
+  REAL dif[3] = {pos[0] - sc[0], pos[1] - sc[1], pos[2] - sc[2]};
+#define ROT_T(v, o) for (int i_ = 0; i_ < 3; i_++) (o)[i_] = rot[i_] * (v)[0] + rot[3 + i_] * (v)[1] + rot[6 + i_] * (v)[2];
+  if (type == 3) { REAL o[3]; ROT_T(cvel, o) return o[comp]; } /* gyro :246-251 */
+  REAL c[3], v[3], lin[3];
+  FN(cross3)(dif, cvel, c);
+  for (int i = 0; i < 3; i++) v[i] = cvel[3 + i] - c[i];
+  ROT_T(v, lin)
+  if (type == 2) return lin[comp]; /* velocimeter :235-245 */
+  /* accelerometer :379-399 with Data.cacc, which no stage of the reference ever writes (zeros from make_data) */
+  REAL ang[3], zero[3] = {0, 0, 0}, ca[3], av[3], acc[3], corr[3];
+  ROT_T(cvel, ang)
+  FN(cross3)(dif, zero, ca);
+  for (int i = 0; i < 3; i++) av[i] = (REAL)0 - ca[i];
+  ROT_T(av, acc)
+  FN(cross3)(ang, lin, corr);
+#undef ROT_T
+  return (acc[comp] + corr[comp]) + 0; /* + gravity term, zero for mujoco >= 3.3.7 (sensor.py:36-38) */
+}
+static void FN(sensors)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  for (int k = 0; k < m->nsensordata; k++) {
+    int s = m->slot_sensor[k];
+    if (s < 0) continue; /* slot keeps the caller's value */
+    w->sensordata[k] = FN(sensor_cut)(FN(sensor_value)(M, w, s, k - m->sns_adr[s]), M->sns_cutoff[s], m->sns_datatype[s]);
+  }
+}
+
 static void FN(forward_env)(const FN(MjoModel) * M, FN(MjoWork) * w, int stages, int flags, int with_cams) {
   const mjhModelDesc* m = M->d;
   if (stages & 0x7f) { FN(kinematics)(M, w, with_cams); FN(com_pos)(M, w); }
@@ -1669,6 +1808,7 @@ static void FN(forward_env)(const FN(MjoModel) * M, FN(MjoWork) * w, int stages,
   if (stages & 0x40) {
     if (m->nefc == 0) { for (int d = 0; d < m->nv; d++) w->qacc[d] = w->qacc_smooth[d]; }
     else FN(solve)(M, w, flags & MJH_FLAG_FIXED_ITERATIONS);
+    if (with_cams && m->nsensor > 0) FN(sensors)(M, w); /* the returned Data carries the sensors of its own forward pass (RK4: stage 0) */
   }
 }
 

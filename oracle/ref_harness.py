@@ -60,19 +60,19 @@ def load():
     return ns
 
 
-def put_model(ref, lite, dtype=None):
-    """reference device_put on an MJCF-subset-compiled model (sensors stripped: out of scope)."""
+def put_model(ref, lite, dtype=None, keep_sensors=True):
+    """reference device_put on an MJCF-subset-compiled model."""
     import copy
 
     lite = copy.copy(lite)
     lite.opt = copy.copy(lite.opt)
-    # sensors never feed dynamics (SURVEY section 2); the stub model carries none
-    lite.nsensor = 0
-    lite.nsensordata = 0
     import numpy as np
 
-    for k in ("sensor_type", "sensor_dim", "sensor_adr", "sensor_objid"):
-        setattr(lite, k, np.zeros(0, dtype=np.int32))
-    lite.sensor_cutoff = np.zeros(0)
+    if not keep_sensors:  # goldens recorded before sensors were on the native path keep their recorded (sensor-less) layout
+        lite.nsensor = 0
+        lite.nsensordata = 0
+        for k in ("sensor_type", "sensor_dim", "sensor_adr", "sensor_objid", "sensor_objtype", "sensor_needstage", "sensor_datatype", "sensor_reftype", "sensor_refid"):
+            setattr(lite, k, np.zeros(0, dtype=np.int32))
+        lite.sensor_cutoff = np.zeros(0)
     mj = ref.mujoco.MjModel(lite)
     return ref.device.device_put(mj, dtype=dtype)

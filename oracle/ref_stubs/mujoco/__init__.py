@@ -109,6 +109,8 @@ for _n in _FLT0:
 _DEFAULTS["mesh_face"] = _empty((0, 3), np.int32)
 _DEFAULTS["mesh_vert"] = _empty((0, 3), np.float64)
 _DEFAULTS["hfield_size"] = _empty((0, 4), np.float64)
+# one opaque dummy material: ray.precompute_ray_data indexes mat_rgba[geom_matid] even for geom_matid == -1
+_DEFAULTS["mat_rgba"] = lambda l: np.ones((1, 4), dtype=np.float32)
 _DEFAULTS["tendon_actfrclimited"] = _empty((0,), np.uint8)
 _DEFAULTS["sensor_intprm"] = lambda l: np.zeros((l.nsensor, 3), dtype=np.int32)
 

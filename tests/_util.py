@@ -18,10 +18,23 @@ INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_a
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz"))
 
 
-def load_model(xml, overrides=None, dtype=torch.float64):
+def strip_sensors(lite):
+    """Drops the model's sensors (the reference cannot run rangefinders in float32: ray.py:317 keeps float64 sizes and the
+    mixed-dtype dot products raise, so float32 goldens of models with rangefinders were recorded without sensors)."""
+    lite.nsensor = 0
+    lite.nsensordata = 0
+    for k in ("sensor_type", "sensor_dim", "sensor_adr", "sensor_objid", "sensor_objtype", "sensor_needstage", "sensor_datatype", "sensor_reftype", "sensor_refid"):
+        setattr(lite, k, np.zeros(0, dtype=np.int32))
+    lite.sensor_cutoff = np.zeros(0)
+    return lite
+
+
+def load_model(xml, overrides=None, dtype=torch.float64, keep_sensors=True):
     lite = mt.mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
     for k, v in (overrides or {}).items():
         setattr(lite.opt, k, v)
+    if not keep_sensors:
+        strip_sensors(lite)
     return mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
 
 
@@ -30,7 +43,7 @@ class Golden:
         self.z = np.load(os.path.join(GOLD, case + ".npz"))
         self.meta = json.loads(str(self.z["meta"]))
         self.dtype = getattr(torch, self.meta["dtype"])
-        self.model = load_model(self.meta["xml"], self.meta["overrides"], self.dtype)
+        self.model = load_model(self.meta["xml"], self.meta["overrides"], self.dtype, keep_sensors=self.meta.get("keep_sensors", False))
         self.nenv, self.nsteps = self.meta["nenv"], self.meta["nsteps"]
 
     def input_data(self, env=None):

@@ -58,6 +58,8 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("convex_meshes", {}, torch.float64, 32),
     ("convex_primitives", {}, torch.float64, 32),
     ("convex_primitives", {}, torch.float32, 32),
+    ("sensor_rig", {}, torch.float64, 64),                                         # sensors: IMU, rangefinders, joint sensors
+    ("sensor_rig", {"integrator": 1}, torch.float32, 64),                          # ... RK4, float32 (rays intersect in double)
     ("ant_frictionloss", {}, torch.float64, 64),                                   # dof frictionloss rows, Newton
     ("ant_frictionloss", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),      # ... CG (100 iterations on a piecewise-quadratic cost amplify rounding)
     ("halfcheetah", {}, torch.float64, 64),
@@ -78,6 +80,12 @@ def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_li
             q[:, a : a + 3] += torch.tensor(0.01 * rng.randn(B, 3))
             q[:, a + 3 : a + 7] += torch.tensor(0.03 * rng.randn(B, 4))
         d = d.replace(qpos=q, qvel=torch.tensor(0.2 * rng.randn(B, mx.nv)))
+    if xml == "sensor_rig":  # move and spin the rover so every sensor reads something different per environment
+        q = d.qpos.clone()
+        q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))
+        q[:, 3:7] += torch.tensor(0.2 * rng.randn(B, 4))
+        q[:, 7:] += torch.tensor(0.3 * rng.randn(B, mx.nq - 7))
+        d = d.replace(qpos=q, qvel=torch.tensor(0.5 * rng.randn(B, mx.nv)))
     if dtype != torch.float64:
         d = d.to(dtype)
     mdev = mx.to("cuda")
