@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 3
+#define MJH_ABI_VERSION 4
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -75,7 +75,8 @@ extern "C" {
 /* double scalars */
 #define MJH_MODEL_REALS(X)                                                                       \
   X(timestep) X(impratio) X(tolerance) X(ls_tolerance) X(meaninertia)                            \
-  X(gravity_x) X(gravity_y) X(gravity_z)
+  X(gravity_x) X(gravity_y) X(gravity_z)                                                         \
+  X(density) X(viscosity) X(wind_x) X(wind_y) X(wind_z) /* fluid model of passive.py:31-78; all zero = no fluid forces */
 
 /* const int32_t* arrays (length in comment) */
 #define MJH_MODEL_INT_ARRAYS(X)                                                                  \

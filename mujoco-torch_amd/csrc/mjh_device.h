@@ -98,6 +98,8 @@ struct DevModel {
   MJH_MODEL_INTS(X)
 #undef X
   REAL timestep, impratio, gravity[3];
+  REAL density, viscosity, wind[3];  // fluid model (passive.py:31-78)
+  int has_fluid;
   double meaninertia, tolerance, ls_tolerance;  // python floats in the reference (solver.py:256-265)
 #define X(n) const int* n;
   MJH_MODEL_INT_ARRAYS(X)

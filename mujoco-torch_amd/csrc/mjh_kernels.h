@@ -1015,6 +1015,7 @@ struct Env {
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
+  template <bool FLUID>
   __device__ __forceinline__ void velocity() {
     const int l = lane();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
@@ -1097,6 +1098,71 @@ struct Env {
       }
       wave_sync();
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
+      if (FLUID) {  // (own kernel instantiation: its registers must not weigh on fluid-free models) passive._fluid :158-173 with _inertia_box_fluid_model :31-78: one lane per body, wrench staged in cfrc
+        for (int b = l; b < nb; b += W) {
+          const REAL pi = (REAL)3.14159265358979323846;
+          const REAL* inr = M.body_inertia + 3 * b;
+          const REAL mass = M.body_mass[b];
+          REAL box[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            REAL s3 = (inr[0] * (i == 0 ? (REAL)-1 : (REAL)1) + inr[1] * (i == 1 ? (REAL)-1 : (REAL)1)) + inr[2] * (i == 2 ? (REAL)-1 : (REAL)1);
+            s3 = s3 > (REAL)1e-12 ? s3 : (REAL)1e-12;
+            const REAL mm = mass > (REAL)(float)1e-12 ? mass : (REAL)(float)1e-12;
+            box[i] = r_sqrt<REAL>(((REAL)6.0 * s3) / mm) * (REAL)(mass > 0);
+          }
+          REAL xi[9];
+#pragma unroll
+          for (int i = 0; i < 9; i++) xi[i] = out.ximat[(e * nb + b) * 9 + i];
+          const REAL* cv = S.cvel() + 6 * b;
+          const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
+          const REAL off[3] = {S.xipos()[3 * b] - rc[0], S.xipos()[3 * b + 1] - rc[1], S.xipos()[3 * b + 2] - rc[2]};
+          REAL c[3], v3[3], lvel[6], lwind[3];
+          cross3(off, cv, c);  // math.transform_motion :437-452
+#pragma unroll
+          for (int i = 0; i < 3; i++) v3[i] = cv[3 + i] - c[i];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            lvel[3 + i] = xi[i] * v3[0] + xi[3 + i] * v3[1] + xi[6 + i] * v3[2];
+            lvel[i] = xi[i] * cv[0] + xi[3 + i] * cv[1] + xi[6 + i] * cv[2];
+            lwind[i] = xi[i] * M.wind[0] + xi[3 + i] * M.wind[1] + xi[6 + i] * M.wind[2];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; i++) lvel[3 + i] = lvel[3 + i] + (-lwind[i]);
+          const REAL diam = ((box[0] + box[1]) + box[2]) / 3;
+          const REAL d3 = diam * diam * diam;
+          REAL fa[3], fv[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            fa[i] = lvel[i] * -pi * d3 * M.viscosity;
+            fv[i] = lvel[3 + i] * (REAL)-3.0 * pi * diam * M.viscosity;
+          }
+          const REAL sv[3] = {box[1] * box[2], box[0] * box[2], box[0] * box[1]};
+          const REAL b4[3] = {r_pow<REAL>(box[0], (REAL)4), r_pow<REAL>(box[1], (REAL)4), r_pow<REAL>(box[2], (REAL)4)};
+          const REAL sa[3] = {box[0] * (b4[1] + b4[2]), box[1] * (b4[0] + b4[2]), box[2] * (b4[0] + b4[1])};
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            fv[i] = fv[i] - (REAL)0.5 * M.density * sv[i] * r_abs(lvel[3 + i]) * lvel[3 + i];
+            fa[i] = fa[i] - ((REAL)1.0 * M.density * sa[i] * r_abs(lvel[i]) * lvel[i] / (REAL)64.0);
+          }
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            S.cfrc()[6 * b + i] = xi[3 * i] * fv[0] + xi[3 * i + 1] * fv[1] + xi[3 * i + 2] * fv[2];        // force
+            S.cfrc()[6 * b + 3 + i] = xi[3 * i] * fa[0] + xi[3 * i + 1] * fa[1] + xi[3 * i + 2] * fa[2];    // torque
+          }
+        }
+        wave_sync();
+        for (int d = l; d < nv; d += W) {  // support.apply_ft :169-181, summed over bodies in order
+          REAL acc = 0;
+          for (int b = 0; b < nb; b++) {
+            REAL jp[3], jr[3];
+            jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+            acc += dot3(jp, S.cfrc() + 6 * b) + dot3(jr, S.cfrc() + 6 * b + 3);
+          }
+          S.qfrc_passive()[d] = S.qfrc_passive()[d] + acc;
+        }
+        wave_sync();
+      }
     }
     wave_sync();
     STAMP(35);
@@ -1729,9 +1795,10 @@ struct Env {
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
+  template <bool FLUID>
   __device__ __forceinline__ void run_vel() {
     STAMP(30);
-    velocity();
+    velocity<FLUID>();
     if (KA.stages & 0x60) actuation();
   }
 
@@ -1838,7 +1905,8 @@ __global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
     if (PHASE == 0) E.run_kin();
     else if (PHASE == 1) E.run_crb();
     else if (PHASE == 2) E.run_con();
-    else if (PHASE == 3) E.run_vel();
+    else if (PHASE == 3) E.template run_vel<false>();
+    else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
     else E.run_sol();
     wave_sync();
   }

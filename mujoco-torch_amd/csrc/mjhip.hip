@@ -77,9 +77,10 @@ const char* const kStageLeaves[] = {
     "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint"};
 // ... plus, for models with convex pairs, the contact leaves the convex kernel hands to the constraint phase
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
-bool is_stage_leaf(const char* name, bool has_convex) {
+bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid) {
   for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
   if (has_convex) for (const char* s : kConvexStageLeaves) if (!strcmp(s, name)) return true;
+  if (has_fluid && !strcmp(name, "ximat")) return true;  // the fluid model needs the inertial frames of the stage (passive.py:31-78)
   return false;
 }
 
@@ -93,6 +94,9 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
   M.timestep = (REAL)d->timestep;
   M.impratio = (REAL)d->impratio;
+  M.density = (REAL)d->density; M.viscosity = (REAL)d->viscosity;
+  M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
+  M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M.gravity[0] = (REAL)d->gravity_x; M.gravity[1] = (REAL)d->gravity_y; M.gravity[2] = (REAL)d->gravity_z;
   M.meaninertia = d->meaninertia; M.tolerance = d->tolerance; M.ls_tolerance = d->ls_tolerance;
 #define X(n) fix.push_back({(const void**)&M.n, bb.add(d->n, sizeof(int32_t) * (size_t)d->len_##n)});
@@ -259,7 +263,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
     };
     for (size_t i = 0; i < out->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0)) out->work_reals += out->leaf_count[i];
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
 
@@ -282,6 +286,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   }
   SET_PACK(0) SET_PACK(3)
 #undef SET_PACK
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
+  if (out->pack2[3]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[3]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   return 0;
 }
@@ -290,20 +296,21 @@ template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
-  a.off = m->off[P];
+  constexpr int A = P == 5 ? 3 : P;  // kernel 5 is the velocity phase with fluid forces: same arena as phase 3
+  a.off = m->off[A];
   a.env_begin = begin; a.env_count = count;
-  a.lds_reals = m->lds_bytes[P] / (int)sizeof(REAL);
+  a.lds_reals = m->lds_bytes[A] / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * m->lds_bytes[P]), stream, a);
+  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * m->lds_bytes[A]), stream, a);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  if ((P == 0 || P == 3) && m->pack2[P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
+  if ((P == 0 || P == 3 || P == 5) && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
     const int64_t even = a.B & ~(int64_t)1;
-    int rc = launch_range<REAL, P, ((P == 0 || P == 3) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
+    int rc = launch_range<REAL, P, ((P == 0 || P == 3 || P == 5) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
     if (rc) return rc;
     return launch_range<REAL, P, MJH_WAVE>(m, a, even, a.B - even, stream);
   }
@@ -324,7 +331,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
-  if ((st & 0x70) && (rc = launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x70) && (rc = a.M.has_fluid ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), 0, stream, a);
@@ -369,7 +376,7 @@ int run(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* 
 #undef X
     };
     for (size_t i = 0; i < m->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
   }
   a.W.qvel0 = w; w += (int64_t)M.nv * B;
   a.W.kqvel = w; w += (int64_t)M.nv * B;

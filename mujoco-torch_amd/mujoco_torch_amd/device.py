@@ -88,8 +88,6 @@ def _validate(m):
         raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
     if np.any(np.asarray(_get(m, "body_gravcomp", lambda: np.zeros(int(m.nbody)))) != 0):
         raise NotImplementedError("gravity compensation is not supported by the native stepper yet.")
-    if float(opt.density) > 0 or float(opt.viscosity) > 0 or np.any(np.asarray(opt.wind) != 0):
-        raise NotImplementedError("fluid forces are outside the hot-path scope.")
 
 
 def _t(x, dtype):
@@ -121,7 +119,7 @@ def _option(opt, dtype) -> Option:
         o_friction=_t(_get(opt, "o_friction", lambda: np.array([1, 1, 0.005, 1e-4, 1e-4])), dtype),
         disableactuator=int(_get(opt, "disableactuator", 0)),
         sdf_initpoints=int(_get(opt, "sdf_initpoints", 40)),
-        has_fluid_params=False,
+        has_fluid_params=bool(float(opt.density) > 0 or float(opt.viscosity) > 0 or np.any(np.asarray(opt.wind) != 0)),
         batch_size=[],
     )
 

@@ -93,6 +93,8 @@ def pack_model(m, dtype: torch.dtype):
         timestep=float(f64(m.opt.timestep)[0]), impratio=float(f64(m.opt.impratio)[0]),
         tolerance=float(m.opt.tolerance), ls_tolerance=float(m.opt.ls_tolerance),
         meaninertia=float(m.stat.meaninertia), gravity_x=float(grav[0]), gravity_y=float(grav[1]), gravity_z=float(grav[2]),
+        density=float(f64(m.opt.density)[0]), viscosity=float(f64(m.opt.viscosity)[0]),
+        wind_x=float(f64(m.opt.wind)[0]), wind_y=float(f64(m.opt.wind)[1]), wind_z=float(f64(m.opt.wind)[2]),
     )
     i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32)).reshape(-1)
     nu = m.nu
@@ -157,7 +159,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 3
+    desc.abi_version = 4
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

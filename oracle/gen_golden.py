@@ -65,6 +65,10 @@ CASES = {
     # geom type / joint sensors, with cutoffs
     "sensor_rig_f64": ("sensor_rig", {}, "float64", 4, 3, "sensor_rig"),
     "sensor_rig_rk4_f64": ("sensor_rig", {"integrator": 1}, "float64", 2, 2, "sensor_rig"),
+    # fluid forces (passive.py:31-78, :158-173): the bundled swimmer (density only) and a variant with viscosity and wind
+    "swimmer_f64": ("swimmer", {}, "float64", 2, 3, "generic"),
+    "swimmer_viscous_wind_f64": ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, "float64", 2, 2, "generic"),
+    "swimmer_rk4_f32": ("swimmer", {"integrator": 1, "viscosity": 0.02}, "float32", 2, 2, "generic"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
@@ -145,7 +149,7 @@ def main(only=None):
         dtype = getattr(torch, dtype_s)
         lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
         for k, v in overrides.items():
-            setattr(lite.opt, k, v)
+            setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
         has_convex = any(int(t) in (6, 7) for t in lite.geom_type)
         # float32 + rangefinder raises inside the reference (float64 ray tables, ray.py:317): record those cases sensor-less
         keep_sensors = not (dtype != torch.float64 and any(int(t) == 7 for t in getattr(lite, "sensor_type", [])))

@@ -28,6 +28,9 @@ static void FN(model_init)(FN(MjoModel) * M, const mjhModelDesc* d) {
   M->timestep = (REAL)d->timestep;
   M->impratio = (REAL)d->impratio;
   M->meaninertia = (REAL)d->meaninertia;
+  M->density = (REAL)d->density; M->viscosity = (REAL)d->viscosity;
+  M->wind[0] = (REAL)d->wind_x; M->wind[1] = (REAL)d->wind_y; M->wind[2] = (REAL)d->wind_z;
+  M->has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M->gravity[0] = (REAL)d->gravity_x; M->gravity[1] = (REAL)d->gravity_y; M->gravity[2] = (REAL)d->gravity_z;
 #define X(n) { M->n = FN(ralloc)((size_t)d->len_##n); for (int64_t i = 0; i < d->len_##n; i++) M->n[i] = (REAL)d->n[i]; }
   MJH_MODEL_REAL_ARRAYS(X)

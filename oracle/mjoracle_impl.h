@@ -81,6 +81,8 @@
 typedef struct FN(MjoModel) {
   const mjhModelDesc* d;
   REAL timestep, impratio, meaninertia, gravity[3];
+  REAL density, viscosity, wind[3];
+  int has_fluid;
 #define X(n) REAL* n;
   MJH_MODEL_REAL_ARRAYS(X)
 #undef X
@@ -1304,6 +1306,57 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
       }
     }
     for (int d = 0; d < nv; d++) w->qfrc_passive[d] = (0 + w->qfrc_passive[d]) - M->dof_damping[d] * w->qvel[d];
+    if (M->has_fluid) { /* passive._fluid :158-173 with _inertia_box_fluid_model :31-78 */
+      const REAL pi = (REAL)3.14159265358979323846;
+      for (int d = 0; d < nv; d++) w->tmp_nv[d] = 0;
+      for (int b = 0; b < nb; b++) {
+        const REAL* inr = M->body_inertia + 3 * b;
+        REAL mass = M->body_mass[b], box[3];
+        for (int i = 0; i < 3; i++) {
+          REAL s3 = (inr[0] * (i == 0 ? (REAL)-1 : (REAL)1) + inr[1] * (i == 1 ? (REAL)-1 : (REAL)1)) + inr[2] * (i == 2 ? (REAL)-1 : (REAL)1);
+          s3 = s3 > (REAL)1e-12 ? s3 : (REAL)1e-12;
+          REAL mm = mass > (REAL)(float)1e-12 ? mass : (REAL)(float)1e-12;
+          box[i] = R_SQRT(((REAL)6.0 * s3) / mm) * (REAL)(mass > 0);
+        }
+        const REAL *xi = w->ximat + 9 * b, *cv = w->cvel + 6 * b;
+        const REAL* rc = w->subtree_com + 3 * m->body_rootid[b];
+        REAL off[3] = {w->xipos[3 * b] - rc[0], w->xipos[3 * b + 1] - rc[1], w->xipos[3 * b + 2] - rc[2]};
+        REAL c[3], v3[3], lvel[6], lwind[3];
+        FN(cross3)(off, cv, c); /* math.transform_motion :437-452 */
+        for (int i = 0; i < 3; i++) v3[i] = cv[3 + i] - c[i];
+        for (int i = 0; i < 3; i++) {
+          lvel[3 + i] = xi[i] * v3[0] + xi[3 + i] * v3[1] + xi[6 + i] * v3[2];
+          lvel[i] = xi[i] * cv[0] + xi[3 + i] * cv[1] + xi[6 + i] * cv[2];
+          lwind[i] = xi[i] * M->wind[0] + xi[3 + i] * M->wind[1] + xi[6 + i] * M->wind[2];
+        }
+        for (int i = 0; i < 3; i++) lvel[3 + i] = lvel[3 + i] + (-lwind[i]);
+        REAL diam = ((box[0] + box[1]) + box[2]) / 3;
+        REAL d3 = diam * diam * diam;
+        REAL fa[3], fv[3];
+        for (int i = 0; i < 3; i++) {
+          fa[i] = lvel[i] * -pi * d3 * M->viscosity;
+          fv[i] = lvel[3 + i] * (REAL)-3.0 * pi * diam * M->viscosity;
+        }
+        REAL sv[3] = {box[1] * box[2], box[0] * box[2], box[0] * box[1]};
+        REAL b4[3] = {R_POW(box[0], (REAL)4), R_POW(box[1], (REAL)4), R_POW(box[2], (REAL)4)};
+        REAL sa[3] = {box[0] * (b4[1] + b4[2]), box[1] * (b4[0] + b4[2]), box[2] * (b4[0] + b4[1])};
+        for (int i = 0; i < 3; i++) {
+          fv[i] = fv[i] - (REAL)0.5 * M->density * sv[i] * R_FABS(lvel[3 + i]) * lvel[3 + i];
+          fa[i] = fa[i] - ((REAL)1.0 * M->density * sa[i] * R_FABS(lvel[i]) * lvel[i] / (REAL)64.0);
+        }
+        REAL force[3], torque[3];
+        for (int i = 0; i < 3; i++) {
+          force[i] = xi[3 * i] * fv[0] + xi[3 * i + 1] * fv[1] + xi[3 * i + 2] * fv[2];
+          torque[i] = xi[3 * i] * fa[0] + xi[3 * i + 1] * fa[1] + xi[3 * i + 2] * fa[2];
+        }
+        for (int d = 0; d < nv; d++) { /* support.apply_ft :169-181, summed over bodies in order */
+          REAL jp[3], jr[3];
+          FN(jac_dof)(M, w, w->xipos + 3 * b, b, d, jp, jr);
+          w->tmp_nv[d] += FN(dot3)(jp, force) + FN(dot3)(jr, torque);
+        }
+      }
+      for (int d = 0; d < nv; d++) w->qfrc_passive[d] = w->qfrc_passive[d] + w->tmp_nv[d];
+    }
   }
   /* smooth.rne :427-467 */
   for (int b = 0; b < nb; b++) {

@@ -32,7 +32,7 @@ def strip_sensors(lite):
 def load_model(xml, overrides=None, dtype=torch.float64, keep_sensors=True):
     lite = mt.mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
     for k, v in (overrides or {}).items():
-        setattr(lite.opt, k, v)
+        setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
     if not keep_sensors:
         strip_sensors(lite)
     return mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)

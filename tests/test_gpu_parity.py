@@ -60,6 +60,7 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("convex_primitives", {}, torch.float32, 32),
     ("sensor_rig", {}, torch.float64, 64),                                         # sensors: IMU, rangefinders, joint sensors
     ("sensor_rig", {"integrator": 1}, torch.float32, 64),                          # ... RK4, float32 (rays intersect in double)
+    ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, torch.float64, 64),  # fluid forces: density + viscosity + wind
     ("ant_frictionloss", {}, torch.float64, 64),                                   # dof frictionloss rows, Newton
     ("ant_frictionloss", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),      # ... CG (100 iterations on a piecewise-quadratic cost amplify rounding)
     ("halfcheetah", {}, torch.float64, 64),
