@@ -365,9 +365,12 @@ __device__ __forceinline__ REAL dot_seq(const REAL* a, int sa, const REAL* b, in
 }
 
 // =====================================================================================================================
-template <typename REAL, int W = 64>
+template <typename REAL, int W = 64, bool FRIC = false>
 struct Env {
   __device__ __forceinline__ static int lane() { return sub_lane<W>(); }
+  // dof-frictionloss rows of the SOLVER phase: its frictionloss-free instantiation (kernel 4) carries none of their code,
+  // models that have such rows run kernel 6
+  __device__ __forceinline__ static int nf_() { return FRIC ? M.nf : 0; }
   LdsView<REAL> S;
   int64_t e;      // environment index
   int flags;
@@ -1347,7 +1350,7 @@ struct Env {
   // efc_J @ v (- sub).  A joint-limit row has one non-zero (column lim_dof[r]); the zeros of the dense product add
   // exact zeros, so the single term is the same value.
   __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {
-    const int nv = M.nv, nl = M.nf + M.nl;  // single-column rows (frictionloss, joint limits) come first
+    const int nv = M.nv, nl = nf_() + M.nl;  // single-column rows (frictionloss, joint limits) come first
     for (int r = lane(); r < M.nefc; r += W) {
       const REAL s = r < nl ? S.efc_Jl()[r] * v[lim_dof_lds()[r]] : dot_seq(S.efc_Jc() + (r - nl) * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
@@ -1358,7 +1361,7 @@ struct Env {
     const int l = lane();
     const int nv = M.nv, nefc = M.nefc;
     REAL part = 0, fneg = 0, fpos = 0;
-    const int nf = M.nf;
+    const int nf = nf_();
     for (int r = l; r < nefc; r += W) {
       const REAL ja = S.s_Jaref()[r];
       bool act = (ja < 0);
@@ -1395,7 +1398,7 @@ struct Env {
   // whether row r (a single-column row: frictionloss first, then joint limits) is in the quadratic (active) set
   __device__ __forceinline__ bool crow_active(int r) const {
     const REAL ja = S.s_Jaref()[r];
-    if (r >= M.nf) return ja < 0;
+    if (r >= nf_()) return ja < 0;
     const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
     const REAL rr = 1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL);
     return !((ja <= -rr * fl) && (fl > 0)) && !((ja >= rr * fl) && (fl > 0));
@@ -1407,9 +1410,9 @@ struct Env {
     const int nv = M.nv, nefc = M.nefc;
     {  // rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
-      const int nl = M.nf + M.nl;
+      const int nl = nf_() + M.nl;
       if (nl > 0 && l < nv) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch column l
-        const int nslot = M.nf > 0 ? 2 : 1;  // without frictionloss rows the second slot of every dof is empty
+        const int nslot = nf_() > 0 ? 2 : 1;  // without frictionloss rows the second slot of every dof is empty
         for (int q = 0; q < nslot; q++) {
           const int lr = dof_limrow_lds()[2 * l + q];
           if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
@@ -1441,14 +1444,14 @@ struct Env {
     } else {
       // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
       // only the lower triangle is ever read by the factorisation: one lane per packed entry (i, j <= i)
-      const int np = (nv * (nv + 1)) / 2, nl = M.nf + M.nl;
+      const int np = (nv * (nv + 1)) / 2, nl = nf_() + M.nl;
       for (int w0 = 0; w0 < np; w0 += W) {
         const int w = w0 + l;
         int i, j;
         tri_unpack(w < np ? w : 0, i, j);
         REAL s = 0;
         if (nl > 0 && i == j) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
-          const int nslot = M.nf > 0 ? 2 : 1;
+          const int nslot = nf_() > 0 ? 2 : 1;
           for (int q = 0; q < nslot; q++) {
             const int lr = dof_limrow_lds()[2 * i + q];
             if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
@@ -1477,7 +1480,7 @@ struct Env {
   __device__ __forceinline__ LSPoint ls_point(const REAL* qg, REAL alpha) {  // point_fn :396-422
     REAL q0 = 0, q1 = 0, q2 = 0;
     REAL f0n = 0, f0p = 0, f1n = 0, f1p = 0;
-    const int nf = M.nf;
+    const int nf = nf_();
     for (int r = lane(); r < M.nefc; r += W) {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
       const REAL x = ja + alpha * jv;
@@ -1613,10 +1616,10 @@ struct Env {
     const int nv = M.nv, nefc = M.nefc;
     if (M.sol_qm_lds) row_load<W>(S.qMs(), out.qM, nv * nv, e);
     if (nefc > 0) {
-      const int l = lane(), nl = M.nf + M.nl;
+      const int l = lane(), nl = nf_() + M.nl;
       const REAL* gJ = out.efc_J + e * nefc * nv;
       for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
-      for (int r = l; r < M.nf; r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
+      for (int r = l; r < nf_(); r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
       if (nl > 0) for (int d = l; d < 2 * nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
       {
         const int n = (nefc - nl) * nv;
@@ -1901,13 +1904,13 @@ __global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
   const int sub = (W == MJH_WAVE) ? 0 : (int)(threadIdx.x / W);  // folded away for a whole-wave environment: everything stays scalar
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
-    Env<REAL, W> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
+    Env<REAL, W, PHASE == 6> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
     if (PHASE == 0) E.run_kin();
     else if (PHASE == 1) E.run_crb();
     else if (PHASE == 2) E.run_con();
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
-    else E.run_sol();
+    else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
     wave_sync();
   }
 }

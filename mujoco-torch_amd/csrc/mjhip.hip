@@ -286,6 +286,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   }
   SET_PACK(0) SET_PACK(3)
 #undef SET_PACK
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
   if (out->pack2[3]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[3]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
@@ -296,7 +297,7 @@ template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
-  constexpr int A = P == 5 ? 3 : P;  // kernel 5 is the velocity phase with fluid forces: same arena as phase 3
+  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : P);  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
   a.off = m->off[A];
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = m->lds_bytes[A] / (int)sizeof(REAL);
@@ -337,7 +338,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), 0, stream, a);
     HIP_TRY(hipGetLastError());
   }
-  if ((st & 0x60) && (rc = launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
+  if ((st & 0x60) && (rc = a.M.nf > 0 ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
 
