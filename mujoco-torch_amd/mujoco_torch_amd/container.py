@@ -95,8 +95,13 @@ class MjTensorClass(metaclass=_Meta):
     def __setattr__(self, name, value):
         if name in type(self)._field_names:
             self._fields[name] = value
+            self._touch()
         else:
             object.__setattr__(self, name, value)
+
+    def _touch(self):
+        """Bumps the leaf-set version (forward.py caches raw device pointers per container and version)."""
+        object.__setattr__(self, "_ver", self.__dict__.get("_ver", 0) + 1)
 
     @classmethod
     def fields(cls):
@@ -119,7 +124,7 @@ class MjTensorClass(metaclass=_Meta):
         object.__setattr__(new, "_fields", d)
         object.__setattr__(new, "_bs", tuple(self._bs if bs is None else bs))
         for k, v in self.__dict__.items():
-            if k not in ("_fields", "_bs"):
+            if k not in ("_fields", "_bs", "_ver", "_ptr_cache"):
                 object.__setattr__(new, k, v)
         return new
 
@@ -138,6 +143,7 @@ class MjTensorClass(metaclass=_Meta):
 
     def update_(self, **kwargs: Any):
         self._fields.update(kwargs)
+        self._touch()
         return self
 
     def tree_replace(self, params: dict):

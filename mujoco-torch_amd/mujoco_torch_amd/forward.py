@@ -72,6 +72,26 @@ def _fill_ptrs(d: Data, names, dtype, device, check=True):
     return ptrs, keep
 
 
+import os as _os
+
+_PTR_CACHE = _os.environ.get("MJH_NO_PTR_CACHE") != "1"  # diagnostic switch (tools/host_overhead.py)
+
+
+def _ptrs_cached(d: Data, tag, names, dtype, device, check=True):
+    """``_fill_ptrs`` memoised on the container: the ~80 attribute walks and ``data_ptr()`` calls are most of the host cost
+    of a step at small batches.  Valid while the leaf SET is unchanged (``replace`` makes a new container, ``update_`` /
+    attribute assignment bump the version); in-place writes into the tensors keep their pointers."""
+    con = d.contact
+    key = (tag, d.__dict__.get("_ver", 0), id(con), con.__dict__.get("_ver", 0), dtype, device)
+    hit = d.__dict__.get("_ptr_cache") if _PTR_CACHE else None
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    ptrs, keep = _fill_ptrs(d, names, dtype, device, check)
+    if all(k is native.data_field_tensor(d, n) for k, n in zip(keep, [n for n in names if native.data_field_tensor(d, n) is not None])):
+        object.__setattr__(d, "_ptr_cache", (key, ptrs, keep))  # only when no contiguous copy had to be made
+    return ptrs, keep
+
+
 def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None = None, stages: int = native.STAGE_ALL) -> Data:
     qpos = d.qpos
     if qpos.device.type != "cuda":
@@ -89,7 +109,7 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
     names = _written_names(m, step)
     if not step and not (stages & 0x40):
         names = [n for n in names if n != "sensordata"]  # sensors belong to complete forward passes
-    in_ptrs, keep_in = _fill_ptrs(d, _ALL_NAMES, dtype, device)
+    in_ptrs, keep_in = _ptrs_cached(d, ("in", id(m.tables)), _ALL_NAMES, dtype, device)
     if out is None:
         new = {}
         for n in names:
@@ -102,7 +122,7 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
             res = res.replace(contact=d.contact.replace(**contact_kw))
     else:
         res = out
-    out_ptrs, keep_out = _fill_ptrs(res, names, dtype, device, check=out is not None)
+    out_ptrs, keep_out = _ptrs_cached(res, ("out", id(m.tables), step, stages), names, dtype, device, check=True) if out is not None else _fill_ptrs(res, names, dtype, device, check=False)
     stream = torch.cuda.current_stream(device).cuda_stream
     flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
     with torch.cuda.device(device):

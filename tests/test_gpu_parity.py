@@ -180,3 +180,28 @@ def test_collision_kat_gpu(name):
 
     xml, check = kat.KATS[name]
     check(*kat.collide(xml, runner))
+
+
+def test_pointer_cache_follows_leaf_replacement():
+    """step(..., out=) memoises raw pointers per container version: swapping a leaf (update_ / attribute assignment) must be
+    seen by the next call, in-place writes must be seen too, and results must equal the uncached path."""
+    mx = load_model("humanoid", {"solver": 1})
+    B = 8
+    rng = np.random.RandomState(5)
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)))
+    mdev, a, b = mx.to("cuda"), d.to("cuda"), d.to("cuda").clone()
+    mt.step(mdev, a, out=b)                       # fills the caches of a (input) and b (output)
+    ref1 = mt.step(mdev, a)                       # fresh outputs, same inputs
+    assert torch.equal(b.qpos, ref1.qpos) and torch.equal(b.qacc, ref1.qacc)
+    a.qvel.mul_(2.0)                              # in-place write: same storage
+    mt.step(mdev, a, out=b)
+    ref2 = mt.step(mdev, a)
+    assert torch.equal(b.qvel, ref2.qvel) and not torch.equal(ref2.qvel, ref1.qvel)
+    a.update_(qvel=(a.qvel * 0.25).contiguous())  # new tensor under the same container
+    mt.step(mdev, a, out=b)
+    ref3 = mt.step(mdev, a)
+    assert torch.equal(b.qvel, ref3.qvel) and not torch.equal(ref3.qvel, ref2.qvel)
+    a.ctrl = torch.full_like(a.ctrl, 0.3)         # attribute assignment
+    mt.step(mdev, a, out=b)
+    ref4 = mt.step(mdev, a)
+    assert torch.equal(b.qacc, ref4.qacc) and not torch.equal(ref4.qacc, ref3.qacc)
