@@ -205,3 +205,36 @@ def test_pointer_cache_follows_leaf_replacement():
     mt.step(mdev, a, out=b)
     ref4 = mt.step(mdev, a)
     assert torch.equal(b.qacc, ref4.qacc) and not torch.equal(ref4.qacc, ref3.qacc)
+
+
+def test_graph_replay_path_is_parity_clean():
+    """MJH_GRAPHS=1 (hipGraph replay of the launch sequence, off by default) must give the same results: a subprocess runs
+    a ping-pong loop with replay on and compares with a fresh-output loop, plus the RK4 ant golden case."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from _util import load_model
+for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32)):
+    mx = load_model(xml, ov, dt)
+    B = 32
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.01 * np.random.RandomState(0).randn(B, mx.nv)))
+    if dt != torch.float64: d = d.to(dt)
+    mdev = mx.to("cuda")
+    bufs = [d.to("cuda"), d.to("cuda").clone()]
+    ref = d.to("cuda")
+    cur = 0
+    for _ in range(6):
+        mt.step(mdev, bufs[cur], out=bufs[1 - cur]); cur = 1 - cur   # replayed from the third call on
+        ref = mt.step(mdev, ref)                                     # fresh buffers every call: captured, never replayed
+    assert torch.equal(bufs[cur].qpos, ref.qpos) and torch.equal(bufs[cur].qvel, ref.qvel), xml
+print("graph replay ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MJH_GRAPHS="1")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "graph replay ok" in r.stdout, r.stdout + r.stderr
