@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 4
+#define MJH_ABI_VERSION 5
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -320,6 +320,14 @@ int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, i
  * sums there; Euler needs none. */
 int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* hip_stream);
 int64_t mjh_model_work_bytes(const mjhModel* m);
+
+/* masked in-place reset of environments -- the env caller's `self._dx[mask] = self._make_batch(n)` (zoo/base.py:266-273,
+ * :289-293 partial reset, :327-331 fused auto-reset) as ONE launch without a host sync.  For every environment e with
+ * mask[e] != 0, every leaf that is non-NULL in `d` is overwritten with that leaf of `d0` (ONE environment, same dtype; the
+ * leaf must be non-NULL there too), except qpos / qvel, which take row e of qpos_rows [B, nq] / qvel_rows [B, nv] when those
+ * are non-NULL (the caller's dx0 + reset noise).  Environments with mask[e] == 0 are untouched.  `mask`: B bytes (torch.bool). */
+int mjh_reset_where(const mjhModel* m, mjhData* d, const mjhData* d0, const unsigned char* mask, const void* qpos_rows,
+                    const void* qvel_rows, int64_t B, void* hip_stream);
 
 /* bytes of dynamic LDS one environment occupies in pipeline phase `phase` (0..4: kinematics, crb/factor,
  * collision/constraint, velocity/acceleration, solve/integrate); the number of phases is 5. */

@@ -15,6 +15,7 @@
 #include "mjh_kernels.h"
 #include "mjh_convex.h"
 #include "mjh_sensor.h"
+#include "mjh_reset.h"
 
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
@@ -507,6 +508,41 @@ int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int
   if (!m || !in || !out) return fail(-22, "null argument");
   return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream)
                              : run<float>(m, m->m32, in, out, work, B, flags, 1, MJH_STAGE_ALL, stream);
+}
+
+int mjh_reset_where(const mjhModel* m, mjhData* d, const mjhData* d0, const unsigned char* mask, const void* qpos_rows,
+                    const void* qvel_rows, int64_t B, void* stream) {
+  if (!m || !d || !d0 || !mask) return fail(-22, "null argument");
+  if (B <= 0) return 0;
+  const int rw = m->dtype == MJH_F64 ? 2 : 1;  // 4-byte words per real
+  ResetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.mask = mask;
+  void* const* dp = reinterpret_cast<void* const*>(d);
+  void* const* sp = reinterpret_cast<void* const*>(d0);
+  const char* names[] = {
+#define X(n) #n,
+      MJH_DATA_REALS(X) MJH_DATA_I32(X) MJH_DATA_I64(X)
+#undef X
+  };
+  const size_t nreal = m->leaf_count.size();
+  const int64_t ncon = m->dtype == MJH_F64 ? m->m64.ncon : m->m32.ncon;
+  const int64_t int_words[] = {ncon /* contact_dim */, 2 * ncon, 2 * ncon, 4 * ncon, 2 * ncon /* geom1, geom2, geom, efc_address (int64) */};
+  const size_t nall = sizeof(names) / sizeof(names[0]);
+  if (nall != nreal + 5 || nall > MJH_RESET_MAX_LEAVES) return fail(-22, "mjh_reset_where: leaf table out of sync with mjhData");
+  for (size_t i = 0; i < nall; i++) {
+    const int64_t words = i < nreal ? m->leaf_count[i] * rw : int_words[i - nreal];
+    if (!dp[i] || words == 0) continue;  // leaf not carried by the caller's Data
+    if (!sp[i]) return fail(-22, std::string("mjh_reset_where: d0.") + names[i] + " is null but d." + names[i] + " is not");
+    ResetLeaf& L = a.leaf[a.nleaf++];
+    L.dst = (unsigned*)dp[i]; L.src = (const unsigned*)sp[i]; L.words = (int)words;
+    const void* rows = !strcmp(names[i], "qpos") ? qpos_rows : !strcmp(names[i], "qvel") ? qvel_rows : nullptr;
+    if (rows) { L.src = (const unsigned*)rows; L.src_stride = (int)words; }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(mjh_reset_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 /* diagnostic (-DMJH_STAMPS builds): device buffer [B, 128] of uint64 receiving in-kernel clock stamps */

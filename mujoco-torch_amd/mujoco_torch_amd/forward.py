@@ -154,3 +154,46 @@ def step(m: Model, d: Data, fixed_iterations: bool = False, *, out: Data | None 
 def forward(m: Model, d: Data, fixed_iterations: bool = False, *, stages: int = native.STAGE_ALL) -> Data:
     """Forward dynamics (reference forward.py:373-401)."""
     return _run(m, d, fixed_iterations, step=False, stages=stages)
+
+
+def reset_where(m: Model, d: Data, d0: Data, mask: torch.Tensor, qpos: torch.Tensor | None = None,
+                qvel: torch.Tensor | None = None) -> Data:
+    """In-place masked reset of a batched ``d``: ``d[mask] = d0`` with ``qpos`` / ``qvel`` rows taken from the given tensors.
+
+    The env caller's ``self._dx[mask] = self._make_batch(n)`` (reference zoo/base.py:266-273, :289-293, :327-331) as one
+    native launch over every leaf and without the host sync of a boolean-mask gather.  ``d0`` holds ONE environment;
+    ``mask``: bool ``[B]``; ``qpos`` ``[B, nq]`` / ``qvel`` ``[B, nv]`` (Data dtype) are the per-environment reset states
+    (``dx0 + noise``; rows of unmasked environments are ignored; None = ``d0``'s).  Returns ``d``.
+    """
+    dq = d.qpos
+    if dq.device.type != "cuda":
+        raise RuntimeError(f"mujoco_torch_amd.reset_where runs only on a HIP device (tensors on {dq.device}); there is no CPU fallback")
+    device, dtype = dq.device, dq.dtype
+    if dq.dim() != 2:
+        raise ValueError("reset_where expects a Data with exactly one batch dimension")
+    B = dq.shape[0]
+    if d0.qpos.dtype != dtype or d0.qpos.device != device:
+        raise RuntimeError(f"d0 is {d0.qpos.dtype} on {d0.qpos.device}, d is {dtype} on {device}")
+    if d0.qpos.numel() != dq.shape[-1]:
+        raise ValueError("d0 must hold exactly one environment")
+    if mask.dtype != torch.bool or tuple(mask.shape) != (B,) or mask.device != device:
+        raise ValueError(f"mask must be a bool tensor of shape ({B},) on {device}")
+    mask = mask.contiguous()
+    rows = []
+    for name, z, n in (("qpos", qpos, dq.shape[-1]), ("qvel", qvel, d.qvel.shape[-1])):
+        if z is not None:
+            if z.dtype != dtype or tuple(z.shape) != (B, n) or z.device != device:
+                raise ValueError(f"{name} must be {dtype} of shape ({B}, {n}) on {device}")
+            z = z.contiguous()
+        rows.append(z)
+    nm = native.get_native_model(m, device, dtype)
+    d_ptrs, keep_d = _ptrs_cached(d, ("reset", id(m.tables)), _ALL_NAMES, dtype, device)
+    s_ptrs, keep_s = _ptrs_cached(d0, ("reset0", id(m.tables)), _ALL_NAMES, dtype, device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    with torch.cuda.device(device):
+        rc = nm.lib.mjh_reset_where(nm.handle, ctypes.byref(d_ptrs), ctypes.byref(s_ptrs), ctypes.c_void_p(mask.data_ptr()),
+                                    ctypes.c_void_p(rows[0].data_ptr() if rows[0] is not None else None),
+                                    ctypes.c_void_p(rows[1].data_ptr() if rows[1] is not None else None), B, ctypes.c_void_p(stream))
+    if rc != 0:
+        raise RuntimeError(f"native reset failed ({rc}): {nm.lib.mjh_last_error().decode()}")
+    return d

@@ -159,7 +159,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 4
+    desc.abi_version = 5
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))
@@ -208,6 +208,8 @@ def load_library(path: str | None = None):
     lib.mjh_forward.restype = ctypes.c_int
     lib.mjh_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     lib.mjh_step.restype = ctypes.c_int
+    lib.mjh_reset_where.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.mjh_reset_where.restype = ctypes.c_int
     lib.mjh_model_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.mjh_model_lds_bytes.restype = ctypes.c_int
     lib.mjh_model_work_bytes.argtypes = [ctypes.c_void_p]

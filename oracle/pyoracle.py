@@ -7,6 +7,7 @@ pointers -- the oracle never feeds the product.
 """
 import ctypes
 import os
+import shutil
 import subprocess
 import sys
 
@@ -30,8 +31,8 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            build()
+        if not os.path.exists(LIB) or shutil.which("make"):
+            build()  # make is a no-op when the library is newer than its sources and include/mjhip.h
         _lib = ctypes.CDLL(LIB)
         _lib.mjo_step.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         _lib.mjo_forward.argtypes = [ctypes.POINTER(native.ModelDesc), ctypes.POINTER(native.DataPtrs), ctypes.POINTER(native.DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]

@@ -15,7 +15,8 @@ REAL_LEAVES = native.LISTS["MJH_DATA_REALS"]
 INT_LEAVES = native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
 
-GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith("traj_"))
+GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith(("traj_", "env_")))
+ENV_CASES = sorted(f[4:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("env_"))
 TRAJECTORY_CASES = sorted(f[5:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("traj_"))
 
 
