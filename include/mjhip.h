@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 5
+#define MJH_ABI_VERSION 6
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -69,6 +69,7 @@ extern "C" {
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
   X(ne) X(nf) X(nl) X(ncon) X(nefc) X(npair) X(nconvex)                                          \
+  X(neq) /* equality constraints of the model = length of the eq_active leaf */ X(neqtab) /* entries of the eq_* tables (0 when equality rows are disabled) */ \
   X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
   X(integrator) X(solver) X(cone) X(disableflags) X(iterations) X(ls_iterations)
 
@@ -124,6 +125,12 @@ extern "C" {
   X(sns_rfadr)      /* nsensor+1: rangefinders, range into rf_geom; geoms in the reference's evaluation order */ \
   X(rf_geom)        /* geom ids a rangefinder ray is tested against (ray.py:292-325: site's own body excluded, invisible geoms dropped) */ \
   X(slot_sensor)    /* nsensordata: sns_* index that produces the slot, -1 = the slot keeps the caller's value */ \
+  X(eq_kind)        /* neqtab: 0 connect (3 rows), 1 weld (6 rows), 2 joint coupling (1 row); reference ROW order = all connects, all welds, all joint couplings (constraint.py:651-656) */ \
+  X(eq_id)          /* neqtab: index of the constraint in the model (eq_active / eq_data / eq_solref / eq_solimp) */ \
+  X(eq_obj1)        /* neqtab: body ids (connect, weld) or joint id (joint coupling) */          \
+  X(eq_obj2)        /* neqtab: second body / joint (-1 = none for a joint coupling) */           \
+  X(eq_row)         /* neqtab: first efc row */                                                  \
+  X(eq_jadr)        /* neqtab*4: joint couplings: dofadr1, dofadr2, qposadr1, qposadr2 (device.py:310-314; a missing second joint reads the LAST joint, as the reference's jnt_dofadr[-1] does) */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
   X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
   X(pair_fn)        /* npair: MJH_FN_* */                                                        \
@@ -172,6 +179,10 @@ extern "C" {
   X(dof_frictionloss) /* nv */                                                                   \
   X(dof_solref)     /* nv*2 */                                                                   \
   X(dof_solimp)     /* nv*5 */                                                                   \
+  X(body_invweight0_rot) /* nbody (rotational component; weld rows 3..5, constraint.py:193-194) */         \
+  X(eq_data)        /* neq*11 (MuJoCo layout: connect anchors; weld anchors, relpose, torquescale; joint polycoef) */ \
+  X(eq_solref)      /* neq*2 */                                                                  \
+  X(eq_solimp)      /* neq*5 */                                                                  \
   X(geom_pos)       /* ngeom*3 */                                                                \
   X(geom_quat)      /* ngeom*4 */                                                                \
   X(geom_size)      /* ngeom*3 */                                                                \
@@ -282,7 +293,7 @@ typedef struct mjhModelDesc {
   X(qacc_smooth)      /* nv */                                                                   \
   X(qfrc_constraint)  /* nv */
 
-#define MJH_DATA_I32(X) X(contact_dim) /* ncon */
+#define MJH_DATA_I32(X) X(contact_dim) /* ncon */ X(eq_active) /* neq: input, enable / disable each equality constraint (types.py:1103) */
 
 #define MJH_DATA_I64(X)                                                                          \
   X(contact_geom1)       /* ncon */                                                              \

@@ -371,6 +371,16 @@ struct Env {
   // dof-frictionloss rows of the SOLVER phase: its frictionloss-free instantiation (kernel 4) carries none of their code,
   // models that have such rows run kernel 6
   __device__ __forceinline__ static int nf_() { return FRIC ? M.nf : 0; }
+  // equality rows (always in the quadratic set).  Inside the solver phase the rows are kept in the order
+  // [frictionloss | joint limits | equality | contacts]: single-column rows first, dense rows after them; the Data leaves
+  // use the reference's order [equality | frictionloss | limits | contacts] and ext_row() maps one to the other.
+  __device__ __forceinline__ static int ne_() { return FRIC ? M.ne : 0; }
+  __device__ __forceinline__ static bool is_eq_row(int r) { return FRIC && (unsigned)(r - (nf_() + M.nl)) < (unsigned)M.ne; }
+  __device__ __forceinline__ static int ext_row(int r) {
+    if (!FRIC) return r;
+    const int ns = nf_() + M.nl, ne = M.ne;
+    return r < ns ? r + ne : (r < ns + ne ? r - ns : r);
+  }
   LdsView<REAL> S;
   int64_t e;      // environment index
   int flags;
@@ -899,23 +909,105 @@ struct Env {
 
   __device__ __forceinline__ void make_constraint() {
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf;
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf, ne = M.ne;
     if (nefc == 0) return;
     load_qpos(false); load_qvel();
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
     row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
-    for (int w = l; w < (nf + nl) * nv; w += W) S.efc_J()[w] = 0;
+    for (int w = l; w < (ne + nf + nl) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
-    for (int r = l; r < nf; r += W) {  // _instantiate_friction :215-251 (dof rows)
-      const int da = M.fric_dof[r];
+    // equality rows (constraint.py:116-212, 254-296): one lane per (constraint, dof) column of a connect / weld, one lane per
+    // joint coupling.  Body frames come from global memory (this pass's kinematics output): few values, read once per lane.
+    for (int w = l; w < M.neqtab * nv; w += W) {
+      int q, d;
+      split_index(w, nv, M.inv_nv, q, d);
+      const int kind = M.eq_kind[q], id = M.eq_id[q], id1 = M.eq_obj1[q], id2 = M.eq_obj2[q], row = M.eq_row[q];
+      const REAL* data = M.eq_data + 11 * id;
+      const REAL active = (REAL)in.eq_active[e * M.neq + id];
+      if (kind == 2) {  // _instantiate_equality_joint :254-296
+        if (d != 0) continue;
+        const int* ja = M.eq_jadr + 4 * q;  // dofadr1, dofadr2, qposadr1, qposadr2
+        const REAL has2 = (REAL)(id2 > -1);
+        const REAL pos1 = S.qpos()[ja[2]], pos2 = S.qpos()[ja[3]] * has2;
+        const REAL ref1 = M.qpos0[ja[2]], ref2 = M.qpos0[ja[3]] * has2;
+        const REAL dif = pos2 - ref2;
+        REAL pw[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) pw[i] = r_pow<REAL>(dif, (REAL)i);
+        REAL deriv = 0, poly = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) deriv += data[1 + i] * pw[i] * (REAL)(i + 1);
+#pragma unroll
+        for (int i = 0; i < 5; i++) poly += data[i] * pw[i];
+        S.efc_J()[row * nv + ja[0]] = 1 * active;
+        S.efc_J()[row * nv + ja[1]] = -deriv * active;  // second scatter wins on a shared dof; without a second joint it lands on the last joint's dof, as in the reference
+        const REAL pos = (pos1 - ref1 - poly) * active;
+        S.efc_pos()[row] = pos;
+        S.efc_pos_norm()[row] = pos;
+        S.efc_invweight()[row] = M.dof_invweight0[ja[0]] + M.dof_invweight0[ja[1]] * has2;
+        continue;
+      }
+      const int nb = M.nbody;
+      const REAL *xm1 = out.xmat + (e * nb + id1) * 9, *xm2 = out.xmat + (e * nb + id2) * 9;
+      const REAL *xp1 = out.xpos + (e * nb + id1) * 3, *xp2 = out.xpos + (e * nb + id2) * 3;
+      // connect: data[0:3] rides on body1 and data[3:6] on body2; weld: the point on body1 is data[3:6], on body2 data[0:3]
+      const REAL* a1 = kind == 0 ? data : data + 3;
+      const REAL* a2 = kind == 0 ? data + 3 : data;
+      REAL pos1[3], pos2[3], cpos[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        pos1[i] = ((xm1[3 * i] * a1[0] + xm1[3 * i + 1] * a1[1]) + xm1[3 * i + 2] * a1[2]) + xp1[i];
+        pos2[i] = ((xm2[3 * i] * a2[0] + xm2[3 * i + 1] * a2[1]) + xm2[3 * i + 2] * a2[2]) + xp2[i];
+        cpos[i] = pos1[i] - pos2[i];
+      }
+      REAL jp1[3], jr1[3], jp2[3], jr2[3];
+      jac_dof(pos1, id1, d, jp1, jr1);
+      jac_dof(pos2, id2, d, jp2, jr2);
+#pragma unroll
+      for (int i = 0; i < 3; i++) S.efc_J()[(row + i) * nv + d] = (jp1[i] - jp2[i]) * active;
+      const REAL iwt = M.body_invweight0[id1] + M.body_invweight0[id2];
+      if (kind == 0) {  // _instantiate_equality_connect :116-157
+        if (d == 0) {
+          const REAL nrm = norm_n<REAL, 3>(cpos);
+#pragma unroll
+          for (int i = 0; i < 3; i++) { S.efc_pos()[row + i] = cpos[i] * active; S.efc_pos_norm()[row + i] = nrm * active; S.efc_invweight()[row + i] = iwt; }
+        }
+        continue;
+      }
+      // _instantiate_equality_weld :160-212
+      const REAL torquescale = data[10];
+      const REAL *xq1 = out.xquat + (e * nb + id1) * 4, *xq2 = out.xquat + (e * nb + id2) * 4;
+      const REAL q1[4] = {xq1[0], xq1[1], xq1[2], xq1[3]}, rel[4] = {data[6], data[7], data[8], data[9]};
+      REAL quat[4], qd[4];
+      quat_mul(q1, rel, quat);
+      const REAL quat1[4] = {xq2[0], xq2[1] * (REAL)-1, xq2[2] * (REAL)-1, xq2[3] * (REAL)-1};
+      const REAL ax[3] = {(jr1[0] - jr2[0]) * torquescale, (jr1[1] - jr2[1]) * torquescale, (jr1[2] - jr2[2]) * torquescale};
+      const REAL t[4] = {-quat1[1] * ax[0] - quat1[2] * ax[1] - quat1[3] * ax[2], quat1[0] * ax[0] + quat1[2] * ax[2] - quat1[3] * ax[1],
+                         quat1[0] * ax[1] + quat1[3] * ax[0] - quat1[1] * ax[2], quat1[0] * ax[2] + quat1[1] * ax[1] - quat1[2] * ax[0]};
+      REAL o[4];
+      quat_mul(t, quat, o);
+#pragma unroll
+      for (int i = 0; i < 3; i++) S.efc_J()[(row + 3 + i) * nv + d] = ((REAL)0.5 * o[1 + i]) * active;
+      if (d == 0) {
+        quat_mul(quat1, quat, qd);
+        const REAL pos6[6] = {cpos[0], cpos[1], cpos[2], qd[1] * torquescale, qd[2] * torquescale, qd[3] * torquescale};
+        const REAL nrm = norm_n<REAL, 6>(pos6);
+        const REAL iwr = M.body_invweight0_rot[id1] + M.body_invweight0_rot[id2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { S.efc_pos()[row + i] = pos6[i] * active; S.efc_pos_norm()[row + i] = nrm * active; S.efc_invweight()[row + i] = i < 3 ? iwt : iwr; }
+      }
+    }
+    for (int r0 = l; r0 < nf; r0 += W) {  // _instantiate_friction :215-251 (dof rows)
+      const int r = ne + r0;
+      const int da = M.fric_dof[r0];
       S.efc_J()[r * nv + da] = 1;
       S.efc_pos()[r] = 0;
       S.efc_pos_norm()[r] = 0;
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
     for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
-      const int r = nf + r0;
+      const int r = ne + nf + r0;
       const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = S.qpos()[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
@@ -983,12 +1075,16 @@ struct Env {
     STAMP(25);
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
-      if (r < nf) {
-        const int da = M.fric_dof[r];
+      if (r < ne) {
+        const int id = M.eq_id[M.efc_row_eq[r]];
+        solref[0] = M.eq_solref[2 * id]; solref[1] = M.eq_solref[2 * id + 1];
+        for (int i = 0; i < 5; i++) solimp[i] = M.eq_solimp[5 * id + i];
+      } else if (r < ne + nf) {
+        const int da = M.fric_dof[r - ne];
         solref[0] = M.dof_solref[2 * da]; solref[1] = M.dof_solref[2 * da + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.dof_solimp[5 * da + i];
-      } else if (r < nf + nl) {
-        const int j = M.lim_jnt[r - nf];
+      } else if (r < ne + nf + nl) {
+        const int j = M.lim_jnt[r - ne - nf];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
       } else {
@@ -1014,7 +1110,7 @@ struct Env {
     STAMP(26);
     put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
     STAMP(27);
-    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = r < nf ? M.dof_frictionloss[M.fric_dof[r]] : (REAL)0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : (REAL)0;
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
@@ -1364,7 +1460,7 @@ struct Env {
     const int nf = nf_();
     for (int r = l; r < nefc; r += W) {
       const REAL ja = S.s_Jaref()[r];
-      bool act = (ja < 0);
+      bool act = (ja < 0) || is_eq_row(r);
       REAL floss_force = 0;
       if (nf > 0 && r < nf) {
         act = true;  // frictionloss row: quadratic inside |Jaref| < R f, linear (saturated force) outside (solver.py:326-342)
@@ -1459,7 +1555,7 @@ struct Env {
         }
         for (int base = nl; base < nefc; base += W) {
           const int r = base + l;
-          unsigned long long mask = __ballot(r < nefc && S.s_Jaref()[r] < 0);
+          unsigned long long mask = __ballot(r < nefc && (S.s_Jaref()[r] < 0 || is_eq_row(r)));
           while (mask) {
             const int row = base + __ffsll((long long)mask) - 1;
             mask &= mask - 1;
@@ -1484,7 +1580,7 @@ struct Env {
     for (int r = lane(); r < M.nefc; r += W) {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
       const REAL x = ja + alpha * jv;
-      bool act = (x < 0);
+      bool act = (x < 0) || is_eq_row(r);
       if (nf > 0 && r < nf) {  // frictionloss row (solver.py:404-416): active unless in a linear zone
         act = true;
         const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
@@ -1618,21 +1714,28 @@ struct Env {
     if (nefc > 0) {
       const int l = lane(), nl = nf_() + M.nl;
       const REAL* gJ = out.efc_J + e * nefc * nv;
-      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[r * nv + dr]; }
+      const int ne = ne_();
+      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[(ne + r) * nv + dr]; }
       for (int r = l; r < nf_(); r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
       if (nl > 0) for (int d = l; d < 2 * nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
       {
-        const int n = (nefc - nl) * nv;
-        const REAL* src = gJ + nl * nv;
+        for (int i = l; i < ne * nv; i += W) S.efc_Jc()[i] = gJ[i];  // equality rows lead the Data leaf and the dense block
+        const int n = (nefc - nl - ne) * nv;
+        const REAL* src = gJ + (nl + ne) * nv;
+        REAL* dstJ = S.efc_Jc() + ne * nv;
         int i = l;
         for (; i + 3 * W < n; i += 4 * W) {
           const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
-          S.efc_Jc()[i] = a; S.efc_Jc()[i + W] = b; S.efc_Jc()[i + 2 * W] = c; S.efc_Jc()[i + 3 * W] = d;
+          dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
         }
-        for (; i < n; i += W) S.efc_Jc()[i] = src[i];
+        for (; i < n; i += W) dstJ[i] = src[i];
       }
-      row_load<W>(S.efc_D(), out.efc_D, nefc, e);
-      row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
+      if (ne > 0) {
+        for (int r = l; r < nefc; r += W) { const int x = ext_row(r); S.efc_D()[r] = out.efc_D[e * nefc + x]; S.efc_aref()[r] = out.efc_aref[e * nefc + x]; }
+      } else {
+        row_load<W>(S.efc_D(), out.efc_D, nefc, e);
+        row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
+      }
       row_load<W>(S.qacc_warm(), KA.warm_src, nv, e);
     }
   }
@@ -1721,7 +1824,8 @@ struct Env {
     wave_sync();
     STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
-    put(out.efc_force, S.s_force(), nefc);
+    if (ne_() > 0) { if (out.efc_force) for (int r = l; r < nefc; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r]; }
+    else put(out.efc_force, S.s_force(), nefc);
     STAMP(62);
   }
 

@@ -88,7 +88,9 @@ const char* const kStageLeaves[] = {
     "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint"};
 // ... plus, for models with convex pairs, the contact leaves the convex kernel hands to the constraint phase
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
-bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid) {
+const char* const kEqStageLeaves[] = {"xpos", "xquat", "xmat"};  // body frames read by the equality rows (constraint.py:116-212)
+bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid, bool has_eq) {
+  if (has_eq) for (const char* s : kEqStageLeaves) if (!strcmp(s, name)) return true;
   for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
   if (has_convex) for (const char* s : kConvexStageLeaves) if (!strcmp(s, name)) return true;
   if (has_fluid && !strcmp(name, "ximat")) return true;  // the fluid model needs the inertial frames of the stage (passive.py:31-78)
@@ -208,6 +210,14 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
   {
+    std::vector<int> row_eq((size_t)d->ne + 1, 0);
+    for (int q = 0; q < d->neqtab; q++) {
+      const int width = d->eq_kind[q] == 0 ? 3 : (d->eq_kind[q] == 1 ? 6 : 1);
+      for (int k = 0; k < width && d->eq_row[q] + k < d->ne; k++) row_eq[d->eq_row[q] + k] = q;
+    }
+    fix.push_back({(const void**)&M.efc_row_eq, bb.add(row_eq.data(), sizeof(int) * row_eq.size())});
+  }
+  {
     std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
     std::vector<int> adr((size_t)nv + 1, 0), ids;
     for (int dd = 0; dd < nv; dd++) {
@@ -274,7 +284,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
     };
     for (size_t i = 0; i < out->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0)) out->work_reals += out->leaf_count[i];
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
 
@@ -349,7 +359,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), 0, stream, a);
     HIP_TRY(hipGetLastError());
   }
-  if ((st & 0x60) && (rc = a.M.nf > 0 ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
+  if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
 
@@ -388,7 +398,7 @@ int run_launches(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, 
 #undef X
     };
     for (size_t i = 0; i < m->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
   }
   a.W.qvel0 = w; w += (int64_t)M.nv * B;
   a.W.kqvel = w; w += (int64_t)M.nv * B;
@@ -481,7 +491,6 @@ int mjh_model_create(const mjhModelDesc* desc, int dtype, mjhModel** out) {
   if (dtype != MJH_F64 && dtype != MJH_F32) return fail(-22, "dtype must be MJH_F64 or MJH_F32");
   if (desc->integrator != INT_EULER && desc->integrator != INT_RK4) return fail(-38, "integrator not implemented");
   if (desc->solver != SOL_CG && desc->solver != SOL_NEWTON) return fail(-38, "solver not implemented");
-  if (desc->ne) return fail(-38, "equality rows not implemented");
   mjhModel* m = new mjhModel();
   m->dtype = dtype;
   int rc = dtype == MJH_F64 ? build<double>(desc, m, m->m64) : build<float>(desc, m, m->m32);
@@ -527,9 +536,10 @@ int mjh_reset_where(const mjhModel* m, mjhData* d, const mjhData* d0, const unsi
   };
   const size_t nreal = m->leaf_count.size();
   const int64_t ncon = m->dtype == MJH_F64 ? m->m64.ncon : m->m32.ncon;
-  const int64_t int_words[] = {ncon /* contact_dim */, 2 * ncon, 2 * ncon, 4 * ncon, 2 * ncon /* geom1, geom2, geom, efc_address (int64) */};
+  const int64_t neq = m->dtype == MJH_F64 ? m->m64.neq : m->m32.neq;
+  const int64_t int_words[] = {ncon /* contact_dim */, neq /* eq_active */, 2 * ncon, 2 * ncon, 4 * ncon, 2 * ncon /* geom1, geom2, geom, efc_address (int64) */};
   const size_t nall = sizeof(names) / sizeof(names[0]);
-  if (nall != nreal + 5 || nall > MJH_RESET_MAX_LEAVES) return fail(-22, "mjh_reset_where: leaf table out of sync with mjhData");
+  if (nall != nreal + 6 || nall > MJH_RESET_MAX_LEAVES) return fail(-22, "mjh_reset_where: leaf table out of sync with mjhData");
   for (size_t i = 0; i < nall; i++) {
     const int64_t words = i < nreal ? m->leaf_count[i] * rw : int_words[i - nreal];
     if (!dp[i] || words == 0) continue;  // leaf not carried by the caller's Data

@@ -160,7 +160,8 @@ def constraint_sizes(m, dims) -> tuple:
     flags = int(m.opt.disableflags)
     if flags & DisableBit.CONSTRAINT:
         return (0, 0, 0, 0, 0)
-    ne = 0  # equality rows are a "next" item; device_put rejects such models
+    et = np.asarray(getattr(m, "eq_type", np.zeros(0, dtype=np.int32)))
+    ne = 0 if flags & DisableBit.EQUALITY else int(3 * (et == 0).sum() + 6 * (et == 1).sum() + (et == 2).sum())
     nf = 0 if flags & DisableBit.FRICTIONLOSS else int((np.asarray(m.dof_frictionloss) > 0).sum())
     nl = 0 if flags & DisableBit.LIMIT else int(np.asarray(m.jnt_limited).sum())
     if flags & DisableBit.CONTACT:

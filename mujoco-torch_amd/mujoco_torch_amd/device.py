@@ -80,8 +80,16 @@ def _validate(m):
         j = int(np.asarray(m.actuator_trnid)[i, 0])
         if int(m.jnt_type[j]) not in (int(JointType.SLIDE), int(JointType.HINGE)):
             raise NotImplementedError("actuators on free/ball joints are a 'next' item.")
-    if int(_get(m, "neq", 0)) or int(_get(m, "ntendon", 0)):
-        raise NotImplementedError("equality constraints and tendons are 'next' items (SURVEY section 8f).")
+    if int(_get(m, "ntendon", 0)):
+        raise NotImplementedError("tendons are a 'next' item (SURVEY section 8f).")
+    et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))
+    if np.any(et > 2):
+        raise NotImplementedError("only connect / weld / joint equality constraints are supported")
+    ot = np.asarray(_get(m, "eq_objtype", lambda: np.ones(len(et), dtype=np.int32)))
+    if np.any((ot == 6) & np.asarray(_get(m, "eq_active0", lambda: np.zeros(len(et), dtype=bool))).astype(bool)):
+        # the reference ignores eq_objtype and reads site ids as body ids (constraint.py:116-212): harmless while the
+        # constraint is inactive (every row is multiplied by eq_active), meaningless once it is active
+        raise NotImplementedError("site-based connect / weld constraints can only be carried inactive")
     if int(m.nmocap):
         raise NotImplementedError("mocap bodies are not supported by the native stepper yet.")
     if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
@@ -239,10 +247,37 @@ def _build_tables(m, dtype) -> StaticTables:
         fric = [d for d in range(int(m.nv)) if float(np.asarray(m.dof_frictionloss)[d]) > 0]
     T.fric_dof = np.array(fric, dtype=np.int32)
     assert len(fric) == nf, (len(fric), nf)
+    T.eq = _equality_tables(m, flags)
+    assert T.eq["nrow"] == ne, (T.eq["nrow"], ne)
     T.sensors = _sensor_tables(m)
     T.lim_jnt = np.array(lim, dtype=np.int32)
     assert len(lim) == nl, (len(lim), nl)
     return T
+
+
+def _equality_tables(m, flags) -> dict:
+    """Equality constraints in the reference's ROW order: all connects, all welds, all joint couplings (constraint.py:651-656,
+    groups from device.py:296-319).  ``jadr`` = (dofadr1, dofadr2, qposadr1, qposadr2) of joint couplings; a missing second
+    joint (id -1) indexes the LAST joint there, exactly as the reference's numpy lookup ``jnt_dofadr[-1]`` does."""
+    et = np.asarray(getattr(m, "eq_type", np.zeros(0, dtype=np.int32)))
+    out = dict(kind=[], id=[], obj1=[], obj2=[], row=[], jadr=[], nrow=0)
+    if (flags & (DisableBit.CONSTRAINT | DisableBit.EQUALITY)) or len(et) == 0:
+        return {k: (np.zeros((0, 4) if k == "jadr" else 0, dtype=np.int32) if k != "nrow" else 0) for k in out}
+    row = 0
+    for kind, width in ((0, 3), (1, 6), (2, 1)):
+        for i in np.nonzero(et == kind)[0]:
+            o1, o2 = int(m.eq_obj1id[i]), int(m.eq_obj2id[i])
+            out["kind"].append(kind); out["id"].append(int(i)); out["obj1"].append(o1); out["obj2"].append(o2); out["row"].append(row)
+            if kind == 2:
+                da, qa = np.asarray(m.jnt_dofadr), np.asarray(m.jnt_qposadr)
+                out["jadr"].append([int(da[o1]), int(da[o2]), int(qa[o1]), int(qa[o2])])
+            else:
+                out["jadr"].append([0, 0, 0, 0])
+            row += width
+    res = {k: np.array(v, dtype=np.int32) for k, v in out.items() if k != "nrow"}
+    res["jadr"] = res["jadr"].reshape(-1, 4)
+    res["nrow"] = row
+    return res
 
 
 def static_contact_fields(m_floats: dict, T: StaticTables, dtype):

@@ -8,6 +8,7 @@ float64 regardless of the model dtype; use ``Data.to(torch.float32)`` for a floa
 
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from .container import UnbatchedTensor
@@ -72,7 +73,7 @@ def make_data(m: Model) -> Data:
         ncon=UnbatchedTensor(torch.tensor(ncon, dtype=torch.int32)),
         time=z(), qpos=m.qpos0.to(dtype=DEFAULT_DTYPE, device="cpu").clone(), qvel=z(m.nv), act=z(m.na),
         qacc_warmstart=z(m.nv), ctrl=z(m.nu), qfrc_applied=z(m.nv), xfrc_applied=z(m.nbody, 6),
-        eq_active=torch.zeros(m.neq, dtype=torch.int32), mocap_pos=z(m.nmocap, 3), mocap_quat=z(m.nmocap, 4),
+        eq_active=torch.as_tensor(np.asarray(m.eq_active0), dtype=torch.int32).reshape(m.neq).clone(), mocap_pos=z(m.nmocap, 3), mocap_quat=z(m.nmocap, 4),
         qacc=z(m.nv), act_dot=z(m.na), userdata=z(getattr(m, "nuserdata", 0) or 0), sensordata=z(m.nsensordata),
         xpos=z(m.nbody, 3), xquat=z(m.nbody, 4), xmat=z(m.nbody, 3, 3), xipos=z(m.nbody, 3),
         ximat=z(m.nbody, 3, 3), xanchor=z(m.njnt, 3), xaxis=z(m.njnt, 3), ten_length=z(m.ntendon),

@@ -640,6 +640,7 @@ class _Compiler:
         jnt_pos, jnt_axis, jnt_range, jnt_limited, jnt_margin = [], [], [], [], []
         jnt_stiffness, jnt_solref, jnt_solimp, jnt_actfrcrange, jnt_actfrclimited, jnt_actgravcomp = [], [], [], [], [], []
         jnt_names = []
+        jnt_springdamper = []
         dof_bodyid, dof_jntid, dof_parentid = [], [], []
         dof_armature, dof_damping, dof_frictionloss, dof_solref, dof_solimp = [], [], [], [], []
         qpos0, qpos_spring = [], []
@@ -686,6 +687,7 @@ class _Compiler:
                 jnt_limited.append(limited)
                 jnt_margin.append(float(a.get("margin", 0.0)))
                 jnt_stiffness.append(float(a.get("stiffness", 0.0)))
+                jnt_springdamper.append(_floats(a["springdamper"]) if "springdamper" in a else None)
                 jnt_solref.append(_pad(_floats(a["solreflimit"]), 2, _DEF_SOLREF) if "solreflimit" in a else _DEF_SOLREF.copy())
                 jnt_solimp.append(_pad(_floats(a["solimplimit"]), 5, _DEF_SOLIMP) if "solimplimit" in a else _DEF_SOLIMP.copy())
                 has_afr = "actuatorfrcrange" in a
@@ -728,6 +730,7 @@ class _Compiler:
             last_dof_of_body[bi] = cur_parent
         m.nq, m.nv, m.njnt = nq, nv, len(jnt_type)
         m.names_jnt = jnt_names
+        self._jnt_springdamper = jnt_springdamper
         m.jnt_type = np.array(jnt_type, dtype=np.int32)
         m.jnt_qposadr = np.array(jnt_qposadr, dtype=np.int32)
         m.jnt_dofadr = np.array(jnt_dofadr, dtype=np.int32)
@@ -797,10 +800,24 @@ class _Compiler:
         self._build_contact(m)
         self._build_actuators(m)
         self._build_sensors(m)
+        self._build_equality(m)
         self._build_empty_sections(m)
         self._build_keyframes(m)
         _set_const(m, self.stat_meaninertia)
+        _equality_set0(m)
+        self._auto_spring_damper(m)
         return m
+
+    def _auto_spring_damper(self, m):
+        """joint springdamper="timeconst dampratio": stiffness and damping of the 1-dof mass-spring-damper with the joint's
+        reference-pose inertia 1 / dof_invweight0 (MuJoCo compiler, mjCModel::AutoSpringDamper)."""
+        for j, sd in enumerate(self._jnt_springdamper):
+            if sd is None or sd[0] <= 0 or sd[1] <= 0:
+                continue
+            adr, w = int(m.jnt_dofadr[j]), JointType(int(m.jnt_type[j])).dof_width()
+            inertia = w / max(mjMINVAL, float(m.dof_invweight0[adr : adr + w].sum()))
+            m.jnt_stiffness[j] = inertia / max(mjMINVAL, sd[0] * sd[0] * sd[1] * sd[1])
+            m.dof_damping[adr : adr + w] = 2 * inertia / max(mjMINVAL, sd[0])
 
     # ---- meshes -----------------------------------------------------------
     def _build_meshes(self, m):
@@ -1281,21 +1298,68 @@ class _Compiler:
         m.sensor_refid = -np.ones(len(sens), dtype=np.int32)
         m.sensor_cutoff = np.array([float(s.get("cutoff", 0.0)) for s in sens], dtype=np.float64)
 
+    def _build_equality(self, m):
+        """<equality>: connect / weld / joint (body form; site form is compiled to site ids like MuJoCo does).
+
+        eq_data follows MuJoCo's layout: connect [anchor in body1 (3), anchor in body2 (3)]; weld [anchor in body2 (3), anchor in
+        body1 (3), relpose quat (4), torquescale]; joint [polycoef (5)].  The qpos0-dependent parts (second anchor, relpose) are
+        filled by ``_equality_set0`` after the reference-pose kinematics, as mj_setConst does."""
+        nodes = [e for en in self.root.findall("equality") for e in en]
+        m.neq = len(nodes)
+        kinds = {"connect": 0, "weld": 1, "joint": 2}
+        m.eq_type = np.zeros(m.neq, dtype=np.int32)
+        m.eq_obj1id = np.zeros(m.neq, dtype=np.int32)
+        m.eq_obj2id = np.zeros(m.neq, dtype=np.int32)
+        m.eq_objtype = np.zeros(m.neq, dtype=np.int32)
+        m.eq_active0 = np.zeros(m.neq, dtype=bool)
+        m.eq_solref = np.tile(_DEF_SOLREF, (m.neq, 1)).reshape(m.neq, 2)
+        m.eq_solimp = np.tile(_DEF_SOLIMP, (m.neq, 1)).reshape(m.neq, 5)
+        m.eq_data = np.zeros((m.neq, 11))
+        m.names_eq = []
+        for i, node in enumerate(nodes):
+            if node.tag not in kinds:
+                raise NotImplementedError(f"equality type <{node.tag}> is outside this build's MJCF subset (connect, weld, joint)")
+            a = dict(self.defaults[node.get("class", "main")].get("equality"))
+            a.pop("__tag__", None)
+            a.update(node.attrib)
+            m.names_eq.append(a.get("name", ""))
+            m.eq_type[i] = kinds[node.tag]
+            m.eq_active0[i] = _bool(a.get("active", "true"))
+            if "solref" in a:
+                m.eq_solref[i] = _pad(_floats(a["solref"]), 2, _DEF_SOLREF)
+            if "solimp" in a:
+                m.eq_solimp[i] = _pad(_floats(a["solimp"]), 5, _DEF_SOLIMP)
+            if node.tag == "joint":
+                m.eq_objtype[i] = 3  # mjOBJ_JOINT
+                m.eq_obj1id[i] = m.names_jnt.index(a["joint1"])
+                m.eq_obj2id[i] = m.names_jnt.index(a["joint2"]) if "joint2" in a else -1
+                m.eq_data[i, :5] = _pad(_floats(a["polycoef"]), 5, np.array([0.0, 1, 0, 0, 0])) if "polycoef" in a else [0.0, 1, 0, 0, 0]
+                continue
+            if "site1" in a:  # site form: MuJoCo stores site ids and no anchors
+                m.eq_objtype[i] = 6  # mjOBJ_SITE
+                m.eq_obj1id[i] = m.names_site.index(a["site1"])
+                m.eq_obj2id[i] = m.names_site.index(a["site2"])
+                if node.tag == "weld":
+                    m.eq_data[i, 10] = float(a.get("torquescale", 1.0))
+                continue
+            m.eq_objtype[i] = 1  # mjOBJ_BODY
+            m.eq_obj1id[i] = m.names_body.index(a["body1"])
+            m.eq_obj2id[i] = m.names_body.index(a["body2"]) if "body2" in a else 0
+            if node.tag == "connect":
+                m.eq_data[i, 0:3] = _floats(a["anchor"])
+            else:
+                if "relpose" in a and np.any(_floats(a["relpose"])[3:] != 0):
+                    raise NotImplementedError("weld with an explicit relpose is outside this build's MJCF subset")
+                m.eq_data[i, 0:3] = _floats(a["anchor"]) if "anchor" in a else np.zeros(3)
+                m.eq_data[i, 10] = float(a.get("torquescale", 1.0))
+
     def _build_empty_sections(self, m):
-        m.neq = len([e for en in self.root.findall("equality") for e in en])
         m.ntendon = len([t for tn in self.root.findall("tendon") for t in tn])
-        if m.neq or m.ntendon:
-            raise NotImplementedError("equality constraints and tendons are outside this build's MJCF subset")
+        if m.ntendon:
+            raise NotImplementedError("tendons are outside this build's MJCF subset")
         m.nwrap = 0
         m.nnumeric = 0
         m.nuserdata = 0
-        m.eq_type = np.zeros(0, dtype=np.int32)
-        m.eq_obj1id = np.zeros(0, dtype=np.int32)
-        m.eq_obj2id = np.zeros(0, dtype=np.int32)
-        m.eq_active0 = np.zeros(0, dtype=bool)
-        m.eq_solref = np.zeros((0, 2))
-        m.eq_solimp = np.zeros((0, 5))
-        m.eq_data = np.zeros((0, 11))
         m.tendon_frictionloss = np.zeros(0)
         m.tendon_limited = np.zeros(0, dtype=bool)
         m.numeric_adr = np.zeros(0, dtype=np.int32)
@@ -1475,6 +1539,25 @@ def _set_const(m, stat_meaninertia=None):
     m.light_pos0 = np.stack([lx[i] - xpos[b] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
     m.light_poscom0 = np.stack([lx[i] - sub[b] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
     m.light_dir0 = np.stack([xmat[b] @ m.light_dir[i] for i, b in enumerate(m.light_bodyid)]) if m.nlight else np.zeros((0, 3))
+
+
+def _equality_set0(m):
+    """Reference-pose parts of eq_data (mj_setConst): the second anchor of body-form connect / weld and the weld relpose."""
+    if not m.neq:
+        return
+    xpos, xquat, xmat, *_ = _kinematics0(m, m.qpos0)
+    for i in range(m.neq):
+        if int(m.eq_objtype[i]) != 1:
+            continue
+        b1, b2 = int(m.eq_obj1id[i]), int(m.eq_obj2id[i])
+        if int(m.eq_type[i]) == 0:  # connect: data[0:3] is in body1, data[3:6] the same point in body2
+            glob = xpos[b1] + xmat[b1] @ m.eq_data[i, 0:3]
+            m.eq_data[i, 3:6] = xmat[b2].T @ (glob - xpos[b2])
+        else:  # weld: data[0:3] is in body2, data[3:6] the same point in body1; relpose = body2 in the frame of body1
+            glob = xpos[b2] + xmat[b2] @ m.eq_data[i, 0:3]
+            m.eq_data[i, 3:6] = xmat[b1].T @ (glob - xpos[b1])
+            q1 = xquat[b1] * np.array([1.0, -1, -1, -1])
+            m.eq_data[i, 6:10] = _quat_mul(q1, xquat[b2])
 
 
 # --------------------------------------------------------------------------

@@ -82,7 +82,7 @@ def pack_model(m, dtype: torch.dtype):
     ne, nf, nl, ncon, nefc = m.constraint_sizes_py
     ints = dict(
         nq=m.nq, nv=m.nv, nu=m.nu, na=m.na, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
-        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=nf, nl=nl, ncon=ncon, nefc=nefc,
+        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=nf, nl=nl, ncon=ncon, nefc=nefc, neq=int(m.neq), neqtab=len(T.eq['kind']),
         npair=len(T.pairs), nconvex=0, nsensor=len(T.sensors["type"]), nsensordata=int(getattr(m, "nsensordata", 0) or 0), integrator=int(m.opt.integrator), solver=int(m.opt.solver),
         cone=int(m.opt.cone), disableflags=int(m.opt.disableflags), iterations=int(m.opt.iterations),
         ls_iterations=int(m.opt.ls_iterations),
@@ -117,6 +117,7 @@ def pack_model(m, dtype: torch.dtype):
         sns_type=i32(T.sensors["type"]), sns_adr=i32(T.sensors["adr"]), sns_objid=i32(T.sensors["objid"]), sns_bodyid=i32(T.sensors["bodyid"]),
         sns_rootid=i32(T.sensors["rootid"]), sns_datatype=i32(T.sensors["datatype"]), sns_rfadr=i32(T.sensors["rfadr"]),
         rf_geom=i32(T.sensors["rf_geom"]), slot_sensor=i32(T.sensors["slot"]),
+        eq_kind=i32(T.eq['kind']), eq_id=i32(T.eq['id']), eq_obj1=i32(T.eq['obj1']), eq_obj2=i32(T.eq['obj2']), eq_row=i32(T.eq['row']), eq_jadr=i32(T.eq['jadr']),
         fric_dof=i32(T.fric_dof), lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
         pair_geom2=i32([p[2].geom2 for p in T.pairs]), pair_ncon=i32([p[1] for p in T.pairs]), pair_dst=i32(T.pair_dst),
         con_dim=i32(T.con_dim), con_geom1=i32(T.con_geom1), con_geom2=i32(T.con_geom2), con_efc_address=i32(T.con_efc_address),
@@ -148,7 +149,9 @@ def pack_model(m, dtype: torch.dtype):
         jnt_axis=f64(m.jnt_axis), jnt_stiffness=f64(m.jnt_stiffness), jnt_range=f64(m.jnt_range),
         jnt_margin=f64(m.jnt_margin), jnt_solref=f64(m.jnt_solref), jnt_solimp=f64(m.jnt_solimp),
         jnt_actfrcrange=f64(m.jnt_actfrcrange), dof_armature=f64(m.dof_armature), dof_damping=f64(m.dof_damping),
-        dof_invweight0=f64(m.dof_invweight0), sns_cutoff=f64(torch.tensor(np.asarray(T.sensors["cutoff"], dtype=np.float64))), dof_frictionloss=f64(m.dof_frictionloss), dof_solref=f64(m.dof_solref), dof_solimp=f64(m.dof_solimp), geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
+        dof_invweight0=f64(m.dof_invweight0), sns_cutoff=f64(torch.tensor(np.asarray(T.sensors["cutoff"], dtype=np.float64))), dof_frictionloss=f64(m.dof_frictionloss), dof_solref=f64(m.dof_solref), dof_solimp=f64(m.dof_solimp),
+        body_invweight0_rot=f64(m.body_invweight0[:, 1]), eq_data=f64(m.eq_data) if m.neq else empty, eq_solref=f64(m.eq_solref) if m.neq else empty, eq_solimp=f64(m.eq_solimp) if m.neq else empty,
+        geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
         geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
         cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
         light_dir=f64(m.light_dir), act_gear=f64(m.actuator_gear) if nu else empty,
@@ -159,7 +162,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 5
+    desc.abi_version = 6
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

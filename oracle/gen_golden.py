@@ -69,6 +69,12 @@ CASES = {
     "swimmer_f64": ("swimmer", {}, "float64", 2, 3, "generic"),
     "swimmer_viscous_wind_f64": ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, "float64", 2, 2, "generic"),
     "swimmer_rk4_f32": ("swimmer", {"integrator": 1, "viscosity": 0.02}, "float32", 2, 2, "generic"),
+    # equality constraints (constraint.py:116-212, 254-296): the bundled model (site-form welds / connect carried inactive, one
+    # active joint coupling) and a model with every body-form kind active: closed loop, weld, couplings, an inactive connect
+    "equality_f64": ("equality", {}, "float64", 2, 3, "generic"),
+    "equality_loops_f64": ("equality_loops", {}, "float64", 3, 3, "generic"),
+    "equality_loops_cg_f64": ("equality_loops", {"solver": 1}, "float64", 2, 2, "generic"),
+    "equality_loops_rk4_f32": ("equality_loops", {"integrator": 1}, "float32", 2, 2, "generic"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),

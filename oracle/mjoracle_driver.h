@@ -156,6 +156,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
     FN(MjoWork) w, w0;
     FN(work_init)(&w, m);
     FN(work_init)(&w0, m);
+    int32_t* eq_zero = (int32_t*)calloc((size_t)m->neq + 1, sizeof(int32_t));
 #pragma omp for schedule(static)
     for (int64_t e = 0; e < B; e++) {
       /* load every provided input leaf */
@@ -167,6 +168,8 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       w.knife_policy = knife_policy;
       w.nf = m->nf; w.ne_nf = m->ne + m->nf; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0;
+      w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;
+      w0.eq_active = w.eq_active;
       w.hint_dist = g_hint_dist ? (const REAL*)g_hint_dist + e * m->ncon : NULL;
       w.hint_pos = g_hint_pos ? (const REAL*)g_hint_pos + e * m->ncon * 3 : NULL;
       w.hint_frame = g_hint_frame ? (const REAL*)g_hint_frame + e * m->ncon * 9 : NULL;
@@ -185,6 +188,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
     }
     FN(work_free)(&w);
     FN(work_free)(&w0);
+    free(eq_zero);
   }
   FN(model_free)(&M);
   return 0;

@@ -119,6 +119,7 @@ typedef struct FN(MjoWork) {
   int tie_on, tie_n, tie_digit[MJO_MAX_TIE], tie_count[MJO_MAX_TIE];
   const REAL *hint_dist, *hint_pos, *hint_frame; /* this env's expected contact leaves or NULL */
   int tie_pairs; /* pairs whose kept outcome is not the natural one */
+  const int32_t* eq_active; /* this env's Data.eq_active (input leaf, types.py:1103) */
 } FN(MjoWork);
 
 /* ---- small vector math (math.py) ------------------------------------------------------------ */
@@ -1144,6 +1145,93 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
   for (int i = 0; i < nefc * nv; i++) w->efc_J[i] = 0;
   int row = 0;
   for (int r = 0; r < nefc; r++) w->efc_frictionloss[r] = 0;
+  for (int q = 0; q < m->neqtab; q++) { /* equality rows: connects, welds, joint couplings (constraint.py:116-212, 254-296) */
+    int kind = m->eq_kind[q], id = m->eq_id[q], id1 = m->eq_obj1[q], id2 = m->eq_obj2[q];
+    const REAL* data = M->eq_data + 11 * id;
+    REAL active = (REAL)w->eq_active[id];
+    int width = kind == 0 ? 3 : (kind == 1 ? 6 : 1);
+    if (row != m->eq_row[q]) abort();
+    for (int r = row; r < row + width; r++) {
+      for (int i = 0; i < 2; i++) w->efc_solref[2 * r + i] = M->eq_solref[2 * id + i];
+      for (int i = 0; i < 5; i++) w->efc_solimp[5 * r + i] = M->eq_solimp[5 * id + i];
+    }
+    if (kind == 2) { /* _instantiate_equality_joint :254-296 */
+      const int* ja = m->eq_jadr + 4 * q; /* dofadr1, dofadr2, qposadr1, qposadr2 */
+      REAL has2 = (REAL)(id2 > -1);
+      REAL pos1 = w->qpos[ja[2]], pos2 = w->qpos[ja[3]] * has2;
+      REAL ref1 = M->qpos0[ja[2]], ref2 = M->qpos0[ja[3]] * has2;
+      REAL dif = pos2 - ref2;
+      REAL pw[5];
+      for (int i = 0; i < 5; i++) pw[i] = R_POW(dif, (REAL)i);
+      REAL deriv = 0, poly = 0;
+      for (int i = 0; i < 4; i++) deriv += data[1 + i] * pw[i] * (REAL)(i + 1);
+      for (int i = 0; i < 5; i++) poly += data[i] * pw[i];
+      w->efc_J[row * nv + ja[0]] = 1;
+      w->efc_J[row * nv + ja[1]] = -deriv; /* second scatter: overwrites the 1 when both joints share the dof (and, without a second joint, lands on the last joint's dof) */
+      for (int d = 0; d < nv; d++) w->efc_J[row * nv + d] = w->efc_J[row * nv + d] * active;
+      REAL pos = (pos1 - ref1 - poly) * active;
+      w->efc_pos[row] = pos;
+      w->efc_pos_norm[row] = pos;
+      w->efc_invweight[row] = M->dof_invweight0[ja[0]] + M->dof_invweight0[ja[1]] * has2;
+      row += 1;
+      continue;
+    }
+    const REAL *xm1 = w->xmat + 9 * id1, *xm2 = w->xmat + 9 * id2;
+    /* connect: anchor1 = data[0:3] on body1, anchor2 = data[3:6] on body2; weld: the point on body1 is data[3:6], on body2 data[0:3] */
+    const REAL* a1 = kind == 0 ? data : data + 3;
+    const REAL* a2 = kind == 0 ? data + 3 : data;
+    REAL pos1[3], pos2[3], cpos[3];
+    for (int i = 0; i < 3; i++) {
+      pos1[i] = ((xm1[3 * i] * a1[0] + xm1[3 * i + 1] * a1[1]) + xm1[3 * i + 2] * a1[2]) + w->xpos[3 * id1 + i];
+      pos2[i] = ((xm2[3 * i] * a2[0] + xm2[3 * i + 1] * a2[1]) + xm2[3 * i + 2] * a2[2]) + w->xpos[3 * id2 + i];
+      cpos[i] = pos1[i] - pos2[i];
+    }
+    if (kind == 0) { /* _instantiate_equality_connect :116-157 */
+      for (int d = 0; d < nv; d++) {
+        REAL jp1[3], jr1[3], jp2[3], jr2[3];
+        FN(jac_dof)(M, w, pos1, id1, d, jp1, jr1);
+        FN(jac_dof)(M, w, pos2, id2, d, jp2, jr2);
+        for (int i = 0; i < 3; i++) w->efc_J[(row + i) * nv + d] = (jp1[i] - jp2[i]) * active;
+      }
+      REAL nrm = FN(norm_n)(cpos, 3);
+      for (int i = 0; i < 3; i++) {
+        w->efc_pos[row + i] = cpos[i] * active;
+        w->efc_pos_norm[row + i] = nrm * active;
+        w->efc_invweight[row + i] = M->body_invweight0[id1] + M->body_invweight0[id2];
+      }
+      row += 3;
+      continue;
+    }
+    /* _instantiate_equality_weld :160-212 */
+    REAL torquescale = data[10];
+    REAL quat[4], quat1[4], qd[4];
+    FN(quat_mul)(w->xquat + 4 * id1, data + 6, quat);
+    quat1[0] = w->xquat[4 * id2]; for (int i = 1; i < 4; i++) quat1[i] = w->xquat[4 * id2 + i] * (REAL)-1;
+    FN(quat_mul)(quat1, quat, qd);
+    REAL pos6[6] = {cpos[0], cpos[1], cpos[2], qd[1] * torquescale, qd[2] * torquescale, qd[3] * torquescale};
+    for (int d = 0; d < nv; d++) {
+      REAL jp1[3], jr1[3], jp2[3], jr2[3];
+      FN(jac_dof)(M, w, pos1, id1, d, jp1, jr1);
+      FN(jac_dof)(M, w, pos2, id2, d, jp2, jr2);
+      REAL ax[3] = {(jr1[0] - jr2[0]) * torquescale, (jr1[1] - jr2[1]) * torquescale, (jr1[2] - jr2[2]) * torquescale};
+      /* quat_mul(quat_mul_axis(quat1, ax), quat)[1:] (math.py:303-321) */
+      REAL t[4] = {-quat1[1] * ax[0] - quat1[2] * ax[1] - quat1[3] * ax[2], quat1[0] * ax[0] + quat1[2] * ax[2] - quat1[3] * ax[1],
+                   quat1[0] * ax[1] + quat1[3] * ax[0] - quat1[1] * ax[2], quat1[0] * ax[2] + quat1[1] * ax[1] - quat1[2] * ax[0]};
+      REAL o[4];
+      FN(quat_mul)(t, quat, o);
+      for (int i = 0; i < 3; i++) {
+        w->efc_J[(row + i) * nv + d] = (jp1[i] - jp2[i]) * active;
+        w->efc_J[(row + 3 + i) * nv + d] = ((REAL)0.5 * o[1 + i]) * active;
+      }
+    }
+    REAL nrm = FN(norm_n)(pos6, 6);
+    for (int i = 0; i < 6; i++) {
+      w->efc_pos[row + i] = pos6[i] * active;
+      w->efc_pos_norm[row + i] = nrm * active;
+      w->efc_invweight[row + i] = i < 3 ? M->body_invweight0[id1] + M->body_invweight0[id2] : M->body_invweight0_rot[id1] + M->body_invweight0_rot[id2];
+    }
+    row += 6;
+  }
   for (int f = 0; f < m->nf; f++, row++) { /* _instantiate_friction :215-251 (dof rows) */
     int da = m->fric_dof[f];
     w->efc_J[row * nv + da] = 1;

@@ -20,6 +20,12 @@ ENV_CASES = sorted(f[4:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f
 TRAJECTORY_CASES = sorted(f[5:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("traj_"))
 
 
+# solver-output tolerance of goldens whose solve is ill-conditioned enough to amplify summation-order rounding beyond the default:
+# CG (100 iterations) on the stiff always-active equality rows of a closed loop -- the pre-solver leaves of these cases agree
+# at the default tolerance
+CASE_TOL_SOL = {"equality_loops_cg_f64": 1e-5}
+
+
 def strip_sensors(lite):
     """Drops the model's sensors (the reference cannot run rangefinders in float32: ray.py:317 keeps float64 sizes and the
     mixed-dtype dot products raise, so float32 goldens of models with rangefinders were recorded without sensors)."""
@@ -62,7 +68,10 @@ class Golden:
         return torch.stack([one(e) for e in range(self.nenv)])
 
     def expected(self, env, step, name):
-        return self.z[f"out/{env}/{step}/{name}"]
+        key = f"out/{env}/{step}/{name}"
+        if name == "eq_active" and key not in self.z:  # goldens recorded before the leaf joined the ABI: models without equality constraints
+            return np.zeros(0, dtype=np.int32)
+        return self.z[key]
 
 
 def leaf(d, name):
