@@ -117,6 +117,8 @@ struct DevModel {
   const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none
   int max_jnt;
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
+  const int* rf_sensor;                    // nrfq: rangefinder (sns_* index) of entry q of rf_geom
+  int nrfq;                                // entries of rf_geom = (rangefinder, geom) ray tests per environment
   const int* efc_row_eq;                   // ne: eq_* table entry of an equality row
   int max_depth;
   const int* qm_pair;                      // nqmpair: i << 8 | j (j <= i) of the inertia-matrix entries that can be non-zero

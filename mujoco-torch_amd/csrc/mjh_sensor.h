@@ -85,8 +85,29 @@ __device__ __forceinline__ double ray_geom(int type, const double* size, const d
   return inf;
 }
 
+// one ray test: rangefinder M.rf_sensor[q] against geom M.rf_geom[q].  The ray starts at the site and runs along its z axis
+// (sensor.py:94-108); it is moved into the geom frame in the Data dtype and intersected in double (ray.py:28-290).
 template <typename REAL>
-__device__ __forceinline__ REAL sensor_value(int64_t e, int s, int comp) {
+__device__ __forceinline__ double rf_task(int64_t e, int q) {
+  const int s = M.rf_sensor[q], g = M.rf_geom[q], obj = M.sns_objid[s];
+  const REAL* rot = out.site_xmat + (e * M.nsite + obj) * 9;
+  const REAL* posp = out.site_xpos + (e * M.nsite + obj) * 3;
+  const REAL pos[3] = {posp[0], posp[1], posp[2]};
+  const REAL vec[3] = {rot[2], rot[5], rot[8]};
+  const REAL *gm = out.geom_xmat + (e * M.ngeom + g) * 9, *gp = out.geom_xpos + (e * M.ngeom + g) * 3;
+  const REAL d3[3] = {pos[0] - gp[0], pos[1] - gp[1], pos[2] - gp[2]};
+  double dp[3], dv[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    dp[i] = (double)(gm[i] * d3[0] + gm[3 + i] * d3[1] + gm[6 + i] * d3[2]);
+    dv[i] = (double)(gm[i] * vec[0] + gm[3 + i] * vec[1] + gm[6 + i] * vec[2]);
+  }
+  const double size[3] = {(double)M.geom_size[3 * g], (double)M.geom_size[3 * g + 1], (double)M.geom_size[3 * g + 2]};
+  return ray_geom(M.geom_type[g], size, dp, dv);
+}
+
+template <typename REAL>
+__device__ __forceinline__ REAL sensor_value(int64_t e, int s, int comp, const double* rf_x) {
   const int type = M.sns_type[s], obj = M.sns_objid[s], body = M.sns_bodyid[s], root = M.sns_rootid[s];
   if (type == 9) return out.qpos[e * M.nq + obj];  // jointpos: the normalised qpos of this pass
   if (type == 10) {                                 // jointvel: the (checked) velocity this pass ran on
@@ -100,23 +121,9 @@ __device__ __forceinline__ REAL sensor_value(int64_t e, int s, int comp) {
   REAL R[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) R[i] = rot[i];
-  if (type == 7) {  // rangefinder: ray along the site's z axis (sensor.py:94-108, ray.py:327-372)
-    const REAL vec[3] = {R[2], R[5], R[8]};
+  if (type == 7) {  // rangefinder: nearest of the per-(sensor, geom) ray tests the wave staged in LDS (ray.py:327-372: min over geoms)
     double best = __builtin_inf();
-    for (int q = M.sns_rfadr[s]; q < M.sns_rfadr[s + 1]; q++) {
-      const int g = M.rf_geom[q];
-      const REAL *gm = out.geom_xmat + (e * M.ngeom + g) * 9, *gp = out.geom_xpos + (e * M.ngeom + g) * 3;
-      const REAL d3[3] = {pos[0] - gp[0], pos[1] - gp[1], pos[2] - gp[2]};
-      double dp[3], dv[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        dp[i] = (double)(gm[i] * d3[0] + gm[3 + i] * d3[1] + gm[6 + i] * d3[2]);
-        dv[i] = (double)(gm[i] * vec[0] + gm[3 + i] * vec[1] + gm[6 + i] * vec[2]);
-      }
-      const double size[3] = {(double)M.geom_size[3 * g], (double)M.geom_size[3 * g + 1], (double)M.geom_size[3 * g + 2]};
-      const double x = ray_geom(M.geom_type[g], size, dp, dv);
-      if (x < best) best = x;
-    }
+    for (int q = M.sns_rfadr[s]; q < M.sns_rfadr[s + 1]; q++) { const double x = rf_x[q]; if (x < best) best = x; }
     return isinf(best) ? (REAL)-1 : (REAL)best;
   }
   const REAL* cv = out.cvel + (e * M.nbody + body) * 6;
@@ -146,15 +153,20 @@ __device__ __forceinline__ REAL sensor_value(int64_t e, int s, int comp) {
 
 template <typename REAL>
 __global__ __launch_bounds__(MJH_WAVE) void mjh_sensor_kernel(KArgs<REAL> args) {
-  const int nsd = M.nsensordata;
+  // rangefinders dominate: their (sensor, geom) ray tests are spread over the lanes first (ant: 8 sensors x 13 geoms = two
+  // trips instead of 13 dependent tests on 8 lanes), then every sensordata slot is produced by one lane
+  extern __shared__ double rf_x[];
+  const int nsd = M.nsensordata, nrf = M.nrfq;
   for (int64_t e = blockIdx.x; e < KA.B; e += gridDim.x) {
+    for (int q = lane_id(); q < nrf; q += MJH_WAVE) rf_x[q] = rf_task<REAL>(e, q);
+    __syncthreads();
     for (int k = lane_id(); k < nsd; k += MJH_WAVE) {
       const int s = M.slot_sensor[k];
       REAL v;
       if (s < 0) {
         v = in.sensordata ? in.sensordata[e * nsd + k] : (REAL)0;  // slot keeps the caller's value
       } else {
-        v = sensor_value<REAL>(e, s, k - M.sns_adr[s]);
+        v = sensor_value<REAL>(e, s, k - M.sns_adr[s], rf_x);
         const REAL cutoff = M.sns_cutoff[s];
         const int dt = M.sns_datatype[s];
         if (cutoff > 0) {  // _apply_cutoff :41-53
@@ -164,6 +176,7 @@ __global__ __launch_bounds__(MJH_WAVE) void mjh_sensor_kernel(KArgs<REAL> args) 
       }
       out.sensordata[e * nsd + k] = v;
     }
+    __syncthreads();  // the next environment of this workgroup reuses rf_x
   }
 }
 

@@ -210,6 +210,14 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
   {
+    const int nrf = d->nsensor > 0 ? d->sns_rfadr[d->nsensor] : 0;
+    std::vector<int> owner((size_t)nrf + 1, 0);
+    for (int sidx = 0; sidx < d->nsensor; sidx++)
+      for (int q = d->sns_rfadr[sidx]; q < d->sns_rfadr[sidx + 1]; q++) owner[q] = sidx;
+    M.nrfq = nrf;
+    fix.push_back({(const void**)&M.rf_sensor, bb.add(owner.data(), sizeof(int) * owner.size())});
+  }
+  {
     std::vector<int> row_eq((size_t)d->ne + 1, 0);
     for (int q = 0; q < d->neqtab; q++) {
       const int width = d->eq_kind[q] == 0 ? 3 : (d->eq_kind[q] == 1 ? 6 : 1);
@@ -356,7 +364,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if ((st & 0x70) && (rc = a.M.has_fluid ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-    hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), 0, stream, a);
+    hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
     HIP_TRY(hipGetLastError());
   }
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
