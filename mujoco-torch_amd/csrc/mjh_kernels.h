@@ -1998,10 +1998,13 @@ struct Env {
 #undef KA
 #undef STAMP
 
-// No minimum-waves launch bound: capping the allocator at 128 VGPRs (4 waves/SIMD) was measured 3-11 % slower
-// than letting it use ~180-230 VGPRs (2 waves/SIMD) because of scratch spills (profiles/r01/notes.md).
+// Occupancy bounds (second launch-bound argument = waves per SIMD the allocator must fit): float64 kernels are left alone --
+// capping them at 128 VGPRs was measured 3-11 % slower than ~180-230 VGPRs at 2 waves/SIMD, their spills are twice as wide
+// (profiles/r01/notes.md).  The float32 solver, packed kinematics / velocity and CRB kernels sit just above an occupancy
+// step (197 / 181 / 185 -> 168 VGPRs = 3 waves, 132 -> 128 = 4 waves) and spill only 5-24 dwords to get under it; with
+// 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W == 32))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? 4 : 1))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
