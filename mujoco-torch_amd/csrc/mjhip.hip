@@ -41,6 +41,11 @@ struct mjhModel {
   mutable std::mutex graph_mutex;
   mutable hipStream_t capture_stream = nullptr;
   mutable unsigned long long graph_clock = 0;
+  mutable std::mutex split_mutex;          // MJH_SPLIT: internal streams the slices of a batch run on, fork / join events
+  mutable bool split_ready = false;
+  mutable hipStream_t split_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  mutable hipEvent_t split_done[4] = {nullptr, nullptr, nullptr, nullptr};
+  mutable hipEvent_t split_fork = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of RK4 workspace (0 for Euler)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
@@ -372,7 +377,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 }
 
 template <typename REAL>
-int run_launches(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, int do_step, int stages, void* stream) {
+int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, int do_step, int stages, void* stream) {
   if (B <= 0) return 0;
   static_assert(sizeof(DevData<REAL>) == sizeof(mjhData), "DevData must mirror mjhData");
   static_assert(sizeof(KArgs<REAL>) <= 4096, "kernel arguments exceed the 4 KiB kernarg segment");
@@ -427,6 +432,61 @@ int run_launches(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, 
     if ((rc = forward_pass<REAL>(m, a, s))) return rc;
   }
   return 0;
+}
+
+int split_ways() {
+  // MJH_SPLIT=n: the batch is cut into n contiguous slices whose launch sequences run on n internal streams, forked from and
+  // joined back into the caller's stream with events.  The phases of different slices then overlap on the CUs (a register-bound
+  // phase of one slice fills the wave slots an LDS-bound phase of another leaves idle).  Default 1 (profiles/r01/notes.md).
+  static const int n = [] { const char* e = getenv("MJH_SPLIT"); int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  return n;
+}
+
+// the Data view of environments [begin, ...): every non-null leaf pointer advanced by begin * (elements per environment)
+template <typename REAL>
+void offset_data(const mjhModel* m, const DevModel<REAL>& M, const mjhData* src, mjhData* dst, int64_t begin) {
+  memcpy(dst, src, sizeof(*dst));
+  unsigned char** p = reinterpret_cast<unsigned char**>(dst);
+  const size_t nreal = m->leaf_count.size();
+  for (size_t i = 0; i < nreal; i++) if (p[i]) p[i] += (size_t)begin * (size_t)m->leaf_count[i] * sizeof(REAL);
+  const int64_t ncon = M.ncon, neq = M.neq;
+  const int64_t int_bytes[] = {4 * ncon, 4 * neq, 8 * ncon, 8 * ncon, 16 * ncon, 8 * ncon};  // contact_dim, eq_active | geom1, geom2, geom, efc_address
+  for (size_t k = 0; k < 6; k++) if (p[nreal + k]) p[nreal + k] += (size_t)begin * (size_t)int_bytes[k];
+}
+
+template <typename REAL>
+int run_launches(const mjhModel* m, const DevModel<REAL>& M, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, int do_step, int stages, void* stream) {
+  const int ways = split_ways();
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = s && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (ways <= 1 || B < 64 * ways || capturing) return run_launches_one<REAL>(m, M, in, out, work, B, flags, do_step, stages, stream);
+  std::lock_guard<std::mutex> lock(m->split_mutex);
+  if (!m->split_ready) {
+    for (int k = 0; k < 4; k++) {
+      HIP_TRY(hipStreamCreateWithFlags(&m->split_stream[k], hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&m->split_done[k], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&m->split_fork, hipEventDisableTiming));
+    m->split_ready = true;
+  }
+  HIP_TRY(hipEventRecord(m->split_fork, s));
+  const int64_t per = ((B + ways - 1) / ways + 1) & ~(int64_t)1;  // even slices keep the two-environments-per-wave phases paired
+  const size_t work_env_bytes = (size_t)m->work_reals * sizeof(REAL);
+  int rc = 0;
+  for (int k = 0; k < ways; k++) {
+    const int64_t begin = (int64_t)k * per, count = (begin + per <= B) ? per : B - begin;
+    if (count <= 0) break;
+    mjhData in_k, out_k;
+    offset_data<REAL>(m, M, in, &in_k, begin);
+    offset_data<REAL>(m, M, out, &out_k, begin);
+    HIP_TRY(hipStreamWaitEvent(m->split_stream[k], m->split_fork, 0));
+    void* work_k = work ? (void*)((unsigned char*)work + (size_t)begin * work_env_bytes) : nullptr;
+    if ((rc = run_launches_one<REAL>(m, M, &in_k, &out_k, work_k, count, flags, do_step, stages, (void*)m->split_stream[k]))) break;
+    HIP_TRY(hipEventRecord(m->split_done[k], m->split_stream[k]));
+    HIP_TRY(hipStreamWaitEvent(s, m->split_done[k], 0));
+  }
+  return rc;
 }
 
 unsigned long long fnv1a(unsigned long long h, const void* p, size_t n) {
@@ -511,6 +571,10 @@ void mjh_model_destroy(mjhModel* m) {
   if (!m) return;
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
+  if (m->split_ready) {
+    for (int k = 0; k < 4; k++) { (void)hipStreamDestroy(m->split_stream[k]); (void)hipEventDestroy(m->split_done[k]); }
+    (void)hipEventDestroy(m->split_fork);
+  }
   if (m->blob) (void)hipFree(m->blob);
   delete m;
 }

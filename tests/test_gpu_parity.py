@@ -244,3 +244,39 @@ print("graph replay ok")
     env = dict(os.environ, MJH_GRAPHS="1")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "graph replay ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_split_stream_path_is_bit_identical():
+    """MJH_SPLIT=3 (batch slices on internal streams, off by default): the sliced step of a batch equals stepping each slice
+    as its own batch -- every leaf, bit for bit (Euler humanoid with contacts, RK4 ant with its workspace, mesh scene with the
+    convex kernel, sensor kernel)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+from _util import load_model, REAL_LEAVES, INT_LEAVES
+for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
+                    ("mesh_contact", {}, torch.float32), ("sensor_rig", {}, torch.float64), ("equality_loops", {}, torch.float64)):
+    mx = load_model(xml, ov, dt)
+    B = 203                                              # slices of 68, 68, 67: odd tail, two-per-wave phases stay paired
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+    if dt != torch.float64: d = d.to(dt)
+    mdev = mx.to("cuda")
+    dg = d.to("cuda")
+    whole = mt.step(mdev, mt.step(mdev, dg))             # B >= 64 * 3: split
+    parts = [mt.step(mdev, mt.step(mdev, dg[a:b].clone())) for a, b in ((0, 68), (68, 136), (136, 203))]   # B < 192: one stream
+    for n in REAL_LEAVES + INT_LEAVES:
+        w = native.data_field_tensor(whole, n)
+        p = torch.cat([native.data_field_tensor(x, n) for x in parts])
+        assert torch.equal(w, p), (xml, n)
+print("split ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MJH_SPLIT="3")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
