@@ -13,8 +13,7 @@ What is different, by design:
     for every environment (``dx0 + U(-noise, noise)``, two elementwise launches) and only the masked rows are consumed;
   * pixels are out of scope (the ray-cast renderer is not on the hot path): ``from_pixels=True`` raises.
 
-With CPU tensors (no GPU: the host-logic tests) the masked reset goes through the container's own index assignment, as in
-the reference; stepping physics still needs the HIP library.
+Like `step`, the masked reset exists only on a HIP device (`reset_where` raises otherwise).
 """
 
 from __future__ import annotations
@@ -174,16 +173,10 @@ class MujocoTorchEnv(EnvBase):
         return batch
 
     def _reset_masked(self, mask: torch.Tensor):
-        """``self._dx[mask] = self._make_batch(n)``; ``self._step_count[mask] = 0``."""
-        if getattr(self._dx.qpos, "is_cuda", False) and hasattr(self, "mx"):
-            q, v = self._reset_state(self.num_envs)
-            reset_where(self.mx, self._dx, self._dx0, mask, q, v)
-            self._step_count.masked_fill_(mask, 0)
-        else:  # CPU tensors: the container's own index assignment, as the reference does it
-            n = int(mask.sum())
-            if n > 0:
-                self._dx[mask] = self._make_batch(n)
-                self._step_count[mask] = 0
+        """``self._dx[mask] = self._make_batch(n)``; ``self._step_count[mask] = 0`` -- one native launch, no host sync."""
+        q, v = self._reset_state(self.num_envs)
+        reset_where(self.mx, self._dx, self._dx0, mask, q, v)  # raises off-device: there is no CPU route
+        self._step_count.masked_fill_(mask, 0)
 
     # ---- TorchRL interface --------------------------------------------------------------------------------------------
 

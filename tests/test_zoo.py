@@ -48,8 +48,16 @@ def _host_env(auto_reset):
     env._physics_step = lambda d: d
     env._ctrl_dtype = env._sim_dtype = torch.float64
     env._dx0 = FakeBatch(torch.zeros(1, 2, dtype=torch.float64), torch.zeros(1, 2, dtype=torch.float64), torch.zeros(1, 1, dtype=torch.float64))
-    for name in ("_reset_state", "_make_batch", "_reset_masked", "_reset", "_step", "_prepare_ctrl"):
+    for name in ("_reset_state", "_make_batch", "_reset", "_step", "_prepare_ctrl"):
         setattr(env, name, MethodType(getattr(MujocoTorchEnv, name), env))
+
+    def reset_masked(mask):  # host stand-in for the native launch: the reference's own route (zoo/base.py:289-293)
+        n = int(mask.sum())
+        if n > 0:
+            env._dx[mask] = env._make_batch(n)
+            env._step_count[mask] = 0
+
+    env._reset_masked = reset_masked
     env._build_obs = lambda: {"observation": env._dx.qpos[..., :1].to(env.dtype)}
     env._compute_reward = lambda qpos_before, action: torch.zeros(4, 1, dtype=env.dtype)
     env._compute_terminated = lambda: torch.zeros(4, 1, dtype=torch.bool)
