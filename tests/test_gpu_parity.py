@@ -280,3 +280,22 @@ print("split ok")
     env = dict(os.environ, MJH_SPLIT="3")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_batch_beyond_the_launch_grid_cap():
+    """B = 2^20 + 5 cartpoles (the launch grid is capped at 2^20 workgroups, the kernels loop over the rest; two environments
+    per wavefront in the packed phases and an odd tail): every environment equals its twin in an 8-environment batch."""
+    mx = load_model("cartpole")
+    U, B = 8, (1 << 20) + 5
+    rng = np.random.RandomState(3)
+    base = mt.make_data(mx).expand(U).clone()
+    base = base.replace(qpos=torch.tensor(0.3 * rng.randn(U, mx.nq)), qvel=torch.tensor(rng.randn(U, mx.nv)), ctrl=torch.tensor(rng.randn(U, mx.nu)))
+    mdev = mx.to("cuda")
+    small = mt.step(mdev, mt.step(mdev, base.to("cuda")))
+    idx = torch.arange(B) % U
+    big = mt.step(mdev, mt.step(mdev, base[idx].clone().to("cuda")))
+    idx = idx.to("cuda")
+    for n in ("qpos", "qvel", "qacc", "xpos", "time", "qfrc_bias", "qM", "qLD"):
+        a, b = leaf(big, n), leaf(small, n)
+        assert torch.equal(a, b[idx]), n
+    torch.cuda.empty_cache()
