@@ -66,7 +66,48 @@ class _Meta(type):
         cls._field_names = tuple(ann)
         cls._field_defaults = defaults
         cls._field_types = ann
+        if bases:  # every concrete container is a pytree node, so torch.vmap / tree_map see its tensor leaves
+            _register_pytree(cls)
         return cls
+
+
+def _register_pytree(cls):
+    """Children = tensor leaves and nested containers; everything else (UnbatchedTensor, None, python values, the host-side
+    attributes) rides in the context.  ``batch_size`` is re-derived from a probe leaf on unflatten, so the per-sample view
+    ``torch.vmap`` hands to the mapped function has batch_size () and the stacked result gets the mapped dimension back."""
+    from torch.utils import _pytree
+
+    def flatten(obj):
+        keys, children, rest = [], [], {}
+        pinned = obj.__dict__.get("_child_keys")  # set by unflatten: placeholder leaves (pytree's own spec arithmetic) keep the structure
+        for k, v in obj._fields.items():
+            if (k in pinned) if pinned is not None else isinstance(v, (torch.Tensor, MjTensorClass)):
+                keys.append(k)
+                children.append(v)
+            else:
+                rest[k] = v
+        probe = next((i for i, c in enumerate(children) if isinstance(c, torch.Tensor)), None)
+        event = children[probe].dim() - len(obj._bs) if probe is not None else 0
+        extra = {k: v for k, v in obj.__dict__.items() if k not in ("_fields", "_bs", "_ver", "_ptr_cache", "_child_keys")}
+        return children, (tuple(keys), rest, probe, event, tuple(obj._fields), extra, tuple(obj._bs))
+
+    def unflatten(children, ctx):
+        keys, rest, probe, event, order, extra, bs = ctx
+        vals = dict(rest)
+        vals.update(zip(keys, children))
+        new = cls.__new__(cls)
+        object.__setattr__(new, "_fields", {k: vals[k] for k in order})
+        if probe is not None and isinstance(children[probe], torch.Tensor):
+            t = children[probe]
+            bs = tuple(t.shape[: t.dim() - event]) if t.dim() >= event else ()
+        object.__setattr__(new, "_bs", tuple(bs))
+        for k, v in extra.items():
+            object.__setattr__(new, k, v)
+        if not all(isinstance(c, (torch.Tensor, MjTensorClass)) for c in children):
+            object.__setattr__(new, "_child_keys", frozenset(keys))
+        return new
+
+    _pytree.register_pytree_node(cls, flatten, unflatten)
 
 
 class MjTensorClass(metaclass=_Meta):
@@ -124,9 +165,21 @@ class MjTensorClass(metaclass=_Meta):
         object.__setattr__(new, "_fields", d)
         object.__setattr__(new, "_bs", tuple(self._bs if bs is None else bs))
         for k, v in self.__dict__.items():
-            if k not in ("_fields", "_bs", "_ver", "_ptr_cache"):
+            if k not in ("_fields", "_bs", "_ver", "_ptr_cache", "_child_keys"):
                 object.__setattr__(new, k, v)
         return new
+
+    def map_tensors(self, fn):
+        """Applies ``fn`` to every tensor leaf, recursing into nested containers; other values are kept."""
+        out = {}
+        for k, v in self._fields.items():
+            if isinstance(v, MjTensorClass):
+                out[k] = v.map_tensors(fn)
+            elif isinstance(v, torch.Tensor):
+                out[k] = fn(v)
+            else:
+                out[k] = v
+        return self._new(out)
 
     def _map(self, fn, bs=None):
         return self._new({k: (fn(v) if _is_node(v) else v) for k, v in self._fields.items()}, bs)

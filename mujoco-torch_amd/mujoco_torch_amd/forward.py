@@ -92,8 +92,41 @@ def _ptrs_cached(d: Data, tag, names, dtype, device, check=True):
     return ptrs, keep
 
 
+def _under_vmap(m, d, fixed_iterations, step, stages):
+    """``torch.vmap(lambda d: step(mx, d))(dx)`` -- the reference's batching idiom (README, benchmarks/_helpers.py:44-60).
+
+    Inside vmap every mapped leaf is a functorch BatchedTensor.  The native step is batched already, so the leaves are
+    unwrapped (mapped dimension moved to the front, unmapped leaves broadcast), stepped as ONE native batch and the result is
+    wrapped back at the same vmap level: the idiom costs one launch sequence, not a per-sample loop."""
+    F = torch._C._functorch
+    level = F.maybe_get_level(d.qpos)
+    raw = F.get_unwrapped(d.qpos)
+    if F.is_batchedtensor(raw):
+        raise NotImplementedError("nested torch.vmap over step is not supported: pass a Data with two leading batch dims instead")
+    B = raw.shape[F.maybe_get_bdim(d.qpos)]
+
+    def unwrap(t):
+        if F.is_batchedtensor(t) and F.maybe_get_level(t) == level:
+            return F.get_unwrapped(t).movedim(F.maybe_get_bdim(t), 0)
+        return t.unsqueeze(0).expand(B, *t.shape)
+
+    plain = d.map_tensors(unwrap)
+    object.__setattr__(plain, "_bs", (B, *plain._bs))
+    if isinstance(plain.contact, type(d.contact)):
+        object.__setattr__(plain.contact, "_bs", (B, *plain.contact._bs))
+    res = _run(m, plain, fixed_iterations, step, None, stages)
+    wrapped = res.map_tensors(lambda t: F._add_batch_dim(t, 0, level))
+    object.__setattr__(wrapped, "_bs", tuple(d._bs))
+    object.__setattr__(wrapped.contact, "_bs", tuple(d.contact._bs))
+    return wrapped
+
+
 def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None = None, stages: int = native.STAGE_ALL) -> Data:
     qpos = d.qpos
+    if torch._C._functorch.is_batchedtensor(qpos):
+        if out is not None:
+            raise ValueError("step(..., out=) cannot be used under torch.vmap")
+        return _under_vmap(m, d, fixed_iterations, step, stages)
     if qpos.device.type != "cuda":
         raise RuntimeError(
             "mujoco_torch_amd.step/forward run only on a HIP device (tensors on "

@@ -299,3 +299,28 @@ def test_batch_beyond_the_launch_grid_cap():
         a, b = leaf(big, n), leaf(small, n)
         assert torch.equal(a, b[idx]), n
     torch.cuda.empty_cache()
+
+
+def test_vmap_idiom_is_one_native_batch():
+    """`torch.vmap(lambda d: step(mx, d))(dx)` -- how the reference batches (README, benchmarks/_helpers.py) -- gives exactly the
+    native batched step, for step and forward, with a closed-over unbatched leaf mixed in, and keeps the container usable."""
+    mx = load_model("humanoid", {"solver": 1})
+    B = 48
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(2).randn(B, mx.nv)))
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    want = mt.step(mdev, dg)
+    got = torch.vmap(lambda x: mt.step(mdev, x))(dg)
+    assert tuple(got.batch_size) == (B,) and tuple(got.contact.batch_size) == tuple(want.contact.batch_size)
+    for n in REAL_LEAVES + INT_LEAVES:
+        assert torch.equal(leaf(got, n), leaf(want, n)), n
+    assert int(got.ncon) == int(want.ncon)
+    again = torch.vmap(lambda x: mt.step(mdev, x))(got)          # the result feeds the next call
+    assert torch.equal(again.qpos, mt.step(mdev, want).qpos)
+    fwd = torch.vmap(lambda x: mt.forward(mdev, x))(dg)
+    assert torch.equal(fwd.qacc, mt.forward(mdev, dg).qacc)
+    ctrl = torch.full((mx.nu,), 0.25, dtype=torch.float64, device="cuda")   # not mapped: the same control for every environment
+    got = torch.vmap(lambda x: mt.step(mdev, x.replace(ctrl=ctrl)))(dg)
+    want = mt.step(mdev, dg.replace(ctrl=ctrl.expand(B, -1).clone()))
+    assert torch.equal(got.qvel, want.qvel)
+    with pytest.raises(NotImplementedError):
+        torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))

@@ -104,3 +104,31 @@ def test_model_blob_packing_roundtrip():
     assert (desc.nv, desc.nefc, desc.ncon, desc.nl, desc.npair) == (27, 53, 8, 21, 4)
     assert desc.len_efc_J if hasattr(desc, "len_efc_J") else True
     assert desc.len_pair_dst == 16 and desc.len_con_friction == 40
+
+
+def test_containers_are_pytrees_and_vmap_sees_their_leaves():
+    """The reference batches with `torch.vmap` over a tensorclass `Data`; the containers here are pytree nodes with the same
+    behaviour: tensor leaves are mapped, `UnbatchedTensor` leaves and host attributes ride along, batch_size follows the view."""
+    from torch.utils import _pytree
+
+    mx = load_model("hopper")
+    d = mt.make_data(mx).expand(5).clone()
+    leaves, spec = _pytree.tree_flatten(d)
+    assert all(isinstance(t, torch.Tensor) for t in leaves) and len(leaves) > 60
+    back = _pytree.tree_unflatten(leaves, spec)
+    assert tuple(back.batch_size) == (5,) and tuple(back.contact.batch_size) == tuple(d.contact.batch_size)
+    assert isinstance(back.ncon, mt.UnbatchedTensor) and int(back.ncon) == int(d.ncon)
+
+    seen = []
+
+    def per_sample(x):
+        seen.append((tuple(x.batch_size), tuple(x.qpos.shape), tuple(x.contact.dist.shape)))
+        return x.replace(qpos=x.qpos * 2, time=x.time + 1)
+
+    out = torch.vmap(per_sample)(d)
+    assert seen == [((), (mx.nq,), (int(d.ncon),))]                       # the mapped function sees ONE environment
+    assert tuple(out.batch_size) == (5,) and torch.equal(out.qpos, d.qpos * 2) and torch.equal(out.time, d.time + 1)
+    doubled = _pytree.tree_map(lambda t: t * 2 if t.is_floating_point() else t, d)
+    assert torch.equal(doubled.qvel, d.qvel * 2) and doubled.contact.geom.dtype == d.contact.geom.dtype
+    with pytest.raises(RuntimeError, match="HIP device"):                  # the native step still refuses CPU tensors under vmap
+        torch.vmap(lambda x: mt.step(mx, x))(d)
