@@ -49,7 +49,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
   X(xanchor, 3 * m.njnt, PH_KIN) X(xaxis, 3 * m.njnt, PH_KIN)                                                  \
   X(jquat, 4 * m.njnt, PH_KIN) /* per-joint local rotation (or slide offset), computed before the chain walk */ \
-  X(geom_xpos, 3 * m.ngeom, PH_CON) X(geom_xmat, 9 * m.ngeom, PH_CON)                                          \
+  X(geom_xpos, 3 * m.ngeom, 0) X(geom_xmat, 9 * m.ngeom, 0) /* PH_CON, aliased over efc_J (dead before the rows are built): see lds_carve */ \
   X(subtree_com, 3 * m.nbody, PH_KIN | PH_CON | PH_VEL) X(cinert, 10 * m.nbody, PH_KIN | PH_CRB | PH_VEL)      \
   X(crb, 10 * m.nbody, PH_CRB) X(cdof, 6 * m.nv, PH_KIN | PH_CRB | PH_CON | PH_VEL)                            \
   X(cdof_dot, 6 * m.nv, PH_VEL) X(cvel, 6 * m.nbody, PH_VEL) X(cacc, 6 * m.nbody, PH_VEL)                      \
@@ -64,13 +64,13 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
-  X(efc_J, m.nefc * m.nv, PH_CON) X(efc_D, m.nefc, PH_CON | PH_SOL)                                            \
+  X(efc_J, m.nefc * m.nv, PH_CON) X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
-  X(efc_aref, m.nefc, PH_CON | PH_SOL)                                                                         \
-  X(efc_pos, m.nefc, PH_CON) X(efc_pos_norm, m.nefc, PH_CON) X(efc_invweight, m.nefc, PH_CON)                  \
+  X(efc_aref, m.nefc, PH_SOL)                                                                                  \
+  X(efc_pos, m.ne + m.nf + m.nl, PH_CON) X(efc_pos_norm, m.ne + m.nf + m.nl, PH_CON) X(efc_invweight, m.ne + m.nf + m.nl, PH_CON) /* contact rows recompute theirs */ \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL)                      \

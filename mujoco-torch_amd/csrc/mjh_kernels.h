@@ -34,6 +34,13 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
 #define X(n, c, p) o.n = off; if ((p) & phase_bit) off += (((c) + 1) & ~1);
   MJH_LDS_ARRAYS(X, m)
 #undef X
+  if (phase_bit == PH_CON) {
+    // the geom frames are only read by the narrow phase, the dense efc_J only written after it: they share storage
+    // (unless the frames are the larger of the two, then they get their own)
+    const int n3 = ((3 * m.ngeom + 1) & ~1), n9 = ((9 * m.ngeom + 1) & ~1), nj = ((m.nefc * m.nv + 1) & ~1);
+    if (n3 + n9 <= nj) { o.geom_xpos = o.efc_J; o.geom_xmat = o.efc_J + n3; }
+    else { o.geom_xpos = off; o.geom_xmat = off + n3; off += n3 + n9; }
+  }
   if (phase_bit == PH_CRB) {
     // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
     // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
@@ -1053,28 +1060,14 @@ struct Env {
       } else {  // _instantiate_contact_elliptic :519-583
         for (int r = 0; r < dim; r++) S.efc_J()[(row0 + r) * nv + d] = diff[r] * active;
       }
-      if (d == 0) {  // per-row scalars of this contact
-        const REAL t = M.body_invweight0[b1] + M.body_invweight0[b2];
-        if (dim == 1) {
-          S.efc_pos()[row0] = dist * active; S.efc_pos_norm()[row0] = dist * active; S.efc_invweight()[row0] = t;
-        } else if (!elliptic) {
-          const REAL mu = fric[0];
-          const REAL iw = (t + mu * mu * t) * 2 * mu * mu / M.impratio;
-          for (int ed = 0; ed < 2 * (dim - 1); ed++) { S.efc_pos()[row0 + ed] = dist * active; S.efc_pos_norm()[row0 + ed] = dist * active; S.efc_invweight()[row0 + ed] = iw; }
-        } else {
-          const REAL iwf = t / M.impratio;
-          for (int r = 0; r < dim; r++) {
-            S.efc_pos()[row0 + r] = (r == 0 ? dist : (REAL)0) * active;
-            S.efc_pos_norm()[row0 + r] = dist;
-            S.efc_invweight()[row0 + r] = (r == 0) ? t : (r == 1 ? iwf : iwf * ((fric[0] * fric[0]) / (fric[r - 1] * fric[r - 1])));
-          }
-        }
-      }
     }
     wave_sync();
     STAMP(25);
+    const int ns = ne + nf + nl;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
+      REAL pos = 0, pos_norm = 0, invweight = 0;
+      if (r < ns) { pos = S.efc_pos()[r]; pos_norm = S.efc_pos_norm()[r]; invweight = S.efc_invweight()[r]; }
       if (r < ne) {
         const int id = M.eq_id[M.efc_row_eq[r]];
         solref[0] = M.eq_solref[2 * id]; solref[1] = M.eq_solref[2 * id + 1];
@@ -1087,28 +1080,43 @@ struct Env {
         const int j = M.lim_jnt[r - ne - nf];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
-      } else {
+      } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
         const int c = M.efc_row_con[r], sub = r - M.con_efc_address[c];
         const REAL* sr = M.con_solref + 2 * c;
         solref[0] = sr[0]; solref[1] = sr[1];
-        if (elliptic && M.con_dim[c] > 1 && sub > 0) {
+        const int dim = M.con_dim[c];
+        if (elliptic && dim > 1 && sub > 0) {
           const REAL* sf = M.con_solreffriction + 2 * c;
           const REAL none = (REAL)(!((sf[0] != 0) || (sf[1] != 0)));
           solref[0] = sf[0] + sr[0] * none; solref[1] = sf[1] + sr[1] * none;
         }
         for (int i = 0; i < 5; i++) solimp[i] = M.con_solimp[5 * c + i];
+        const REAL* fric = M.con_friction + 5 * c;
+        const REAL dist = S.con_dist()[c] - M.con_includemargin[c];
+        const REAL active = (REAL)(dist < 0);
+        const REAL t = M.body_invweight0[M.geom_bodyid[M.con_geom1[c]]] + M.body_invweight0[M.geom_bodyid[M.con_geom2[c]]];
+        if (dim == 1) {
+          pos = dist * active; pos_norm = dist * active; invweight = t;
+        } else if (!elliptic) {
+          const REAL mu = fric[0];
+          pos = dist * active; pos_norm = dist * active; invweight = (t + mu * mu * t) * 2 * mu * mu / M.impratio;
+        } else {
+          const REAL iwf = t / M.impratio;
+          pos = (sub == 0 ? dist : (REAL)0) * active;
+          pos_norm = dist;
+          invweight = (sub == 0) ? t : (sub == 1 ? iwf : iwf * ((fric[0] * fric[0]) / (fric[sub - 1] * fric[sub - 1])));
+        }
       }
       REAL k, b, imp;
-      kbi(solref, solimp, S.efc_pos_norm()[r], k, b, imp);
-      REAL rr = S.efc_invweight()[r] * (1 - imp) / imp;
+      kbi(solref, solimp, pos_norm, k, b, imp);
+      REAL rr = invweight * (1 - imp) / imp;
       rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
       const REAL jv = dot_seq(S.efc_J() + r * nv, 1, S.qvel(), 1, nv);
-      S.efc_aref()[r] = -b * jv - k * imp * S.efc_pos()[r];
-      S.efc_D()[r] = 1 / rr;
+      if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
+      if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
     }
-    wave_sync();
     STAMP(26);
-    put(out.efc_J, S.efc_J(), nefc * nv); put(out.efc_D, S.efc_D(), nefc); put(out.efc_aref, S.efc_aref(), nefc);
+    put(out.efc_J, S.efc_J(), nefc * nv);
     STAMP(27);
     if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : (REAL)0;
   }
