@@ -56,6 +56,67 @@ def algorithmic_bytes_per_env_step(mx, dtype):
     return in_b, out_b
 
 
+# Data leaves each kernel of the step reads from / writes to global memory (mjh_kernels.h: the row_load / put calls of each phase).
+# Kernel ids as mjh_debug_phase_times reports them; 5 = velocity phase with fluid forces, 6 = solver phase with frictionloss /
+# equality rows (same I/O as 3 / 4).  "contact_*" stands for the per-contact leaves.
+_CONTACT_OUT = ("contact_dist contact_pos contact_frame contact_includemargin contact_friction contact_solref contact_solreffriction "
+                "contact_solimp contact_dim contact_geom1 contact_geom2 contact_geom contact_efc_address").split()
+KERNEL_IO = {
+    0: ("qpos", "qpos xpos xquat xmat xipos ximat xanchor xaxis geom_xpos geom_xmat site_xpos site_xmat cam_xpos cam_xmat light_xpos "
+             "light_xdir subtree_com cdof cinert"),
+    1: ("cinert cdof", "crb qM qLD"),
+    2: ("geom_xpos geom_xmat subtree_com cdof qpos qvel", " ".join(_CONTACT_OUT) + " efc_J efc_D efc_aref efc_frictionloss"),
+    3: ("qpos qvel act ctrl qfrc_applied xfrc_applied cdof cinert subtree_com xipos",
+        "actuator_length actuator_moment actuator_velocity cvel cdof_dot qfrc_bias qfrc_passive actuator_force qfrc_actuator qfrc_smooth act_dot"),
+    4: ("qLD qM efc_J efc_D efc_aref qfrc_smooth qacc_warmstart qpos qvel act act_dot time",
+        "qacc_smooth qacc qacc_warmstart efc_force qfrc_constraint qpos qvel act time"),
+    7: ("geom_xpos geom_xmat", "contact_dist contact_pos contact_frame"),
+    8: ("site_xpos site_xmat geom_xpos geom_xmat cvel subtree_com qpos qvel", "sensordata"),
+}
+KERNEL_IO[5], KERNEL_IO[6] = KERNEL_IO[3], KERNEL_IO[4]
+KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kernel<{r}, 1, 64> (crb / factor)", 2: "mjh_phase_kernel<{r}, 2, 64> (collision / constraint)",
+               3: "mjh_phase_kernel<{r}, 3, W> (velocity)", 4: "mjh_phase_kernel<{r}, 4, 64> (solve / integrate)", 5: "mjh_phase_kernel<{r}, 5, W> (velocity + fluid)",
+               6: "mjh_phase_kernel<{r}, 6, 64> (solve / integrate, general rows)", 7: "mjh_convex_kernel<{r}>", 8: "mjh_sensor_kernel<{r}>"}
+
+
+def kernel_algorithmic_bytes(mx, dtype):
+    """{kernel id: bytes of the Data leaves one environment's launch of that kernel reads + writes} (leaves absent from the model count 0)."""
+    d = mt.make_data(mx)
+    if dtype != torch.float64:
+        d = d.to(dtype)
+
+    def nbytes(name):
+        t = native.data_field_tensor(d, name)
+        return 0 if t is None else t.numel() * t.element_size()
+
+    return {k: sum(nbytes(n) for n in r.split()) + sum(nbytes(n) for n in w.split()) for k, (r, w) in KERNEL_IO.items()}
+
+
+def per_kernel_times(mdev, bufs, cur, steps, device):
+    """Average duration of every kernel of a step, from HIP events recorded on the launch stream around each launch."""
+    import ctypes
+
+    lib = native.load_library()
+    lib.mjh_debug_phase_timing(1)
+    ms = (ctypes.c_float * 96)()
+    ids = (ctypes.c_int * 96)()
+    tot, cnt = {}, {}
+    try:
+        for _ in range(steps):
+            mt.step(mdev, bufs[cur], out=bufs[1 - cur])
+            cur = 1 - cur
+            n = lib.mjh_debug_phase_times(ms, ids, 96)
+            if n < 0:
+                raise RuntimeError(lib.mjh_last_error().decode())
+            for i in range(n):
+                tot[ids[i]] = tot.get(ids[i], 0.0) + ms[i]
+                cnt[ids[i]] = cnt.get(ids[i], 0) + 1
+    finally:
+        lib.mjh_debug_phase_timing(0)
+    torch.cuda.synchronize(device)
+    return {k: dict(avg_ms=tot[k] / cnt[k], launches_per_step=cnt[k] / steps, ms_per_step=tot[k] / steps) for k in tot}, cur
+
+
 def build_inputs(mx, B, dtype, device, seed=42):
     d = mt.make_data(mx).expand(B).clone()
     d = d.replace(qvel=torch.tensor(0.01 * np.random.RandomState(seed).randn(B, mx.nv)))
@@ -76,11 +137,15 @@ def cpu_baseline(mx, dtype, B_sample, steps):
         d = d.to(dtype)
     d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))  # warm
     t0 = time.perf_counter()
-    for _ in range(steps):
+    done = 0
+    while True:  # a bounded sample: at least `steps` steps and ~12 s of CPU work, at most 40 s
         d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))
-    dt = time.perf_counter() - t0
-    return dict(value=B_sample * steps / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{B_sample} envs x {steps} steps, oracle/mjoracle.c with OpenMP over environments ({dt:.1f} s)")
+        done += 1
+        dt = time.perf_counter() - t0
+        if (done >= steps and dt >= 12.0) or dt >= 40.0:
+            break
+    return dict(value=B_sample * done / dt, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"{B_sample} envs x {done} steps, oracle/mjoracle.c with OpenMP over environments ({dt:.1f} s)")
 
 
 def main():
@@ -149,6 +214,9 @@ def main():
         elapsed = float(t.item())
     final = bufs[cur]
     assert torch.isfinite(final.qpos).all(), "non-finite state after the timed steps"
+    kernels = None
+    if rank == 0:  # per-kernel durations of the same loop (events around every launch; outside the timed region)
+        kernels, cur = per_kernel_times(mdev, bufs, cur, min(args.steps, 50), device)
 
     if rank == 0:
         traffic = None
@@ -160,6 +228,21 @@ def main():
         alg = in_b + out_b
         achieved = alg * B / (kernel_ms * 1e-3) / 1e9
         value = B * world * args.steps / elapsed
+        rname = "double" if dtype == torch.float64 else "float"
+        kbytes = kernel_algorithmic_bytes(mx, dtype)
+        per_kernel = []
+        for k, t in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+            gbs = kbytes[k] * B / (t["avg_ms"] * 1e-3) / 1e9
+            per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
+                               "algorithmic_bytes_per_env": kbytes[k], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
+        dom = per_kernel[0]
+        ktraffic = None
+        if os.path.exists(tfile):
+            with open(tfile) as f:
+                tj = json.load(f)
+            for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
+                if dom["kernel"].split(" (")[0].replace(" ", "").replace("W>", "") in name.replace(" ", ""):
+                    ktraffic = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -168,10 +251,14 @@ def main():
             "config": {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"independent-envs x{world} (no collectives)",
                        "lds_bytes_per_env_by_phase": native.get_native_model(mdev, device, dtype).lds_bytes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_per_step": alg * B,
-                         "kernel": "mjh_phase_kernel<REAL,0..4> (+ mjh_convex_kernel for box/mesh pairs): the launches of one step (HIP events on the launch stream)",
-                         "kernel_ms": kernel_ms},
+            # dominant kernel of the step: its Data-leaf bytes per launch / its average launch duration (HIP events around each launch,
+            # on the launch stream); "step" = the same for the whole launch sequence of a step (SURVEY section 8(d) per-unit figure)
+            "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": ktraffic,
+                         "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_env"] * B,
+                         "per_kernel": per_kernel,
+                         "step": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_env_step": alg,
+                                  "algorithmic_bytes_per_step": alg * B, "kernel_ms": kernel_ms,
+                                  "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}},
         }
         if not args.no_cpu_baseline and world == 1:
             nB = min(B, 4096)

@@ -344,6 +344,13 @@ int mjh_reset_where(const mjhModel* m, mjhData* d, const mjhData* d0, const unsi
  * collision/constraint, velocity/acceleration, solve/integrate); the number of phases is 5. */
 int mjh_model_lds_bytes(const mjhModel* m, int phase);
 
+/* measurement aid used by bench.py for the per-kernel roofline: while enabled, every kernel launch of mjh_step / mjh_forward is
+ * bracketed by HIP events on the launch stream; mjh_debug_phase_times() waits for the most recent call and returns, per launch,
+ * the elapsed milliseconds and the kernel id (0..4 pipeline phases, 5 velocity phase with fluid, 6 solver phase with frictionloss /
+ * equality rows, 7 convex narrow phase, 8 sensors).  Returns the number of launches (<= max) or a negative code. */
+int mjh_debug_phase_timing(int enable);
+int mjh_debug_phase_times(float* ms, int* kernel_ids, int max);
+
 /* last error message of the calling thread ("" if none) */
 const char* mjh_last_error(void);
 

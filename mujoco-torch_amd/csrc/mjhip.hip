@@ -20,6 +20,19 @@
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+// ---- per-launch timing (mjh_debug_phase_timing): HIP events on the launch stream around every kernel of a call ----------------
+#define MJH_TIMING_MAX 96
+static struct {
+  bool on = false;
+  int n = 0;                          // launches recorded by the last call
+  int id[MJH_TIMING_MAX];             // 0..6 phase-kernel ids, 7 convex narrow phase, 8 sensors
+  hipEvent_t ev[MJH_TIMING_MAX + 1];  // ev[i] .. ev[i + 1] brackets launch i
+} g_timing;
+static inline void timing_begin(hipStream_t s) { if (g_timing.on) { g_timing.n = 0; (void)hipEventRecord(g_timing.ev[0], s); } }
+static inline void timing_mark(hipStream_t s, int id) {
+  if (g_timing.on && g_timing.n < MJH_TIMING_MAX) { g_timing.id[g_timing.n] = id; g_timing.n++; (void)hipEventRecord(g_timing.ev[g_timing.n], s); }
+}
 #define HIP_TRY(x)                                                                                         \
   do {                                                                                                     \
     hipError_t e_ = (x);                                                                                   \
@@ -339,6 +352,7 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * m->lds_bytes[A]), stream, a);
   HIP_TRY(hipGetLastError());
+  timing_mark(stream, P);
   return 0;
 }
 template <typename REAL, int P>
@@ -363,6 +377,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
     hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
+    timing_mark(stream, 7);
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
@@ -371,6 +386,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
     HIP_TRY(hipGetLastError());
+    timing_mark(stream, 8);
   }
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
@@ -383,6 +399,7 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
   static_assert(sizeof(KArgs<REAL>) <= 4096, "kernel arguments exceed the 4 KiB kernarg segment");
   KArgs<REAL> a;
   memset(&a, 0, sizeof(a));
+  timing_begin((hipStream_t)stream);
   a.M = M;
   memcpy(&a.in, in, sizeof(a.in));
   memcpy(&a.fin, out, sizeof(a.fin));
@@ -625,6 +642,27 @@ int mjh_reset_where(const mjhModel* m, mjhData* d, const mjhData* d0, const unsi
   hipLaunchKernelGGL(mjh_reset_kernel, dim3((unsigned)B), dim3(256), 0, s, a);
   HIP_TRY(hipGetLastError());
   return 0;
+}
+
+/* measurement aid (bench.py): while enabled, every kernel launch of mjh_step / mjh_forward is bracketed by HIP events recorded
+ * on the launch stream; mjh_debug_phase_times() waits for the last call and returns the elapsed time of each of its launches.
+ * Not for concurrent callers; costs one hipEventRecord per launch while on. */
+int mjh_debug_phase_timing(int enable) {
+  if (enable && !g_timing.on) {
+    for (int i = 0; i <= MJH_TIMING_MAX; i++) HIP_TRY(hipEventCreate(&g_timing.ev[i]));
+    g_timing.on = true; g_timing.n = 0;
+  } else if (!enable && g_timing.on) {
+    for (int i = 0; i <= MJH_TIMING_MAX; i++) (void)hipEventDestroy(g_timing.ev[i]);
+    g_timing.on = false; g_timing.n = 0;
+  }
+  return 0;
+}
+int mjh_debug_phase_times(float* ms, int* ids, int max) {
+  if (!g_timing.on) return fail(-22, "mjh_debug_phase_timing(1) has not been called");
+  const int n = g_timing.n < max ? g_timing.n : max;
+  if (n > 0) HIP_TRY(hipEventSynchronize(g_timing.ev[g_timing.n]));
+  for (int i = 0; i < n; i++) { HIP_TRY(hipEventElapsedTime(&ms[i], g_timing.ev[i], g_timing.ev[i + 1])); ids[i] = g_timing.id[i]; }
+  return n;
 }
 
 /* diagnostic (-DMJH_STAMPS builds): device buffer [B, 128] of uint64 receiving in-kernel clock stamps */

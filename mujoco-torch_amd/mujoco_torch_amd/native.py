@@ -213,6 +213,10 @@ def load_library(path: str | None = None):
     lib.mjh_step.restype = ctypes.c_int
     lib.mjh_reset_where.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     lib.mjh_reset_where.restype = ctypes.c_int
+    lib.mjh_debug_phase_timing.argtypes = [ctypes.c_int]
+    lib.mjh_debug_phase_timing.restype = ctypes.c_int
+    lib.mjh_debug_phase_times.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    lib.mjh_debug_phase_times.restype = ctypes.c_int
     lib.mjh_model_lds_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.mjh_model_lds_bytes.restype = ctypes.c_int
     lib.mjh_model_work_bytes.argtypes = [ctypes.c_void_p]
