@@ -506,6 +506,18 @@ struct Env {
           }
         }
       }
+      if (M.nmocap > 0) {  // mocap bodies take the caller's pose after the tree pass (smooth.py:105-113); children of the world, no joints
+        const int k = M.body_mocapid[b];
+        if (k >= 0) {
+          const REAL* mp = in.mocap_pos + (e * M.nmocap + k) * 3;
+          const REAL* mq = in.mocap_quat + (e * M.nmocap + k) * 4;
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = mp[i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) quat[i] = mq[i];
+          normalize_n<REAL, 4>(quat);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
 #pragma unroll

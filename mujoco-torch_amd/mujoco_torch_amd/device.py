@@ -90,8 +90,6 @@ def _validate(m):
         # the reference ignores eq_objtype and reads site ids as body ids (constraint.py:116-212): harmless while the
         # constraint is inactive (every row is multiplied by eq_active), meaningless once it is active
         raise NotImplementedError("site-based connect / weld constraints can only be carried inactive")
-    if int(m.nmocap):
-        raise NotImplementedError("mocap bodies are not supported by the native stepper yet.")
     if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
         raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
     if np.any(np.asarray(_get(m, "body_gravcomp", lambda: np.zeros(int(m.nbody)))) != 0):

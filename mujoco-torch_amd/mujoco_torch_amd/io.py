@@ -92,4 +92,11 @@ def make_data(m: Model) -> Data:
         subtree_linvel=z(m.nbody, 3), subtree_angmom=z(m.nbody, 3),
         batch_size=[],
     )
+    if m.nmocap > 0:  # mocap bodies start at their model pose (reference io.py:208-219, as the C library does)
+        ids = np.asarray(m.body_mocapid)
+        mask = ids >= 0
+        mp, mq = z(m.nmocap, 3), z(m.nmocap, 4)
+        mp[ids[mask]] = m.body_pos.to(DEFAULT_DTYPE).cpu()[mask]
+        mq[ids[mask]] = m.body_quat.to(DEFAULT_DTYPE).cpu()[mask]
+        d = d.replace(mocap_pos=mp, mocap_quat=mq)
     return d

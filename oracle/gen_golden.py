@@ -75,13 +75,16 @@ CASES = {
     "equality_loops_f64": ("equality_loops", {}, "float64", 3, 3, "generic"),
     "equality_loops_cg_f64": ("equality_loops", {"solver": 1}, "float64", 2, 2, "generic"),
     "equality_loops_rk4_f32": ("equality_loops", {"integrator": 1}, "float32", 2, 2, "generic"),
+    # mocap bodies (smooth.py:105-113): a free capsule resting on a mocap-driven sphere and pad over a plane
+    "mocap_f64": ("mocap_target", {}, "float64", 3, 3, "mocap"),
+    "mocap_rk4_f32": ("mocap_target", {"integrator": 1}, "float32", 2, 2, "mocap"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
     "ant_frictionloss_rk4_ell_f32": ("ant_frictionloss", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 2, 2, "bench_ctrl"),
 }
 
-INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
+INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
 
 
 def make_inputs(recipe, lite, env):
@@ -120,6 +123,10 @@ def make_inputs(recipe, lite, env):
     elif recipe == "friction_hinge":  # stick (small torque), slip both ways (large torque): reference test/solver_test.py:77-108
         out["qvel"] = np.array([0.0, 0.5, -0.5][env % 3]) * np.ones(nv)
         out["qfrc_applied"] = np.array([0.5, 100.0, -100.0][env % 3]) * np.ones(nv)
+    elif recipe == "mocap":  # the caller moves the mocap bodies (un-normalised quaternion on purpose); free bodies get velocities
+        out["qvel"] = 0.3 * rng.randn(nv)
+        out["mocap_pos"] = lite.body_pos[lite.body_mocapid >= 0] + 0.05 * rng.randn(lite.nmocap, 3) * (env > 0)
+        out["mocap_quat"] = lite.body_quat[lite.body_mocapid >= 0] + 0.3 * rng.randn(lite.nmocap, 4) * (env > 0)
     elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
         out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
         out["qvel"] = 0.3 * rng.randn(nv)

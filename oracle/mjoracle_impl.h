@@ -348,6 +348,16 @@ static void FN(kinematics)(const FN(MjoModel) * M, FN(MjoWork) * w, int with_cam
     for (int i = 0; i < 4; i++) w->xquat[4 * b + i] = quat[i];
     FN(quat_to_mat)(quat, w->xmat + 9 * b);
   }
+  for (int b = 0; b < m->nbody && m->nmocap > 0; b++) { /* mocap bodies take the caller's pose after the tree pass (smooth.py:105-113) */
+    int k = m->body_mocapid[b];
+    if (k < 0) continue;
+    REAL q[4];
+    for (int i = 0; i < 3; i++) w->xpos[3 * b + i] = w->mocap_pos[3 * k + i];
+    for (int i = 0; i < 4; i++) q[i] = w->mocap_quat[4 * k + i];
+    FN(normalize_n)(q, 4);
+    for (int i = 0; i < 4; i++) w->xquat[4 * b + i] = q[i];
+    FN(quat_to_mat)(q, w->xmat + 9 * b);
+  }
   for (int b = 0; b < m->nbody; b++)
     FN(local_to_global)(w->xpos + 3 * b, w->xquat + 4 * b, M->body_ipos + 3 * b, M->body_iquat + 4 * b, w->xipos + 3 * b, w->ximat + 9 * b);
   for (int g = 0; g < m->ngeom; g++) {

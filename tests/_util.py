@@ -13,7 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 REAL_LEAVES = native.LISTS["MJH_DATA_REALS"]
 INT_LEAVES = native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
-INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com"]
+INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
 
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith(("traj_", "env_")))
 ENV_CASES = sorted(f[4:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("env_"))
@@ -60,7 +60,7 @@ class Golden:
             d = mt.make_data(self.model)
             if self.dtype != torch.float64:
                 d = d.to(self.dtype)
-            kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES}
+            kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES if f"in/{e}/{n}" in self.z}  # older recordings have no mocap leaves
             return d.replace(**kw)
 
         if env is not None:
