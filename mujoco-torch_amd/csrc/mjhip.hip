@@ -332,6 +332,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     out->pack2[P] = 1;                                                                                                       \
   }
   SET_PACK(0) SET_PACK(3)
+  if (sizeof(REAL) == 4 && d->nv <= 16) { SET_PACK(1) }  // float32 CRB of small models: register-bound at 4 waves/SIMD, two environments per wave double the residents
 #undef SET_PACK
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
@@ -357,9 +358,9 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  if ((P == 0 || P == 3 || P == 5) && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
+  if ((P == 0 || P == 1 || P == 3 || P == 5) && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
     const int64_t even = a.B & ~(int64_t)1;
-    int rc = launch_range<REAL, P, ((P == 0 || P == 3 || P == 5) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
+    int rc = launch_range<REAL, P, ((P == 0 || P == 1 || P == 3 || P == 5) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
     if (rc) return rc;
     return launch_range<REAL, P, MJH_WAVE>(m, a, even, a.B - even, stream);
   }
