@@ -324,3 +324,34 @@ def test_vmap_idiom_is_one_native_batch():
     assert torch.equal(got.qvel, want.qvel)
     with pytest.raises(NotImplementedError):
         torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))
+
+
+@pytest.mark.parametrize("scale,batch,nsteps", [(2.0, 64, 500), (50.0, 16, 200)])
+def test_halfcheetah_no_nan_stress(scale, batch, nsteps):
+    """The reference's TestNaNStress (test/mjx_correctness_test.py:337-383), through the same `torch.vmap(step)` idiom: extreme
+    initial velocities and random controls every step must never produce a non-finite state."""
+    mx = load_model("halfcheetah")
+    rng = np.random.RandomState(0)
+    d = mt.make_data(mx).expand(batch).clone().replace(qvel=torch.tensor(rng.randn(batch, mx.nv) * scale))
+    mdev, d = mx.to("cuda"), d.to("cuda")
+    vmap_step = torch.vmap(lambda x: mt.step(mdev, x))
+    for s in range(nsteps):
+        d = d.replace(ctrl=torch.tensor(rng.uniform(-1, 1, (batch, mx.nu)), device="cuda"))
+        d = vmap_step(d)
+        if s % 25 == 0 or s == nsteps - 1:
+            assert torch.isfinite(d.qpos).all() and torch.isfinite(d.qvel).all(), f"non-finite state at step {s}"
+
+
+def test_check_state_resets_bad_entries(oracle_lib):
+    """forward.py:44-59: non-finite or > 1e10 entries of qpos / qvel / qacc are replaced (qpos0 / 0 / 0) before the step."""
+    mx = load_model("hopper")
+    B = 6
+    d = mt.make_data(mx).expand(B).clone()
+    q, v, a = d.qpos.clone(), 0.1 * torch.ones(B, mx.nv, dtype=torch.float64), torch.zeros(B, mx.nv, dtype=torch.float64)
+    q[1, 2] = float("nan"); q[2, 0] = 3e10; v[3, 1] = float("inf"); v[4, 4] = -2e10; a[5, 0] = float("nan")
+    d = d.replace(qpos=q, qvel=v, qacc=a)
+    out = gpu_out_to_numpy(mt.step(mx.to("cuda"), d.to("cuda")))
+    want = pyoracle.run(mx, d, step=True)
+    for n in ("qpos", "qvel", "qacc", "xpos", "qfrc_bias"):
+        assert np.isfinite(out[n]).all(), n
+        assert rel_err(out[n], want[n], 1e-3) < 1e-7, n
