@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 6
+#define MJH_ABI_VERSION 7
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -93,6 +93,7 @@ extern "C" {
   X(jnt_dofadr)     /* njnt */                                                                   \
   X(jnt_bodyid)     /* njnt */                                                                   \
   X(jnt_actfrclimited) /* njnt */                                                                \
+  X(jnt_actgravcomp) /* njnt: gravity compensation of the joint's dofs is applied as an actuator force (forward.py:206-207) */ \
   X(dof_bodyid)     /* nv */                                                                     \
   X(dof_jntid)      /* nv */                                                                     \
   X(dof_parentid)   /* nv */                                                                     \
@@ -179,6 +180,7 @@ extern "C" {
   X(dof_frictionloss) /* nv */                                                                   \
   X(dof_solref)     /* nv*2 */                                                                   \
   X(dof_solimp)     /* nv*5 */                                                                   \
+  X(body_gravcomp)  /* nbody: fraction of the body's weight compensated (passive.py:148-156); all zero = none */ \
   X(body_invweight0_rot) /* nbody (rotational component; weld rows 3..5, constraint.py:193-194) */         \
   X(eq_data)        /* neq*11 (MuJoCo layout: connect anchors; weld anchors, relpose, torquescale; joint polycoef) */ \
   X(eq_solref)      /* neq*2 */                                                                  \
@@ -287,6 +289,7 @@ typedef struct mjhModelDesc {
   X(cdof_dot)         /* nv*6 */                                                                 \
   X(qfrc_bias)        /* nv */                                                                   \
   X(qfrc_passive)     /* nv */                                                                   \
+  X(qfrc_gravcomp)    /* nv (written only by models with gravity compensation; otherwise the caller's value stays, passive.py:190-194) */ \
   X(actuator_force)   /* nu */                                                                   \
   X(qfrc_actuator)    /* nv */                                                                   \
   X(qfrc_smooth)      /* nv */                                                                   \

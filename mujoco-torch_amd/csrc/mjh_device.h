@@ -73,7 +73,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(efc_pos, m.ne + m.nf + m.nl, PH_CON) X(efc_pos_norm, m.ne + m.nf + m.nl, PH_CON) X(efc_invweight, m.ne + m.nf + m.nl, PH_CON) /* contact rows recompute theirs */ \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
-  X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL)                      \
+  X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
   X(qfrc_smooth, m.nv, PH_VEL | PH_SOL) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
   X(qacc_warm, m.nv, PH_SOL) X(qacc, m.nv, PH_SOL) X(qfrc_constraint, m.nv, PH_SOL)                            \
   X(s_qacc, m.nv, PH_SOL) X(s_qfrc, m.nv, PH_SOL) X(s_Ma, m.nv, PH_SOL) X(s_grad, m.nv, PH_SOL)                \
@@ -100,6 +100,7 @@ struct DevModel {
   REAL timestep, impratio, gravity[3];
   REAL density, viscosity, wind[3];  // fluid model (passive.py:31-78)
   int has_fluid;
+  int has_gravcomp;  // some body_gravcomp != 0 (device.py:667)
   double meaninertia, tolerance, ls_tolerance;  // python floats in the reference (solver.py:256-265)
 #define X(n) const int* n;
   MJH_MODEL_INT_ARRAYS(X)

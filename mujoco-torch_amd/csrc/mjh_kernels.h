@@ -1198,6 +1198,7 @@ struct Env {
     // passive forces
     if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = 0;
+      if (FLUID && M.has_gravcomp) for (int d = l; d < nv; d += W) { S.qfrc_gravcomp()[d] = 0; if (out.qfrc_gravcomp) out.qfrc_gravcomp[e * nv + d] = 0; }  // passive.py:178-183
     } else {
       for (int j = l; j < M.njnt; j += W) {
         const int t = M.jnt_type[j], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
@@ -1217,7 +1218,30 @@ struct Env {
       }
       wave_sync();
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
-      if (FLUID) {  // (own kernel instantiation: its registers must not weigh on fluid-free models) passive._fluid :158-173 with _inertia_box_fluid_model :31-78: one lane per body, wrench staged in cfrc
+      if (FLUID && M.has_gravcomp && (M.disableflags & DSBL_GRAVITY)) {  // gravity off: the caller's leaf is carried (passive.py:190-194) and still feeds the actuator term
+        for (int d = l; d < nv; d += W) {
+          const REAL v = in.qfrc_gravcomp ? in.qfrc_gravcomp[e * nv + d] : (REAL)0;
+          S.qfrc_gravcomp()[d] = v;
+          if (out.qfrc_gravcomp) out.qfrc_gravcomp[e * nv + d] = v;
+        }
+      }
+      if (FLUID && M.has_gravcomp && !(M.disableflags & DSBL_GRAVITY)) {  // passive._gravcomp :148-156: -gravity * mass * gravcomp at every body's inertial origin
+        wave_sync();
+        for (int d = l; d < nv; d += W) {
+          REAL acc = 0;
+          for (int b = 0; b < nb; b++) {
+            const REAL mg = M.body_mass[b] * M.body_gravcomp[b];
+            const REAL f[3] = {-M.gravity[0] * mg, -M.gravity[1] * mg, -M.gravity[2] * mg};
+            REAL jp[3], jr[3];
+            jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+            acc += dot3(jp, f);
+          }
+          S.qfrc_gravcomp()[d] = acc;
+          if (out.qfrc_gravcomp) out.qfrc_gravcomp[e * nv + d] = acc;
+          S.qfrc_passive()[d] = S.qfrc_passive()[d] + acc * (REAL)(1 - M.jnt_actgravcomp[M.dof_jntid[d]]);
+        }
+      }
+      if (FLUID && M.has_fluid) {  // (own kernel instantiation: its registers must not weigh on fluid-free models) passive._fluid :158-173 with _inertia_box_fluid_model :31-78: one lane per body, wrench staged in cfrc
         for (int b = l; b < nb; b += W) {
           const REAL pi = (REAL)3.14159265358979323846;
           const REAL* inr = M.body_inertia + 3 * b;
@@ -1339,6 +1363,7 @@ struct Env {
   }
 
   // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
+  template <bool FLUID>
   __device__ __forceinline__ void actuation() {
     const int l = lane();
     const int nv = M.nv, nu = M.nu;
@@ -1395,6 +1420,7 @@ struct Env {
         // moment^T force: only the actuators on this dof have a non-zero moment entry (actuator order kept)
         for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) { const int i = M.dof_act_id[q]; s += M.act_gear[6 * i] * S.act_force()[i]; }
         const int j = M.dof_jntid[d];
+        if (FLUID && M.has_gravcomp) s = s + S.qfrc_gravcomp()[d] * (REAL)M.jnt_actgravcomp[j];  // forward.py:206-207 (the leaf is zero while gravity is disabled)
         if (M.jnt_actfrclimited[j]) {
           const REAL lo = M.jnt_actfrcrange[2 * j], hi = M.jnt_actfrcrange[2 * j + 1];
           s = s < lo ? lo : (s > hi ? hi : s);
@@ -1926,7 +1952,7 @@ struct Env {
   __device__ __forceinline__ void run_vel() {
     STAMP(30);
     velocity<FLUID>();
-    if (KA.stages & 0x60) actuation();
+    if (KA.stages & 0x60) actuation<FLUID>();
   }
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.

@@ -93,7 +93,7 @@ std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
   F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
   F(efc_D, nefc) F(efc_aref, nefc) F(efc_force, nefc) F(actuator_velocity, nu) F(cvel, nb * 6) F(cdof_dot, nv * 6)
-  F(qfrc_bias, nv) F(qfrc_passive, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
+  F(qfrc_bias, nv) F(qfrc_passive, nv) F(qfrc_gravcomp, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
   F(qacc_smooth, nv) F(qfrc_constraint, nv)
 #undef F
   return v;
@@ -108,6 +108,7 @@ const char* const kStageLeaves[] = {
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
 const char* const kEqStageLeaves[] = {"xpos", "xquat", "xmat"};  // body frames read by the equality rows (constraint.py:116-212)
 bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid, bool has_eq) {
+  if (!strcmp(name, "qfrc_gravcomp")) return false;  // staged in LDS inside the velocity phase; the leaf itself is written by stage 0 only
   if (has_eq) for (const char* s : kEqStageLeaves) if (!strcmp(s, name)) return true;
   for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
   if (has_convex) for (const char* s : kConvexStageLeaves) if (!strcmp(s, name)) return true;
@@ -128,6 +129,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   M.density = (REAL)d->density; M.viscosity = (REAL)d->viscosity;
   M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
   M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
+  M.has_gravcomp = 0;
+  for (int b = 0; b < d->nbody; b++) if (d->body_gravcomp[b] != 0) M.has_gravcomp = 1;
   M.gravity[0] = (REAL)d->gravity_x; M.gravity[1] = (REAL)d->gravity_y; M.gravity[2] = (REAL)d->gravity_z;
   M.meaninertia = d->meaninertia; M.tolerance = d->tolerance; M.ls_tolerance = d->ls_tolerance;
 #define X(n) fix.push_back({(const void**)&M.n, bb.add(d->n, sizeof(int32_t) * (size_t)d->len_##n)});
@@ -382,7 +385,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
-  if ((st & 0x70) && (rc = a.M.has_fluid ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);

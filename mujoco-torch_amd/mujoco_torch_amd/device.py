@@ -92,8 +92,6 @@ def _validate(m):
         raise NotImplementedError("site-based connect / weld constraints can only be carried inactive")
     if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
         raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
-    if np.any(np.asarray(_get(m, "body_gravcomp", lambda: np.zeros(int(m.nbody)))) != 0):
-        raise NotImplementedError("gravity compensation is not supported by the native stepper yet.")
 
 
 def _t(x, dtype):
@@ -348,7 +346,7 @@ def device_put(value, *, dtype: torch.dtype | None = None):
     m = Model(
         opt=_option(value.opt, fdtype),
         stat=stat,
-        has_gravcomp=False,
+        has_gravcomp=bool(np.any(np.asarray(_get(value, "body_gravcomp", lambda: np.zeros(int(value.nbody)))) != 0)),
         dof_tri_row=np.array(rows, dtype=np.int64),
         dof_tri_col=np.array(cols, dtype=np.int64),
         actuator_info=tuple(actuator_info),

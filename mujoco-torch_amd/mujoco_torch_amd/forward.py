@@ -48,6 +48,8 @@ def _written_names(m: Model, step: bool):
         names += _WRITTEN_EFC
     if len(m.tables.sensors["type"]) > 0:
         names += ["sensordata"]
+    if m.has_gravcomp:
+        names += ["qfrc_gravcomp"]
     if step:
         names += _WRITTEN_STEP
     return names

@@ -104,7 +104,7 @@ def pack_model(m, dtype: torch.dtype):
         body_parentid=i32(A("body_parentid")), body_rootid=i32(A("body_rootid")), body_jntadr=i32(A("body_jntadr")),
         body_jntnum=i32(A("body_jntnum")), body_dofadr=i32(A("body_dofadr")), body_dofnum=i32(A("body_dofnum")),
         body_mocapid=i32(A("body_mocapid")), jnt_type=i32(m.jnt_type.data.cpu().numpy()), jnt_qposadr=i32(A("jnt_qposadr")),
-        jnt_dofadr=i32(A("jnt_dofadr")), jnt_bodyid=i32(A("jnt_bodyid")), jnt_actfrclimited=i32(A("jnt_actfrclimited")),
+        jnt_dofadr=i32(A("jnt_dofadr")), jnt_bodyid=i32(A("jnt_bodyid")), jnt_actfrclimited=i32(A("jnt_actfrclimited")), jnt_actgravcomp=i32(A("jnt_actgravcomp")),
         dof_bodyid=i32(A("dof_bodyid")), dof_jntid=i32(A("dof_jntid")), dof_parentid=i32(A("dof_parentid")),
         geom_type=i32(A("geom_type")), geom_bodyid=i32(A("geom_bodyid")), geom_convexid=-np.ones(m.ngeom, dtype=np.int32),
         site_bodyid=i32(A("site_bodyid")), cam_bodyid=i32(A("cam_bodyid")), cam_mode=i32(A("cam_mode")),
@@ -150,7 +150,7 @@ def pack_model(m, dtype: torch.dtype):
         jnt_margin=f64(m.jnt_margin), jnt_solref=f64(m.jnt_solref), jnt_solimp=f64(m.jnt_solimp),
         jnt_actfrcrange=f64(m.jnt_actfrcrange), dof_armature=f64(m.dof_armature), dof_damping=f64(m.dof_damping),
         dof_invweight0=f64(m.dof_invweight0), sns_cutoff=f64(torch.tensor(np.asarray(T.sensors["cutoff"], dtype=np.float64))), dof_frictionloss=f64(m.dof_frictionloss), dof_solref=f64(m.dof_solref), dof_solimp=f64(m.dof_solimp),
-        body_invweight0_rot=f64(m.body_invweight0[:, 1]), eq_data=f64(m.eq_data) if m.neq else empty, eq_solref=f64(m.eq_solref) if m.neq else empty, eq_solimp=f64(m.eq_solimp) if m.neq else empty,
+        body_gravcomp=f64(m.body_gravcomp), body_invweight0_rot=f64(m.body_invweight0[:, 1]), eq_data=f64(m.eq_data) if m.neq else empty, eq_solref=f64(m.eq_solref) if m.neq else empty, eq_solimp=f64(m.eq_solimp) if m.neq else empty,
         geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
         geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
         cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
@@ -162,7 +162,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 6
+    desc.abi_version = 7
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

@@ -78,6 +78,9 @@ CASES = {
     # mocap bodies (smooth.py:105-113): a free capsule resting on a mocap-driven sphere and pad over a plane
     "mocap_f64": ("mocap_target", {}, "float64", 3, 3, "mocap"),
     "mocap_rk4_f32": ("mocap_target", {"integrator": 1}, "float32", 2, 2, "mocap"),
+    # gravity compensation (passive.py:148-156, forward.py:206-207): passive on two links, through the actuator channel on the third
+    "gravcomp_f64": ("gravcomp_arm", {}, "float64", 3, 3, "generic"),
+    "gravcomp_rk4_f32": ("gravcomp_arm", {"integrator": 1}, "float32", 2, 2, "generic"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),

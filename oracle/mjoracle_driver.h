@@ -15,7 +15,7 @@ static int FN(field_count)(const mjhModelDesc* m, const char* name) {
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
   F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
   F(efc_D, nefc) F(efc_aref, nefc) F(efc_force, nefc) F(actuator_velocity, nu) F(cvel, nb * 6) F(cdof_dot, nv * 6)
-  F(qfrc_bias, nv) F(qfrc_passive, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
+  F(qfrc_bias, nv) F(qfrc_passive, nv) F(qfrc_gravcomp, nv) F(actuator_force, nu) F(qfrc_actuator, nv) F(qfrc_smooth, nv)
   F(qacc_smooth, nv) F(qfrc_constraint, nv)
 #undef F
   return 0;
@@ -31,6 +31,8 @@ static void FN(model_init)(FN(MjoModel) * M, const mjhModelDesc* d) {
   M->density = (REAL)d->density; M->viscosity = (REAL)d->viscosity;
   M->wind[0] = (REAL)d->wind_x; M->wind[1] = (REAL)d->wind_y; M->wind[2] = (REAL)d->wind_z;
   M->has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
+  M->has_gravcomp = 0;
+  for (int b = 0; b < d->nbody; b++) if (d->body_gravcomp[b] != 0) M->has_gravcomp = 1;
   M->gravity[0] = (REAL)d->gravity_x; M->gravity[1] = (REAL)d->gravity_y; M->gravity[2] = (REAL)d->gravity_z;
 #define X(n) { M->n = FN(ralloc)((size_t)d->len_##n); for (int64_t i = 0; i < d->len_##n; i++) M->n[i] = (REAL)d->n[i]; }
   MJH_MODEL_REAL_ARRAYS(X)

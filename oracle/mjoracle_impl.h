@@ -83,6 +83,7 @@ typedef struct FN(MjoModel) {
   REAL timestep, impratio, meaninertia, gravity[3];
   REAL density, viscosity, wind[3];
   int has_fluid;
+  int has_gravcomp;
 #define X(n) REAL* n;
   MJH_MODEL_REAL_ARRAYS(X)
 #undef X
@@ -1386,6 +1387,7 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
   /* passive.passive :176-200, _spring_damper :80-145 */
   if (m->disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
     for (int d = 0; d < nv; d++) w->qfrc_passive[d] = 0;
+    for (int d = 0; d < nv; d++) w->qfrc_gravcomp[d] = 0; /* passive.py:178-183 */
   } else {
     for (int j = 0; j < m->njnt; j++) {
       int t = m->jnt_type[j], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
@@ -1404,6 +1406,20 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
       }
     }
     for (int d = 0; d < nv; d++) w->qfrc_passive[d] = (0 + w->qfrc_passive[d]) - M->dof_damping[d] * w->qvel[d];
+    if (M->has_gravcomp && !(m->disableflags & DSBL_GRAVITY)) { /* passive._gravcomp :148-156; with gravity off the input leaf is carried (:190-194) */
+      for (int d = 0; d < nv; d++) {
+        REAL acc = 0;
+        for (int b = 0; b < nb; b++) {
+          REAL mg = M->body_mass[b] * M->body_gravcomp[b];
+          REAL f[3] = {-M->gravity[0] * mg, -M->gravity[1] * mg, -M->gravity[2] * mg};
+          REAL jp[3], jr[3];
+          FN(jac_dof)(M, w, w->xipos + 3 * b, b, d, jp, jr);
+          acc += (jp[0] * f[0] + jp[1] * f[1]) + jp[2] * f[2];
+        }
+        w->qfrc_gravcomp[d] = acc;
+        w->qfrc_passive[d] = w->qfrc_passive[d] + acc * (REAL)(1 - m->jnt_actgravcomp[m->dof_jntid[d]]);
+      }
+    }
     if (M->has_fluid) { /* passive._fluid :158-173 with _inertia_box_fluid_model :31-78 */
       const REAL pi = (REAL)3.14159265358979323846;
       for (int d = 0; d < nv; d++) w->tmp_nv[d] = 0;
@@ -1536,6 +1552,7 @@ static void FN(actuation)(const FN(MjoModel) * M, FN(MjoWork) * w) {
       REAL s = 0;
       for (int i = 0; i < nu; i++) s += w->actuator_moment[i * nv + d] * w->actuator_force[i];
       int j = m->dof_jntid[d];
+      if (M->has_gravcomp) s = s + w->qfrc_gravcomp[d] * (REAL)m->jnt_actgravcomp[j]; /* forward.py:206-207 */
       if (m->jnt_actfrclimited[j]) {
         REAL lo = M->jnt_actfrcrange[2 * j], hi = M->jnt_actfrcrange[2 * j + 1];
         s = s < lo ? lo : (s > hi ? hi : s);
