@@ -71,7 +71,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
   X(efc_pos, m.ne + m.nf + m.nl, PH_CON) X(efc_pos_norm, m.ne + m.nf + m.nl, PH_CON) X(efc_invweight, m.ne + m.nf + m.nl, PH_CON) /* contact rows recompute theirs */ \
-  X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL)                         \
+  X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
   X(qfrc_smooth, m.nv, PH_VEL | PH_SOL) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
@@ -128,6 +128,13 @@ struct DevModel {
   const REAL* act_moment;                  // nu*nv: the (constant) moment matrix of joint transmissions (reference device.py:588-629)
   const int* dof_act_adr;                  // nv+1: CSR of the actuators driving each dof, in actuator order
   const int* dof_act_id;
+  const REAL* dof_act_coef;                // per entry of dof_act_id: the constant moment coefficient (a gear component)
+  const int* dof_act_rot;                  // per entry: -1, or the component of the actuator's rotated gear axis that is the coefficient
+  const int* act_ent_adr;                  // nu+1: CSR of the non-zeros of each actuator's moment row
+  const int* act_ent_dof;
+  const REAL* act_ent_coef;
+  const int* act_ent_rot;
+  int act_has_rot;                         // some JOINTINPARENT transmission on a ball / free joint (moment depends on qpos)
   float inv_nv;                            // 1 / nv for the index splits below
   const int* dof_limrow;                   // 2*nv: the (up to two: frictionloss, then joint limit) single-column rows of dof d, -1 = none
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
@@ -302,6 +309,15 @@ template <typename R>
 __device__ __forceinline__ void axis_angle_to_quat(const R* axis, R angle, R* q) {  // :363-374
   R s = r_sin<R>(angle * (R)0.5), c = r_cos<R>(angle * (R)0.5);
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+template <typename R>
+__device__ __forceinline__ void quat_to_axis_angle(const R* q, R* axis, R& angle) {  // :354-360
+  axis[0] = q[1]; axis[1] = q[2]; axis[2] = q[3];
+  const R sin_a_2 = normalize_n<R, 3>(axis);
+  R a = 2 * r_atan2<R>(sin_a_2, q[0]);
+  const R pi = (R)3.14159265358979323846;
+  if (a > pi) a = a - 2 * pi;
+  angle = a;
 }
 template <typename R>
 __device__ __forceinline__ void quat_sub(const R* u, const R* v, R* o) {  // :276-280, :354-360

@@ -1145,12 +1145,39 @@ struct Env {
     row_load<W>(S.xipos(), out.xipos, 3 * nb, e);
     wave_sync();
     STAMP(31);
+    row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
     for (int i = l; i < nu; i += W) {
-      const REAL gear = M.act_gear[6 * i];
-      S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
-      S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
+      const REAL* gear = M.act_gear + 6 * i;
+      const int jt = M.act_jnttype[i], qa = M.act_qposadr[i];
+      REAL len = 0;
+      if (jt == JNT_SLIDE || jt == JNT_HINGE) {
+        len = S.qpos()[qa] * gear[0];
+      } else {  // ball / free joints (:565-583)
+        const bool inparent = M.act_trntype[i] == 1;
+        const REAL* qp = S.qpos() + qa + (jt == JNT_FREE ? 3 : 0);
+        const REAL qn[4] = {qp[0], qp[1] * (REAL)-1, qp[2] * (REAL)-1, qp[3] * (REAL)-1};
+        REAL ga[3] = {gear[0], gear[1], gear[2]};
+        if (inparent) {
+          rotate(gear + (jt == JNT_FREE ? 3 : 0), qn, ga);
+          if (M.act_has_rot) { S.act_rot()[3 * i] = ga[0]; S.act_rot()[3 * i + 1] = ga[1]; S.act_rot()[3 * i + 2] = ga[2]; }
+        }
+        if (jt == JNT_BALL) {
+          const REAL q[4] = {qp[0], qp[1], qp[2], qp[3]};
+          REAL axis[3], angle;
+          quat_to_axis_angle(q, axis, angle);
+          len = ((axis[0] * angle) * ga[0] + (axis[1] * angle) * ga[1]) + (axis[2] * angle) * ga[2];
+        }
+      }
+      REAL vel = 0;  // moment . qvel over the row's non-zeros, in dof order
+      for (int q = M.act_ent_adr[i]; q < M.act_ent_adr[i + 1]; q++) {
+        const int rot = M.act_ent_rot[q], dd = M.act_ent_dof[q];
+        const REAL coef = rot < 0 ? M.act_ent_coef[q] : S.act_rot()[3 * i + rot];
+        vel += coef * S.qvel()[dd];
+        if (rot >= 0 && out.actuator_moment) out.actuator_moment[(e * nu + i) * nv + dd] = coef;  // after the row_store above: same wave, program order
+      }
+      S.act_length()[i] = len;
+      S.act_velocity()[i] = vel;
     }
-    row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // joint transmissions: a model constant (smooth.py:535-591)
     STAMP(32);
     // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
     for (int b = l; b < nb; b += W) {
@@ -1418,7 +1445,11 @@ struct Env {
       REAL s = 0;
       if (!off) {
         // moment^T force: only the actuators on this dof have a non-zero moment entry (actuator order kept)
-        for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) { const int i = M.dof_act_id[q]; s += M.act_gear[6 * i] * S.act_force()[i]; }
+        for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) {
+          const int i = M.dof_act_id[q];
+          const REAL coef = (M.act_has_rot && M.dof_act_rot[q] >= 0) ? S.act_rot()[3 * i + M.dof_act_rot[q]] : M.dof_act_coef[q];
+          s += coef * S.act_force()[i];
+        }
         const int j = M.dof_jntid[d];
         if (FLUID && M.has_gravcomp) s = s + S.qfrc_gravcomp()[d] * (REAL)M.jnt_actgravcomp[j];  // forward.py:206-207 (the leaf is zero while gravity is disabled)
         if (M.jnt_actfrclimited[j]) {

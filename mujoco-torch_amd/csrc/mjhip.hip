@@ -247,17 +247,47 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     fix.push_back({(const void**)&M.efc_row_eq, bb.add(row_eq.data(), sizeof(int) * row_eq.size())});
   }
   {
+    // transmission tables (smooth.transmission :535-591): the non-zeros of every actuator's moment row, actuator-major (length /
+    // velocity of an actuator) and dof-major (qfrc_actuator of a dof).  A coefficient is a model constant (gear component) except
+    // for JOINTINPARENT on ball / free joints, where it is a component of the gear axis rotated into the child frame (rot >= 0).
     std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
-    std::vector<int> adr((size_t)nv + 1, 0), ids;
+    std::vector<int> a_adr((size_t)d->nu + 1, 0), a_dof, a_rot;
+    std::vector<REAL> a_coef;
+    int has_rot = 0;
+    for (int i = 0; i < d->nu; i++) {
+      a_adr[i] = (int)a_dof.size();
+      const int jt = d->act_jnttype[i], da = d->act_dofadr[i];
+      const bool inparent = d->act_trntype[i] == 1;
+      const int width = jt == JNT_FREE ? 6 : (jt == JNT_BALL ? 3 : 1);
+      for (int k = 0; k < width; k++) {
+        const bool rot = inparent && ((jt == JNT_BALL) || (jt == JNT_FREE && k >= 3));
+        a_dof.push_back(da + k);
+        a_coef.push_back((REAL)d->act_gear[6 * i + k]);
+        a_rot.push_back(rot ? (jt == JNT_FREE ? k - 3 : k) : -1);
+        if (rot) has_rot = 1; else moment[(size_t)i * nv + da + k] = (REAL)d->act_gear[6 * i + k];
+      }
+    }
+    a_adr[d->nu] = (int)a_dof.size();
+    std::vector<int> adr((size_t)nv + 1, 0), ids, d_rot;
+    std::vector<REAL> d_coef;
     for (int dd = 0; dd < nv; dd++) {
       adr[dd] = (int)ids.size();
-      for (int i = 0; i < d->nu; i++) if (d->act_dofadr[i] == dd) ids.push_back(i);
+      for (int i = 0; i < d->nu; i++)
+        for (int q = a_adr[i]; q < a_adr[i + 1]; q++)
+          if (a_dof[q] == dd) { ids.push_back(i); d_coef.push_back(a_coef[q]); d_rot.push_back(a_rot[q]); }
     }
     adr[nv] = (int)ids.size();
-    for (int i = 0; i < d->nu; i++) moment[(size_t)i * nv + d->act_dofadr[i]] = (REAL)d->act_gear[6 * i];
+    M.act_has_rot = has_rot;
+    a_dof.push_back(0); a_rot.push_back(-1); a_coef.push_back(0); ids.push_back(0); d_rot.push_back(-1); d_coef.push_back(0);  // never empty
     fix.push_back({(const void**)&M.act_moment, bb.add(moment.data(), sizeof(REAL) * moment.size())});
     fix.push_back({(const void**)&M.dof_act_adr, bb.add(adr.data(), sizeof(int) * adr.size())});
     fix.push_back({(const void**)&M.dof_act_id, bb.add(ids.data(), sizeof(int) * ids.size())});
+    fix.push_back({(const void**)&M.dof_act_coef, bb.add(d_coef.data(), sizeof(REAL) * d_coef.size())});
+    fix.push_back({(const void**)&M.dof_act_rot, bb.add(d_rot.data(), sizeof(int) * d_rot.size())});
+    fix.push_back({(const void**)&M.act_ent_adr, bb.add(a_adr.data(), sizeof(int) * a_adr.size())});
+    fix.push_back({(const void**)&M.act_ent_dof, bb.add(a_dof.data(), sizeof(int) * a_dof.size())});
+    fix.push_back({(const void**)&M.act_ent_coef, bb.add(a_coef.data(), sizeof(REAL) * a_coef.size())});
+    fix.push_back({(const void**)&M.act_ent_rot, bb.add(a_rot.data(), sizeof(int) * a_rot.size())});
     M.inv_nv = nv > 0 ? 1.0f / (float)nv : 0.0f;
   }
   // single-column rows: dof-frictionloss rows (J = e_dof) first, then slide/hinge limit rows (J = +-e_dof or 0)

@@ -68,7 +68,7 @@ def _validate(m):
     ):
         raise NotImplementedError("Only condim=1, 3, 4 and 6 are supported.")
     for name, enum, ok in (
-        ("actuator_trntype", TrnType, (TrnType.JOINT,)),
+        ("actuator_trntype", TrnType, (TrnType.JOINT, TrnType.JOINTINPARENT)),
         ("actuator_dyntype", DynType, (DynType.NONE, DynType.INTEGRATOR, DynType.FILTER, DynType.FILTEREXACT)),
         ("actuator_gaintype", GainType, (GainType.FIXED, GainType.AFFINE)),
         ("actuator_biastype", BiasType, (BiasType.NONE, BiasType.AFFINE)),
@@ -76,10 +76,6 @@ def _validate(m):
         for v in np.asarray(getattr(m, name)).reshape(-1):
             if int(v) not in [int(x) for x in ok]:
                 raise NotImplementedError(f"{enum(int(v)).name} {name} not implemented.")
-    for i in range(int(m.nu)):
-        j = int(np.asarray(m.actuator_trnid)[i, 0])
-        if int(m.jnt_type[j]) not in (int(JointType.SLIDE), int(JointType.HINGE)):
-            raise NotImplementedError("actuators on free/ball joints are a 'next' item.")
     if int(_get(m, "ntendon", 0)):
         raise NotImplementedError("tendons are a 'next' item (SURVEY section 8f).")
     et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))

@@ -35,7 +35,8 @@ def is_sparse(m: Model) -> bool:
 def actuator_static_moment(m: Model):
     mom = torch.zeros((m.nu, m.nv), dtype=DEFAULT_DTYPE)
     for i, (trntype, trnid, jnt_type, dofadr, qposadr) in enumerate(m.actuator_info):
-        mom[i, dofadr] = float(m.actuator_gear[i, 0])
+        width = {0: 6, 1: 3}.get(int(jnt_type), 1)  # free / ball joints take the gear vector (smooth.py:565-583)
+        mom[i, dofadr : dofadr + width] = m.actuator_gear[i, :width].to(DEFAULT_DTYPE)
     return mom
 
 

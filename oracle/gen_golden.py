@@ -81,6 +81,9 @@ CASES = {
     # gravity compensation (passive.py:148-156, forward.py:206-207): passive on two links, through the actuator channel on the third
     "gravcomp_f64": ("gravcomp_arm", {}, "float64", 3, 3, "generic"),
     "gravcomp_rk4_f32": ("gravcomp_arm", {"integrator": 1}, "float32", 2, 2, "generic"),
+    # motors on ball / free joints, child-frame and parent-frame transmissions (smooth.py:565-583)
+    "ball_free_actuators_f64": ("ball_free_actuators", {}, "float64", 3, 3, "generic"),
+    "ball_free_actuators_rk4_f32": ("ball_free_actuators", {"integrator": 1}, "float32", 2, 2, "generic"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),

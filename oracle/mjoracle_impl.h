@@ -1347,9 +1347,31 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
   /* smooth.transmission :535-591 (joint transmissions on slide/hinge) */
   for (int i = 0; i < nu * nv; i++) w->actuator_moment[i] = 0;
   for (int i = 0; i < nu; i++) {
-    REAL gear = M->act_gear[6 * i];
-    w->actuator_length[i] = w->qpos[m->act_qposadr[i]] * gear;
-    w->actuator_moment[i * nv + m->act_dofadr[i]] = gear;
+    const REAL* gear = M->act_gear + 6 * i;
+    int jt = m->act_jnttype[i], da = m->act_dofadr[i], qa = m->act_qposadr[i];
+    int inparent = m->act_trntype[i] == 1; /* TrnType.JOINTINPARENT */
+    if (jt == JNT_FREE) { /* :565-574 */
+      REAL vals[6] = {gear[0], gear[1], gear[2], gear[3], gear[4], gear[5]};
+      if (inparent) {
+        REAL qn[4] = {w->qpos[qa + 3], w->qpos[qa + 4] * (REAL)-1, w->qpos[qa + 5] * (REAL)-1, w->qpos[qa + 6] * (REAL)-1};
+        FN(rotate)(gear + 3, qn, vals + 3);
+      }
+      w->actuator_length[i] = 0;
+      for (int k = 0; k < 6; k++) w->actuator_moment[i * nv + da + k] = vals[k];
+    } else if (jt == JNT_BALL) { /* :575-583 */
+      REAL q[4] = {w->qpos[qa], w->qpos[qa + 1], w->qpos[qa + 2], w->qpos[qa + 3]};
+      REAL axis[3], angle, ga[3] = {gear[0], gear[1], gear[2]};
+      FN(quat_to_axis_angle)(q, axis, &angle);
+      if (inparent) {
+        REAL qn[4] = {q[0], q[1] * (REAL)-1, q[2] * (REAL)-1, q[3] * (REAL)-1};
+        FN(rotate)(gear, qn, ga);
+      }
+      w->actuator_length[i] = ((axis[0] * angle) * ga[0] + (axis[1] * angle) * ga[1]) + (axis[2] * angle) * ga[2];
+      for (int k = 0; k < 3; k++) w->actuator_moment[i * nv + da + k] = ga[k];
+    } else { /* slide / hinge :584-586 */
+      w->actuator_length[i] = w->qpos[qa] * gear[0];
+      w->actuator_moment[i * nv + da] = gear[0];
+    }
   }
   /* forward._velocity :87-99 */
   for (int i = 0; i < nu; i++) {
