@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 7
+#define MJH_ABI_VERSION 8
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -68,7 +68,7 @@ extern "C" {
 /* int32 scalars */
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
-  X(ne) X(nf) X(nl) X(ncon) X(nefc) X(npair) X(nconvex)                                          \
+  X(ne) X(nf) X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(nefc) X(npair) X(nconvex) \
   X(neq) /* equality constraints of the model = length of the eq_active leaf */ X(neqtab) /* entries of the eq_* tables (0 when equality rows are disabled) */ \
   X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
   X(integrator) X(solver) X(cone) X(disableflags) X(iterations) X(ls_iterations)
@@ -133,6 +133,7 @@ extern "C" {
   X(eq_row)         /* neqtab: first efc row */                                                  \
   X(eq_jadr)        /* neqtab*4: joint couplings: dofadr1, dofadr2, qposadr1, qposadr2 (device.py:310-314; a missing second joint reads the LAST joint, as the reference's jnt_dofadr[-1] does) */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
+  X(lim_ball_jnt)   /* nlb: joint id of each ball-joint limit row (constraint.py:299-335); these rows precede the slide / hinge ones */ \
   X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
   X(pair_fn)        /* npair: MJH_FN_* */                                                        \
   X(pair_geom1)     /* npair */                                                                  \

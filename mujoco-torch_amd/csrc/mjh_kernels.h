@@ -382,11 +382,20 @@ struct Env {
   // [frictionloss | joint limits | equality | contacts]: single-column rows first, dense rows after them; the Data leaves
   // use the reference's order [equality | frictionloss | limits | contacts] and ext_row() maps one to the other.
   __device__ __forceinline__ static int ne_() { return FRIC ? M.ne : 0; }
+  __device__ __forceinline__ static int nlim_rows() { return FRIC ? M.nlb + M.nlt : 0; }
   __device__ __forceinline__ static bool is_eq_row(int r) { return FRIC && (unsigned)(r - (nf_() + M.nl)) < (unsigned)M.ne; }
+  // dense limit rows (ball joints, tendons) sit between the equality rows and the contacts in the solver's dense block:
+  //   solver order  [frictionloss | slide-hinge limits || equality | ball limits | tendon limits | contacts]
+  //   Data order    [equality | frictionloss | ball limits | slide-hinge limits | tendon limits | contacts]
   __device__ __forceinline__ static int ext_row(int r) {
     if (!FRIC) return r;
-    const int ns = nf_() + M.nl, ne = M.ne;
-    return r < ns ? r + ne : (r < ns + ne ? r - ns : r);
+    const int nf = nf_(), s1 = nf + M.nl, ne = M.ne, nlb = M.nlb, nlt = M.nlt;
+    if (r < nf) return ne + r;
+    if (r < s1) return ne + nlb + r;
+    if (r < s1 + ne) return r - s1;
+    if (r < s1 + ne + nlb) return r - s1 + nf;          // ne + nf + (r - s1 - ne)
+    if (r < s1 + ne + nlb + nlt) return r;              // ne + nf + nlb + nl + (r - s1 - ne - nlb), and s1 = nf + nl
+    return r;
   }
   LdsView<REAL> S;
   int64_t e;      // environment index
@@ -928,12 +937,12 @@ struct Env {
 
   __device__ __forceinline__ void make_constraint() {
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf, ne = M.ne;
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf, ne = M.ne, nlb = M.nlb, nlt = M.nlt;
     if (nefc == 0) return;
     load_qpos(false); load_qvel();
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
     row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
-    for (int w = l; w < (ne + nf + nl) * nv; w += W) S.efc_J()[w] = 0;
+    for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
     // equality rows (constraint.py:116-212, 254-296): one lane per (constraint, dof) column of a connect / weld, one lane per
@@ -1025,8 +1034,23 @@ struct Env {
       S.efc_pos_norm()[r] = 0;
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
-    for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
+    for (int r0 = l; r0 < nlb; r0 += W) {  // _instantiate_limit_ball :299-335
       const int r = ne + nf + r0;
+      const int j = M.lim_ball_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+      const REAL q[4] = {S.qpos()[qa], S.qpos()[qa + 1], S.qpos()[qa + 2], S.qpos()[qa + 3]};
+      REAL axis[3], angle;
+      quat_to_axis_angle(q, axis, angle);
+      const REAL r0_ = M.jnt_range[2 * j], r1_ = M.jnt_range[2 * j + 1];
+      const REAL pos = ((r0_ > r1_ ? r0_ : r1_) - angle) - M.jnt_margin[j];
+      const REAL active = (REAL)(pos < 0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) S.efc_J()[r * nv + da + k] = (-axis[k]) * active;
+      S.efc_pos()[r] = pos * active;
+      S.efc_pos_norm()[r] = pos * active;
+      S.efc_invweight()[r] = M.dof_invweight0[da];
+    }
+    for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
+      const int r = ne + nf + nlb + r0;
       const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = S.qpos()[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
@@ -1075,7 +1099,7 @@ struct Env {
     }
     wave_sync();
     STAMP(25);
-    const int ns = ne + nf + nl;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
+    const int ns = ne + nf + nlb + nl + nlt;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
@@ -1088,8 +1112,8 @@ struct Env {
         const int da = M.fric_dof[r - ne];
         solref[0] = M.dof_solref[2 * da]; solref[1] = M.dof_solref[2 * da + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.dof_solimp[5 * da + i];
-      } else if (r < ne + nf + nl) {
-        const int j = M.lim_jnt[r - ne - nf];
+      } else if (r < ne + nf + nlb + nl) {
+        const int j = r < ne + nf + nlb ? M.lim_ball_jnt[r - ne - nf] : M.lim_jnt[r - ne - nf - nlb];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
@@ -1146,6 +1170,13 @@ struct Env {
     wave_sync();
     STAMP(31);
     row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
+    if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
+      for (int i = l; i < nu; i += W) {
+        const REAL gear = M.act_gear[6 * i];
+        S.act_length()[i] = S.qpos()[M.act_qposadr[i]] * gear;
+        S.act_velocity()[i] = gear * S.qvel()[M.act_dofadr[i]];
+      }
+    } else
     for (int i = l; i < nu; i += W) {
       const REAL* gear = M.act_gear + 6 * i;
       const int jt = M.act_jnttype[i], qa = M.act_qposadr[i];
@@ -1447,7 +1478,7 @@ struct Env {
         // moment^T force: only the actuators on this dof have a non-zero moment entry (actuator order kept)
         for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) {
           const int i = M.dof_act_id[q];
-          const REAL coef = (M.act_has_rot && M.dof_act_rot[q] >= 0) ? S.act_rot()[3 * i + M.dof_act_rot[q]] : M.dof_act_coef[q];
+          const REAL coef = M.act_simple ? M.act_gear[6 * i] : ((M.act_has_rot && M.dof_act_rot[q] >= 0) ? S.act_rot()[3 * i + M.dof_act_rot[q]] : M.dof_act_coef[q]);
           s += coef * S.act_force()[i];
         }
         const int j = M.dof_jntid[d];
@@ -1792,14 +1823,19 @@ struct Env {
       const int l = lane(), nl = nf_() + M.nl;
       const REAL* gJ = out.efc_J + e * nefc * nv;
       const int ne = ne_();
-      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[(ne + r) * nv + dr]; }
+      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[ext_row(r) * nv + dr]; }
       for (int r = l; r < nf_(); r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
       if (nl > 0) for (int d = l; d < 2 * nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
       {
-        for (int i = l; i < ne * nv; i += W) S.efc_Jc()[i] = gJ[i];  // equality rows lead the Data leaf and the dense block
-        const int n = (nefc - nl - ne) * nv;
-        const REAL* src = gJ + (nl + ne) * nv;
-        REAL* dstJ = S.efc_Jc() + ne * nv;
+        const int nlim = FRIC ? M.nlb + M.nlt : 0;  // dense limit rows: gathered row by row
+        for (int i = l; i < (ne + nlim) * nv; i += W) {
+          int k, c;
+          split_index(i, nv, M.inv_nv, k, c);
+          S.efc_Jc()[i] = gJ[ext_row(nl + k) * nv + c];
+        }
+        const int n = (nefc - nl - ne - nlim) * nv;  // the contact rows are contiguous in both orders
+        const REAL* src = gJ + (nl + ne + nlim) * nv;
+        REAL* dstJ = S.efc_Jc() + (ne + nlim) * nv;
         int i = l;
         for (; i + 3 * W < n; i += 4 * W) {
           const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
@@ -1807,7 +1843,7 @@ struct Env {
         }
         for (; i < n; i += W) dstJ[i] = src[i];
       }
-      if (ne > 0) {
+      if (ne > 0 || nlim_rows() > 0) {
         for (int r = l; r < nefc; r += W) { const int x = ext_row(r); S.efc_D()[r] = out.efc_D[e * nefc + x]; S.efc_aref()[r] = out.efc_aref[e * nefc + x]; }
       } else {
         row_load<W>(S.efc_D(), out.efc_D, nefc, e);
@@ -1901,7 +1937,7 @@ struct Env {
     wave_sync();
     STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
-    if (ne_() > 0) { if (out.efc_force) for (int r = l; r < nefc; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r]; }
+    if (ne_() > 0 || nlim_rows() > 0) { if (out.efc_force) for (int r = l; r < nefc; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r]; }
     else put(out.efc_force, S.s_force(), nefc);
     STAMP(62);
   }

@@ -278,6 +278,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     }
     adr[nv] = (int)ids.size();
     M.act_has_rot = has_rot;
+    M.act_simple = 1;
+    for (int i = 0; i < d->nu; i++) if (d->act_jnttype[i] != JNT_SLIDE && d->act_jnttype[i] != JNT_HINGE) M.act_simple = 0;
     a_dof.push_back(0); a_rot.push_back(-1); a_coef.push_back(0); ids.push_back(0); d_rot.push_back(-1); d_coef.push_back(0);  // never empty
     fix.push_back({(const void**)&M.act_moment, bb.add(moment.data(), sizeof(REAL) * moment.size())});
     fix.push_back({(const void**)&M.dof_act_adr, bb.add(adr.data(), sizeof(int) * adr.size())});
@@ -422,7 +424,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     timing_mark(stream, 8);
   }
-  if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
+  if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
 

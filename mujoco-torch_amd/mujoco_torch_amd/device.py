@@ -86,8 +86,6 @@ def _validate(m):
         # the reference ignores eq_objtype and reads site ids as body ids (constraint.py:116-212): harmless while the
         # constraint is inactive (every row is multiplied by eq_active), meaningless once it is active
         raise NotImplementedError("site-based connect / weld constraints can only be carried inactive")
-    if np.any((np.asarray(m.jnt_type) == int(JointType.BALL)) & np.asarray(m.jnt_limited).astype(bool)):
-        raise NotImplementedError("ball joint limits are a 'next' item (SURVEY section 8f).")
 
 
 def _t(x, dtype):
@@ -228,12 +226,15 @@ def _build_tables(m, dtype) -> StaticTables:
     # the address collision() writes first (pyramidal-style, collision_driver.py:847-850) is
     # overwritten by make_constraint's cone-aware one (constraint.py:636-646): only the latter
     # reaches the returned Data.
-    lim = []
+    lim, lim_ball = [], []
     if not (flags & (DisableBit.CONSTRAINT | DisableBit.LIMIT)):
         jt = np.asarray(m.jnt_type)
         for j in range(int(m.njnt)):
             if bool(np.asarray(m.jnt_limited)[j]) and int(jt[j]) in (int(JointType.SLIDE), int(JointType.HINGE)):
                 lim.append(j)
+            elif bool(np.asarray(m.jnt_limited)[j]) and int(jt[j]) == int(JointType.BALL):
+                lim_ball.append(j)
+    T.lim_ball_jnt = np.array(lim_ball, dtype=np.int32)
     fric = []
     if not (flags & (DisableBit.CONSTRAINT | DisableBit.FRICTIONLOSS)):
         fric = [d for d in range(int(m.nv)) if float(np.asarray(m.dof_frictionloss)[d]) > 0]
@@ -243,7 +244,8 @@ def _build_tables(m, dtype) -> StaticTables:
     assert T.eq["nrow"] == ne, (T.eq["nrow"], ne)
     T.sensors = _sensor_tables(m)
     T.lim_jnt = np.array(lim, dtype=np.int32)
-    assert len(lim) == nl, (len(lim), nl)
+    T.nlt = 0  # tendon limit rows
+    assert len(lim) + len(lim_ball) + T.nlt == nl, (len(lim), len(lim_ball), nl)
     return T
 
 

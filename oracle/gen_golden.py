@@ -84,6 +84,9 @@ CASES = {
     # motors on ball / free joints, child-frame and parent-frame transmissions (smooth.py:565-583)
     "ball_free_actuators_f64": ("ball_free_actuators", {}, "float64", 3, 3, "generic"),
     "ball_free_actuators_rk4_f32": ("ball_free_actuators", {"integrator": 1}, "float32", 2, 2, "generic"),
+    # ball-joint limits (constraint.py:299-335)
+    "ball_limits_f64": ("ball_limits", {}, "float64", 3, 3, "ball_limits"),
+    "ball_limits_cg_rk4_f32": ("ball_limits", {"integrator": 1, "solver": 1}, "float32", 2, 2, "ball_limits"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
@@ -133,6 +136,18 @@ def make_inputs(recipe, lite, env):
         out["qvel"] = 0.3 * rng.randn(nv)
         out["mocap_pos"] = lite.body_pos[lite.body_mocapid >= 0] + 0.05 * rng.randn(lite.nmocap, 3) * (env > 0)
         out["mocap_quat"] = lite.body_quat[lite.body_mocapid >= 0] + 0.3 * rng.randn(lite.nmocap, 4) * (env > 0)
+    elif recipe == "ball_limits":  # swing the ball joints past their cones: big rotations about random axes
+        q = lite.qpos0.copy()
+        for j in range(lite.njnt):
+            a = int(lite.jnt_qposadr[j])
+            if int(lite.jnt_type[j]) == 1:
+                ax = rng.randn(3); ax /= np.linalg.norm(ax)
+                ang = [0.3, 0.6, 0.9][env % 3] * (1 + 0.3 * j)
+                q[a : a + 4] = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax]) * (1 + 0.05 * rng.randn())  # un-normalised
+            else:
+                q[a] += 0.3 * rng.randn()
+        out["qpos"] = q
+        out["qvel"] = 0.5 * rng.randn(nv)
     elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
         out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
         out["qvel"] = 0.3 * rng.randn(nv)

@@ -1253,6 +1253,20 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
     for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->dof_solref[2 * da + i];
     for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->dof_solimp[5 * da + i];
   }
+  for (int l = 0; l < m->nlb; l++, row++) { /* _instantiate_limit_ball :299-335 */
+    int j = m->lim_ball_jnt[l], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    REAL q[4] = {w->qpos[qa], w->qpos[qa + 1], w->qpos[qa + 2], w->qpos[qa + 3]}, axis[3], angle;
+    FN(quat_to_axis_angle)(q, axis, &angle);
+    REAL rmax = M->jnt_range[2 * j] > M->jnt_range[2 * j + 1] ? M->jnt_range[2 * j] : M->jnt_range[2 * j + 1];
+    REAL pos = rmax - angle - M->jnt_margin[j];
+    REAL active = (REAL)(pos < 0);
+    for (int k = 0; k < 3; k++) w->efc_J[row * nv + da + k] = (-axis[k]) * active;
+    w->efc_pos[row] = pos * active;
+    w->efc_pos_norm[row] = pos * active;
+    w->efc_invweight[row] = M->dof_invweight0[da];
+    for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->jnt_solref[2 * j + i];
+    for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->jnt_solimp[5 * j + i];
+  }
   for (int l = 0; l < m->nl; l++, row++) { /* _instantiate_limit_slide_hinge :338-372 */
     int j = m->lim_jnt[l], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
     REAL q = w->qpos[qa];
