@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 8
+#define MJH_ABI_VERSION 9
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -69,6 +69,7 @@ extern "C" {
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
   X(ne) X(nf) X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(nefc) X(npair) X(nconvex) \
+  X(ntendon) /* fixed tendons = length of the ten_length / ten_velocity leaves */ X(nwrapj) /* joint terms of all tendons (entries of ten_dof / ten_qposadr / ten_coef) */ \
   X(neq) /* equality constraints of the model = length of the eq_active leaf */ X(neqtab) /* entries of the eq_* tables (0 when equality rows are disabled) */ \
   X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
   X(integrator) X(solver) X(cone) X(disableflags) X(iterations) X(ls_iterations)
@@ -133,6 +134,11 @@ extern "C" {
   X(eq_row)         /* neqtab: first efc row */                                                  \
   X(eq_jadr)        /* neqtab*4: joint couplings: dofadr1, dofadr2, qposadr1, qposadr2 (device.py:310-314; a missing second joint reads the LAST joint, as the reference's jnt_dofadr[-1] does) */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
+  X(ten_adr)        /* ntendon+1: CSR of the joint terms of each fixed tendon (smooth.py:470-497) */ \
+  X(ten_dof)        /* nwrapj: dof of the term */                                                \
+  X(ten_qposadr)    /* nwrapj: qpos address of the term */                                       \
+  X(lim_tendon)     /* nlt: tendon id of each tendon limit row (constraint.py:375-405); these rows follow the slide / hinge ones */ \
+  X(act_trnid)      /* nu: joint id, or tendon id for tendon transmissions (act_trntype 3) */    \
   X(lim_ball_jnt)   /* nlb: joint id of each ball-joint limit row (constraint.py:299-335); these rows precede the slide / hinge ones */ \
   X(lim_jnt)        /* nl: joint id of each slide/hinge limit row, reference row order */        \
   X(pair_fn)        /* npair: MJH_FN_* */                                                        \
@@ -181,6 +187,15 @@ extern "C" {
   X(dof_frictionloss) /* nv */                                                                   \
   X(dof_solref)     /* nv*2 */                                                                   \
   X(dof_solimp)     /* nv*5 */                                                                   \
+  X(ten_coef)       /* nwrapj: coefficient of the term */                                        \
+  X(tendon_range)   /* ntendon*2 */                                                              \
+  X(tendon_margin)  /* ntendon */                                                                \
+  X(tendon_invweight0) /* ntendon */                                                             \
+  X(tendon_solref_lim) /* ntendon*2 */                                                           \
+  X(tendon_solimp_lim) /* ntendon*5 */                                                           \
+  X(tendon_stiffness) /* ntendon */                                                              \
+  X(tendon_damping) /* ntendon */                                                                \
+  X(tendon_lengthspring) /* ntendon*2: the spring is slack between the two lengths (passive.py:121-127) */ \
   X(body_gravcomp)  /* nbody: fraction of the body's weight compensated (passive.py:148-156); all zero = none */ \
   X(body_invweight0_rot) /* nbody (rotational component; weld rows 3..5, constraint.py:193-194) */         \
   X(eq_data)        /* neq*11 (MuJoCo layout: connect anchors; weld anchors, relpose, torquescale; joint polycoef) */ \
@@ -267,6 +282,9 @@ typedef struct mjhModelDesc {
   X(cdof)             /* nv*6 */                                                                 \
   X(cinert)           /* nbody*10 */                                                             \
   X(crb)              /* nbody*10 */                                                             \
+  X(ten_length)       /* ntendon */                                                              \
+  X(ten_J)            /* ntendon*nv (dense; constant for fixed tendons) */                       \
+  X(ten_velocity)     /* ntendon */                                                              \
   X(actuator_length)  /* nu */                                                                   \
   X(actuator_moment)  /* nu*nv */                                                                \
   X(qM)               /* nv*nv (dense) */                                                        \

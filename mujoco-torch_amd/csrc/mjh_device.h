@@ -71,7 +71,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
   X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
-  X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL)                         \
+  X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL) X(ten_len, m.ntendon, PH_VEL) X(ten_frc, m.ntendon, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
   X(qfrc_smooth, m.nv, PH_VEL | PH_SOL) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
@@ -134,6 +134,7 @@ struct DevModel {
   const int* act_ent_dof;
   const REAL* act_ent_coef;
   const int* act_ent_rot;
+  const REAL* ten_J0;                      // ntendon*nv: the constant Jacobian of the fixed tendons (ten_J[t, dof] = coef, last term wins: smooth.py:492-494)
   int act_simple;                          // every actuator drives a slide / hinge joint
   int act_has_rot;                         // some JOINTINPARENT transmission on a ball / free joint (moment depends on qpos)
   float inv_nv;                            // 1 / nv for the index splits below

@@ -74,14 +74,22 @@ struct RkWork {
 // segment pointer (constant address space => scalar loads, nothing is copied to scratch).  That pointer only
 // exists inside the kernel function itself, so everything below must inline into the kernel (build.sh checks
 // the ISA for calls).
+// the state leaves an advance writes (the only leaves of the "next stage" / "returned" Data the kernels touch)
+template <typename REAL>
+struct StatePtrs {
+  REAL *qpos, *qvel, *act, *time;
+};
+template <typename REAL>
+inline StatePtrs<REAL> state_of(const DevData<REAL>& d) { return StatePtrs<REAL>{d.qpos, d.qvel, d.act, d.time}; }
+
 template <typename REAL>
 struct KArgs {
   DevModel<REAL> M;
   LdsOff off;          // arena of this launch's phase
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
-  DevData<REAL> nxt;   // where an RK stage writes the next stage's state (workspace Data)
-  DevData<REAL> fin;   // the returned Data (final advance)
+  StatePtrs<REAL> nxt; // where an RK stage writes the next stage's state (workspace Data)
+  StatePtrs<REAL> fin; // the returned Data (final advance)
   RkWork<REAL> W;
   int64_t B;
   int64_t env_begin, env_count;  // environments of THIS launch (a packed launch covers an even count, a second one the odd tail)
@@ -1049,6 +1057,20 @@ struct Env {
       S.efc_pos_norm()[r] = pos * active;
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
+    for (int r0 = l; r0 < nlt; r0 += W) {  // _instantiate_limit_tendon :375-405
+      const int r = ne + nf + nlb + nl + r0;
+      const int t = M.lim_tendon[r0];
+      REAL len = 0;
+      for (int q = M.ten_adr[t]; q < M.ten_adr[t + 1]; q++) len += M.ten_coef[q] * S.qpos()[M.ten_qposadr[q]];
+      const REAL dist_min = len - M.tendon_range[2 * t], dist_max = M.tendon_range[2 * t + 1] - len;
+      const REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M.tendon_margin[t];
+      const REAL active = (REAL)(pos < 0);
+      const REAL sign = ((REAL)(dist_min < dist_max) * 2 - 1) * active;
+      for (int d = 0; d < nv; d++) S.efc_J()[r * nv + d] = M.ten_J0[t * nv + d] * sign;
+      S.efc_pos()[r] = pos * active;
+      S.efc_pos_norm()[r] = pos * active;
+      S.efc_invweight()[r] = M.tendon_invweight0[t];
+    }
     for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
       const int r = ne + nf + nlb + r0;
       const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
@@ -1116,6 +1138,10 @@ struct Env {
         const int j = r < ne + nf + nlb ? M.lim_ball_jnt[r - ne - nf] : M.lim_jnt[r - ne - nf - nlb];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
+      } else if (r < ns) {
+        const int t = M.lim_tendon[r - ne - nf - nlb - nl];
+        solref[0] = M.tendon_solref_lim[2 * t]; solref[1] = M.tendon_solref_lim[2 * t + 1];
+        for (int i = 0; i < 5; i++) solimp[i] = M.tendon_solimp_lim[5 * t + i];
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
         const int c = M.efc_row_con[r], sub = r - M.con_efc_address[c];
         const REAL* sr = M.con_solref + 2 * c;
@@ -1169,6 +1195,24 @@ struct Env {
     row_load<W>(S.xipos(), out.xipos, 3 * nb, e);
     wave_sync();
     STAMP(31);
+    if (FLUID && M.ntendon > 0) {  // smooth.tendon :470-497 and forward._velocity :93-94 for fixed tendons: one lane per tendon
+      const int nt = M.ntendon;
+      for (int t = l; t < nt; t += W) {
+        REAL len = 0, vel = 0;
+        for (int q = M.ten_adr[t]; q < M.ten_adr[t + 1]; q++) len += M.ten_coef[q] * S.qpos()[M.ten_qposadr[q]];
+        for (int d = 0; d < nv; d++) vel += M.ten_J0[t * nv + d] * S.qvel()[d];
+        S.ten_len()[t] = len;
+        if (out.ten_length) out.ten_length[e * nt + t] = len;
+        if (out.ten_velocity) out.ten_velocity[e * nt + t] = vel;
+        // tendon-level spring (slack between the two rest lengths) and damper, passive.py:119-132
+        const REAL below = M.tendon_lengthspring[2 * t] - len, above = M.tendon_lengthspring[2 * t + 1] - len;
+        REAL fs = below > 0 ? M.tendon_stiffness[t] * below : (REAL)0;
+        fs = above < 0 ? M.tendon_stiffness[t] * above : fs;
+        S.ten_frc()[t] = fs + (-M.tendon_damping[t] * vel);
+      }
+      row_store<W>(out.ten_J, M.ten_J0, nt * nv, e);
+      wave_sync();
+    }
     row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
     if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
       for (int i = l; i < nu; i += W) {
@@ -1181,7 +1225,9 @@ struct Env {
       const REAL* gear = M.act_gear + 6 * i;
       const int jt = M.act_jnttype[i], qa = M.act_qposadr[i];
       REAL len = 0;
-      if (jt == JNT_SLIDE || jt == JNT_HINGE) {
+      if (FLUID && M.act_trntype[i] == 3) {  // tendon transmission :558-561 (its moment row is a model constant)
+        len = S.ten_len()[M.act_trnid[i]] * gear[0];
+      } else if (jt == JNT_SLIDE || jt == JNT_HINGE) {
         len = S.qpos()[qa] * gear[0];
       } else {  // ball / free joints (:565-583)
         const bool inparent = M.act_trntype[i] == 1;
@@ -1276,6 +1322,13 @@ struct Env {
       }
       wave_sync();
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = (0 + S.qfrc_passive()[d]) - M.dof_damping[d] * S.qvel()[d];
+      if (FLUID && M.ntendon > 0) {  // qfrc += ten_J^T (spring + damper), tendons in order (passive.py:134-143)
+        for (int d = l; d < nv; d += W) {
+          REAL acc = 0;
+          for (int t = 0; t < M.ntendon; t++) acc += M.ten_J0[t * nv + d] * S.ten_frc()[t];
+          S.qfrc_passive()[d] = S.qfrc_passive()[d] + acc;
+        }
+      }
       if (FLUID && M.has_gravcomp && (M.disableflags & DSBL_GRAVITY)) {  // gravity off: the caller's leaf is carried (passive.py:190-194) and still feeds the actuator term
         for (int d = l; d < nv; d += W) {
           const REAL v = in.qfrc_gravcomp ? in.qfrc_gravcomp[e * nv + d] : (REAL)0;
@@ -1989,7 +2042,7 @@ struct Env {
   __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
     const int l = lane();
     const REAL dt = M.timestep;
-    const DevData<REAL>& fin = KA.fin;
+    const StatePtrs<REAL>& fin = KA.fin;
     advance_act(act0, act_dot, fin.act);
     for (int d = l; d < M.nv; d += W) S.tmp_nv()[d] = qvel0[d] + qacc[d] * dt;
     wave_sync();

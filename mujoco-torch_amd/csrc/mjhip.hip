@@ -88,7 +88,7 @@ std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
   F(xpos, nb * 3) F(xquat, nb * 4) F(xmat, nb * 9) F(xipos, nb * 3) F(ximat, nb * 9) F(xanchor, nj * 3) F(xaxis, nj * 3)
   F(geom_xpos, ng * 3) F(geom_xmat, ng * 9) F(site_xpos, m->nsite * 3) F(site_xmat, m->nsite * 9)
   F(cam_xpos, m->ncam * 3) F(cam_xmat, m->ncam * 9) F(light_xpos, m->nlight * 3) F(light_xdir, m->nlight * 3)
-  F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(actuator_length, nu)
+  F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(ten_length, m->ntendon) F(ten_J, m->ntendon * nv) F(ten_velocity, m->ntendon) F(actuator_length, nu)
   F(actuator_moment, nu * nv) F(qM, nv * nv) F(qLD, nv * nv) F(contact_dist, ncon) F(contact_pos, ncon * 3)
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
   F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
@@ -108,7 +108,7 @@ const char* const kStageLeaves[] = {
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
 const char* const kEqStageLeaves[] = {"xpos", "xquat", "xmat"};  // body frames read by the equality rows (constraint.py:116-212)
 bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid, bool has_eq) {
-  if (!strcmp(name, "qfrc_gravcomp")) return false;  // staged in LDS inside the velocity phase; the leaf itself is written by stage 0 only
+  if (!strcmp(name, "qfrc_gravcomp") || !strncmp(name, "ten_", 4)) return false;  // tendon quantities are recomputed from qpos where they are used  // staged in LDS inside the velocity phase; the leaf itself is written by stage 0 only
   if (has_eq) for (const char* s : kEqStageLeaves) if (!strcmp(s, name)) return true;
   for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
   if (has_convex) for (const char* s : kConvexStageLeaves) if (!strcmp(s, name)) return true;
@@ -250,6 +250,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     // transmission tables (smooth.transmission :535-591): the non-zeros of every actuator's moment row, actuator-major (length /
     // velocity of an actuator) and dof-major (qfrc_actuator of a dof).  A coefficient is a model constant (gear component) except
     // for JOINTINPARENT on ball / free joints, where it is a component of the gear axis rotated into the child frame (rot >= 0).
+    std::vector<REAL> tenJ((size_t)d->ntendon * nv + 1, (REAL)0);
+    for (int t = 0; t < d->ntendon; t++)
+      for (int q = d->ten_adr[t]; q < d->ten_adr[t + 1]; q++) tenJ[(size_t)t * nv + d->ten_dof[q]] = (REAL)d->ten_coef[q];
+    fix.push_back({(const void**)&M.ten_J0, bb.add(tenJ.data(), sizeof(REAL) * tenJ.size())});
     std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
     std::vector<int> a_adr((size_t)d->nu + 1, 0), a_dof, a_rot;
     std::vector<REAL> a_coef;
@@ -258,6 +262,15 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       a_adr[i] = (int)a_dof.size();
       const int jt = d->act_jnttype[i], da = d->act_dofadr[i];
       const bool inparent = d->act_trntype[i] == 1;
+      if (d->act_trntype[i] == 3) {  // tendon transmission: moment row = ten_J[t] * gear[0] (smooth.py:558-561), dense row in dof order
+        const int t = d->act_trnid[i];
+        for (int dd = 0; dd < nv; dd++) {
+          const REAL c = tenJ[(size_t)t * nv + dd] * (REAL)d->act_gear[6 * i];
+          moment[(size_t)i * nv + dd] = c;
+          if (tenJ[(size_t)t * nv + dd] != 0) { a_dof.push_back(dd); a_coef.push_back(c); a_rot.push_back(-1); }
+        }
+        continue;
+      }
       const int width = jt == JNT_FREE ? 6 : (jt == JNT_BALL ? 3 : 1);
       for (int k = 0; k < width; k++) {
         const bool rot = inparent && ((jt == JNT_BALL) || (jt == JNT_FREE && k >= 3));
@@ -279,7 +292,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     adr[nv] = (int)ids.size();
     M.act_has_rot = has_rot;
     M.act_simple = 1;
-    for (int i = 0; i < d->nu; i++) if (d->act_jnttype[i] != JNT_SLIDE && d->act_jnttype[i] != JNT_HINGE) M.act_simple = 0;
+    for (int i = 0; i < d->nu; i++) if ((d->act_jnttype[i] != JNT_SLIDE && d->act_jnttype[i] != JNT_HINGE) || d->act_trntype[i] == 3) M.act_simple = 0;
     a_dof.push_back(0); a_rot.push_back(-1); a_coef.push_back(0); ids.push_back(0); d_rot.push_back(-1); d_coef.push_back(0);  // never empty
     fix.push_back({(const void**)&M.act_moment, bb.add(moment.data(), sizeof(REAL) * moment.size())});
     fix.push_back({(const void**)&M.dof_act_adr, bb.add(adr.data(), sizeof(int) * adr.size())});
@@ -417,7 +430,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
-  if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
@@ -438,15 +451,17 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
   timing_begin((hipStream_t)stream);
   a.M = M;
   memcpy(&a.in, in, sizeof(a.in));
-  memcpy(&a.fin, out, sizeof(a.fin));
-  a.cur = a.fin;
+  DevData<REAL> fin;
+  memcpy(&fin, out, sizeof(fin));
+  a.fin = state_of(fin);
+  a.cur = fin;
   a.B = B; a.flags = flags; a.do_step = do_step; a.stages = do_step ? MJH_STAGE_ALL : stages;
   a.rk_stage = -1; a.state_from_cur = 0;
   a.warm_src = a.in.qacc_warmstart;
   a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
-  if ((a.stages & 0x60) && !(a.fin.qM && a.fin.qLD && a.fin.qfrc_smooth)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
-  if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(a.fin.contact_dist && a.fin.contact_pos && a.fin.contact_frame && a.fin.geom_xpos && a.fin.geom_xmat))
+  if ((a.stages & 0x60) && !(fin.qM && fin.qLD && fin.qfrc_smooth)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
+  if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(fin.contact_dist && fin.contact_pos && fin.contact_frame && fin.geom_xpos && fin.geom_xmat))
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
   if (!do_step || M.integrator == INT_EULER) return forward_pass<REAL>(m, a, s);
@@ -472,15 +487,15 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
   a.W.sum_qacc = w; w += (int64_t)M.nv * B;
   a.W.act0 = w; w += (int64_t)M.na * B;
   a.W.sum_actdot = w; w += (int64_t)M.na * B;
-  a.nxt = scr;
+  a.nxt = state_of(scr);
   int rc = 0;
   for (int stage = 0; stage < 4; stage++) {
     a.rk_stage = stage;
     if (stage == 0) {
-      a.cur = a.fin; a.state_from_cur = 0; a.warm_src = a.in.qacc_warmstart;
+      a.cur = fin; a.state_from_cur = 0; a.warm_src = a.in.qacc_warmstart;
     } else {
       a.cur = scr; a.state_from_cur = 1;
-      a.warm_src = (stage == 1) ? a.fin.qacc_warmstart : scr.qacc_warmstart;  // solver.py:547-552 writes it every pass
+      a.warm_src = (stage == 1) ? fin.qacc_warmstart : scr.qacc_warmstart;  // solver.py:547-552 writes it every pass
     }
     if ((rc = forward_pass<REAL>(m, a, s))) return rc;
   }

@@ -68,7 +68,7 @@ def _validate(m):
     ):
         raise NotImplementedError("Only condim=1, 3, 4 and 6 are supported.")
     for name, enum, ok in (
-        ("actuator_trntype", TrnType, (TrnType.JOINT, TrnType.JOINTINPARENT)),
+        ("actuator_trntype", TrnType, (TrnType.JOINT, TrnType.JOINTINPARENT, TrnType.TENDON)),
         ("actuator_dyntype", DynType, (DynType.NONE, DynType.INTEGRATOR, DynType.FILTER, DynType.FILTEREXACT)),
         ("actuator_gaintype", GainType, (GainType.FIXED, GainType.AFFINE)),
         ("actuator_biastype", BiasType, (BiasType.NONE, BiasType.AFFINE)),
@@ -77,7 +77,12 @@ def _validate(m):
             if int(v) not in [int(x) for x in ok]:
                 raise NotImplementedError(f"{enum(int(v)).name} {name} not implemented.")
     if int(_get(m, "ntendon", 0)):
-        raise NotImplementedError("tendons are a 'next' item (SURVEY section 8f).")
+        if np.any(np.asarray(_get(m, "wrap_type", lambda: np.ones(0))) != 1):
+            raise NotImplementedError("only fixed tendons (joint wraps) are supported; spatial tendons are a 'next' item.")
+        if np.any(np.asarray(_get(m, "tendon_frictionloss", lambda: np.zeros(0))) > 0):
+            raise NotImplementedError("tendon frictionloss rows are a 'next' item (SURVEY section 8f).")
+        if np.any(np.asarray(_get(m, "tendon_armature", lambda: np.zeros(0))) != 0):
+            raise NotImplementedError("tendon armature is not supported by the native stepper yet.")
     et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))
     if np.any(et > 2):
         raise NotImplementedError("only connect / weld / joint equality constraints are supported")
@@ -244,9 +249,26 @@ def _build_tables(m, dtype) -> StaticTables:
     assert T.eq["nrow"] == ne, (T.eq["nrow"], ne)
     T.sensors = _sensor_tables(m)
     T.lim_jnt = np.array(lim, dtype=np.int32)
-    T.nlt = 0  # tendon limit rows
+    T.tendon = _tendon_tables(m, flags)
+    T.nlt = len(T.tendon["lim"])  # tendon limit rows
     assert len(lim) + len(lim_ball) + T.nlt == nl, (len(lim), len(lim_ball), nl)
     return T
+
+
+def _tendon_tables(m, flags) -> dict:
+    """Fixed tendons as CSR rows over dofs (smooth.tendon :470-497: length = sum coef * qpos, ten_J[t, dof] = coef) and the list of
+    limited tendons in row order (device.py:371-375)."""
+    nt = int(_get(m, "ntendon", 0))
+    out = dict(adr=[0], dof=[], qpos=[], coef=[], lim=[])
+    for t in range(nt):
+        a, n = int(m.tendon_adr[t]), int(m.tendon_num[t])
+        for w in range(a, a + n):
+            j = int(m.wrap_objid[w])
+            out["dof"].append(int(m.jnt_dofadr[j])); out["qpos"].append(int(m.jnt_qposadr[j])); out["coef"].append(float(m.wrap_prm[w]))
+        out["adr"].append(len(out["dof"]))
+    if nt and not (flags & (DisableBit.CONSTRAINT | DisableBit.LIMIT)):
+        out["lim"] = [t for t in range(nt) if bool(np.asarray(m.tendon_limited)[t])]
+    return out
 
 
 def _equality_tables(m, flags) -> dict:
@@ -338,6 +360,9 @@ def device_put(value, *, dtype: torch.dtype | None = None):
     actuator_info = []
     for i in range(int(value.nu)):
         trnid = int(np.asarray(value.actuator_trnid)[i, 0])
+        if int(value.actuator_trntype[i]) == int(TrnType.TENDON):  # no joint behind the transmission: type / addresses are placeholders
+            actuator_info.append((int(TrnType.TENDON), trnid, int(JointType.SLIDE), 0, 0))
+            continue
         actuator_info.append((int(value.actuator_trntype[i]), trnid, int(value.jnt_type[trnid]), int(value.jnt_dofadr[trnid]), int(value.jnt_qposadr[trnid])))
     T = _build_tables(value, fdtype)
     L = lambda a: torch.as_tensor(np.array(a), dtype=torch.long)

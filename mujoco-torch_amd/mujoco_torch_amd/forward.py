@@ -50,6 +50,8 @@ def _written_names(m: Model, step: bool):
         names += ["sensordata"]
     if m.has_gravcomp:
         names += ["qfrc_gravcomp"]
+    if int(m.ntendon) > 0:
+        names += ["ten_length", "ten_J", "ten_velocity"]
     if step:
         names += _WRITTEN_STEP
     return names

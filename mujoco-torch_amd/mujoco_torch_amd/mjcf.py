@@ -798,6 +798,7 @@ class _Compiler:
         self._build_inertia(m, bodies)
         self._build_sites_cams_lights(m, remap)
         self._build_contact(m)
+        self._build_tendons(m)
         self._build_actuators(m)
         self._build_sensors(m)
         self._build_equality(m)
@@ -1214,8 +1215,11 @@ class _Compiler:
             elif "jointinparent" in a:
                 m.actuator_trntype[i] = TrnType.JOINTINPARENT
                 m.actuator_trnid[i, 0] = m.names_jnt.index(a["jointinparent"])
+            elif "tendon" in a:
+                m.actuator_trntype[i] = TrnType.TENDON
+                m.actuator_trnid[i, 0] = m.names_tendon.index(a["tendon"])
             else:
-                raise NotImplementedError("only joint / jointinparent transmissions are supported")
+                raise NotImplementedError("only joint / jointinparent / tendon transmissions are supported")
             g = _floats(a["gear"]) if "gear" in a else np.array([1.0])
             m.actuator_gear[i, : len(g)] = g
             if "gear" not in a:
@@ -1353,15 +1357,74 @@ class _Compiler:
                 m.eq_data[i, 0:3] = _floats(a["anchor"]) if "anchor" in a else np.zeros(3)
                 m.eq_data[i, 10] = float(a.get("torquescale", 1.0))
 
+    def _build_tendons(self, m):
+        """<tendon><fixed>: linear combinations of scalar joint positions (MuJoCo wrap objects of type JOINT)."""
+        nodes = [t for tn in self.root.findall("tendon") for t in tn]
+        m.ntendon = len(nodes)
+        nt = m.ntendon
+        m.names_tendon = []
+        m.tendon_adr = np.zeros(nt, dtype=np.int32)
+        m.tendon_num = np.zeros(nt, dtype=np.int32)
+        m.tendon_limited = np.zeros(nt, dtype=bool)
+        m.tendon_range = np.zeros((nt, 2))
+        m.tendon_margin = np.zeros(nt)
+        m.tendon_stiffness = np.zeros(nt)
+        m.tendon_damping = np.zeros(nt)
+        m.tendon_armature = np.zeros(nt)
+        m.tendon_frictionloss = np.zeros(nt)
+        m.tendon_lengthspring = -np.ones((nt, 2))
+        m.tendon_length0 = np.zeros(nt)
+        m.tendon_invweight0 = np.zeros(nt)
+        m.tendon_solref_lim = np.tile(_DEF_SOLREF, (nt, 1)).reshape(nt, 2)
+        m.tendon_solimp_lim = np.tile(_DEF_SOLIMP, (nt, 1)).reshape(nt, 5)
+        m.tendon_solref_fri = np.tile(_DEF_SOLREF, (nt, 1)).reshape(nt, 2)
+        m.tendon_solimp_fri = np.tile(_DEF_SOLIMP, (nt, 1)).reshape(nt, 5)
+        wrap_type, wrap_objid, wrap_prm = [], [], []
+        for i, node in enumerate(nodes):
+            if node.tag != "fixed":
+                raise NotImplementedError("only <fixed> tendons are inside this build's MJCF subset (spatial tendons need wrapping)")
+            a = dict(self.defaults[node.get("class", "main")].get("tendon"))
+            a.pop("__tag__", None)
+            a.update(node.attrib)
+            m.names_tendon.append(a.get("name", ""))
+            m.tendon_adr[i] = len(wrap_type)
+            for jn in node.findall("joint"):
+                j = m.names_jnt.index(jn.get("joint"))
+                if int(m.jnt_type[j]) not in (int(JointType.SLIDE), int(JointType.HINGE)):
+                    raise ValueError("fixed tendons act on slide / hinge joints")
+                wrap_type.append(1)  # mjWRAP_JOINT
+                wrap_objid.append(j)
+                wrap_prm.append(float(jn.get("coef")))
+            m.tendon_num[i] = len(wrap_type) - int(m.tendon_adr[i])
+            has_range = "range" in a
+            if has_range:
+                m.tendon_range[i] = _floats(a["range"])
+            lim = a.get("limited", "auto")
+            m.tendon_limited[i] = (has_range and self.autolimits) if lim == "auto" else _bool(lim)
+            m.tendon_margin[i] = float(a.get("margin", 0.0))
+            m.tendon_stiffness[i] = float(a.get("stiffness", 0.0))
+            m.tendon_damping[i] = float(a.get("damping", 0.0))
+            m.tendon_armature[i] = float(a.get("armature", 0.0))
+            m.tendon_frictionloss[i] = float(a.get("frictionloss", 0.0))
+            if "springlength" in a:
+                v = _floats(a["springlength"])
+                m.tendon_lengthspring[i] = [v[0], v[1] if len(v) > 1 else v[0]]
+            if "solreflimit" in a:
+                m.tendon_solref_lim[i] = _pad(_floats(a["solreflimit"]), 2, _DEF_SOLREF)
+            if "solimplimit" in a:
+                m.tendon_solimp_lim[i] = _pad(_floats(a["solimplimit"]), 5, _DEF_SOLIMP)
+            if "solreffriction" in a:
+                m.tendon_solref_fri[i] = _pad(_floats(a["solreffriction"]), 2, _DEF_SOLREF)
+            if "solimpfriction" in a:
+                m.tendon_solimp_fri[i] = _pad(_floats(a["solimpfriction"]), 5, _DEF_SOLIMP)
+        m.nwrap = len(wrap_type)
+        m.wrap_type = np.array(wrap_type, dtype=np.int32)
+        m.wrap_objid = np.array(wrap_objid, dtype=np.int32)
+        m.wrap_prm = np.array(wrap_prm, dtype=np.float64)
+
     def _build_empty_sections(self, m):
-        m.ntendon = len([t for tn in self.root.findall("tendon") for t in tn])
-        if m.ntendon:
-            raise NotImplementedError("tendons are outside this build's MJCF subset")
-        m.nwrap = 0
         m.nnumeric = 0
         m.nuserdata = 0
-        m.tendon_frictionloss = np.zeros(0)
-        m.tendon_limited = np.zeros(0, dtype=bool)
         m.numeric_adr = np.zeros(0, dtype=np.int32)
         m.numeric_data = np.zeros(0)
         m.name_numericadr = np.zeros(0, dtype=np.int32)
@@ -1510,10 +1573,24 @@ def _set_const(m, stat_meaninertia=None):
         extent=float(max(np.linalg.norm(xipos - center, axis=1).max(), 1e-5)) if m.nbody > 1 else 1.0,
         center=center,
     )
+    # tendons at qpos0: length, spring rest lengths (springlength -1 = the reference length), invweight0 = J M^-1 J^T
+    ten_J = np.zeros((m.ntendon, nv))
+    for t in range(m.ntendon):
+        a, n = int(m.tendon_adr[t]), int(m.tendon_num[t])
+        for w_ in range(a, a + n):
+            j = int(m.wrap_objid[w_])
+            ten_J[t, int(m.jnt_dofadr[j])] += m.wrap_prm[w_]
+            m.tendon_length0[t] += m.wrap_prm[w_] * m.qpos0[int(m.jnt_qposadr[j])]
+        if m.tendon_lengthspring[t, 0] == -1 and m.tendon_lengthspring[t, 1] == -1:
+            m.tendon_lengthspring[t] = m.tendon_length0[t]
+        m.tendon_invweight0[t] = float(ten_J[t] @ Minv @ ten_J[t]) if nv else 0.0
     # actuator_acc0 = || M^-1 moment ||
     for i in range(m.nu):
         mom = np.zeros(nv)
         j = int(m.actuator_trnid[i, 0])
+        if int(m.actuator_trntype[i]) == int(TrnType.TENDON):
+            m.actuator_acc0[i] = float(np.linalg.norm(Minv @ (ten_J[j] * m.actuator_gear[i, 0])))
+            continue
         d = int(m.jnt_dofadr[j])
         jt = int(m.jnt_type[j])
         w = JointType(jt).dof_width()

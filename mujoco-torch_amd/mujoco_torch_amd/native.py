@@ -75,6 +75,17 @@ DATA_PATH = {n: (("contact", n[len("contact_"):]) if n.startswith("contact_") el
 DATA_PATH["contact_dim"] = ("contact", "contact_dim")
 
 
+def _tendon_reals(src, T, dtype):
+    """Tendon parameters from the source model, rounded through the compute dtype like every other real table."""
+    nt = len(T.tendon["adr"]) - 1
+    r = lambda a, shape: np.ascontiguousarray(torch.tensor(np.asarray(a, dtype=np.float64).reshape(shape)).to(dtype).to(torch.float64).numpy()).reshape(-1)
+    g = lambda name, shape: r(getattr(src, name), shape) if nt else np.zeros(0)
+    return dict(ten_coef=r(T.tendon["coef"], (-1,)), tendon_range=g("tendon_range", (nt, 2)), tendon_margin=g("tendon_margin", (nt,)),
+                tendon_invweight0=g("tendon_invweight0", (nt,)), tendon_solref_lim=g("tendon_solref_lim", (nt, 2)),
+                tendon_solimp_lim=g("tendon_solimp_lim", (nt, 5)), tendon_stiffness=g("tendon_stiffness", (nt,)),
+                tendon_damping=g("tendon_damping", (nt,)), tendon_lengthspring=g("tendon_lengthspring", (nt, 2)))
+
+
 def pack_model(m, dtype: torch.dtype):
     """Model -> (ModelDesc, keepalive list of numpy arrays). Floats are evaluated in ``dtype``."""
     T = m.tables
@@ -82,7 +93,7 @@ def pack_model(m, dtype: torch.dtype):
     ne, nf, nl, ncon, nefc = m.constraint_sizes_py
     ints = dict(
         nq=m.nq, nv=m.nv, nu=m.nu, na=m.na, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
-        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=nf, nl=len(T.lim_jnt), nlb=len(T.lim_ball_jnt), nlt=int(T.nlt), ncon=ncon, nefc=nefc, neq=int(m.neq), neqtab=len(T.eq['kind']),
+        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=nf, nl=len(T.lim_jnt), nlb=len(T.lim_ball_jnt), nlt=int(T.nlt), ncon=ncon, nefc=nefc, neq=int(m.neq), neqtab=len(T.eq['kind']), ntendon=int(m.ntendon), nwrapj=len(T.tendon['dof']),
         npair=len(T.pairs), nconvex=0, nsensor=len(T.sensors["type"]), nsensordata=int(getattr(m, "nsensordata", 0) or 0), integrator=int(m.opt.integrator), solver=int(m.opt.solver),
         cone=int(m.opt.cone), disableflags=int(m.opt.disableflags), iterations=int(m.opt.iterations),
         ls_iterations=int(m.opt.ls_iterations),
@@ -118,7 +129,8 @@ def pack_model(m, dtype: torch.dtype):
         sns_rootid=i32(T.sensors["rootid"]), sns_datatype=i32(T.sensors["datatype"]), sns_rfadr=i32(T.sensors["rfadr"]),
         rf_geom=i32(T.sensors["rf_geom"]), slot_sensor=i32(T.sensors["slot"]),
         eq_kind=i32(T.eq['kind']), eq_id=i32(T.eq['id']), eq_obj1=i32(T.eq['obj1']), eq_obj2=i32(T.eq['obj2']), eq_row=i32(T.eq['row']), eq_jadr=i32(T.eq['jadr']),
-        fric_dof=i32(T.fric_dof), lim_ball_jnt=i32(T.lim_ball_jnt), lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
+        fric_dof=i32(T.fric_dof), ten_adr=i32(T.tendon['adr']), ten_dof=i32(T.tendon['dof']), ten_qposadr=i32(T.tendon['qpos']), lim_tendon=i32(T.tendon['lim']), act_trnid=i32([x[1] for x in info]),
+        lim_ball_jnt=i32(T.lim_ball_jnt), lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
         pair_geom2=i32([p[2].geom2 for p in T.pairs]), pair_ncon=i32([p[1] for p in T.pairs]), pair_dst=i32(T.pair_dst),
         con_dim=i32(T.con_dim), con_geom1=i32(T.con_geom1), con_geom2=i32(T.con_geom2), con_efc_address=i32(T.con_efc_address),
         convex_nvert=i32([]), convex_nface=i32([]), convex_nfv=i32([]), convex_nedge=i32([]), convex_vertadr=i32([]),
@@ -150,7 +162,7 @@ def pack_model(m, dtype: torch.dtype):
         jnt_margin=f64(m.jnt_margin), jnt_solref=f64(m.jnt_solref), jnt_solimp=f64(m.jnt_solimp),
         jnt_actfrcrange=f64(m.jnt_actfrcrange), dof_armature=f64(m.dof_armature), dof_damping=f64(m.dof_damping),
         dof_invweight0=f64(m.dof_invweight0), sns_cutoff=f64(torch.tensor(np.asarray(T.sensors["cutoff"], dtype=np.float64))), dof_frictionloss=f64(m.dof_frictionloss), dof_solref=f64(m.dof_solref), dof_solimp=f64(m.dof_solimp),
-        body_gravcomp=f64(m.body_gravcomp), body_invweight0_rot=f64(m.body_invweight0[:, 1]), eq_data=f64(m.eq_data) if m.neq else empty, eq_solref=f64(m.eq_solref) if m.neq else empty, eq_solimp=f64(m.eq_solimp) if m.neq else empty,
+        **_tendon_reals(src, T, dtype), body_gravcomp=f64(m.body_gravcomp), body_invweight0_rot=f64(m.body_invweight0[:, 1]), eq_data=f64(m.eq_data) if m.neq else empty, eq_solref=f64(m.eq_solref) if m.neq else empty, eq_solimp=f64(m.eq_solimp) if m.neq else empty,
         geom_pos=f64(m.geom_pos), geom_quat=f64(m.geom_quat),
         geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
         cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
@@ -162,7 +174,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 8
+    desc.abi_version = 9
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

@@ -87,6 +87,9 @@ CASES = {
     # ball-joint limits (constraint.py:299-335)
     "ball_limits_f64": ("ball_limits", {}, "float64", 3, 3, "ball_limits"),
     "ball_limits_cg_rk4_f32": ("ball_limits", {"integrator": 1, "solver": 1}, "float32", 2, 2, "ball_limits"),
+    # fixed tendons: lengths, limit rows, springs / dampers, tendon transmissions (smooth.py:470-497, constraint.py:375-405, passive.py:119-144)
+    "tendon_fixed_f64": ("tendon_fixed", {}, "float64", 3, 3, "tendon"),
+    "tendon_fixed_cg_rk4_f32": ("tendon_fixed", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
@@ -148,6 +151,10 @@ def make_inputs(recipe, lite, env):
                 q[a] += 0.3 * rng.randn()
         out["qpos"] = q
         out["qvel"] = 0.5 * rng.randn(nv)
+    elif recipe == "tendon":  # joint angles large enough to put the tendons beyond their ranges on both sides
+        out["qpos"] = lite.qpos0 + np.concatenate([[0.6, 0.5, 0.4, 0.3, 0.5][: nq - 7] * np.array([1, -1, 1, -1, 1])[: nq - 7] * (0.5 + env), 0.02 * rng.randn(7) * (env > 0)])
+        out["qvel"] = 0.5 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.5 * rng.randn(nu), -1, 1)
     elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
         out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
         out["qvel"] = 0.3 * rng.randn(nv)

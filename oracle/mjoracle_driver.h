@@ -10,7 +10,7 @@ static int FN(field_count)(const mjhModelDesc* m, const char* name) {
   F(xpos, nb * 3) F(xquat, nb * 4) F(xmat, nb * 9) F(xipos, nb * 3) F(ximat, nb * 9) F(xanchor, nj * 3) F(xaxis, nj * 3)
   F(geom_xpos, ng * 3) F(geom_xmat, ng * 9) F(site_xpos, m->nsite * 3) F(site_xmat, m->nsite * 9)
   F(cam_xpos, m->ncam * 3) F(cam_xmat, m->ncam * 9) F(light_xpos, m->nlight * 3) F(light_xdir, m->nlight * 3)
-  F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(actuator_length, nu)
+  F(subtree_com, nb * 3) F(cdof, nv * 6) F(cinert, nb * 10) F(crb, nb * 10) F(ten_length, m->ntendon) F(ten_J, m->ntendon * nv) F(ten_velocity, m->ntendon) F(actuator_length, nu)
   F(actuator_moment, nu * nv) F(qM, nv * nv) F(qLD, nv * nv) F(contact_dist, ncon) F(contact_pos, ncon * 3)
   F(contact_frame, ncon * 9) F(contact_includemargin, ncon) F(contact_friction, ncon * 5) F(contact_solref, ncon * 2)
   F(contact_solreffriction, ncon * 2) F(contact_solimp, ncon * 5) F(sensordata, m->nsensordata) F(efc_J, nefc * nv) F(efc_frictionloss, nefc)
@@ -48,6 +48,7 @@ static void FN(work_init)(FN(MjoWork) * w, const mjhModelDesc* m) {
   int nv = m->nv, nefc = m->nefc, nb = m->nbody, nq = m->nq;
   int big = nefc > nq ? nefc : nq;
   if (nv > big) big = nv;
+  if (m->ntendon > big) big = m->ntendon;
 #define X(n) w->n = FN(ralloc)((size_t)FN(field_count)(m, #n));
   MJH_DATA_REALS(X)
 #undef X

@@ -1281,6 +1281,20 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
     for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->jnt_solref[2 * j + i];
     for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->jnt_solimp[5 * j + i];
   }
+  for (int l = 0; l < m->nlt; l++, row++) { /* _instantiate_limit_tendon :375-405 */
+    int t = m->lim_tendon[l];
+    REAL length = w->ten_length[t];
+    REAL dist_min = length - M->tendon_range[2 * t], dist_max = M->tendon_range[2 * t + 1] - length;
+    REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M->tendon_margin[t];
+    REAL active = (REAL)(pos < 0);
+    REAL sign = ((REAL)(dist_min < dist_max) * 2 - 1) * active;
+    for (int d = 0; d < nv; d++) w->efc_J[row * nv + d] = w->ten_J[t * nv + d] * sign;
+    w->efc_pos[row] = pos * active;
+    w->efc_pos_norm[row] = pos * active;
+    w->efc_invweight[row] = M->tendon_invweight0[t];
+    for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->tendon_solref_lim[2 * t + i];
+    for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->tendon_solimp_lim[5 * t + i];
+  }
   int elliptic = m->cone == CONE_ELLIPTIC;
   for (int c = 0; c < m->ncon; c++) {
     int dim = m->con_dim[c];
@@ -1354,6 +1368,21 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
   }
 }
 
+/* smooth.tendon :470-497 (fixed tendons): length = sum coef * qpos, ten_J[t, dof] = coef */
+static void FN(tendon)(const FN(MjoModel) * M, FN(MjoWork) * w) {
+  const mjhModelDesc* m = M->d;
+  int nv = m->nv;
+  for (int i = 0; i < m->ntendon * nv; i++) w->ten_J[i] = 0;
+  for (int t = 0; t < m->ntendon; t++) {
+    REAL len = 0;
+    for (int q = m->ten_adr[t]; q < m->ten_adr[t + 1]; q++) {
+      len += M->ten_coef[q] * w->qpos[m->ten_qposadr[q]];
+      w->ten_J[t * nv + m->ten_dof[q]] = M->ten_coef[q];
+    }
+    w->ten_length[t] = len;
+  }
+}
+
 /* ---- velocity stage: transmission, com_vel, passive, rne ------------------------------------- */
 static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
   const mjhModelDesc* m = M->d;
@@ -1364,7 +1393,11 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
     const REAL* gear = M->act_gear + 6 * i;
     int jt = m->act_jnttype[i], da = m->act_dofadr[i], qa = m->act_qposadr[i];
     int inparent = m->act_trntype[i] == 1; /* TrnType.JOINTINPARENT */
-    if (jt == JNT_FREE) { /* :565-574 */
+    if (m->act_trntype[i] == 3) { /* TrnType.TENDON :558-561 */
+      int t = m->act_trnid[i];
+      w->actuator_length[i] = w->ten_length[t] * gear[0];
+      for (int d = 0; d < nv; d++) w->actuator_moment[i * nv + d] = w->ten_J[t * nv + d] * gear[0];
+    } else if (jt == JNT_FREE) { /* :565-574 */
       REAL vals[6] = {gear[0], gear[1], gear[2], gear[3], gear[4], gear[5]};
       if (inparent) {
         REAL qn[4] = {w->qpos[qa + 3], w->qpos[qa + 4] * (REAL)-1, w->qpos[qa + 5] * (REAL)-1, w->qpos[qa + 6] * (REAL)-1};
@@ -1388,6 +1421,11 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
     }
   }
   /* forward._velocity :87-99 */
+  for (int t = 0; t < m->ntendon; t++) {
+    REAL s = 0;
+    for (int d = 0; d < nv; d++) s += w->ten_J[t * nv + d] * w->qvel[d];
+    w->ten_velocity[t] = s;
+  }
   for (int i = 0; i < nu; i++) {
     REAL s = 0;
     for (int d = 0; d < nv; d++) s += w->actuator_moment[i * nv + d] * w->qvel[d];
@@ -1442,6 +1480,19 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
       }
     }
     for (int d = 0; d < nv; d++) w->qfrc_passive[d] = (0 + w->qfrc_passive[d]) - M->dof_damping[d] * w->qvel[d];
+    if (m->ntendon > 0) { /* tendon-level springs and dampers :119-144 (both flags are clear on this branch) */
+      for (int t = 0; t < m->ntendon; t++) {
+        REAL below = M->tendon_lengthspring[2 * t] - w->ten_length[t], above = M->tendon_lengthspring[2 * t + 1] - w->ten_length[t];
+        REAL fs = below > 0 ? M->tendon_stiffness[t] * below : (REAL)0;
+        fs = above < 0 ? M->tendon_stiffness[t] * above : fs;
+        w->tmp_nefc[t] = fs + (-M->tendon_damping[t] * w->ten_velocity[t]);
+      }
+      for (int d = 0; d < nv; d++) {
+        REAL s = 0;
+        for (int t = 0; t < m->ntendon; t++) s += w->ten_J[t * nv + d] * w->tmp_nefc[t];
+        w->qfrc_passive[d] = w->qfrc_passive[d] + s;
+      }
+    }
     if (M->has_gravcomp && !(m->disableflags & DSBL_GRAVITY)) { /* passive._gravcomp :148-156; with gravity off the input leaf is carried (:190-194) */
       for (int d = 0; d < nv; d++) {
         REAL acc = 0;
@@ -2003,7 +2054,7 @@ static void FN(sensors)(const FN(MjoModel) * M, FN(MjoWork) * w) {
 
 static void FN(forward_env)(const FN(MjoModel) * M, FN(MjoWork) * w, int stages, int flags, int with_cams) {
   const mjhModelDesc* m = M->d;
-  if (stages & 0x7f) { FN(kinematics)(M, w, with_cams); FN(com_pos)(M, w); }
+  if (stages & 0x7f) { FN(kinematics)(M, w, with_cams); FN(com_pos)(M, w); if (m->ntendon > 0) FN(tendon)(M, w); }
   if (stages & 0x7e) FN(crb_factor)(M, w);
   if (stages & 0x7c) { if (m->ncon > 0) FN(collision)(M, w); }
   if (stages & 0x78) FN(make_constraint)(M, w);

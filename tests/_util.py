@@ -72,6 +72,8 @@ class Golden:
         if key not in self.z:  # leaves that joined the ABI after the golden was recorded (models without the feature: empty / zeros)
             if name == "eq_active":
                 return np.zeros(0, dtype=np.int32)
+            if name in ("ten_length", "ten_velocity", "ten_J"):
+                return np.zeros((0, int(self.model.nv)) if name == "ten_J" else 0, dtype=np.float32 if self.dtype == torch.float32 else np.float64)
             if name == "qfrc_gravcomp":
                 return np.zeros(int(self.model.nv), dtype=np.float32 if self.dtype == torch.float32 else np.float64)
         return self.z[key]
