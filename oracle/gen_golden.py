@@ -90,6 +90,10 @@ CASES = {
     # fixed tendons: lengths, limit rows, springs / dampers, tendon transmissions (smooth.py:470-497, constraint.py:375-405, passive.py:119-144)
     "tendon_fixed_f64": ("tendon_fixed", {}, "float64", 3, 3, "tendon"),
     "tendon_fixed_cg_rk4_f32": ("tendon_fixed", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
+    # the last bundled model: every joint type stacked, ball limits, gravity compensation, mocap bodies, fixed tendons, motors on
+    # ball / free joints, camera modes (contacts disabled in the XML)
+    "pendula_f64": ("pendula", {}, "float64", 3, 3, "pendula"),
+    "pendula_rk4_f32": ("pendula", {"integrator": 1}, "float32", 2, 2, "pendula"),
     "frictionloss_dof_f64": ("frictionloss_dof", {}, "float64", 3, 3, "friction_hinge"),
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
@@ -155,6 +159,12 @@ def make_inputs(recipe, lite, env):
         out["qpos"] = lite.qpos0 + np.concatenate([[0.6, 0.5, 0.4, 0.3, 0.5][: nq - 7] * np.array([1, -1, 1, -1, 1])[: nq - 7] * (0.5 + env), 0.02 * rng.randn(7) * (env > 0)])
         out["qvel"] = 0.5 * rng.randn(nv)
         out["ctrl"] = np.clip(0.5 * rng.randn(nu), -1, 1)
+    elif recipe == "pendula":  # generic state plus moved mocap bodies
+        out["qpos"] = lite.qpos0 + 0.3 * rng.randn(nq) * (env > 0)
+        out["qvel"] = 0.5 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.5 * rng.randn(nu), -1, 1)
+        out["mocap_pos"] = lite.body_pos[lite.body_mocapid >= 0] + 0.1 * rng.randn(lite.nmocap, 3)
+        out["mocap_quat"] = lite.body_quat[lite.body_mocapid >= 0] + 0.2 * rng.randn(lite.nmocap, 4)
     elif recipe == "generic":  # any model: jittered qpos (env 0 keeps qpos0), velocities, clipped controls
         out["qpos"] = lite.qpos0 + 0.05 * rng.randn(nq) * (env > 0)
         out["qvel"] = 0.3 * rng.randn(nv)
@@ -191,7 +201,7 @@ def main(only=None):
         lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
         for k, v in overrides.items():
             setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
-        has_convex = any(int(t) in (6, 7) for t in lite.geom_type)
+        has_convex = any(int(t) in (6, 7) for t in lite.geom_type) and not (int(lite.opt.disableflags) & (1 << 4))  # convex tables matter only with contacts on
         # float32 + rangefinder raises inside the reference (float64 ray tables, ray.py:317): record those cases sensor-less
         keep_sensors = not (dtype != torch.float64 and any(int(t) == 7 for t in getattr(lite, "sensor_type", [])))
         if has_convex:

@@ -68,6 +68,8 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("equality_loops", {}, torch.float64, 64),                                     # equality rows: closed loop, weld, joint couplings
     ("equality_loops", {"integrator": 1, "solver": 1, "_tol_sol": 1e-4}, torch.float64, 32),  # RK4 + CG: 100 CG iterations on the stiff always-active rows amplify rounding (float32: golden equality_loops_rk4_f32)
     ("equality", {}, torch.float64, 32),                                           # bundled: site-form constraints carried inactive
+    ("pendula", {}, torch.float64, 64),                                            # bundled: every joint type, ball limits, gravcomp, mocap, tendons
+    ("tendon_fixed", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),
 ])
 def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_lib):
     """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs."""
