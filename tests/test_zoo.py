@@ -88,7 +88,7 @@ def test_auto_reset_keeps_dtypes_and_counts():
 
 
 def test_registry_matches_the_reference_zoo():
-    # names: reference zoo/*.py @register_env decorators (cmg is the one environment not carried: its model is not bundled)
+    # names: every @register_env of the reference zoo (zoo/cmg.py holds steering math, not an environment)
     assert set(ENVS) == {"ant", "cartpole", "halfcheetah", "hopper", "humanoid", "humanoid_rich", "swimmer", "walker2d",
                          "satellite_large", "satellite_small"}
     expect = {"ant": (27, 5, 0.1), "cartpole": (4, 1, 0.01), "halfcheetah": (17, 5, 0.1), "hopper": (11, 1, 0.01),
