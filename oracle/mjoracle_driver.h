@@ -170,7 +170,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       w.knife = 0;
       w.knife_policy = knife_policy;
       w.nf = m->nf; w.ne_nf = m->ne + m->nf; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
-      w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0;
+      w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0; w.prim_hint_n = NULL; w.prim_adopted = 0; w0.prim_hint_n = NULL; w0.prim_adopted = 0;
       w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;
       w0.eq_active = w.eq_active;
       w.hint_dist = g_hint_dist ? (const REAL*)g_hint_dist + e * m->ncon : NULL;

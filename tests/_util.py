@@ -87,6 +87,8 @@ SOLVER_FLOOR = 1e-3  # solver outputs (accelerations, forces) are O(1..1e3); bel
 
 
 def rel_err(got, want, floor=1e-6):
+    if np.asarray(want).dtype == np.float32:
+        floor = max(floor, 1e-3)  # float32 leaves that are all cancellation residue (|x| ~ 1e-8 from O(1) terms) carry no relative information
     got = np.asarray(got, dtype=np.float64).reshape(-1)
     want = np.asarray(want, dtype=np.float64).reshape(-1)
     if want.size == 0:
@@ -130,7 +132,7 @@ def oracle_alternatives(model, d, step=True, hint=None, **kw):
     outputs show (pyoracle.run)."""
     import pyoracle
 
-    if hint is not None and model.constraint_sizes_py[3] > 0 and any(p[0] >= 5 for p in model.tables.pairs):
+    if hint is not None and model.constraint_sizes_py[3] > 0:  # convex pairs: index ties; sphere / capsule pairs: coincident centres
         kw["contact_hint"] = {k: hint[k] for k in HINT_LEAVES}
 
     B = int(np.prod(d.qpos.shape[:-1])) if d.qpos.ndim > 1 else 1
