@@ -23,7 +23,7 @@ from ._enums import (  # noqa: F401
     TrnType,
 )
 from .container import MjTensorClass, UnbatchedTensor  # noqa: F401
-from .device import device_put  # noqa: F401
+from .device import device_get_into, device_put  # noqa: F401
 from .forward import forward, reset_where, step  # noqa: F401
 from .io import make_data  # noqa: F401
 from .types import Contact, Data, Model, Option, Statistic  # noqa: F401

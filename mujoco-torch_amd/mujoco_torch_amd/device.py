@@ -271,6 +271,77 @@ def _tendon_tables(m, flags) -> dict:
     return out
 
 
+# state / input fields of MjData that device_put(MjData) carries over; everything derived is recomputed by the first step
+_DATA_STATE_FIELDS = ("time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat",
+                      "qacc", "act_dot", "eq_active", "sensordata", "userdata")
+
+
+def _device_put_data(value, dtype):
+    """``device_put(MjData)`` (reference device.py:1011-1112) for any object with MjData's array attributes: a ``Data`` whose state
+    and input leaves are copied from ``value``.  The model comes from ``value.model`` (MuJoCo >= 3.1 keeps it on MjData)."""
+    from .io import make_data
+
+    model = getattr(value, "model", None)
+    if model is None:
+        raise NotImplementedError("device_put(MjData) needs value.model (mujoco >= 3.1) to size the Data")
+    mx = model if isinstance(model, Model) else device_put(model)
+    d = make_data(mx)
+    kw = {}
+    for name in _DATA_STATE_FIELDS:
+        if not hasattr(value, name):
+            continue
+        cur = getattr(d, name)
+        a = np.asarray(getattr(value, name))
+        if a.size != cur.numel():
+            continue
+        kw[name] = torch.as_tensor(a.reshape(tuple(cur.shape))).to(cur.dtype).clone()
+    d = d.replace(**kw)
+    return d.to(dtype) if dtype is not None else d
+
+
+def device_get_into(result, value):
+    """Copies a ``Data`` off the device into MjData-like object(s) (reference device.py:1119-1205): a single object receives the
+    arrays with the batch dimension intact, a list must have one entry per environment.  Fields are matched by attribute name
+    (contact leaves go to ``result.contact`` when it exists); fields the target lacks or holds with another shape are skipped."""
+    if isinstance(result, (list, tuple)):
+        bs = tuple(value.batch_size)
+        if len(bs) < 1:
+            raise ValueError("unrecognizable batch dimension in value")
+        if len(result) != bs[0]:
+            raise ValueError(f"result length ({len(result)}) doesn't match value batch size ({bs[0]})")
+        host = value.to("cpu")
+        for i, r in enumerate(result):
+            device_get_into(r, host[i])
+        return
+
+    def put(target, name, v):
+        if isinstance(v, UnbatchedTensor):
+            v = v.data
+        if not isinstance(v, torch.Tensor):
+            return
+        a = v.detach().cpu().numpy()
+        cur = getattr(target, name, None)
+        if cur is None:
+            return
+        if hasattr(cur, "shape") and tuple(np.shape(cur)) != a.shape:
+            if np.size(cur) != a.size:
+                return
+            a = a.reshape(np.shape(cur))
+        try:
+            setattr(target, name, a)
+        except (AttributeError, ValueError, TypeError):
+            getattr(target, name)[...] = a
+
+    for name, v in value.items():
+        if name == "contact":
+            con = getattr(result, "contact", None)
+            if con is not None:
+                for cn, cv in v.items():
+                    put(con, "dim" if cn == "contact_dim" else cn, cv)
+            continue
+        put(result, name, v)
+
+
 def _equality_tables(m, flags) -> dict:
     """Equality constraints in the reference's ROW order: all connects, all welds, all joint couplings (constraint.py:651-656,
     groups from device.py:296-319).  ``jadr`` = (dofadr1, dofadr2, qposadr1, qposadr2) of joint couplings; a missing second
@@ -319,6 +390,8 @@ def device_put(value, *, dtype: torch.dtype | None = None):
     ``value``: ``mjcf.MjModelLite`` or ``mujoco.MjModel``.  ``dtype`` overrides the floating
     dtype of every float leaf (default float64, like the reference).
     """
+    if not hasattr(value, "nq") and hasattr(value, "qpos") and hasattr(value, "qvel"):
+        return _device_put_data(value, dtype)  # an MjData-like object (device.py:1081-1082)
     if not hasattr(value, "nq") or not hasattr(value, "opt"):
         raise NotImplementedError(f"{type(value)} is not supported for device_put.")
     _validate(value)

@@ -3,12 +3,16 @@
 Known answers are the model facts the reference's own tests state:
 humanoid sizes nq 28 / nv 27 / nu 21 / nbody 17 / njnt 22 / ngeom 20 / ncon 8 / nefc 53; ant ncon == 60
 (reference test/collision_driver_test.py:451-458), nefc 248 pyramidal / 188 elliptic; cartpole nefc 0."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 import mujoco_torch_amd as mt
 from _util import load_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_humanoid_sizes_and_contact_table():
@@ -132,3 +136,35 @@ def test_containers_are_pytrees_and_vmap_sees_their_leaves():
     assert torch.equal(doubled.qvel, d.qvel * 2) and doubled.contact.geom.dtype == d.contact.geom.dtype
     with pytest.raises(RuntimeError, match="HIP device"):                  # the native step still refuses CPU tensors under vmap
         torch.vmap(lambda x: mt.step(mx, x))(d)
+
+
+def test_device_put_data_and_device_get_into_roundtrip():
+    """`device_put(MjData)` / `device_get_into(MjData | list, Data)` (reference device.py:1011-1205) on duck-typed MjData objects."""
+    from types import SimpleNamespace
+
+    lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", "hopper.xml"))
+    mx = mt.device_put(lite)
+    nq, nv, nu, nb = mx.nq, mx.nv, mx.nu, mx.nbody
+
+    def mjdata():
+        return SimpleNamespace(model=lite, time=0.25, qpos=np.arange(nq) * 0.1, qvel=np.ones(nv), act=np.zeros(0), ctrl=np.full(nu, 0.5),
+                               qacc=np.zeros(nv), qacc_warmstart=np.zeros(nv), qfrc_applied=np.zeros(nv), xfrc_applied=np.zeros((nb, 6)),
+                               xpos=np.zeros((nb, 3)), cvel=np.zeros((nb, 6)), qM=np.zeros(7), contact=SimpleNamespace(dist=np.zeros(int(mt.make_data(mx).ncon))))
+
+    d_mj = mjdata()
+    d = mt.device_put(d_mj)
+    assert isinstance(d, mt.Data) and d.qpos.dtype == torch.float64 and float(d.time) == 0.25
+    assert torch.equal(d.qpos, torch.tensor(d_mj.qpos)) and torch.equal(d.ctrl, torch.full((nu,), 0.5, dtype=torch.float64))
+    assert mt.device_put(d_mj, dtype=torch.float32).qvel.dtype == torch.float32
+    # single target: arrays keep the batch dimension; wrong-shaped targets (sparse qM here) are skipped
+    batch = d.expand(3).clone().replace(qpos=torch.arange(3.0).reshape(3, 1).expand(3, nq).clone(), xpos=torch.ones(3, nb, 3, dtype=torch.float64))
+    outs = [mjdata() for _ in range(3)]
+    mt.device_get_into(outs, batch)
+    for i, o in enumerate(outs):
+        assert np.array_equal(o.qpos, np.full(nq, float(i))) and np.array_equal(o.xpos, np.ones((nb, 3))) and o.qM.shape == (7,)
+        assert o.contact.dist.shape == (int(d.ncon),)
+    with pytest.raises(ValueError, match="batch size"):
+        mt.device_get_into(outs[:2], batch)
+    one = mjdata()
+    mt.device_get_into(one, batch[1])
+    assert np.array_equal(one.qpos, np.full(nq, 1.0))
