@@ -1773,6 +1773,53 @@ struct Env {
     p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
     return p;
   }
+  // the three candidates of a line-search iteration in ONE pass over the rows (each row's Jaref / jv / quad read once, nine
+  // interleaved reductions): per candidate the same per-lane partial sums in the same order as ls_point, so the same bits.
+  // Used by the float32 instantiations (+2.5 % on the ant, where 188 rows make three trips; -1.3 % on the float64 humanoid).
+  __device__ __forceinline__ void ls_points3(const REAL* qg, const REAL (&alpha)[3], LSPoint (&p)[3]) {
+    REAL q0[3] = {0, 0, 0}, q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
+    REAL f0n[3] = {0, 0, 0}, f0p[3] = {0, 0, 0}, f1n[3] = {0, 0, 0}, f1p[3] = {0, 0, 0};
+    const int nf = nf_();
+    for (int r = lane(); r < M.nefc; r += W) {
+      const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
+      const REAL u0 = S.s_quad()[3 * r], u1 = S.s_quad()[3 * r + 1], u2 = S.s_quad()[3 * r + 2];
+      const bool eq = is_eq_row(r);
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const REAL x = ja + alpha[k] * jv;
+        bool act = (x < 0) || eq;
+        if (nf > 0 && r < nf) {
+          act = true;
+          const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+          const REAL rf = (1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL)) * fl;
+          const bool ln = (x <= -rf) && (fl > 0), lp = (x >= rf) && (fl > 0);
+          f0n[k] = (REAL)ln * fl * ((REAL)-0.5 * rf - ja);
+          f0p[k] = (REAL)lp * fl * ((REAL)-0.5 * rf + ja);
+          f1n[k] = (REAL)ln * (-fl * jv);
+          f1p[k] = (REAL)lp * (fl * jv);
+          act = act && !ln && !lp;
+        }
+        const REAL a = (REAL)act;
+        q0[k] += u0 * a; q1[k] += u1 * a; q2[k] += u2 * a;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { q0[k] = wave_sum(q0[k]); q1[k] = wave_sum(q1[k]); q2[k] = wave_sum(q2[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      REAL fa0 = 0, fa1 = 0;
+      if (nf > 0) {
+        REAL s0n = 0, s0p = 0, s1n = 0, s1p = 0;
+        for (int r = 0; r < nf; r++) { s0n += read_lane(f0n[k], r); s0p += read_lane(f0p[k], r); s1n += read_lane(f1n[k], r); s1p += read_lane(f1p[k], r); }
+        fa0 = s0n + s0p; fa1 = s1n + s1p;
+      }
+      const REAL t0 = (qg[0] + q0[k]) + fa0, t1 = (qg[1] + q1[k]) + fa1, t2 = (qg[2] + q2[k]) + 0;
+      p[k].alpha = alpha[k];
+      p[k].cost = alpha[k] * alpha[k] * t2 + alpha[k] * t1 + t0;
+      p[k].d0 = 2 * alpha[k] * t2 + t1;
+      p[k].d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
+    }
+  }
   __device__ __forceinline__ static bool ls_swap(REAL cur, REAL cand, bool not_bracketed) {  // _swap :440-449
     const bool in_bracket = ((cur < cand) && (cand < 0)) || ((cur > cand) && (cand > 0));
     return in_bracket || (not_bracketed && (r_abs(cand) < r_abs(cur)));
@@ -1822,9 +1869,17 @@ struct Env {
         done |= (hi.d0 > 0) && (hi.d0 < gtol);
         if (done) break;
       }
-      const LSPoint lo_next = ls_point(qg, lo.alpha - lo.d0 / lo.d1);
-      const LSPoint hi_next = ls_point(qg, hi.alpha - hi.d0 / hi.d1);
-      const LSPoint mid = ls_point(qg, (REAL)0.5 * (lo.alpha + hi.alpha));
+      LSPoint lo_next, hi_next, mid;
+      if (sizeof(REAL) == 4) {
+        const REAL al[3] = {lo.alpha - lo.d0 / lo.d1, hi.alpha - hi.d0 / hi.d1, (REAL)0.5 * (lo.alpha + hi.alpha)};
+        LSPoint pp[3];
+        ls_points3(qg, al, pp);
+        lo_next = pp[0]; hi_next = pp[1]; mid = pp[2];
+      } else {
+        lo_next = ls_point(qg, lo.alpha - lo.d0 / lo.d1);
+        hi_next = ls_point(qg, hi.alpha - hi.d0 / hi.d1);
+        mid = ls_point(qg, (REAL)0.5 * (lo.alpha + hi.alpha));
+      }
       const bool nb = (lo.d0 < 0) == (hi.d0 < 0);
       const bool s1 = ls_swap(lo.d0, lo_next.d0, nb); if (s1) lo = lo_next;
       const bool s2 = ls_swap(lo.d0, mid.d0, nb); if (s2) lo = mid;
