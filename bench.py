@@ -265,6 +265,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(mx, dtype, nB, 20 if args.workload != "ant" else 4)
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()  # rank 0 runs the per-kernel pass after the timed region: leave together
         dist.destroy_process_group()
 
 
