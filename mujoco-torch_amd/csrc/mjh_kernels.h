@@ -934,8 +934,13 @@ struct Env {
     if (dampratio <= 0) kk = -dampratio / (dmax * dmax);
     if (timeconst <= 0) bb = -timeconst / dmax;
     const REAL imp_x = r_abs(pos) / width;
-    const REAL imp_a = (1 / r_pow<REAL>(mid, power - 1)) * r_pow<REAL>(imp_x, power);
-    const REAL imp_b = 1 - (1 / r_pow<REAL>(1 - mid, power - 1)) * r_pow<REAL>(1 - imp_x, power);
+    // solimp's default power is 2: x^1 and x^2 are exact products, no need for the general pow (four calls per row otherwise)
+    const bool sq = (power == (REAL)2);
+    const REAL om = 1 - mid, ox = 1 - imp_x;
+    const REAL pm = sq ? mid : r_pow<REAL>(mid, power - 1), pom = sq ? om : r_pow<REAL>(om, power - 1);
+    const REAL px = sq ? imp_x * imp_x : r_pow<REAL>(imp_x, power), pox = sq ? ox * ox : r_pow<REAL>(ox, power);
+    const REAL imp_a = (1 / pm) * px;
+    const REAL imp_b = 1 - (1 / pom) * pox;
     const REAL imp_y = imp_x < mid ? imp_a : imp_b;
     REAL im = dmin + imp_y * (dmax - dmin);
     im = clampf(im, dmin, dmax);
