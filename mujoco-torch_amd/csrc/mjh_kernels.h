@@ -1566,6 +1566,10 @@ struct Env {
     // qacc_smooth = M^-1 qfrc_smooth (forward.py:222-228) is the first thing the solver phase computes: the factor is
     // resident there anyway, and without it this phase's arena is small enough for two environments per wavefront
     if (!off) put(out.actuator_force, S.act_force(), nu);
+    else if (out.actuator_force && in.actuator_force)  // actuation disabled: the reference returns before touching the leaf (forward.py:102-108), the caller's values stay
+      for (int i = l; i < nu; i += W) out.actuator_force[e * nu + i] = in.actuator_force[e * nu + i];
+    else if (out.actuator_force)
+      for (int i = l; i < nu; i += W) out.actuator_force[e * nu + i] = 0;
     put(out.act_dot, S.act_dot(), M.na);
     put(out.qfrc_actuator, S.qfrc_actuator(), nv); put(out.qfrc_smooth, S.qfrc_smooth(), nv);
     STAMP(42);

@@ -68,6 +68,11 @@ def test_step_matches_reference_golden(case, oracle_lib):
     ("equality_loops", {}, torch.float64, 64),                                     # equality rows: closed loop, weld, joint couplings
     ("equality_loops", {"integrator": 1, "solver": 1, "_tol_sol": 1e-4}, torch.float64, 32),  # RK4 + CG: 100 CG iterations on the stiff always-active rows amplify rounding (float32: golden equality_loops_rk4_f32)
     ("equality", {}, torch.float64, 32),                                           # bundled: site-form constraints carried inactive
+    ("ant", {"disableflags": 1 << 4}, torch.float64, 32),                          # disable flags (test/constraint_test.py:148-200): contacts off
+    ("humanoid", {"disableflags": 1}, torch.float64, 32),                          # ... every constraint off (nefc = 0)
+    ("ant", {"disableflags": (1 << 12) | (1 << 9) | (1 << 8)}, torch.float64, 32), # ... refsafe, warm start and ctrl clamping off
+    ("hopper", {"disableflags": (1 << 7) | (1 << 11), "_tol_sol": 1e-6}, torch.float64, 32),  # ... gravity and actuation off
+    ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, torch.float64, 32),     # ... springs (hence every passive force) and limits off
     ("pendula", {}, torch.float64, 64),                                            # bundled: every joint type, ball limits, gravcomp, mocap, tendons
     ("tendon_fixed", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),
 ])
@@ -357,3 +362,33 @@ def test_check_state_resets_bad_entries(oracle_lib):
     for n in ("qpos", "qvel", "qacc", "xpos", "qfrc_bias"):
         assert np.isfinite(out[n]).all(), n
         assert rel_err(out[n], want[n], 1e-3) < 1e-7, n
+
+
+@pytest.mark.parametrize("xml,overrides,dtype", [
+    ("humanoid", {"solver": 1}, torch.float64), ("humanoid", {"disableflags": 1}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
+    ("ant", {"disableflags": 1 << 4}, torch.float64), ("hopper", {"disableflags": (1 << 7) | (1 << 11)}, torch.float64), ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, torch.float64),
+    ("cartpole", {}, torch.float64), ("swimmer", {"disableflags": 1 << 6}, torch.float64), ("mesh_contact", {}, torch.float32), ("sensor_rig", {"integrator": 1}, torch.float64),
+    ("pendula", {}, torch.float64), ("pendula", {"disableflags": (1 << 4) | (1 << 7) | (1 << 5)}, torch.float64), ("equality", {"disableflags": 1 << 1}, torch.float64),
+    ("gravcomp_arm", {"disableflags": 1 << 7}, torch.float64), ("tendon_fixed", {"disableflags": 1 << 3, "integrator": 1}, torch.float64), ("frictionloss_dof", {"disableflags": 1 << 2}, torch.float64),
+])
+def test_every_written_leaf_is_written(xml, overrides, dtype):
+    """`step` hands the kernels uninitialised storage for every leaf it reports as written: whatever the model options and disable
+    flags, each of those leaves must be overwritten in full (poisoned with NaN / -7 here)."""
+    from mujoco_torch_amd.forward import _written_names
+
+    mx = load_model(xml, overrides, dtype)
+    B = 9
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    out = dg.clone()
+    names = _written_names(mx, step=True)
+    for n in names:
+        t = leaf(out, n)
+        t.fill_(float("nan") if t.is_floating_point() else -7)
+    mt.step(mdev, dg, out=out)
+    for n in names:
+        t = leaf(out, n)
+        ok = torch.isfinite(t).all() if t.is_floating_point() else (t != -7).all()
+        assert bool(ok), f"{xml} {overrides}: leaf {n} was not (fully) written"

@@ -168,3 +168,55 @@ def test_device_put_data_and_device_get_into_roundtrip():
     one = mjdata()
     mt.device_get_into(one, batch[1])
     assert np.array_equal(one.qpos, np.full(nq, 1.0))
+
+
+_TWO_SPHERES = """
+<mujoco>
+  <option cone="{cone}"/>
+  <worldbody>
+    <geom type="plane" size="2 2 .01" condim="{c0}"/>
+    <body pos="0 0 .1"><freejoint/><geom type="sphere" size=".1" condim="{c1}"/></body>
+    <body pos=".5 0 .1"><freejoint/><geom type="sphere" size=".1" condim="{c2}"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+@pytest.mark.parametrize("cone,c0,c1,c2,rows", [
+    ("pyramidal", 3, 3, 3, [4, 4, 4]),      # condim 3: 2 * (3 - 1) edges
+    ("pyramidal", 1, 4, 1, [1, 6, 6]),      # max(condim) per pair: sphere-sphere 4 -> 6 rows, plane-sphere(4) 6, plane-sphere(1) 1 (test/constraint_test.py:355-367)
+    ("elliptic", 3, 3, 3, [3, 3, 3]),       # elliptic condim 3 -> 3 rows (:536-548)
+    ("elliptic", 1, 6, 3, [3, 6, 6]),       # mixed (:578-590)
+])
+def test_constraint_row_counts_per_condim(cone, c0, c1, c2, rows):
+    """nefc = sum over contacts of 1 (condim 1), 2 (condim - 1) (pyramidal) or condim (elliptic): reference device.py:252-262."""
+    lite = mt.mjcf.from_xml_string(_TWO_SPHERES.format(cone=cone, c0=c0, c1=c1, c2=c2))
+    mx = mt.device_put(lite)
+    ne, nf, nl, ncon, nefc = mx.constraint_sizes_py
+    assert (ne, nf, nl, ncon) == (0, 0, 0, 3)
+    assert nefc == sum(rows)
+    d = mt.make_data(mx)
+    adr = d.contact.efc_address.tolist()
+    assert sorted(np.diff(adr + [nefc]).tolist()) == sorted(rows)
+    assert d.contact.contact_dim.tolist() == sorted(d.contact.contact_dim.tolist())   # contacts are ordered by condim (collision_driver.py:842)
+
+
+def test_disable_flags_shrink_the_constraint_sizes():
+    """test/constraint_test.py:148-200: each disable bit removes its block of rows (device.py:226-264)."""
+    from mujoco_torch_amd import DisableBit
+
+    def sizes(xml, flag):
+        lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", xml + ".xml"))
+        lite.opt.disableflags = int(lite.opt.disableflags) | int(flag)
+        return mt.device_put(lite).constraint_sizes_py
+
+    ne, nf, nl, ncon, nefc = sizes("equality_loops", 0)
+    assert ne == 14 and ncon > 0
+    assert sizes("equality_loops", DisableBit.EQUALITY)[0] == 0
+    assert sizes("equality_loops", DisableBit.CONSTRAINT) == (0, 0, 0, 0, 0)
+    assert sizes("ant_frictionloss", 0)[1] == 8 and sizes("ant_frictionloss", DisableBit.FRICTIONLOSS)[1] == 0
+    assert sizes("ant", 0)[2] == 8 and sizes("ant", DisableBit.LIMIT)[2] == 0
+    full = sizes("ant", 0)
+    off = sizes("ant", DisableBit.CONTACT)
+    assert full[3] == 60 and off[3] == 0 and off[4] == off[2]
+    assert sizes("pendula", 0)[3] == 0          # the XML disables contacts itself; 4 + 11 limit rows remain
