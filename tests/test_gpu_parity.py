@@ -392,3 +392,25 @@ def test_every_written_leaf_is_written(xml, overrides, dtype):
         t = leaf(out, n)
         ok = torch.isfinite(t).all() if t.is_floating_point() else (t != -7).all()
         assert bool(ok), f"{xml} {overrides}: leaf {n} was not (fully) written"
+
+
+@pytest.mark.parametrize("xml,overrides,dtype", [
+    ("humanoid", {}, torch.float64), ("ant", {"cone": 1}, torch.float32), ("mesh_contact", {}, torch.float64), ("sensor_rig", {}, torch.float64),
+    ("pendula", {}, torch.float64), ("equality_loops", {}, torch.float64), ("swimmer", {}, torch.float64), ("ant_frictionloss", {"disableflags": 1 << 11}, torch.float64),
+])
+def test_forward_matches_oracle_on_every_leaf(xml, overrides, dtype, oracle_lib):
+    """`forward` (no integration, reference forward.py:373-401) over a seeded batch: every leaf of the returned Data against the
+    oracle's forward -- including the leaves a forward pass does not write, which must come back as the caller's."""
+    mx = load_model(xml, overrides, dtype)
+    B = 24
+    rng = np.random.RandomState(5)
+    d = mt.make_data(mx).expand(B).clone()
+    d = d.replace(qpos=d.qpos + 0.05 * torch.tensor(rng.randn(B, mx.nq)), qvel=torch.tensor(0.3 * rng.randn(B, mx.nv)), ctrl=torch.tensor(0.4 * rng.randn(B, mx.nu)),
+                  time=torch.tensor(rng.rand(B)), actuator_force=torch.tensor(rng.randn(B, mx.nu)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    got = gpu_out_to_numpy(mt.forward(mx.to("cuda"), d.to("cuda")))
+    tol_pre = 1e-9 if dtype == torch.float64 else 3e-4
+    check_against_oracle(mx, d, got, tol_pre, 1e-6 if dtype == torch.float64 else 5e-3, what=f"{xml} forward", step=False, nthreads=4)
+    for n in ("time", "qvel", "ctrl"):  # not written by forward: the caller's values
+        assert np.array_equal(got[n], leaf(d, n).numpy()), n
