@@ -414,3 +414,34 @@ def test_forward_matches_oracle_on_every_leaf(xml, overrides, dtype, oracle_lib)
     check_against_oracle(mx, d, got, tol_pre, 1e-6 if dtype == torch.float64 else 5e-3, what=f"{xml} forward", step=False, nthreads=4)
     for n in ("time", "qvel", "ctrl"):  # not written by forward: the caller's values
         assert np.array_equal(got[n], leaf(d, n).numpy()), n
+
+
+def test_strided_inputs_side_streams_and_interleaved_models():
+    """Host-side robustness of the call: broadcast (stride-0) and transposed leaves are made contiguous, the launches follow the
+    caller's current stream, and two models can be stepped alternately."""
+    mh, ma = load_model("humanoid", {"solver": 1}), load_model("ant", {}, torch.float64)
+    B = 16
+    rng = np.random.RandomState(9)
+    dh = mt.make_data(mh).expand(B).clone().replace(qvel=torch.tensor(0.05 * rng.randn(B, mh.nv))).to("cuda")
+    da = mt.make_data(ma).expand(B).clone().replace(qvel=torch.tensor(0.05 * rng.randn(B, ma.nv))).to("cuda")
+    mhd, mad = mh.to("cuda"), ma.to("cuda")
+    ref_h, ref_a = mt.step(mhd, dh), mt.step(mad, da)
+    # stride-0 batch (expand without clone) and a transposed-storage leaf
+    bcast = mt.make_data(mh).to("cuda").expand(B)
+    want = mt.step(mhd, bcast.clone())
+    got = mt.step(mhd, bcast)
+    assert torch.equal(got.qpos, want.qpos) and torch.equal(got.qacc, want.qacc)
+    weird = dh.replace(qvel=dh.qvel.t().contiguous().t(), ctrl=torch.zeros(mh.nu, B, dtype=torch.float64, device="cuda").t())
+    assert not weird.qvel.is_contiguous()
+    assert torch.equal(mt.step(mhd, weird).qvel, ref_h.qvel)
+    # side stream: results identical, and ordered after work queued on that stream
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        scaled = dh.replace(qvel=dh.qvel * 1.0)      # produced on the side stream just before the step consumes it
+        on_side = mt.step(mhd, scaled)
+    s.synchronize()
+    assert torch.equal(on_side.qpos, ref_h.qpos)
+    # two models alternately (nothing about a model is cached per process in a way that leaks into the other)
+    for _ in range(3):
+        h, a = mt.step(mhd, dh), mt.step(mad, da)
+        assert torch.equal(h.qacc, ref_h.qacc) and torch.equal(a.qacc, ref_a.qacc)
