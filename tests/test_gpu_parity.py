@@ -445,3 +445,18 @@ def test_strided_inputs_side_streams_and_interleaved_models():
     for _ in range(3):
         h, a = mt.step(mhd, dh), mt.step(mad, da)
         assert torch.equal(h.qacc, ref_h.qacc) and torch.equal(a.qacc, ref_a.qacc)
+
+
+def test_two_leading_batch_dims_equal_the_flat_batch():
+    """A Data with batch shape [E, T] (every leaf [E, T, ...]) is one native batch of E * T environments."""
+    mx = load_model("hopper")
+    E, T = 3, 5
+    rng = np.random.RandomState(4)
+    flat = mt.make_data(mx).expand(E * T).clone().replace(qvel=torch.tensor(0.2 * rng.randn(E * T, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(E * T, mx.nu)))
+    mdev = mx.to("cuda")
+    want = mt.step(mdev, flat.to("cuda"))
+    two = mt.make_data(mx).expand(E, T).clone().replace(qvel=flat.qvel.reshape(E, T, -1), ctrl=flat.ctrl.reshape(E, T, -1)).to("cuda")
+    got = mt.step(mdev, two)
+    assert tuple(got.qpos.shape) == (E, T, mx.nq) and tuple(got.contact.dist.shape)[:2] == (E, T)
+    for n in ("qpos", "qvel", "qacc", "efc_J", "contact_frame", "xpos"):
+        assert torch.equal(leaf(got, n).reshape(leaf(want, n).shape), leaf(want, n)), n
