@@ -86,13 +86,19 @@ def _ptrs_cached(d: Data, tag, names, dtype, device, check=True):
     of a step at small batches.  Valid while the leaf SET is unchanged (``replace`` makes a new container, ``update_`` /
     attribute assignment bump the version); in-place writes into the tensors keep their pointers."""
     con = d.contact
-    key = (tag, d.__dict__.get("_ver", 0), id(con), con.__dict__.get("_ver", 0), dtype, device)
-    hit = d.__dict__.get("_ptr_cache") if _PTR_CACHE else None
-    if hit is not None and hit[0] == key:
-        return hit[1], hit[2]
+    key = (d.__dict__.get("_ver", 0), id(con), con.__dict__.get("_ver", 0), dtype, device)
+    cache = d.__dict__.get("_ptr_cache") if _PTR_CACHE else None
+    if cache is not None:
+        hit = cache.get(tag)  # one slot per role: a ping-pong buffer is the input of one call and the output of the next
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
     ptrs, keep = _fill_ptrs(d, names, dtype, device, check)
-    if all(k is native.data_field_tensor(d, n) for k, n in zip(keep, [n for n in names if native.data_field_tensor(d, n) is not None])):
-        object.__setattr__(d, "_ptr_cache", (key, ptrs, keep))  # only when no contiguous copy had to be made
+    present = [n for n in names if native.data_field_tensor(d, n) is not None]
+    if _PTR_CACHE and all(k is native.data_field_tensor(d, n) for k, n in zip(keep, present)):  # only when no contiguous copy had to be made
+        if cache is None:
+            cache = {}
+            object.__setattr__(d, "_ptr_cache", cache)
+        cache[tag] = (key, ptrs, keep)
     return ptrs, keep
 
 
