@@ -567,7 +567,7 @@ bool graphs_enabled() {
   // opt-in (MJH_GRAPHS=1): measured on MI355X the replay saves ~3 % of wall time at B <= 1024 (the step is bound by the
   // latency of its dependent kernels there, not by the host) and costs 1-2 % at B = 4096 (profiles/r01/notes.md)
   static const bool on = [] { const char* e = getenv("MJH_GRAPHS"); return e && e[0] == '1'; }();
-  return on && !g_stamps;
+  return on && !g_stamps && !g_timing.on;  // per-launch events cannot be recorded into a replayed graph
 }
 
 template <typename REAL>
