@@ -2024,7 +2024,13 @@ struct Env {
         for (int d = l; d < nv; d += W) S.s_qacc()[d] = src[d];
         wave_sync();
         mul_J(S.s_qacc(), S.s_Jaref(), S.efc_aref());
-        mul_M(S.s_qacc(), S.s_Ma());
+        if (ph == P_SMOOTH) {
+          // cost-only context at qacc = qacc_smooth: its Gauss term is (Ma - qfrc_smooth) . (qacc - qacc_smooth) = x . 0, an exact zero for
+          // any finite Ma -- the M product (27 dependent row reads from L2) is skipped; if this context wins, P_START rebuilds it in full
+          for (int d = l; d < nv; d += W) S.s_Ma()[d] = 0;
+        } else {
+          mul_M(S.s_qacc(), S.s_Ma());
+        }
         c.gauss = 0; c.cost = (REAL)INFINITY; c.prev_cost = 0; c.niter = 0;
         for (int d = l; d < nv; d += W) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
         wave_sync();
