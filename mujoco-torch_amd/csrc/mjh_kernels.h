@@ -319,8 +319,21 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
     if (j < n) {
       REAL s = sub_read<W>(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
       if (big) s = s + (REAL)1e-10;                  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
-      const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
-      const REAL lij = (i == j) ? d : ((i < n) ? row[j] / d : (REAL)0);  // lanes i < j hold zeros: harmless; lanes >= n stay zero
+      REAL d, lij;
+      if (big && sizeof(REAL) == 8) {
+        // n > 16 is LAPACK's blocked factorisation in the reference: its operation order is not part of the algorithm, so the
+        // column scale is taken as a refined reciprocal square root (hardware estimate + two Newton steps, ~1 ulp) instead
+        // of a square-root sequence followed by a divide sequence -- the two longest dependent chains of the CRB phase
+        const double sd = (double)s, hs = 0.5 * sd;
+        double y = __builtin_amdgcn_rsq(sd);
+        y = y * (1.5 - hs * y * y);
+        y = y * (1.5 - hs * y * y);
+        d = (REAL)(sd * y);
+        lij = (i == j) ? d : ((i < n) ? row[j] * (REAL)y : (REAL)0);
+      } else {
+        d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
+        lij = (i == j) ? d : ((i < n) ? row[j] / d : (REAL)0);  // lanes i < j hold zeros: harmless; lanes >= n stay zero
+      }
       row[j] = lij;
 #pragma unroll
       for (int k = j + 1; k < NMAX; k++) {             // no k < n guard: lanes / columns >= n carry exact zeros, the update is a no-op there
