@@ -963,7 +963,9 @@ struct Env {
 
   __device__ __forceinline__ void make_constraint() {
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = M.nf, ne = M.ne, nlb = M.nlb, nlt = M.nlt;
+    // FRIC = false: the plain instantiation (slide / hinge limits and contacts only); equality, frictionloss, ball- and tendon-limit
+    // rows compile away and cost the headline kernel no registers
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = FRIC ? M.nf : 0, ne = FRIC ? M.ne : 0, nlb = FRIC ? M.nlb : 0, nlt = FRIC ? M.nlt : 0;
     if (nefc == 0) return;
     load_qpos(false); load_qvel();
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
@@ -973,7 +975,7 @@ struct Env {
     STAMP(23);
     // equality rows (constraint.py:116-212, 254-296): one lane per (constraint, dof) column of a connect / weld, one lane per
     // joint coupling.  Body frames come from global memory (this pass's kinematics output): few values, read once per lane.
-    for (int w = l; w < M.neqtab * nv; w += W) {
+    for (int w = l; w < (FRIC ? M.neqtab : 0) * nv; w += W) {
       int q, d;
       split_index(w, nv, M.inv_nv, q, d);
       const int kind = M.eq_kind[q], id = M.eq_id[q], id1 = M.eq_obj1[q], id2 = M.eq_obj2[q], row = M.eq_row[q];
@@ -2260,10 +2262,10 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 |
   const int sub = (W == MJH_WAVE) ? 0 : (int)(threadIdx.x / W);  // folded away for a whole-wave environment: everything stays scalar
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
-    Env<REAL, W, PHASE == 6> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
+    Env<REAL, W, PHASE == 6 || PHASE == 7> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
     if (PHASE == 0) E.run_kin();
     else if (PHASE == 1) E.run_crb();
-    else if (PHASE == 2) E.run_con();
+    else if (PHASE == 2 || PHASE == 7) E.run_con();  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows

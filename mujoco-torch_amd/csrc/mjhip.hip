@@ -383,6 +383,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   if (sizeof(REAL) == 4 && d->nv <= 16) { SET_PACK(1) }  // float32 CRB of small models: register-bound at 4 waves/SIMD, two environments per wave double the residents
 #undef SET_PACK
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 7, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
   if (out->pack2[3]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[3]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
@@ -393,7 +394,7 @@ template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
-  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : P);  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
+  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : (P == 7 ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
   a.off = m->off[A];
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = m->lds_bytes[A] / (int)sizeof(REAL);
@@ -429,7 +430,8 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     timing_mark(stream, 7);
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
-  if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) && (rc = launch_phase<REAL, 2>(m, a, stream))) return rc;
+  if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
+      (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 7>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream))) return rc;
   if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
