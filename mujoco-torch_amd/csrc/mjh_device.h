@@ -43,7 +43,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 #define PH_SOL 16  /* solve + Euler / RK4 bookkeeping           */
 #define MJH_NPHASE 5
 #define MJH_LDS_ARRAYS(X, m)                                                                                   \
-  X(qpos, m.nq, PH_KIN | PH_CON | PH_VEL | PH_SOL) X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL)                     \
+  X(qpos, m.nq, PH_KIN | PH_VEL | PH_SOL) X(qpos_con, m.con_general ? m.nq : 0, PH_CON) /* general constraint phase only */ X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL)                     \
   X(act, m.na, PH_VEL | PH_SOL)                                                                                \
   X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, 9 * m.nbody, PH_KIN)                      \
   X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
@@ -64,13 +64,13 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
-  X(efc_J, m.nefc * m.nv, PH_CON) X(efc_D, m.nefc, PH_SOL)                                            \
+  X(efc_J, (m.con_general ? m.nefc : m.nefc - m.nl) * m.nv, PH_CON) X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
-  X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
+  X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.con_general ? m.ne + m.nf + m.nlb + m.nl + m.nlt : 0, PH_CON) /* plain: equal to efc_pos for slide / hinge limits */ X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL) X(ten_len, m.ntendon, PH_VEL) X(ten_frc, m.ntendon, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
@@ -135,6 +135,7 @@ struct DevModel {
   const REAL* act_ent_coef;
   const int* act_ent_rot;
   const REAL* ten_J0;                      // ntendon*nv: the constant Jacobian of the fixed tendons (ten_J[t, dof] = coef, last term wins: smooth.py:492-494)
+  int con_general;                         // equality / frictionloss / ball- or tendon-limit rows present: constraint phase kernel 7
   int act_simple;                          // every actuator drives a slide / hinge joint
   int act_has_rot;                         // some JOINTINPARENT transmission on a ball / free joint (moment depends on qpos)
   float inv_nv;                            // 1 / nv for the index splits below

@@ -37,7 +37,7 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
   if (phase_bit == PH_CON) {
     // the geom frames are only read by the narrow phase, the dense efc_J only written after it: they share storage
     // (unless the frames are the larger of the two, then they get their own)
-    const int n3 = ((3 * m.ngeom + 1) & ~1), n9 = ((9 * m.ngeom + 1) & ~1), nj = ((m.nefc * m.nv + 1) & ~1);
+    const int n3 = ((3 * m.ngeom + 1) & ~1), n9 = ((9 * m.ngeom + 1) & ~1), nj = (((m.con_general ? m.nefc : m.nefc - m.nl) * m.nv + 1) & ~1);
     if (n3 + n9 <= nj) { o.geom_xpos = o.efc_J; o.geom_xmat = o.efc_J + n3; }
     else { o.geom_xpos = off; o.geom_xmat = off + n3; off += n3 + n9; }
   }
@@ -967,10 +967,15 @@ struct Env {
     // rows compile away and cost the headline kernel no registers
     const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = FRIC ? M.nf : 0, ne = FRIC ? M.ne : 0, nlb = FRIC ? M.nlb : 0, nlt = FRIC ? M.nlt : 0;
     if (nefc == 0) return;
-    load_qpos(false); load_qvel();
+    // plain instantiation: the slide / hinge limit rows have one non-zero each -- they go straight to global memory and the LDS copy
+    // of efc_J holds the contact rows only (4.5 KB less for the humanoid); qpos is read from global by the few lanes that need it
+    const int jrow0 = FRIC ? 0 : nl;                       // first efc row held in S.efc_J()
+    const REAL* gq = KA.cur.qpos + e * M.nq;               // the normalised qpos of this pass
+    if (FRIC) { for (int i = l; i < M.nq; i += W) S.qpos_con()[i] = gq[i]; }
+    load_qvel();
     row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
     row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
-    for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
+    if (FRIC) for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
     // equality rows (constraint.py:116-212, 254-296): one lane per (constraint, dof) column of a connect / weld, one lane per
@@ -985,7 +990,7 @@ struct Env {
         if (d != 0) continue;
         const int* ja = M.eq_jadr + 4 * q;  // dofadr1, dofadr2, qposadr1, qposadr2
         const REAL has2 = (REAL)(id2 > -1);
-        const REAL pos1 = S.qpos()[ja[2]], pos2 = S.qpos()[ja[3]] * has2;
+        const REAL pos1 = S.qpos_con()[ja[2]], pos2 = S.qpos_con()[ja[3]] * has2;
         const REAL ref1 = M.qpos0[ja[2]], ref2 = M.qpos0[ja[3]] * has2;
         const REAL dif = pos2 - ref2;
         REAL pw[5];
@@ -1065,7 +1070,7 @@ struct Env {
     for (int r0 = l; r0 < nlb; r0 += W) {  // _instantiate_limit_ball :299-335
       const int r = ne + nf + r0;
       const int j = M.lim_ball_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
-      const REAL q[4] = {S.qpos()[qa], S.qpos()[qa + 1], S.qpos()[qa + 2], S.qpos()[qa + 3]};
+      const REAL q[4] = {S.qpos_con()[qa], S.qpos_con()[qa + 1], S.qpos_con()[qa + 2], S.qpos_con()[qa + 3]};
       REAL axis[3], angle;
       quat_to_axis_angle(q, axis, angle);
       const REAL r0_ = M.jnt_range[2 * j], r1_ = M.jnt_range[2 * j + 1];
@@ -1081,7 +1086,7 @@ struct Env {
       const int r = ne + nf + nlb + nl + r0;
       const int t = M.lim_tendon[r0];
       REAL len = 0;
-      for (int q = M.ten_adr[t]; q < M.ten_adr[t + 1]; q++) len += M.ten_coef[q] * S.qpos()[M.ten_qposadr[q]];
+      for (int q = M.ten_adr[t]; q < M.ten_adr[t + 1]; q++) len += M.ten_coef[q] * S.qpos_con()[M.ten_qposadr[q]];
       const REAL dist_min = len - M.tendon_range[2 * t], dist_max = M.tendon_range[2 * t + 1] - len;
       const REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M.tendon_margin[t];
       const REAL active = (REAL)(pos < 0);
@@ -1094,14 +1099,15 @@ struct Env {
     for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
       const int r = ne + nf + nlb + r0;
       const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
-      const REAL q = S.qpos()[qa];
+      const REAL q = FRIC ? S.qpos_con()[qa] : gq[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
       const REAL val = (REAL)(dist_min < dist_max) * 2 - 1;
       const REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M.jnt_margin[j];
       const REAL active = (REAL)(pos < 0);
-      S.efc_J()[r * nv + da] = val * active;
+      if (FRIC) S.efc_J()[r * nv + da] = val * active;
+      else S.efc_jl()[r0] = val * active;
       S.efc_pos()[r] = pos * active;
-      S.efc_pos_norm()[r] = pos * active;
+      if (FRIC) S.efc_pos_norm()[r] = pos * active;
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
     const bool elliptic = M.cone == CONE_ELLIPTIC;
@@ -1128,15 +1134,15 @@ struct Env {
         diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
       }
       if (dim == 1) {
-        S.efc_J()[row0 * nv + d] = diff[0] * active;
+        S.efc_J()[(row0 - jrow0) * nv + d] = diff[0] * active;
       } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
         const int nedge = 2 * (dim - 1);
         for (int ed = 0; ed < nedge; ed++) {
           const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
-          S.efc_J()[(row0 + ed) * nv + d] = (diff[0] + diff[1 + (ed >> 1)] * f) * active;
+          S.efc_J()[(row0 - jrow0 + ed) * nv + d] = (diff[0] + diff[1 + (ed >> 1)] * f) * active;
         }
       } else {  // _instantiate_contact_elliptic :519-583
-        for (int r = 0; r < dim; r++) S.efc_J()[(row0 + r) * nv + d] = diff[r] * active;
+        for (int r = 0; r < dim; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = diff[r] * active;
       }
     }
     wave_sync();
@@ -1145,7 +1151,7 @@ struct Env {
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
-      if (r < ns) { pos = S.efc_pos()[r]; pos_norm = S.efc_pos_norm()[r]; invweight = S.efc_invweight()[r]; }
+      if (r < ns) { pos = S.efc_pos()[r]; pos_norm = FRIC ? S.efc_pos_norm()[r] : pos; invweight = S.efc_invweight()[r]; }
       if (r < ne) {
         const int id = M.eq_id[M.efc_row_eq[r]];
         solref[0] = M.eq_solref[2 * id]; solref[1] = M.eq_solref[2 * id + 1];
@@ -1193,12 +1199,21 @@ struct Env {
       kbi(solref, solimp, pos_norm, k, b, imp);
       REAL rr = invweight * (1 - imp) / imp;
       rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
-      const REAL jv = dot_seq(S.efc_J() + r * nv, 1, S.qvel(), 1, nv);
+      const REAL jv = (!FRIC && r < nl) ? (0 + S.efc_jl()[r] * S.qvel()[M.jnt_dofadr[M.lim_jnt[r]]]) : dot_seq(S.efc_J() + (r - jrow0) * nv, 1, S.qvel(), 1, nv);
       if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
       if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
     }
     STAMP(26);
-    put(out.efc_J, S.efc_J(), nefc * nv);
+    if (FRIC) put(out.efc_J, S.efc_J(), nefc * nv);
+    else if (out.efc_J) {
+      REAL* gJ = out.efc_J + e * nefc * nv;
+      for (int w = l; w < nl * nv; w += W) {  // single-column rows: zeros and the one entry, written once, coalesced
+        int r, d;
+        split_index(w, nv, M.inv_nv, r, d);
+        gJ[w] = (d == M.jnt_dofadr[M.lim_jnt[r]]) ? S.efc_jl()[r] : (REAL)0;
+      }
+      for (int w = l; w < (nefc - nl) * nv; w += W) gJ[nl * nv + w] = S.efc_J()[w];
+    }
     STAMP(27);
     if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : (REAL)0;
   }
@@ -2255,7 +2270,7 @@ struct Env {
 // step (197 / 181 / 185 -> 168 VGPRs = 3 waves, 132 -> 128 = 4 waves) and spill only 5-24 dwords to get under it; with
 // 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W == 32))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W == 32 ? 3 : 4) : 1))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W == 32))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W == 32 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? 4 : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each

@@ -130,6 +130,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
   M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M.has_gravcomp = 0;
+  M.con_general = (d->nf > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0) ? 1 : 0;
   for (int b = 0; b < d->nbody; b++) if (d->body_gravcomp[b] != 0) M.has_gravcomp = 1;
   M.gravity[0] = (REAL)d->gravity_x; M.gravity[1] = (REAL)d->gravity_y; M.gravity[2] = (REAL)d->gravity_z;
   M.meaninertia = d->meaninertia; M.tolerance = d->tolerance; M.ls_tolerance = d->ls_tolerance;
@@ -431,7 +432,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
-      (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 7>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream))) return rc;
+      (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream))) return rc;
   if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
