@@ -482,7 +482,7 @@ struct Env {
       REAL bq_n[4] = {M.body_quat[4 * c_n], M.body_quat[4 * c_n + 1], M.body_quat[4 * c_n + 2], M.body_quat[4 * c_n + 3]};
       int jn_n = M.body_jntnum[c_n], j0_n = M.body_jntadr[c_n];
       for (int k = 0; k < md; k++) {  // uniform trip count, lanes past their depth idle
-        const int c = c_n, jn = jn_n, j0 = j0_n;
+        const int jn = jn_n, j0 = j0_n;
         const REAL bp[3] = {bp_n[0], bp_n[1], bp_n[2]}, bq[4] = {bq_n[0], bq_n[1], bq_n[2], bq_n[3]};
         if (k + 1 < md) {
           c_n = (k + 1 < depth) ? M.body_chain[b * md + k + 1] : 0;
