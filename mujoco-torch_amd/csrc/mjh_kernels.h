@@ -1945,10 +1945,20 @@ struct Env {
     const int l = lane(), nv = M.nv;
     row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
     const REAL* gL = out.qLD + e * nv * nv;
-    for (int w = l; w < nv * nv; w += W) {  // lower triangle of the factor, packed rows
-      int i, k;
-      split_index(w, nv, M.inv_nv, i, k);
-      if (k <= i) S.qLDp()[tri_at<true>(i, k, nv)] = gL[w];
+    {  // lower triangle of the factor into packed rows: only the entries that are kept are requested, three loads in flight per trip
+      const int np = (nv * (nv + 1)) / 2;
+      int p = l;
+      for (; p + 2 * W < np; p += 3 * W) {
+        int i0, k0, i1, k1, i2, k2;
+        tri_unpack(p, i0, k0); tri_unpack(p + W, i1, k1); tri_unpack(p + 2 * W, i2, k2);
+        const REAL a = gL[i0 * nv + k0], b = gL[i1 * nv + k1], c = gL[i2 * nv + k2];
+        S.qLDp()[p] = a; S.qLDp()[p + W] = b; S.qLDp()[p + 2 * W] = c;
+      }
+      for (; p < np; p += W) {
+        int i, k;
+        tri_unpack(p, i, k);
+        S.qLDp()[p] = gL[i * nv + k];
+      }
     }
     if (solving) {  // every other input of the phase is requested now too: one wait for all of them
       load_qpos(false); load_qvel(); load_act();
