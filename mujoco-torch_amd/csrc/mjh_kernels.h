@@ -151,6 +151,34 @@ __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t 
   for (; i < n; i += W) l[i] = src[i];
 }
 
+// Several leaves of one environment into LDS with ALL their loads in flight before the first LDS store: consecutive row_load calls
+// are separate loops, so each one pays a full L2 round trip before the next starts -- at a phase start that was a quarter of the
+// phase.  The first T * W elements of each of the K arrays are requested up front (predicated), then stored; longer tails loop.
+template <int W, int K, int T, typename REAL>
+__device__ __forceinline__ void multi_load(REAL* const (&dst)[K], const REAL* const (&src)[K], const int (&n)[K], int64_t env) {
+  const int l = sub_lane<W>();
+  REAL v[K][T];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int i = l + t * W;
+      v[k][t] = (src[k] && i < n[k]) ? src[k][env * n[k] + i] : (REAL)0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int i = l + t * W;
+      if (i < n[k]) dst[k][i] = v[k][t];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++)
+    for (int i = l + T * W; i < n[k]; i += W) dst[k][i] = src[k] ? src[k][env * n[k] + i] : (REAL)0;
+}
+
 // =====================================================================================================================
 // dense Cholesky in LDS (math.small_cholesky :87-129).  Right-looking: once column j is final, every row
 // subtracts its rank-1 contribution from the trailing columns.  Each element still receives its updates in
@@ -716,8 +744,12 @@ struct Env {
     const int l = lane();
     const int nb = M.nbody, nv = M.nv;
     STAMP(10);
-    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);
-    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
+    {
+      REAL* const dst[2] = {S.cinert(), S.cdof()};
+      const REAL* const src[2] = {out.cinert, out.cdof};
+      const int cnt[2] = {10 * nb, 6 * nv};
+      multi_load<W, 2, 3>(dst, src, cnt, e);
+    }
     wave_sync();
     STAMP(11);
     for (int w = l; w < nb * 10; w += W) {
@@ -818,8 +850,12 @@ struct Env {
 
   __device__ __forceinline__ void collision() {
     const int l = lane();
-    row_load<W>(S.geom_xpos(), out.geom_xpos, 3 * M.ngeom, e);
-    row_load<W>(S.geom_xmat(), out.geom_xmat, 9 * M.ngeom, e);
+    {
+      REAL* const dst[2] = {S.geom_xpos(), S.geom_xmat()};
+      const REAL* const src[2] = {out.geom_xpos, out.geom_xmat};
+      const int cnt[2] = {3 * M.ngeom, 9 * M.ngeom};
+      multi_load<W, 2, 3>(dst, src, cnt, e);
+    }
     if (M.ncvxpair > 0) {  // box / mesh pairs were narrow-phased by mjh_convex_kernel (mjh_convex.h) into their contact slots
       row_load<W>(S.con_dist(), out.contact_dist, M.ncon, e);
       row_load<W>(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
@@ -973,8 +1009,12 @@ struct Env {
     const REAL* gq = KA.cur.qpos + e * M.nq;               // the normalised qpos of this pass
     if (FRIC) { for (int i = l; i < M.nq; i += W) S.qpos_con()[i] = gq[i]; }
     load_qvel();
-    row_load<W>(S.subtree_com(), out.subtree_com, 3 * M.nbody, e);
-    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
+    {
+      REAL* const dst[2] = {S.subtree_com(), S.cdof()};
+      const REAL* const src[2] = {out.subtree_com, out.cdof};
+      const int cnt[2] = {3 * M.nbody, 6 * nv};
+      multi_load<W, 2, 3>(dst, src, cnt, e);
+    }
     if (FRIC) for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
@@ -1224,10 +1264,14 @@ struct Env {
     const int l = lane();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     load_qpos(false); load_qvel(); load_act();
-    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);
-    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);
-    row_load<W>(S.subtree_com(), out.subtree_com, 3 * nb, e);
-    row_load<W>(S.xipos(), out.xipos, 3 * nb, e);
+    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);      // the two long arrays batch four loads per trip on their own; this phase has no
+    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);  // registers to spare for holding more of them in flight
+    {
+      REAL* const dst[2] = {S.subtree_com(), S.xipos()};
+      const REAL* const src[2] = {out.subtree_com, out.xipos};
+      const int cnt[2] = {3 * nb, 3 * nb};
+      multi_load<W, 2, 2>(dst, src, cnt, e);
+    }
     wave_sync();
     STAMP(31);
     if (FLUID && M.ntendon > 0) {  // smooth.tendon :470-497 and forward._velocity :93-94 for fixed tendons: one lane per tendon
@@ -1943,7 +1987,19 @@ struct Env {
   // first half of the solver phase's inputs and _acceleration's solve (forward.py:222-228): qacc_smooth = M^-1 qfrc_smooth
   __device__ __forceinline__ void load_factor_and_accelerate(bool solving) {
     const int l = lane(), nv = M.nv;
-    row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
+    if (solving) {  // the small vectors of the phase in one batch of loads (one L2 round trip instead of eight)
+      const bool from_in = !KA.state_from_cur;
+      const bool perm = ne_() > 0 || nlim_rows() > 0;  // permuted row order: efc_D / efc_aref are gathered in load_solver_inputs
+      const int nrow = (M.nefc > 0 && !perm) ? M.nefc : 0;
+      REAL* const dst[8] = {S.qfrc_smooth(), S.qpos(), S.qvel(), S.act(), S.act_dot(), S.qacc_warm(), S.efc_D(), S.efc_aref()};
+      const REAL* const src[8] = {out.qfrc_smooth, KA.cur.qpos, from_in ? in.qvel : KA.cur.qvel, KA.state_from_cur ? KA.cur.act : in.act,
+                                  out.act_dot, KA.warm_src, out.efc_D, out.efc_aref};
+      const int cnt[8] = {nv, M.nq, nv, M.na, M.na, M.nefc > 0 ? nv : 0, nrow, nrow};
+      multi_load<W, 8, 1>(dst, src, cnt, e);
+      if (from_in && KA.do_step) for (int i = l; i < nv; i += W) S.qvel()[i] = checked(S.qvel()[i], (REAL)0);  // _check_state (same lane wrote it)
+    } else {
+      row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
+    }
     const REAL* gL = out.qLD + e * nv * nv;
     {  // lower triangle of the factor into packed rows: only the entries that are kept are requested, three loads in flight per trip
       const int np = (nv * (nv + 1)) / 2;
@@ -1960,11 +2016,7 @@ struct Env {
         S.qLDp()[p] = gL[i * nv + k];
       }
     }
-    if (solving) {  // every other input of the phase is requested now too: one wait for all of them
-      load_qpos(false); load_qvel(); load_act();
-      row_load<W>(S.act_dot(), out.act_dot, M.na, e);
-      load_solver_inputs();
-    }
+    if (solving) load_solver_inputs();  // the constraint Jacobian and the row tables: requested before the first wait too
     wave_sync();
     STAMP(51);
     chol_inv_diag<W, true>(S.qLDp(), S.qLD_inv(), nv);
@@ -2002,11 +2054,7 @@ struct Env {
       }
       if (ne > 0 || nlim_rows() > 0) {
         for (int r = l; r < nefc; r += W) { const int x = ext_row(r); S.efc_D()[r] = out.efc_D[e * nefc + x]; S.efc_aref()[r] = out.efc_aref[e * nefc + x]; }
-      } else {
-        row_load<W>(S.efc_D(), out.efc_D, nefc, e);
-        row_load<W>(S.efc_aref(), out.efc_aref, nefc, e);
-      }
-      row_load<W>(S.qacc_warm(), KA.warm_src, nv, e);
+      }  // (the unpermuted efc_D / efc_aref and the warm start came with the batch in load_factor_and_accelerate)
     }
   }
 
