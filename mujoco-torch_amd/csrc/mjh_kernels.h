@@ -2032,9 +2032,21 @@ struct Env {
       const int l = lane(), nl = nf_() + M.nl;
       const REAL* gJ = out.efc_J + e * nefc * nv;
       const int ne = ne_();
-      for (int r = l; r < nl; r += W) { const int dr = M.lim_dof[r]; lim_dof_lds()[r] = dr; S.efc_Jl()[r] = gJ[ext_row(r) * nv + dr]; }
-      for (int r = l; r < nf_(); r += W) S.efc_fl()[r] = M.dof_frictionloss[M.fric_dof[r]];
-      if (nl > 0) for (int d = l; d < 2 * nv; d += W) dof_limrow_lds()[d] = M.dof_limrow[d];
+      {  // the three small row tables in ONE loop: their loads overlap instead of queueing behind each other's LDS stores
+        const int nfr = nf_(), n2 = nl > 0 ? 2 * nv : 0;
+        const int nmax = nl > n2 ? nl : n2;
+        for (int r = l; r < nmax; r += W) {
+          const bool a = r < nl, b = r < nfr, c = r < n2;
+          const int dr = a ? M.lim_dof[r] : 0;
+          const int fd = b ? M.fric_dof[r] : 0;
+          const int lr = c ? M.dof_limrow[r] : 0;
+          const REAL jl = a ? gJ[ext_row(r) * nv + dr] : (REAL)0;
+          const REAL fl = b ? M.dof_frictionloss[fd] : (REAL)0;
+          if (a) { lim_dof_lds()[r] = dr; S.efc_Jl()[r] = jl; }
+          if (b) S.efc_fl()[r] = fl;
+          if (c) dof_limrow_lds()[r] = lr;
+        }
+      }
       {
         const int nlim = FRIC ? M.nlb + M.nlt : 0;  // dense limit rows: gathered row by row
         for (int i = l; i < (ne + nlim) * nv; i += W) {
