@@ -1008,12 +1008,13 @@ struct Env {
     const int jrow0 = FRIC ? 0 : nl;                       // first efc row held in S.efc_J()
     const REAL* gq = KA.cur.qpos + e * M.nq;               // the normalised qpos of this pass
     if (FRIC) { for (int i = l; i < M.nq; i += W) S.qpos_con()[i] = gq[i]; }
-    load_qvel();
     {
-      REAL* const dst[2] = {S.subtree_com(), S.cdof()};
-      const REAL* const src[2] = {out.subtree_com, out.cdof};
-      const int cnt[2] = {3 * M.nbody, 6 * nv};
-      multi_load<W, 2, 3>(dst, src, cnt, e);
+      const bool from_in = !KA.state_from_cur;
+      REAL* const dst[3] = {S.qvel(), S.subtree_com(), S.cdof()};
+      const REAL* const src[3] = {from_in ? in.qvel : KA.cur.qvel, out.subtree_com, out.cdof};
+      const int cnt[3] = {nv, 3 * M.nbody, 6 * nv};
+      multi_load<W, 3, 3>(dst, src, cnt, e);
+      if (from_in && KA.do_step) for (int i = l; i < nv; i += W) S.qvel()[i] = checked(S.qvel()[i], (REAL)0);  // _check_state (same lane wrote it)
     }
     if (FRIC) for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
