@@ -2059,6 +2059,13 @@ struct Env {
         const REAL* src = gJ + (nl + ne + nlim) * nv;
         REAL* dstJ = S.efc_Jc() + (ne + nlim) * nv;
         int i = l;
+        for (; i + 7 * W < n; i += 8 * W) {  // eight requests in flight per trip: this copy is most of the phase's input bytes
+          REAL t[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) t[q] = src[i + q * W];
+#pragma unroll
+          for (int q = 0; q < 8; q++) dstJ[i + q * W] = t[q];
+        }
         for (; i + 3 * W < n; i += 4 * W) {
           const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
           dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
