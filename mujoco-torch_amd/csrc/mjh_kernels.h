@@ -139,6 +139,25 @@ __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t
   }
   for (; i < n; i += W) dst[i] = l[i];
 }
+// global -> global copy of a model constant into a leaf (the source is L2-resident): eight requests in flight per trip
+template <int W, typename REAL>
+__device__ __forceinline__ void row_copy_const(REAL* g, const REAL* c, int n, int64_t env) {
+  if (!g) return;
+  REAL* dst = g + env * n;
+  int i = sub_lane<W>();
+  for (; i + 7 * W < n; i += 8 * W) {
+    REAL t[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) t[q] = c[i + q * W];
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[i + q * W] = t[q];
+  }
+  for (; i + 3 * W < n; i += 4 * W) {
+    const REAL a = c[i], b = c[i + W], cc = c[i + 2 * W], d = c[i + 3 * W];
+    dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = cc; dst[i + 3 * W] = d;
+  }
+  for (; i < n; i += W) dst[i] = c[i];
+}
 template <int W, typename REAL>
 __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
   if (!g) { for (int i = sub_lane<W>(); i < n; i += W) l[i] = 0; return; }
@@ -1293,7 +1312,7 @@ struct Env {
       row_store<W>(out.ten_J, M.ten_J0, nt * nv, e);
       wave_sync();
     }
-    row_store<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
+    row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
     if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
       for (int i = l; i < nu; i += W) {
         const REAL gear = M.act_gear[6 * i];
