@@ -354,6 +354,11 @@ int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, i
 int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* hip_stream);
 int64_t mjh_model_work_bytes(const mjhModel* m);
 
+/* per-environment ELEMENT count of every mjhData leaf in ABI order (reals, then int32, then int64 leaves): a leaf handed to
+ * mjh_forward / mjh_step / mjh_reset_where must hold exactly B * count elements.  The binding validates tensor sizes against
+ * this before it passes raw pointers (the kernels index `ptr + env * count` unchecked).  Writes min(n, max) entries, returns n. */
+int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max);
+
 /* masked in-place reset of environments -- the env caller's `self._dx[mask] = self._make_batch(n)` (zoo/base.py:266-273,
  * :289-293 partial reset, :327-331 fused auto-reset) as ONE launch without a host sync.  For every environment e with
  * mask[e] != 0, every leaf that is non-NULL in `d` is overwritten with that leaf of `d0` (ONE environment, same dtype; the

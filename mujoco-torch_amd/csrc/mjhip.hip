@@ -722,6 +722,16 @@ int mjh_debug_phase_times(float* ms, int* ids, int max) {
 /* diagnostic (-DMJH_STAMPS builds): device buffer [B, 128] of uint64 receiving in-kernel clock stamps */
 void mjh_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; }
 
+int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
+  if (!m || !counts) return fail(-22, "null argument");
+  const int64_t ncon = m->dtype == MJH_F64 ? m->m64.ncon : m->m32.ncon, neq = m->dtype == MJH_F64 ? m->m64.neq : m->m32.neq;
+  std::vector<int64_t> all(m->leaf_count);
+  const int64_t ints[] = {ncon /* contact_dim */, neq /* eq_active */, ncon, ncon, 2 * ncon, ncon /* geom1, geom2, geom, efc_address */};
+  all.insert(all.end(), ints, ints + 6);
+  for (int i = 0; i < (int)all.size() && i < max; i++) counts[i] = all[i];
+  return (int)all.size();
+}
+
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
 int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NPHASE) ? m->lds_bytes[phase] : 0; }
 const char* mjh_last_error(void) { return g_err.c_str(); }

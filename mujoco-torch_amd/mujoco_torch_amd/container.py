@@ -45,6 +45,16 @@ class UnbatchedTensor:
         return f"UnbatchedTensor({self.data!r})"
 
 
+# host-side attributes that belong to ONE container instance and are never inherited by containers derived from it
+_PRIVATE = ("_fields", "_bs", "_ver", "_child_keys", "_lazy", "_ptab", "_native_cache")
+
+
+def _carve(spec):
+    """A leaf of a step's output slab: (slab uint8 1-D, byte offset, byte length, dtype, shape) -> tensor view."""
+    slab, off, nbytes, dtype, shape = spec
+    return slab.narrow(0, off, nbytes).view(dtype).view(shape)
+
+
 def _is_node(v) -> bool:
     return isinstance(v, (torch.Tensor, MjTensorClass, UnbatchedTensor))
 
@@ -80,7 +90,7 @@ def _register_pytree(cls):
     def flatten(obj):
         keys, children, rest = [], [], {}
         pinned = obj.__dict__.get("_child_keys")  # set by unflatten: placeholder leaves (pytree's own spec arithmetic) keep the structure
-        for k, v in obj._fields.items():
+        for k, v in obj._all().items():
             if (k in pinned) if pinned is not None else isinstance(v, (torch.Tensor, MjTensorClass)):
                 keys.append(k)
                 children.append(v)
@@ -88,7 +98,7 @@ def _register_pytree(cls):
                 rest[k] = v
         probe = next((i for i, c in enumerate(children) if isinstance(c, torch.Tensor)), None)
         event = children[probe].dim() - len(obj._bs) if probe is not None else 0
-        extra = {k: v for k, v in obj.__dict__.items() if k not in ("_fields", "_bs", "_ver", "_ptr_cache", "_child_keys")}
+        extra = {k: v for k, v in obj.__dict__.items() if k not in _PRIVATE}
         return children, (tuple(keys), rest, probe, event, tuple(obj._fields), extra, tuple(obj._bs))
 
     def unflatten(children, ctx):
@@ -128,21 +138,45 @@ class MjTensorClass(metaclass=_Meta):
 
     # ---- attribute access ---------------------------------------------------------------
     def __getattr__(self, name):
+        d = object.__getattribute__(self, "__dict__")
         try:
-            return object.__getattribute__(self, "_fields")[name]
+            return d["_fields"][name]
         except KeyError:
+            lz = d.get("_lazy")
+            if lz and name in lz:  # a leaf of a step's output slab, carved on first access (forward.py)
+                t = _carve(lz.pop(name))
+                d["_fields"][name] = t
+                return t
             raise AttributeError(f"{type(self).__name__} has no field {name!r}") from None
 
     def __setattr__(self, name, value):
         if name in type(self)._field_names:
+            lz = self.__dict__.get("_lazy")
+            if lz:
+                lz.pop(name, None)
             self._fields[name] = value
-            self._touch()
+            self._touch((name,))
         else:
             object.__setattr__(self, name, value)
 
-    def _touch(self):
-        """Bumps the leaf-set version (forward.py caches raw device pointers per container and version)."""
+    def _all(self):
+        """The field dict with every lazily carved leaf materialised, in declaration order."""
+        lz = self.__dict__.get("_lazy")
+        if lz is not None:  # (possibly emptied by attribute reads, which append to the dict in access order)
+            f = self._fields
+            for k in list(lz):
+                f[k] = _carve(lz.pop(k))
+            del self.__dict__["_lazy"]
+            order = self.__dict__.get("_order") or type(self)._field_names  # the field order of the container the step was given
+            object.__setattr__(self, "_fields", {k: f[k] for k in order if k in f} | {k: v for k, v in f.items() if k not in order})
+        return self._fields
+
+    def _touch(self, names=None):
+        """Bumps the leaf-set version and tells the container's device-pointer table (forward.py) which leaves changed."""
         object.__setattr__(self, "_ver", self.__dict__.get("_ver", 0) + 1)
+        tab = self.__dict__.get("_ptab")
+        if tab is not None:
+            tab.mark(names)
 
     @classmethod
     def fields(cls):
@@ -157,7 +191,7 @@ class MjTensorClass(metaclass=_Meta):
         return torch.Size(self._bs)
 
     def items(self):
-        return self._fields.items()
+        return self._all().items()
 
     # ---- functional updates (reference dataclasses.py:101-127) ---------------------------
     def _new(self, d, bs=None):
@@ -165,14 +199,14 @@ class MjTensorClass(metaclass=_Meta):
         object.__setattr__(new, "_fields", d)
         object.__setattr__(new, "_bs", tuple(self._bs if bs is None else bs))
         for k, v in self.__dict__.items():
-            if k not in ("_fields", "_bs", "_ver", "_ptr_cache", "_child_keys"):
+            if k not in _PRIVATE:
                 object.__setattr__(new, k, v)
         return new
 
     def map_tensors(self, fn):
         """Applies ``fn`` to every tensor leaf, recursing into nested containers; other values are kept."""
         out = {}
-        for k, v in self._fields.items():
+        for k, v in self._all().items():
             if isinstance(v, MjTensorClass):
                 out[k] = v.map_tensors(fn)
             elif isinstance(v, torch.Tensor):
@@ -182,21 +216,36 @@ class MjTensorClass(metaclass=_Meta):
         return self._new(out)
 
     def _map(self, fn, bs=None):
-        return self._new({k: (fn(v) if _is_node(v) else v) for k, v in self._fields.items()}, bs)
+        return self._new({k: (fn(v) if _is_node(v) else v) for k, v in self._all().items()}, bs)
 
     def clone(self, recurse: bool = True):
         if recurse:
             return self._map(lambda v: v.clone())
-        return self._new(dict(self._fields))
+        new = self._new(dict(self._fields))
+        lz = self.__dict__.get("_lazy")
+        if lz:
+            object.__setattr__(new, "_lazy", dict(lz))  # same slab regions, carved independently
+        return new
 
     def replace(self, **kwargs: Any):
         new = self.clone(recurse=False)
+        lz = new.__dict__.get("_lazy")
+        if lz:
+            for k in kwargs:
+                lz.pop(k, None)
         new._fields.update(kwargs)
+        tab = self.__dict__.get("_ptab")
+        if tab is not None:  # the pointer table follows the container: only the replaced leaves are looked at again
+            object.__setattr__(new, "_ptab", tab.child(kwargs))
         return new
 
     def update_(self, **kwargs: Any):
+        lz = self.__dict__.get("_lazy")
+        if lz:
+            for k in kwargs:
+                lz.pop(k, None)
         self._fields.update(kwargs)
-        self._touch()
+        self._touch(kwargs)
         return self
 
     def tree_replace(self, params: dict):
@@ -255,7 +304,7 @@ class MjTensorClass(metaclass=_Meta):
         return self._map(ix, bs=bs)
 
     def __setitem__(self, idx, value):
-        for k, v in self._fields.items():
+        for k, v in self._all().items():
             if isinstance(v, UnbatchedTensor) or not _is_node(v):
                 continue
             src = getattr(value, k)
@@ -275,6 +324,8 @@ class MjTensorClass(metaclass=_Meta):
             dim = kwargs.get("dim", args[1] if len(args) > 1 else 0)
             first = items[0]
             out = {}
+            for it in items:
+                it._all()
             for k, v in first._fields.items():
                 if isinstance(v, UnbatchedTensor) or not _is_node(v):
                     out[k] = v
@@ -289,4 +340,4 @@ class MjTensorClass(metaclass=_Meta):
         return NotImplemented
 
     def __repr__(self):
-        return f"{type(self).__name__}(batch_size={list(self._bs)}, fields={len(self._fields)})"
+        return f"{type(self).__name__}(batch_size={list(self._bs)}, fields={len(self._fields) + len(self.__dict__.get('_lazy') or ())})"

@@ -182,6 +182,7 @@ class StaticTables:
 
     def __init__(self):
         self.native = {}
+        self.uid = next(_cache_id_counter)  # never reused (unlike id()): keys the host-side plan / pointer caches
 
 
 def _build_tables(m, dtype) -> StaticTables:
@@ -468,5 +469,6 @@ def device_put(value, *, dtype: torch.dtype | None = None):
         **kw,
     )
     T.source = value
+    T.structure_key = (int(value.opt.cone), int(value.opt.disableflags) & (0b11111 | (1 << 13)), int(value.opt.jacobian))  # native._structure_key
     object.__setattr__(m, "_tables", T)
     return m

@@ -2,11 +2,20 @@
 
 Signatures and ownership rules follow reference ``_src/forward.py``: ``step(m, d,
 fixed_iterations=False) -> Data`` (:463-496) and ``forward`` (:373-401).  The caller's ``Data``
-is never mutated; every leaf the step writes is a fresh tensor, untouched leaves alias the
+is never mutated; every leaf the step writes is fresh storage, untouched leaves alias the
 input (forward.py:473-475, dataclasses.py:112-120).  Unlike the reference, a *batched* ``Data``
 (leading dims on every leaf, exactly what ``make_data(mx).expand(B).clone()`` produces) is
 stepped natively in one launch sequence -- no ``torch.vmap`` -- and an un-batched ``Data`` is the
 B = 1 case.
+
+Host side of one call (what keeps ``d = step(mx, d)`` device-bound at B = 4096):
+
+* the written leaves of a call are ONE allocation (``torch.empty`` of the summed, 256-byte aligned sizes) -- fresh storage per
+  call, as the reference's ``update_`` of new tensors -- carved by a plan cached per (model, batch shape, dtype, stages); the
+  returned ``Data`` materialises a leaf's tensor view only when somebody reads it (``container._carve``);
+* every ``Data`` carries a table of the raw device pointers of its leaves (``_PtrTab``) that follows it through ``replace`` /
+  ``update_`` / attribute assignment: only leaves that changed are looked at (and validated) again, and the result of a step
+  gets its table from the plan's offsets, so a rollout loop never walks the ~80 leaves in Python.
 
 There is no fallback: tensors must live on a HIP device and ``libmjhip.so`` must be built.
 """
@@ -16,6 +25,7 @@ from __future__ import annotations
 import ctypes
 import math
 
+import numpy as np
 import torch
 
 from . import native
@@ -36,7 +46,14 @@ _WRITTEN_EFC = "efc_J efc_frictionloss efc_D efc_aref efc_force qacc_warmstart q
 _WRITTEN_STEP = "qvel act time".split()
 
 _ALL_NAMES = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
-_REAL_NAMES = set(native.LISTS["MJH_DATA_REALS"])
+_NLEAF = len(_ALL_NAMES)
+_IDX = {n: i for i, n in enumerate(_ALL_NAMES)}
+_NREAL = len(native.LISTS["MJH_DATA_REALS"])
+_INT_DTYPE = {n: torch.int32 for n in native.LISTS["MJH_DATA_I32"]} | {n: torch.int64 for n in native.LISTS["MJH_DATA_I64"]}
+_KEY = {n: native.DATA_PATH[n][-1] for n in _ALL_NAMES}          # field key inside its container
+_IN_CONTACT = [len(native.DATA_PATH[n]) == 2 for n in _ALL_NAMES]
+_CONTACT_IDX = frozenset(i for i in range(_NLEAF) if _IN_CONTACT[i])
+_ALIGN = 256
 
 
 def _written_names(m: Model, step: bool):
@@ -57,49 +74,194 @@ def _written_names(m: Model, step: bool):
     return names
 
 
-def _fill_ptrs(d: Data, names, dtype, device, check=True):
-    ptrs = native.DataPtrs()
-    keep = []
-    for n in names:
-        t = native.data_field_tensor(d, n)
-        if t is None:
+class _PtrTab:
+    """Raw device pointers of one ``Data``'s leaves in ABI order (the ``mjhData`` struct the library takes), kept current
+    incrementally: ``dirty`` holds the leaves whose tensor may have changed since the pointer was read."""
+
+    __slots__ = ("struct", "arr", "dirty", "keep", "con", "con_ver", "sig")
+
+    def __init__(self):
+        self.struct = native.DataPtrs()
+        self.arr = np.frombuffer(self.struct, dtype=np.uint64)  # shares the struct's memory
+        self.dirty = set(range(_NLEAF))
+        self.keep = {}          # contiguous copies of strided input leaves (re-made every call: the source may be written in place)
+        self.con = None
+        self.con_ver = -1
+        self.sig = None
+
+    def child(self, names):
+        """The table of a container derived by ``replace(**names)``."""
+        t = _PtrTab()
+        t.arr[:] = self.arr
+        t.dirty = set(self.dirty)
+        t.keep = dict(self.keep)
+        t.con, t.con_ver, t.sig = self.con, self.con_ver, self.sig
+        t.mark(names)
+        return t
+
+    def mark(self, names):
+        if names is None:       # an update of unknown extent
+            self.dirty = set(range(_NLEAF))
+            return
+        for n in names:
+            if n == "contact":
+                self.dirty |= _CONTACT_IDX
+                self.con = None
+            else:
+                i = _IDX.get(n)
+                if i is not None:
+                    self.dirty.add(i)
+
+
+def _table(d: Data, sig, counts, B: int, dtype, device, dest: bool = False) -> _PtrTab:
+    """``d``'s pointer table, refreshed and validated for this (model, dtype, device, batch).
+
+    Every leaf handed to the kernels is checked ONCE per tensor (device, dtype, element count == B * per-environment count --
+    the kernels index ``ptr + env * count`` unchecked) when its pointer is read.  A strided input leaf is copied to contiguous
+    storage every call; a strided leaf of a destination container (``out=``, ``reset_where``) is an error: the kernels would
+    fill a temporary and the caller's tensor would silently keep its old contents."""
+    tab = d.__dict__.get("_ptab")
+    if tab is None:
+        tab = _PtrTab()
+        object.__setattr__(d, "_ptab", tab)
+    if tab.sig != sig:
+        tab.dirty = set(range(_NLEAF))
+        tab.keep = {}
+        tab.sig = sig
+    con = d._fields["contact"]
+    cver = con.__dict__.get("_ver", 0)
+    if tab.con is not con or tab.con_ver != cver:
+        tab.dirty |= _CONTACT_IDX
+        tab.con, tab.con_ver = con, cver
+    if not tab.dirty:
+        return tab
+    arr, again = tab.arr, set()
+    for i in tab.dirty:
+        obj = con if _IN_CONTACT[i] else d
+        key = _KEY[_ALL_NAMES[i]]
+        lz = obj.__dict__.get("_lazy")
+        if lz:
+            spec = lz.get(key)
+            if spec is not None:  # a leaf of a previous step's slab that nobody has touched: sized by the plan that made it
+                arr[i] = spec[0].data_ptr() + spec[1]
+                continue
+        t = obj._fields.get(key)
+        if t is None or not isinstance(t, torch.Tensor):
+            arr[i] = 0
             continue
-        if check and t.numel():
-            if t.device != device:
-                raise RuntimeError(f"Data.{n} is on {t.device}, expected {device}")
-            if n in _REAL_NAMES and t.dtype != dtype:
-                raise RuntimeError(f"Data.{n} has dtype {t.dtype}, expected {dtype} (mixed-precision Data is not supported)")
-            if not t.is_contiguous():
-                t = t.contiguous()
-        keep.append(t)
-        setattr(ptrs, n, t.data_ptr() if t.numel() else None)
-    return ptrs, keep
+        n = t.numel()
+        if n == 0:
+            arr[i] = 0
+            continue
+        name = _ALL_NAMES[i]
+        if t.device != device:
+            raise RuntimeError(f"Data.{name} is on {t.device}, expected {device}")
+        want = dtype if i < _NREAL else _INT_DTYPE[name]
+        if t.dtype != want:
+            raise RuntimeError(f"Data.{name} has dtype {t.dtype}, expected {want}" + (" (mixed-precision Data is not supported)" if i < _NREAL else ""))
+        if n != B * int(counts[i]):
+            raise ValueError(f"Data.{name} holds {n} elements (shape {tuple(t.shape)}); a batch of {B} environments of this model needs "
+                             f"{B} x {int(counts[i])}.  Every leaf of a batched Data must carry the batch dimensions (make_data(mx).expand(B).clone()).")
+        if not t.is_contiguous():
+            if dest:
+                raise ValueError(f"Data.{name} of a destination container is not contiguous (shape {tuple(t.shape)}, strides {t.stride()}): "
+                                 "the kernels write batch-major contiguous leaves; pass cloned / contiguous storage.")
+            t = t.contiguous()
+            tab.keep[i] = t
+            again.add(i)
+        arr[i] = t.data_ptr()
+    tab.dirty = again
+    return tab
 
 
-import os as _os
+class _Plan:
+    """Where the leaves one call writes live inside its output slab (cached per model / batch shape / dtype / stages)."""
 
-_PTR_CACHE = _os.environ.get("MJH_NO_PTR_CACHE") != "1"  # diagnostic switch (tools/host_overhead.py)
+    __slots__ = ("names", "widx", "wmask", "off", "total", "top", "con", "top_names", "con_names", "empties")
 
 
-def _ptrs_cached(d: Data, tag, names, dtype, device, check=True):
-    """``_fill_ptrs`` memoised on the container: the ~80 attribute walks and ``data_ptr()`` calls are most of the host cost
-    of a step at small batches.  Valid while the leaf SET is unchanged (``replace`` makes a new container, ``update_`` /
-    attribute assignment bump the version); in-place writes into the tensors keep their pointers."""
-    con = d.contact
-    key = (d.__dict__.get("_ver", 0), id(con), con.__dict__.get("_ver", 0), dtype, device)
-    cache = d.__dict__.get("_ptr_cache") if _PTR_CACHE else None
-    if cache is not None:
-        hit = cache.get(tag)  # one slot per role: a ping-pong buffer is the input of one call and the output of the next
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[2]
-    ptrs, keep = _fill_ptrs(d, names, dtype, device, check)
-    present = [n for n in names if native.data_field_tensor(d, n) is not None]
-    if _PTR_CACHE and all(k is native.data_field_tensor(d, n) for k, n in zip(keep, present)):  # only when no contiguous copy had to be made
-        if cache is None:
-            cache = {}
-            object.__setattr__(d, "_ptr_cache", cache)
-        cache[tag] = (key, ptrs, keep)
-    return ptrs, keep
+_PLANS = {}
+
+
+def _peek(obj, key):
+    """(shape, dtype) of a leaf without materialising a lazily carved one."""
+    lz = obj.__dict__.get("_lazy")
+    if lz and key in lz:
+        return tuple(lz[key][4]), lz[key][3]
+    t = obj._fields[key]
+    return tuple(t.shape), t.dtype
+
+
+def _plan(m: Model, d: Data, names, batch, dtype, device, plan_key) -> _Plan:
+    p = _PLANS.get(plan_key)
+    if p is not None:
+        return p
+    p = _Plan()
+    p.names = list(names)
+    p.wmask = np.zeros(_NLEAF, dtype=bool)
+    p.off = np.zeros(_NLEAF, dtype=np.uint64)
+    p.top, p.con, p.empties = [], [], {}
+    off = 0
+    con = d._fields["contact"]
+    for n in names:
+        i = _IDX[n]
+        obj = con if _IN_CONTACT[i] else d
+        shape, dt = _peek(obj, _KEY[n])
+        want = dtype if i < _NREAL else _INT_DTYPE[n]
+        nel = int(math.prod(shape))
+        if nel == 0:
+            p.empties[n] = torch.empty(shape, dtype=want, device=device)
+            continue
+        nbytes = nel * torch.empty((), dtype=want).element_size()
+        (p.con if _IN_CONTACT[i] else p.top).append((_KEY[n], off, nbytes, want, shape))
+        p.wmask[i] = True
+        p.off[i] = off
+        off += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+    p.total = off
+    p.widx = np.nonzero(p.wmask)[0]
+    p.top_names = [s[0] for s in p.top] + [_KEY[n] for n in p.empties if not _IN_CONTACT[_IDX[n]]]
+    p.con_names = [s[0] for s in p.con] + [_KEY[n] for n in p.empties if _IN_CONTACT[_IDX[n]]]
+    if len(_PLANS) > 256:
+        _PLANS.clear()
+    _PLANS[plan_key] = p
+    return p
+
+
+_COUNT_CACHE = {}
+
+
+def _counts(m: Model, device):
+    """ncon / nefc as the unbatched device scalars the reference's Data carries (types.py:1172-1178); constant per model."""
+    ne, nf, nl, ncon, nefc = m.constraint_sizes_py
+    key = (ncon, nefc, device)
+    hit = _COUNT_CACHE.get(key)
+    if hit is None:
+        hit = (UnbatchedTensor(torch.full((), ncon, dtype=torch.int32, device=device)),
+               UnbatchedTensor(torch.full((), nefc, dtype=torch.int32, device=device)))
+        _COUNT_CACHE[key] = hit
+    return hit
+
+
+def _require_device(device):
+    """There is no CPU / PyTorch path: anything but a HIP device is an error (tests swap this check out to drive the host
+    logic against the CPU oracle)."""
+    if device.type != "cuda":
+        raise RuntimeError(
+            "mujoco_torch_amd.step/forward run only on a HIP device (tensors on "
+            f"{device}); there is no CPU or PyTorch fallback. Move Model/Data with .to('cuda')."
+        )
+
+
+def _stream_and_guard(device):
+    """(raw stream handle of the caller's current stream, device to restore or None)."""
+    if device.type != "cuda":
+        return 0, None
+    stream = torch.cuda.current_stream(device).cuda_stream
+    prev = torch.cuda.current_device()
+    if prev != device.index:
+        torch.cuda.set_device(device)
+        return stream, prev
+    return stream, None
 
 
 def _under_vmap(m, d, fixed_iterations, step, stages):
@@ -137,11 +299,7 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
         if out is not None:
             raise ValueError("step(..., out=) cannot be used under torch.vmap")
         return _under_vmap(m, d, fixed_iterations, step, stages)
-    if qpos.device.type != "cuda":
-        raise RuntimeError(
-            "mujoco_torch_amd.step/forward run only on a HIP device (tensors on "
-            f"{qpos.device}); there is no CPU or PyTorch fallback. Move Model/Data with .to('cuda')."
-        )
+    _require_device(qpos.device)
     dtype = qpos.dtype
     if dtype not in (torch.float64, torch.float32):
         raise RuntimeError(f"unsupported Data dtype {dtype}")
@@ -149,47 +307,97 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
     batch = tuple(qpos.shape[:-1])
     B = int(math.prod(batch)) if batch else 1
     nm = native.get_native_model(m, device, dtype)
-    names = _written_names(m, step)
-    if not step and not (stages & 0x40):
-        names = [n for n in names if n != "sensordata"]  # sensors belong to complete forward passes
-    in_ptrs, keep_in = _ptrs_cached(d, ("in", id(m.tables)), _ALL_NAMES, dtype, device)
+    T = m.tables
+    sig = (T.uid, dtype, device, B)
+    tab = _table(d, sig, nm.leaf_counts, B, dtype, device)
+    plan_key = (T.uid, step, stages, batch, dtype, device)
+    plan = _PLANS.get(plan_key)
+    if plan is None:
+        names = _written_names(m, step)
+        if not step and not (stages & 0x40):
+            names = [n for n in names if n != "sensordata"]  # sensors belong to complete forward passes
+        plan = _plan(m, d, names, batch, dtype, device, plan_key)
+    out_struct = native.DataPtrs()
+    out_arr = np.frombuffer(out_struct, dtype=np.uint64)
     if out is None:
-        new = {}
-        for n in names:
-            src = native.data_field_tensor(d, n)
-            new[n] = torch.empty_like(src, memory_format=torch.contiguous_format)
-        contact_kw = {n[len("contact_"):] if n != "contact_dim" else "contact_dim": t for n, t in new.items() if n.startswith("contact_")}
-        top_kw = {n: t for n, t in new.items() if not n.startswith("contact_")}
-        res = d.replace(**top_kw)
-        if contact_kw:
-            res = res.replace(contact=d.contact.replace(**contact_kw))
+        slab = torch.empty(plan.total, dtype=torch.uint8, device=device)
+        out_arr[:] = plan.off
+        out_arr[plan.widx] += np.uint64(slab.data_ptr())
     else:
-        res = out
-    out_ptrs, keep_out = _ptrs_cached(res, ("out", id(m.tables), step, stages), names, dtype, device, check=True) if out is not None else _fill_ptrs(res, names, dtype, device, check=False)
-    stream = torch.cuda.current_stream(device).cuda_stream
+        if out is d:
+            raise ValueError("step(..., out=d) with out being the input itself is not supported: use a second buffer (ping-pong)")
+        otab = _table(out, sig, nm.leaf_counts, B, dtype, device, dest=True)
+        np.multiply(otab.arr, plan.wmask, out=out_arr, casting="unsafe")  # only the leaves this call writes are handed over
+        missing = plan.wmask & (out_arr == 0)
+        if missing.any():
+            raise ValueError(f"out= lacks storage for written leaves: {[_ALL_NAMES[i] for i in np.nonzero(missing)[0]][:6]}")
+        if (out_arr[plan.widx] == tab.arr[plan.widx]).any():
+            raise ValueError("out= shares storage with the input on leaves the step writes: the phases read the caller's state "
+                             "after the first outputs are written (and RK4 reads it in every stage); use distinct buffers")
     flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
-    with torch.cuda.device(device):
+    stream, prev = _stream_and_guard(device)
+    try:
         if step:
-            work = nm.workspace(B)
-            rc = nm.lib.mjh_step(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs),
+            work = nm.workspace(B, stream)
+            rc = nm.lib.mjh_step(nm.handle, ctypes.byref(tab.struct), ctypes.byref(out_struct),
                                  ctypes.c_void_p(work.data_ptr() if work is not None else None), B, flags, ctypes.c_void_p(stream))
         else:
-            rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(in_ptrs), ctypes.byref(out_ptrs), B, stages, flags, ctypes.c_void_p(stream))
+            rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(tab.struct), ctypes.byref(out_struct), B, stages, flags, ctypes.c_void_p(stream))
+    finally:
+        if prev is not None:
+            torch.cuda.set_device(prev)
     if rc != 0:
         raise RuntimeError(f"native step failed ({rc}): {nm.lib.mjh_last_error().decode()}")
-    ne, nf, nl, ncon, nefc = m.constraint_sizes_py
-    res.update_(
-        ncon=UnbatchedTensor(torch.full((), ncon, dtype=torch.int32, device=device)),
-        nefc=UnbatchedTensor(torch.full((), nefc, dtype=torch.int32, device=device)),
-    ) if out is None else None
+    if out is not None:
+        return out
+    # ---- the returned Data: the caller's container with the written leaves swapped for (lazy) views of the slab ----
+    res = d.clone(recurse=False)
+    f = res._fields
+    if "_order" not in res.__dict__:
+        object.__setattr__(res, "_order", tuple(f))  # leaves re-enter the dict when they are carved: keep the caller's field order
+    for k in plan.top_names:
+        f.pop(k, None)
+    lz = res.__dict__.get("_lazy")
+    if lz is None:
+        lz = {}
+        object.__setattr__(res, "_lazy", lz)
+    for sp in plan.top:
+        lz[sp[0]] = (slab, sp[1], sp[2], sp[3], sp[4])
+    con = f["contact"]
+    if plan.con or any(_IN_CONTACT[_IDX[n]] for n in plan.empties):
+        con = con.clone(recurse=False)
+        cf = con._fields
+        if "_order" not in con.__dict__:
+            object.__setattr__(con, "_order", tuple(cf))
+        for k in plan.con_names:
+            cf.pop(k, None)
+        clz = con.__dict__.get("_lazy")
+        if clz is None:
+            clz = {}
+            object.__setattr__(con, "_lazy", clz)
+        for sp in plan.con:
+            clz[sp[0]] = (slab, sp[1], sp[2], sp[3], sp[4])
+        f["contact"] = con
+    for n, t in plan.empties.items():
+        (con._fields if _IN_CONTACT[_IDX[n]] else f)[_KEY[n]] = t
+    f["ncon"], f["nefc"] = _counts(m, device)
+    rt = _PtrTab.__new__(_PtrTab)
+    rt.struct = native.DataPtrs()
+    rt.arr = np.frombuffer(rt.struct, dtype=np.uint64)
+    np.copyto(rt.arr, np.where(plan.wmask, out_arr, tab.arr))
+    rt.dirty = {i for i in tab.dirty if not plan.wmask[i]}
+    rt.keep = {i: t for i, t in tab.keep.items() if not plan.wmask[i]}
+    rt.con, rt.con_ver, rt.sig = con, con.__dict__.get("_ver", 0), sig
+    object.__setattr__(res, "_ptab", rt)
     return res
 
 
 def step(m: Model, d: Data, fixed_iterations: bool = False, *, out: Data | None = None) -> Data:
     """Advance simulation by one timestep (reference forward.py:463-496).
 
-    ``out`` (extension): an existing ``Data`` of the same shape whose storage receives the
-    result instead of freshly allocated tensors (ping-pong buffers for tight loops).
+    ``out`` (extension): an existing ``Data`` of the same shape whose storage receives the written leaves instead of fresh
+    storage (ping-pong buffers).  Leaves the step does not write (``ctrl``, ``qfrc_applied``, ``xfrc_applied``, ``mocap_*``,
+    ``eq_active`` ...) are NOT carried from ``d`` into ``out``: ``out`` keeps its own.  ``out`` must not share storage with ``d``.
     """
     return _run(m, d, fixed_iterations, step=True, out=out)
 
@@ -209,8 +417,7 @@ def reset_where(m: Model, d: Data, d0: Data, mask: torch.Tensor, qpos: torch.Ten
     (``dx0 + noise``; rows of unmasked environments are ignored; None = ``d0``'s).  Returns ``d``.
     """
     dq = d.qpos
-    if dq.device.type != "cuda":
-        raise RuntimeError(f"mujoco_torch_amd.reset_where runs only on a HIP device (tensors on {dq.device}); there is no CPU fallback")
+    _require_device(dq.device)
     device, dtype = dq.device, dq.dtype
     if dq.dim() != 2:
         raise ValueError("reset_where expects a Data with exactly one batch dimension")
@@ -230,13 +437,17 @@ def reset_where(m: Model, d: Data, d0: Data, mask: torch.Tensor, qpos: torch.Ten
             z = z.contiguous()
         rows.append(z)
     nm = native.get_native_model(m, device, dtype)
-    d_ptrs, keep_d = _ptrs_cached(d, ("reset", id(m.tables)), _ALL_NAMES, dtype, device)
-    s_ptrs, keep_s = _ptrs_cached(d0, ("reset0", id(m.tables)), _ALL_NAMES, dtype, device)
-    stream = torch.cuda.current_stream(device).cuda_stream
-    with torch.cuda.device(device):
-        rc = nm.lib.mjh_reset_where(nm.handle, ctypes.byref(d_ptrs), ctypes.byref(s_ptrs), ctypes.c_void_p(mask.data_ptr()),
+    T = m.tables
+    dtab = _table(d, (T.uid, dtype, device, B), nm.leaf_counts, B, dtype, device, dest=True)
+    stab = _table(d0, (T.uid, dtype, device, 1), nm.leaf_counts, 1, dtype, device)
+    stream, prev = _stream_and_guard(device)
+    try:
+        rc = nm.lib.mjh_reset_where(nm.handle, ctypes.byref(dtab.struct), ctypes.byref(stab.struct), ctypes.c_void_p(mask.data_ptr()),
                                     ctypes.c_void_p(rows[0].data_ptr() if rows[0] is not None else None),
                                     ctypes.c_void_p(rows[1].data_ptr() if rows[1] is not None else None), B, ctypes.c_void_p(stream))
+    finally:
+        if prev is not None:
+            torch.cuda.set_device(prev)
     if rc != 0:
         raise RuntimeError(f"native reset failed ({rc}): {nm.lib.mjh_last_error().decode()}")
     return d

@@ -233,6 +233,8 @@ def load_library(path: str | None = None):
     lib.mjh_model_lds_bytes.restype = ctypes.c_int
     lib.mjh_model_work_bytes.argtypes = [ctypes.c_void_p]
     lib.mjh_model_work_bytes.restype = ctypes.c_int64
+    lib.mjh_model_leaf_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    lib.mjh_model_leaf_counts.restype = ctypes.c_int
     for fn in ("mjh_last_error", "mjh_data_fields", "mjh_model_fields"):
         getattr(lib, fn).restype = ctypes.c_char_p
     lib.mjh_abi_version.restype = ctypes.c_int
@@ -254,12 +256,12 @@ def check_abi(lib):
 
 
 class NativeModel:
-    """Device-resident constant blob for one (device, dtype)."""
+    """Device-resident constant blob for one (device, dtype) and one set of model VALUES."""
 
-    def __init__(self, m, device: torch.device, dtype: torch.dtype):
+    def __init__(self, desc, keep, device: torch.device, dtype: torch.dtype):
+        # `keep`: the host arrays `desc` points into; the library copies them into its device blob, nothing is retained
         self.lib = load_library()
         check_abi(self.lib)
-        desc, keep = pack_model(m, dtype)
         handle = ctypes.c_void_p()
         with torch.cuda.device(device):
             rc = self.lib.mjh_model_create(ctypes.byref(desc), MJH_F64 if dtype == torch.float64 else MJH_F32, ctypes.byref(handle))
@@ -270,16 +272,30 @@ class NativeModel:
         self.dtype = dtype
         self.work_bytes = int(self.lib.mjh_model_work_bytes(handle))
         self.lds_bytes = [int(self.lib.mjh_model_lds_bytes(handle, p)) for p in range(5)]
+        n = len(DATA_PATH)
+        buf = (ctypes.c_int64 * n)()
+        got = int(self.lib.mjh_model_leaf_counts(handle, buf, n))
+        if got != n:
+            raise RuntimeError("libmjhip.so leaf table does not match include/mjhip.h")
+        self.leaf_counts = np.array(list(buf), dtype=np.int64)  # per-environment element count of every Data leaf, ABI order
         self._work = {}
+        self._work_clock = 0
 
-    def workspace(self, B: int):
-        """Caller-owned scratch for RK4 (stage Data + running sums), cached per batch size."""
+    def workspace(self, B: int, stream: int = 0):
+        """Scratch for RK4 (stage Data + running sums), one per (batch size, stream): two streams stepping the same model
+        must not share stage storage, and a buffer is only ever reused on the stream it was allocated on."""
         if self.work_bytes == 0:
             return None
-        w = self._work.get(B)
-        if w is None:
-            w = torch.empty(self.work_bytes * B, dtype=torch.uint8, device=self.device)
-            self._work = {B: w}
+        key = (B, stream)
+        self._work_clock += 1
+        hit = self._work.get(key)
+        if hit is not None:
+            hit[1] = self._work_clock
+            return hit[0]
+        if len(self._work) >= 4:  # small LRU: ping-pong between a few batch sizes / streams without re-allocating
+            del self._work[min(self._work, key=lambda k: self._work[k][1])]
+        w = torch.empty(self.work_bytes * B, dtype=torch.uint8, device=self.device)
+        self._work[key] = [w, self._work_clock]
         return w
 
     def __del__(self):
@@ -290,11 +306,67 @@ class NativeModel:
             pass
 
 
+# option bits that decide the STATIC tables built by device_put (row counts, contact list, sensor list): changing them on a
+# Model after device_put would need new tables and a new Data layout (the reference's own constraint_sizes_py goes stale too)
+_STRUCT_DISABLE = 0b11111 | (1 << 13)  # CONSTRAINT, EQUALITY, FRICTIONLOSS, LIMIT, CONTACT, SENSOR
+
+
+def _structure_key(opt):
+    return (int(opt.cone), int(opt.disableflags) & _STRUCT_DISABLE, int(opt.jacobian))
+
+
+def _stamp(m):
+    """Cheap per-call check that nothing pack_model reads has changed since the blob was cached ON THIS CONTAINER: container
+    versions (update_ / attribute assignment) and the in-place version counters of the tensor leaves."""
+    opt, stat = m.opt, m.stat
+    v = 0
+    for t in m._fields.values():
+        if isinstance(t, torch.Tensor):
+            v += t._version
+    for t in opt._fields.values():
+        if isinstance(t, torch.Tensor):
+            v += t._version
+    return (m.__dict__.get("_ver", 0), id(opt), opt.__dict__.get("_ver", 0), id(stat), stat.__dict__.get("_ver", 0), v)
+
+
+def _desc_digest(desc, keep):
+    import hashlib
+
+    h = hashlib.blake2b(digest_size=16)
+    h.update(bytes(memoryview(desc))[: ModelDesc.__dict__[LISTS["MJH_MODEL_INT_ARRAYS"][0]].offset])  # the scalar head: ints and reals
+    for a in keep:
+        h.update(a.dtype.str.encode())
+        h.update(np.int64(a.size).tobytes())
+        h.update(a.tobytes())
+    return h.digest()
+
+
 def get_native_model(m, device: torch.device, dtype: torch.dtype) -> NativeModel:
-    key = (device.index if device.index is not None else torch.cuda.current_device(), dtype)
-    cache = m.tables.native
-    nm = cache.get(key)
+    """The device blob for this Model's CURRENT values.  Blobs are shared through ``m.tables.native`` keyed by a digest of
+    everything ``pack_model`` hands to the library, so ``mx.replace(body_mass=...)`` / ``mx.tree_replace({'opt.timestep': ..})``
+    (reference test/smooth_test.py:204) get a blob of their own while ``mx.to(...)`` copies share one."""
+    key = (device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1), dtype)
+    stamp = _stamp(m)
+    local = m.__dict__.get("_native_cache")
+    if local is not None:
+        hit = local.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+    T = m.tables
+    built = getattr(T, "structure_key", None)
+    if built is not None and _structure_key(m.opt) != built:
+        raise NotImplementedError(
+            "opt.cone / opt.jacobian / the constraint-, contact- or sensor-disabling bits of opt.disableflags changed after "
+            "device_put: they size the static row and contact tables (and the Data layout).  Set them on the source model and "
+            "call device_put again.")
+    desc, keep = pack_model(m, dtype)
+    shared_key = (key, _desc_digest(desc, keep))
+    nm = T.native.get(shared_key)
     if nm is None:
-        nm = NativeModel(m, torch.device("cuda", key[0]), dtype)
-        cache[key] = nm
+        nm = NativeModel(desc, keep, torch.device(device.type, key[0]) if key[0] >= 0 else device, dtype)
+        T.native[shared_key] = nm
+    if local is None:
+        local = {}
+        object.__setattr__(m, "_native_cache", local)
+    local[key] = (stamp, nm)
     return nm

@@ -98,6 +98,12 @@ CASES = {
     "ant_frictionloss_newton_f64": ("ant_frictionloss", {}, "float64", 2, 3, "bench_ctrl"),
     "ant_frictionloss_cg_f64": ("ant_frictionloss", {"solver": 1}, "float64", 2, 2, "bench_ctrl"),
     "ant_frictionloss_rk4_ell_f32": ("ant_frictionloss", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 2, 2, "bench_ctrl"),
+    # step(..., fixed_iterations=True): the static-graph loops torch.compile users of the reference run (solver.py:64 fixed_loop,
+    # :484-487 line search, :536-537 main loop) -- every iteration executes, converged or not
+    "humanoid_cg_iter100_fixed_f64": ("humanoid", {"solver": 1, "iterations": 100, "ls_iterations": 50}, "float64", 2, 2, "perturbed", True),
+    "humanoid_cg_fixed_f64": ("humanoid", {"solver": 1}, "float64", 3, 3, "bench", True),
+    "ant_newton_fixed_f64": ("ant", {}, "float64", 2, 2, "bench_ctrl", True),
+    "ant_rk4_newton_ell_fixed_f32": ("ant", {"integrator": 1, "solver": 2, "cone": 1, "iterations": 8, "ls_iterations": 6}, "float32", 2, 2, "bench_ctrl", True),
 }
 
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
@@ -194,7 +200,9 @@ def main(only=None):
     ref = ref_harness.load()
     os.makedirs(GOLD, exist_ok=True)
     names = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
-    for case, (xml, overrides, dtype_s, nenv, nsteps, recipe) in CASES.items():
+    for case, spec in CASES.items():
+        xml, overrides, dtype_s, nenv, nsteps, recipe = spec[:6]
+        fixed = bool(spec[6]) if len(spec) > 6 else False
         if only and case not in only:
             continue
         dtype = getattr(torch, dtype_s)
@@ -226,11 +234,11 @@ def main(only=None):
             for n in INPUT_LEAVES:
                 store[f"in/{env}/{n}"] = leaf(d, n).numpy().copy()
             for s in range(nsteps):
-                d = ref.forward.step(mref, d)
+                d = ref.forward.step(mref, d, fixed_iterations=fixed)
                 for n in names:
                     t = leaf(d, n)
                     store[f"out/{env}/{s}/{n}"] = t.numpy().copy()
-        meta = dict(xml=xml, overrides=overrides, dtype=dtype_s, nenv=nenv, nsteps=nsteps, recipe=recipe, keep_sensors=keep_sensors,
+        meta = dict(xml=xml, overrides=overrides, dtype=dtype_s, nenv=nenv, nsteps=nsteps, recipe=recipe, keep_sensors=keep_sensors, fixed_iterations=fixed,
                     constraint_sizes=list(mref.constraint_sizes_py), torch=torch.__version__)
         store["meta"] = np.array(json.dumps(meta))
         path = os.path.join(GOLD, case + ".npz")

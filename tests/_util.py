@@ -53,6 +53,7 @@ class Golden:
         self.dtype = getattr(torch, self.meta["dtype"])
         self.model = load_model(self.meta["xml"], self.meta["overrides"], self.dtype, keep_sensors=self.meta.get("keep_sensors", False))
         self.nenv, self.nsteps = self.meta["nenv"], self.meta["nsteps"]
+        self.fixed_iterations = bool(self.meta.get("fixed_iterations", False))  # step(..., fixed_iterations=True) recordings
 
     def input_data(self, env=None):
         """Data for one env, or all envs stacked on a leading batch dim (env=None)."""
@@ -60,7 +61,7 @@ class Golden:
             d = mt.make_data(self.model)
             if self.dtype != torch.float64:
                 d = d.to(self.dtype)
-            kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES if f"in/{e}/{n}" in self.z}  # older recordings have no mocap leaves
+            kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES}
             return d.replace(**kw)
 
         if env is not None:
@@ -68,15 +69,7 @@ class Golden:
         return torch.stack([one(e) for e in range(self.nenv)])
 
     def expected(self, env, step, name):
-        key = f"out/{env}/{step}/{name}"
-        if key not in self.z:  # leaves that joined the ABI after the golden was recorded (models without the feature: empty / zeros)
-            if name == "eq_active":
-                return np.zeros(0, dtype=np.int32)
-            if name in ("ten_length", "ten_velocity", "ten_J"):
-                return np.zeros((0, int(self.model.nv)) if name == "ten_J" else 0, dtype=np.float32 if self.dtype == torch.float32 else np.float64)
-            if name == "qfrc_gravcomp":
-                return np.zeros(int(self.model.nv), dtype=np.float32 if self.dtype == torch.float32 else np.float64)
-        return self.z[key]
+        return self.z[f"out/{env}/{step}/{name}"]  # every ABI leaf is recorded (oracle/gen_golden.py writes the full list)
 
 
 def leaf(d, name):

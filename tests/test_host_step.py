@@ -1,0 +1,240 @@
+"""Host logic of ``step`` / ``forward`` (mujoco_torch_amd/forward.py, native.get_native_model) on CPU.
+
+The device library is replaced by tests/_hostsim.py (same pointer structs, answered by the CPU oracle), so everything the
+Python side does per call -- output slab + lazily carved leaves, the per-container pointer tables, size / dtype / layout
+validation, detection of Model edits after device_put -- runs for real.  The kernels themselves are covered by `-m gpu`.
+"""
+import numpy as np
+import pytest
+import torch
+
+import _hostsim
+import mujoco_torch_amd as mt
+import pyoracle
+from _util import INT_LEAVES, REAL_LEAVES, leaf, load_model
+from mujoco_torch_amd import DisableBit
+
+
+@pytest.fixture
+def sim(monkeypatch, oracle_lib):
+    return _hostsim.install(monkeypatch)
+
+
+def seeded(mx, B, seed=0, dtype=torch.float64):
+    rng = np.random.RandomState(seed)
+    d = mt.make_data(mx).expand(B).clone() if B else mt.make_data(mx)
+    shape = (B,) if B else ()
+    d = d.replace(qvel=torch.tensor(0.1 * rng.randn(*shape, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(*shape, mx.nu)))
+    return d.to(dtype) if dtype != torch.float64 else d
+
+
+def assert_same(got, want, names=REAL_LEAVES + INT_LEAVES):
+    for n in names:
+        g, w = leaf(got, n).numpy(), np.asarray(want[n])
+        assert g.shape == w.shape and np.array_equal(g, w, equal_nan=True), n
+
+
+@pytest.mark.parametrize("xml,overrides,dtype,B", [
+    ("humanoid", {"solver": 1}, torch.float64, 5), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 3),
+    ("mesh_contact", {}, torch.float64, 2), ("cartpole", {}, torch.float64, 0), ("pendula", {}, torch.float64, 2),
+])
+def test_step_and_forward_fill_every_leaf_like_the_backend(sim, xml, overrides, dtype, B):
+    """The Data returned by step / forward holds, leaf for leaf, what the backend wrote (written leaves) or the caller's
+    tensors (everything else), in the schema order of make_data."""
+    mx = load_model(xml, overrides, dtype)
+    d = seeded(mx, B, dtype=dtype)
+    before = {n: leaf(d, n).clone() for n in REAL_LEAVES + INT_LEAVES}
+    got = mt.step(mx, d)
+    assert_same(got, pyoracle.run(mx, d, step=True))
+    for n in REAL_LEAVES + INT_LEAVES:  # the caller's Data is never mutated (forward.py:473-475)
+        assert torch.equal(leaf(d, n), before[n]), n
+    assert list(k for k, _ in got.items()) == list(k for k, _ in d.items())
+    assert list(k for k, _ in got.contact.items()) == list(k for k, _ in d.contact.items())
+    assert tuple(got.batch_size) == tuple(d.batch_size) and got.qpos.shape == d.qpos.shape and got.contact.frame.shape == d.contact.frame.shape
+    assert int(got.ncon) == mx.constraint_sizes_py[3] and int(got.nefc) == mx.constraint_sizes_py[4]
+    fwd = mt.forward(mx, d)
+    assert_same(fwd, pyoracle.run(mx, d, step=False))
+    assert fwd.qvel.data_ptr() == d.qvel.data_ptr() and fwd.time.data_ptr() == d.time.data_ptr()  # forward does not integrate
+
+
+def test_ownership_and_aliasing_rules(sim):
+    mx = load_model("humanoid", {"solver": 1})
+    d = seeded(mx, 4)
+    out = mt.step(mx, d)
+    assert out.xfrc_applied.data_ptr() == d.xfrc_applied.data_ptr() and out.ctrl.data_ptr() == d.ctrl.data_ptr()  # untouched: alias the input
+    assert out.qpos.data_ptr() != d.qpos.data_ptr() and out.contact.dist.data_ptr() != d.contact.dist.data_ptr()      # written: fresh storage
+    assert out.qacc.data_ptr() != out.qacc_warmstart.data_ptr() and torch.equal(out.qacc, out.qacc_warmstart)         # solver.py:541-548
+    again = mt.step(mx, d)
+    assert again.qpos.data_ptr() != out.qpos.data_ptr() and torch.equal(again.qpos, out.qpos)                         # fresh per call
+    for n in ("qpos", "efc_J", "contact_frame", "contact_geom", "contact_dim"):
+        t = leaf(out, n)
+        assert t.is_contiguous() and t.data_ptr() % 64 == 0, n  # offsets are 256-byte multiples; the CPU allocator aligns the slab to 64
+
+
+def test_rollout_with_replace_update_and_assignment_tracks_the_oracle(sim):
+    """`d = step(mx, d)` in a loop, with controls swapped the three ways callers do it; each step equals the backend run on the
+    same inputs, i.e. the pointer table followed every leaf replacement and no leaf went stale."""
+    mx = load_model("hopper")
+    B = 3
+    rng = np.random.RandomState(1)
+    d = seeded(mx, B)
+    ref = d
+    for s in range(9):
+        ctrl = torch.tensor(rng.uniform(-1, 1, (B, mx.nu)))
+        if s % 3 == 0:
+            d = d.replace(ctrl=ctrl)
+        elif s % 3 == 1:
+            d.update_(ctrl=ctrl)
+        else:
+            d.ctrl = ctrl
+        ref = ref.replace(ctrl=ctrl.clone())
+        d = mt.step(mx, d)
+        ref = pyoracle.apply(ref, pyoracle.run(mx, ref, step=True))
+        assert torch.equal(d.qpos, ref.qpos) and torch.equal(d.qvel, ref.qvel) and torch.equal(d.ctrl, ref.ctrl), s
+    d.qvel.mul_(0.5)                                   # in-place write into a (lazily carved) output leaf: same storage, seen by the next call
+    ref = ref.replace(qvel=ref.qvel * 0.5)
+    assert torch.equal(mt.step(mx, d).qpos, pyoracle.apply(ref, pyoracle.run(mx, ref, step=True)).qpos)
+    d2 = d.replace(contact=d.contact.replace(dist=torch.full_like(d.contact.dist, 7.0)))  # replaced contact leaf: an input nobody reads, but a new pointer
+    assert torch.equal(mt.step(mx, d2).qpos, mt.step(mx, d).qpos)
+
+
+def test_result_is_a_full_container(sim):
+    """Leaves of a result are carved lazily from one slab; every container operation must still see all of them."""
+    mx = load_model("ant", {}, torch.float64)
+    d = seeded(mx, 4)
+    out = mt.step(mx, d)
+    want = pyoracle.run(mx, d, step=True)
+    assert_same(out.clone(), want)
+    assert_same(out[1:3], {n: want[n][1:3] for n in want})
+    assert_same(torch.stack([out[0], out[1]]), {n: want[n][:2] for n in want})
+    assert out.to(torch.float32).qpos.dtype == torch.float32 and out.to(torch.float32).contact.geom1.dtype == torch.int64
+    flat, spec = torch.utils._pytree.tree_flatten(out)
+    back = torch.utils._pytree.tree_unflatten(flat, spec)
+    assert_same(back, want)
+    out2 = mt.step(mx, out)                                 # result feeds the next call straight from the slab offsets
+    assert_same(out2, pyoracle.run(mx, pyoracle.apply(d, want), step=True))
+    sliced = mt.step(mx, out[:2].clone())
+    assert torch.equal(sliced.qpos, out2.qpos[:2])
+
+
+def test_out_buffers(sim):
+    mx = load_model("humanoid", {"solver": 1})
+    d = seeded(mx, 4)
+    a, b = d.clone(), d.clone()
+    r = mt.step(mx, a, out=b)
+    assert r is b
+    want = pyoracle.run(mx, d, step=True)
+    from mujoco_torch_amd.forward import _written_names
+
+    assert_same(b, want, names=_written_names(mx, step=True))
+    assert torch.equal(b.ctrl, d.ctrl)
+    for _ in range(3):                                      # ping-pong
+        mt.step(mx, b, out=a)
+        a, b = b, a
+    ref = d
+    for _ in range(4):
+        ref = pyoracle.apply(ref, pyoracle.run(mx, ref, step=True))
+    assert torch.equal(b.qpos, ref.qpos)
+    with pytest.raises(ValueError, match="out being the input"):
+        mt.step(mx, a, out=a)
+    shared = b.replace(qvel=a.qvel)
+    with pytest.raises(ValueError, match="shares storage"):
+        mt.step(mx, a, out=shared)
+    with pytest.raises(ValueError, match="not contiguous"):
+        mt.step(mx, a, out=mt.make_data(mx).expand(4))     # stride-0 destination: would be filled in a temporary
+    with pytest.raises(ValueError, match="holds"):
+        mt.step(mx, a, out=d[:2].clone())                   # smaller batch: the kernels would write out of bounds
+
+
+def test_leaf_sizes_are_validated_before_pointers_are_handed_over(sim):
+    mx = load_model("humanoid", {"solver": 1})
+    d = seeded(mx, 4)
+    with pytest.raises(ValueError, match="ctrl holds"):
+        mt.step(mx, d.replace(ctrl=torch.zeros(mx.nu, dtype=torch.float64)))           # unbatched leaf in a batched Data
+    with pytest.raises(ValueError, match="xfrc_applied holds"):
+        mt.step(mx, d.replace(xfrc_applied=d.xfrc_applied[:2]))                        # short batch
+    with pytest.raises(RuntimeError, match="dtype"):
+        mt.step(mx, d.replace(qvel=d.qvel.float()))
+    with pytest.raises(RuntimeError, match="dtype"):
+        mt.step(mx, d.replace(contact=d.contact.replace(geom1=d.contact.geom1.int())))
+    other = load_model("ant", {}, torch.float64)
+    with pytest.raises(ValueError, match="holds"):
+        mt.step(other, d)                                                               # Data of another model
+    ok = mt.step(mx, d)                                                                 # and a valid call still goes through afterwards
+    assert torch.isfinite(ok.qpos).all()
+    bad = d.replace(ctrl=torch.zeros(mx.nu, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        mt.step(mx, bad)
+    fixed = bad.replace(ctrl=d.ctrl)
+    assert torch.equal(mt.step(mx, fixed).qpos, ok.qpos)                                # the table inherited from `bad` re-reads the replaced leaf
+
+
+def test_strided_inputs_are_copied_each_call(sim):
+    mx = load_model("hopper")
+    B = 3
+    d = seeded(mx, B)
+    strided = d.replace(qvel=d.qvel.t().contiguous().t(), ctrl=torch.zeros(mx.nu, B, dtype=torch.float64).t())
+    assert not strided.qvel.is_contiguous()
+    assert torch.equal(mt.step(mx, strided).qvel, mt.step(mx, d.replace(ctrl=torch.zeros(B, mx.nu, dtype=torch.float64))).qvel)
+    strided.qvel.mul_(2.0)                                  # the strided source changes in place: the next call must see it
+    want = mt.step(mx, d.replace(qvel=d.qvel * 2.0, ctrl=torch.zeros(B, mx.nu, dtype=torch.float64)))
+    assert torch.equal(mt.step(mx, strided).qvel, want.qvel)
+    bcast = mt.make_data(mx).expand(B)                      # stride-0 batch
+    assert torch.equal(mt.step(mx, bcast).qpos, mt.step(mx, bcast.clone()).qpos)
+
+
+def test_model_edits_after_device_put_reach_the_backend(sim):
+    """the blob was cached per (device, dtype) on the shared tables, so `mx.replace(...)` /
+    `mx.tree_replace(...)` (reference test/smooth_test.py:204) silently kept stepping the first model."""
+    mx = load_model("hopper")
+    d = seeded(mx, 2)
+    base = mt.step(mx, d)
+    built0 = sim.built
+
+    def check(m2, differs=True):
+        got = mt.step(m2, d)
+        assert_same(got, pyoracle.run(m2, d, step=True))
+        assert (not torch.equal(got.qpos, base.qpos)) == differs
+        return got
+
+    check(mx.replace(body_mass=mx.body_mass * 2.0))
+    check(mx.tree_replace({"opt.timestep": mx.opt.timestep * 0.5}))
+    check(mx.tree_replace({"opt.disableflags": mx.opt.disableflags | DisableBit.GRAVITY}))
+    check(mx.tree_replace({"opt.gravity": torch.tensor([0.0, 0.0, -3.0])}))
+    check(mx.replace(dof_damping=mx.dof_damping + 0.5))
+    check(mx.replace(geom_friction=mx.geom_friction * 0.1))
+    assert sim.built == built0 + 6
+    check(mx, differs=False)                                # the original still steps the original values ...
+    check(mx.replace(body_mass=mx.body_mass.clone()), differs=False)   # ... and an equal-valued copy shares its blob
+    assert sim.built == built0 + 6
+    m3 = mx.replace(body_mass=mx.body_mass.clone())
+    check(m3, differs=False)
+    m3.body_mass[2] *= 3.0                                  # in-place edit of a leaf of a model that has been stepped already
+    check(m3)
+    m3.opt.update_(timestep=mx.opt.timestep * 2.0)          # nested container edited in place
+    check(m3)
+    # options that size the static tables cannot change after device_put
+    for bad in ({"opt.disableflags": mx.opt.disableflags | DisableBit.CONTACT}, {"opt.cone": mt.ConeType.ELLIPTIC},
+                {"opt.disableflags": mx.opt.disableflags | DisableBit.LIMIT}):
+        with pytest.raises(NotImplementedError, match="device_put again"):
+            mt.step(mx.tree_replace(bad), d)
+
+
+def test_unbatched_and_two_batch_dims(sim):
+    mx = load_model("hopper")
+    E, T = 2, 3
+    flat = seeded(mx, E * T)
+    two = mt.make_data(mx).expand(E, T).clone().replace(qvel=flat.qvel.reshape(E, T, -1), ctrl=flat.ctrl.reshape(E, T, -1))
+    got, want = mt.step(mx, two), mt.step(mx, flat)
+    assert tuple(got.qpos.shape) == (E, T, mx.nq) and tuple(got.contact.dist.shape)[:2] == (E, T) and tuple(got.batch_size) == (E, T)
+    assert torch.equal(got.qpos.reshape(E * T, -1), want.qpos) and torch.equal(got.efc_J.reshape(want.efc_J.shape), want.efc_J)
+    one = mt.step(mx, flat[0])
+    assert one.qpos.shape == (mx.nq,) and torch.equal(one.qpos, want.qpos[0])
+
+
+def test_cpu_tensors_are_still_rejected_without_the_test_backend():
+    mx = load_model("cartpole")
+    with pytest.raises(RuntimeError, match="HIP device"):
+        mt.step(mx, mt.make_data(mx))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        mt.forward(mx, mt.make_data(mx))

@@ -30,7 +30,7 @@ def test_oracle_matches_reference_golden(case, oracle_lib):
         for s in range(g.nsteps):
             want = lambda n: g.expected(env, s, n)
             what = f"{case} env{env} step{s}"
-            alts = oracle_alternatives(g.model, d, hint={n: want(n) for n in HINT_LEAVES})
+            alts = oracle_alternatives(g.model, d, hint={n: want(n) for n in HINT_LEAVES}, fixed_iterations=g.fixed_iterations)
             assert_leaves_close(lambda n: alts[0][n], want, tol, names=PRE_SOLVER, what=what)
             assert_ints_equal(lambda n: alts[0][n], want, what=what)
             errs = [max(rel_err(o[n], want(n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for o in alts]
