@@ -1,20 +1,61 @@
 """bench.py -- env-steps/s of the native batched step on the BASELINE.json workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload humanoid|ant|cartpole]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload humanoid|humanoid32k|ant|mesh|cartpole]
 
-One process per GPU (the driver launches N > 1 with torch.distributed.run); independent environments
-are sharded across ranks with no data-path collective (weak scaling: B environments PER GPU).  A "step"
-is one `mujoco_torch.step` over the whole resident batch; state is carried across steps (ping-pong
-buffers), inputs follow the reference's bench recipe (benchmarks/_helpers.py:25-42: make_data state,
-qvel = 0.01 * RandomState(42).randn(B, nv), ctrl = 0).  Rank 0 prints ONE JSON line.
+One process per GPU.  The driver launches N > 1 with torch.distributed.run; `python bench.py --gpus N` run directly spawns
+that launch itself (as a child process, BEFORE this process touches the GPU) and relays rank 0's line.  Independent
+environments are sharded across ranks with no data-path collective (weak scaling: B environments PER GPU).
+
+A "step" is one `d = mujoco_torch.step(mx, d)` -- the reference's own signature (forward.py:463), fresh output storage every
+call -- over the whole resident batch; state is carried across steps; inputs follow the reference's bench recipe
+(benchmarks/_helpers.py:25-42: make_data state, qvel = 0.01 * RandomState(42).randn(B, nv), ctrl = 0).  `value` is that
+loop; `out_buffers` reports the `step(..., out=)` ping-pong extension beside it.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
+    ap.add_argument("--workload", default="humanoid", choices=["humanoid", "humanoid32k", "ant", "mesh", "cartpole"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1 humanoid runs also time BASELINE config 4 (32768 envs/GPU); skip it")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` as a CHILD (this process has made no HIP call
+    and makes none), one rank per GPU, and relay rank 0's JSON line and the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1])
+    else:
+        sys.stdout.write(r.stdout)
+    sys.exit(r.returncode if r.returncode else (0 if lines else 1))
+
+
+ARGS = parse_args() if __name__ == "__main__" else None
+if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    spawn_ranks(ARGS)  # never returns
+
 for p in (os.path.join(ROOT, "mujoco-torch_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
@@ -30,6 +71,9 @@ WORKLOADS = {
     # BASELINE.json configs[1]: humanoid.xml, batch 4096, Euler + CG, float64 (XML iterations=1, ls_iterations=4)
     "humanoid": dict(xml="humanoid", overrides={"solver": 1}, dtype=torch.float64, batch=4096,
                      name="humanoid.xml batch=4096/GPU Euler+CG float64 (iterations=1, ls_iterations=4)"),
+    # configs[3]: the same model at 262144 = 8 x 32768 environments
+    "humanoid32k": dict(xml="humanoid", overrides={"solver": 1}, dtype=torch.float64, batch=32768,
+                        name="humanoid.xml batch=32768/GPU Euler+CG float64 (iterations=1, ls_iterations=4; config 4 = 8 x 32768)"),
     # configs[2]: ant.xml, RK4 + Newton, elliptic, float32
     "ant": dict(xml="ant", overrides={"integrator": 1, "solver": 2, "cone": 1}, dtype=torch.float32, batch=16384,
                 name="ant.xml batch=16384/GPU RK4+Newton elliptic float32"),
@@ -56,43 +100,26 @@ def algorithmic_bytes_per_env_step(mx, dtype):
     return in_b, out_b
 
 
-# Data leaves each kernel of the step reads from / writes to global memory (mjh_kernels.h: the row_load / put calls of each phase).
-# Kernel ids as mjh_debug_phase_times reports them; 5 = velocity phase with fluid forces, 6 = solver phase with frictionloss /
-# equality rows (same I/O as 3 / 4).  "contact_*" stands for the per-contact leaves.
-_CONTACT_OUT = ("contact_dist contact_pos contact_frame contact_includemargin contact_friction contact_solref contact_solreffriction "
-                "contact_solimp contact_dim contact_geom1 contact_geom2 contact_geom contact_efc_address").split()
-KERNEL_IO = {
-    0: ("qpos", "qpos xpos xquat xmat xipos ximat xanchor xaxis geom_xpos geom_xmat site_xpos site_xmat cam_xpos cam_xmat light_xpos "
-             "light_xdir subtree_com cdof cinert"),
-    1: ("cinert cdof", "crb qM qLD"),
-    2: ("geom_xpos geom_xmat subtree_com cdof qpos qvel", " ".join(_CONTACT_OUT) + " efc_J efc_D efc_aref efc_frictionloss"),
-    3: ("qpos qvel act ctrl qfrc_applied xfrc_applied cdof cinert subtree_com xipos",
-        "actuator_length actuator_moment actuator_velocity cvel cdof_dot qfrc_bias qfrc_passive actuator_force qfrc_actuator qfrc_smooth act_dot"),
-    4: ("qLD qM efc_J efc_D efc_aref qfrc_smooth qacc_warmstart qpos qvel act act_dot time",
-        "qacc_smooth qacc qacc_warmstart efc_force qfrc_constraint qpos qvel act time"),
-    7: ("geom_xpos geom_xmat", "contact_dist contact_pos contact_frame"),
-    8: ("site_xpos site_xmat geom_xpos geom_xmat cvel subtree_com qpos qvel", "sensordata"),
-}
-KERNEL_IO[5], KERNEL_IO[6] = KERNEL_IO[3], KERNEL_IO[4]
-KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kernel<{r}, 1, 64> (crb / factor)", 2: "mjh_phase_kernel<{r}, 2, 64> (collision / constraint)",
-               3: "mjh_phase_kernel<{r}, 3, W> (velocity)", 4: "mjh_phase_kernel<{r}, 4, 64> (solve / integrate)", 5: "mjh_phase_kernel<{r}, 5, W> (velocity + fluid)",
-               6: "mjh_phase_kernel<{r}, 6, 64> (solve / integrate, general rows)", 7: "mjh_convex_kernel<{r}>", 8: "mjh_sensor_kernel<{r}>"}
+KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kernel<{r}, 1, W> (crb / factor)", 2: "mjh_phase_kernel<{r}, 2, W> (collision / constraint)",
+               3: "mjh_phase_kernel<{r}, 3, W> (velocity)", 4: "mjh_phase_kernel<{r}, 4, W> (solve / integrate)", 5: "mjh_phase_kernel<{r}, 5, W> (velocity + fluid)",
+               6: "mjh_phase_kernel<{r}, 6, 64> (solve / integrate, general rows)", 7: "mjh_phase_kernel<{r}, 7, 64> (collision / constraint, general rows)",
+               8: "mjh_convex_kernel<{r}>", 9: "mjh_sensor_kernel<{r}>"}
 
 
-def kernel_algorithmic_bytes(mx, dtype):
-    """{kernel id: bytes of the Data leaves one environment's launch of that kernel reads + writes} (leaves absent from the model count 0)."""
-    d = mt.make_data(mx)
-    if dtype != torch.float64:
-        d = d.to(dtype)
+def kernel_algorithmic_bytes(nm):
+    """{kernel id: (bytes read, bytes written) per environment and launch}: the library's own account of the global-memory
+    extents each kernel touches (mjh_model_kernel_io: written next to the kernels' load / store code, csrc/mjh_io.h)."""
+    import ctypes
 
-    def nbytes(name):
-        t = native.data_field_tensor(d, name)
-        return 0 if t is None else t.numel() * t.element_size()
+    out = {}
+    for k in range(10):
+        rw = (ctypes.c_int64 * 2)()
+        if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
+            out[k] = (int(rw[0]), int(rw[1]))
+    return out
 
-    return {k: sum(nbytes(n) for n in r.split()) + sum(nbytes(n) for n in w.split()) for k, (r, w) in KERNEL_IO.items()}
 
-
-def per_kernel_times(mdev, bufs, cur, steps, device):
+def per_kernel_times(stepper, steps, device):
     """Average duration of every kernel of a step, from HIP events recorded on the launch stream around each launch."""
     import ctypes
 
@@ -103,8 +130,7 @@ def per_kernel_times(mdev, bufs, cur, steps, device):
     tot, cnt = {}, {}
     try:
         for _ in range(steps):
-            mt.step(mdev, bufs[cur], out=bufs[1 - cur])
-            cur = 1 - cur
+            stepper()
             n = lib.mjh_debug_phase_times(ms, ids, 96)
             if n < 0:
                 raise RuntimeError(lib.mjh_last_error().decode())
@@ -114,7 +140,7 @@ def per_kernel_times(mdev, bufs, cur, steps, device):
     finally:
         lib.mjh_debug_phase_timing(0)
     torch.cuda.synchronize(device)
-    return {k: dict(avg_ms=tot[k] / cnt[k], launches_per_step=cnt[k] / steps, ms_per_step=tot[k] / steps) for k in tot}, cur
+    return {k: dict(avg_ms=tot[k] / cnt[k], launches_per_step=cnt[k] / steps, ms_per_step=tot[k] / steps) for k in tot}
 
 
 def build_inputs(mx, B, dtype, device, seed=42):
@@ -148,24 +174,74 @@ def cpu_baseline(mx, dtype, B_sample, steps):
                 sample=f"{B_sample} envs x {done} steps, oracle/mjoracle.c with OpenMP over environments ({dt:.1f} s)")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
-    ap.add_argument("--workload", default="humanoid", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class Loop:
+    """The two ways to drive the step: the reference signature (fresh outputs per call) and ping-pong `out=` buffers."""
 
+    def __init__(self, mdev, d):
+        self.mdev, self.d = mdev, d
+        self.bufs = None
+
+    def dropin(self, n):
+        d, m = self.d, self.mdev
+        for _ in range(n):
+            d = mt.step(m, d)
+        self.d = d
+
+    def pingpong(self, n):
+        if self.bufs is None:
+            self.bufs, self.cur = [self.d.clone(), self.d.clone()], 0
+        for _ in range(n):
+            mt.step(self.mdev, self.bufs[self.cur], out=self.bufs[1 - self.cur])
+            self.cur = 1 - self.cur
+
+
+def timed(fn, steps, device, world, backend):
+    """barrier + synchronize on both sides of exactly `steps` steps; wall time (max over ranks) and device time (events)."""
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev0.record()
+    fn(steps)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ev0.elapsed_time(ev1) / steps
+
+
+def lib_fingerprint():
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "mujoco-torch_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N spawns them itself)")
     # test hooks for a one-GPU box: MJH_BENCH_BACKEND=gloo + MJH_BENCH_SHARE_GPU=1 run every rank on cuda:0 (RCCL refuses
     # two ranks on one device); the driver's multi-GPU runs use the defaults (RCCL, one GPU per rank)
     backend = os.environ.get("MJH_BENCH_BACKEND", "nccl")
     if os.environ.get("MJH_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} devices are visible")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
@@ -178,88 +254,94 @@ def main():
     wl = WORKLOADS[args.workload]
     B = args.batch or wl["batch"]
     dtype = wl["dtype"]
-    lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", wl["xml"] + ".xml"))
+    lite = mt.mjcf.from_xml_path(mt.test_data_path(wl["xml"] + ".xml"))
     for k, v in wl["overrides"].items():
         setattr(lite.opt, k, v)
     mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
     mdev = mx.to(device)
     # different seeds per rank: independent environments, no collective on the data path
-    bufs = [build_inputs(mx, B, dtype, device, seed=42 + rank), None]
-    bufs[1] = bufs[0].clone()
+    loop = Loop(mdev, build_inputs(mx, B, dtype, device, seed=42 + rank))
 
-    def run(n, cur):
-        for _ in range(n):
-            mt.step(mdev, bufs[cur], out=bufs[1 - cur])
-            cur = 1 - cur
-        return cur
+    loop.dropin(args.warmup)
+    elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)
+    assert torch.isfinite(loop.d.qpos).all(), "non-finite state after the timed steps"
+    loop.pingpong(args.warmup)
+    elapsed_pp, kernel_ms_pp = timed(loop.pingpong, args.steps, device, world, backend)  # extension: step(mx, a, out=b)
 
-    cur = run(args.warmup, 0)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    ev0.record()
-    cur = run(args.steps, cur)
-    ev1.record()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # device time of one step (its phase kernels) on this stream
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    final = bufs[cur]
-    assert torch.isfinite(final.qpos).all(), "non-finite state after the timed steps"
-    kernels = None
-    if rank == 0:  # per-kernel durations of the same loop (events around every launch; outside the timed region)
-        kernels, cur = per_kernel_times(mdev, bufs, cur, min(args.steps, 50), device)
+    config4 = None
+    if world > 1 and args.workload == "humanoid" and not args.batch and not args.no_config4:
+        # BASELINE config 4 beside the headline batch: 32768 environments per GPU (262144 on 8 GPUs), same loop
+        big = Loop(mdev, build_inputs(mx, 32768, dtype, device, seed=1042 + rank))
+        big.dropin(max(2, args.warmup // 4))
+        n4 = max(5, args.steps // 4)
+        e4, k4 = timed(big.dropin, n4, device, world, backend)
+        config4 = {"workload": WORKLOADS["humanoid32k"]["name"], "envs_per_gpu": 32768, "global_batch": 32768 * world, "steps": n4,
+                   "value": 32768 * world * n4 / e4, "unit": "env-steps/s", "ms_per_step": 1e3 * e4 / n4, "device_ms_per_step": k4}
+        del big
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", f"hbm_traffic_{args.workload}_b{B}_{'f64' if dtype == torch.float64 else 'f32'}.json")
-        if os.path.exists(tfile):  # PMC counters cannot be collected from inside this process: committed rocprofv3 result
+        nm = native.get_native_model(mdev, device, dtype)
+        kernels = per_kernel_times(lambda: loop.dropin(1), min(args.steps, 50), device)  # events around every launch; outside the timed region
+        fp = lib_fingerprint()
+        tag = f"{args.workload}_b{B}_{'f64' if dtype == torch.float64 else 'f32'}"
+        tfile = next((p for p in (os.path.join(ROOT, "profiles", "r02", f"hbm_traffic_{tag}.json"), os.path.join(ROOT, "profiles", f"hbm_traffic_{tag}.json"))
+                      if os.path.exists(p)), None)
+        tj = None
+        if tfile:  # PMC counters cannot be collected from inside this process: the committed rocprofv3 result (tools/hbm_traffic.sh)
             with open(tfile) as f:
-                traffic = json.load(f)["hbm_bytes_per_step"]
+                tj = json.load(f)
         in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
         alg = in_b + out_b
         achieved = alg * B / (kernel_ms * 1e-3) / 1e9
         value = B * world * args.steps / elapsed
         rname = "double" if dtype == torch.float64 else "float"
-        kbytes = kernel_algorithmic_bytes(mx, dtype)
+        kio = kernel_algorithmic_bytes(nm)
         per_kernel = []
         for k, t in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"]):
-            gbs = kbytes[k] * B / (t["avg_ms"] * 1e-3) / 1e9
-            per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
-                               "algorithmic_bytes_per_env": kbytes[k], "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
+            rd, wr = kio.get(k, (0, 0))
+            gbs = (rd + wr) * B / (t["avg_ms"] * 1e-3) / 1e9
+            per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "id": k, "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
+                               "algorithmic_bytes_per_env": rd + wr, "read_bytes_per_env": rd, "written_bytes_per_env": wr, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
         dom = per_kernel[0]
-        ktraffic = None
-        if os.path.exists(tfile):
-            with open(tfile) as f:
-                tj = json.load(f)
-            for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
-                if dom["kernel"].split(" (")[0].replace(" ", "").replace("W>", "") in name.replace(" ", ""):
-                    ktraffic = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
+        ktraffic, traffic, tsrc = None, None, None
+        if tj is not None:
+            stale = tj.get("lib_fingerprint") != fp
+            tsrc = {"file": os.path.relpath(tfile, ROOT), "git_commit": tj.get("git_commit"), "lib_fingerprint": tj.get("lib_fingerprint"),
+                    "measured_in_this_run": False, "kernels_changed_since": stale}
+            if not stale:
+                traffic = tj.get("hbm_bytes_per_step")
+                for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
+                    if f"Li{dom['id']}E" in name or dom["kernel"].split(" (")[0].replace(" ", "").replace("W>", "") in name.replace(" ", ""):
+                        ktraffic = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if dtype == torch.float64 else "f32", "data": "synthetic",
             "config": {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world,
+                       "call": "d = mujoco_torch.step(mx, d)  (reference signature, forward.py:463; fresh output storage every call)",
                        "parallelism": f"independent-envs x{world} (no collectives)",
-                       "lds_bytes_per_env_by_phase": native.get_native_model(mdev, device, dtype).lds_bytes},
-            # dominant kernel of the step: its Data-leaf bytes per launch / its average launch duration (HIP events around each launch,
-            # on the launch stream); "step" = the same for the whole launch sequence of a step (SURVEY section 8(d) per-unit figure)
+                       "lds_bytes_per_env_by_phase": nm.lds_bytes},
+            # the same loop through the `out=` extension (ping-pong buffers, no allocation): how far the drop-in call is from it
+            "out_buffers": {"value": B * world * args.steps / elapsed_pp, "ms_per_step": 1e3 * elapsed_pp / args.steps, "device_ms_per_step": kernel_ms_pp,
+                            "call": "mujoco_torch.step(mx, a, out=b)"},
+            # dominant kernel of the step: the global-memory bytes its code reads + writes per launch / its average launch duration (HIP
+            # events around each launch, on the launch stream); "step" = the same for the whole launch sequence (SURVEY 8(d) per-unit figure)
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": ktraffic,
                          "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_env"] * B,
-                         "per_kernel": per_kernel,
+                         "traffic_source": tsrc, "per_kernel": per_kernel,
                          "step": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_env_step": alg,
-                                  "algorithmic_bytes_per_step": alg * B, "kernel_ms": kernel_ms,
+                                  "algorithmic_bytes_per_step": alg * B, "device_ms_per_step": kernel_ms,
                                   "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}},
         }
+        if config4 is not None:
+            line["config4"] = config4
+        pfile = os.path.join(ROOT, "profiles", "r02", "parity.json")
+        if os.path.exists(pfile):  # "float64 max rel-err" half of BASELINE's metric: written by tests/test_gpu_parity.py::test_parity_report
+            with open(pfile) as f:
+                pj = json.load(f)
+            line["parity"] = {"file": "profiles/r02/parity.json", "measured_in_this_run": False, **{k: pj[k] for k in ("reference", "summary") if k in pj}}
         if not args.no_cpu_baseline and world == 1:
             nB = min(B, 4096)
             line["cpu_baseline"] = cpu_baseline(mx, dtype, nB, 20 if args.workload != "ant" else 4)
@@ -270,4 +352,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(ARGS)

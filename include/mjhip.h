@@ -373,10 +373,16 @@ int mjh_model_lds_bytes(const mjhModel* m, int phase);
 
 /* measurement aid used by bench.py for the per-kernel roofline: while enabled, every kernel launch of mjh_step / mjh_forward is
  * bracketed by HIP events on the launch stream; mjh_debug_phase_times() waits for the most recent call and returns, per launch,
- * the elapsed milliseconds and the kernel id (0..4 pipeline phases, 5 velocity phase with fluid, 6 solver phase with frictionloss /
- * equality rows, 7 convex narrow phase, 8 sensors).  Returns the number of launches (<= max) or a negative code. */
+ * the elapsed milliseconds and the kernel id (0..4 pipeline phases, 5 velocity phase with fluid / gravcomp / tendons, 6 solver phase
+ * with frictionloss / equality / dense limit rows, 7 constraint phase with those rows, 8 convex narrow phase, 9 sensors).  Returns
+ * the number of launches (<= max) or a negative code. */
 int mjh_debug_phase_timing(int enable);
 int mjh_debug_phase_times(float* ms, int* kernel_ids, int max);
+
+/* global-memory bytes ONE launch of kernel `kernel` (ids as above) reads and writes per environment in a step: the library's own
+ * account of its loads / stores through the Data leaves (csrc/mjh_io.h) -- the per-kernel "algorithmic bytes" of the roofline.
+ * read_write_bytes[0] = read, [1] = written.  Returns 0, or -2 when this model's step does not launch that kernel. */
+int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes);
 
 /* last error message of the calling thread ("" if none) */
 const char* mjh_last_error(void);

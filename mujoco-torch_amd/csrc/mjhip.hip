@@ -16,6 +16,7 @@
 #include "mjh_convex.h"
 #include "mjh_sensor.h"
 #include "mjh_reset.h"
+#include "mjh_io.h"
 
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
@@ -26,7 +27,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static struct {
   bool on = false;
   int n = 0;                          // launches recorded by the last call
-  int id[MJH_TIMING_MAX];             // 0..6 phase-kernel ids, 7 convex narrow phase, 8 sensors
+  int id[MJH_TIMING_MAX];             // 0..7 phase-kernel ids, 8 convex narrow phase, 9 sensors
   hipEvent_t ev[MJH_TIMING_MAX + 1];  // ev[i] .. ev[i + 1] brackets launch i
 } g_timing;
 static inline void timing_begin(hipStream_t s) { if (g_timing.on) { g_timing.n = 0; (void)hipEventRecord(g_timing.ev[0], s); } }
@@ -428,7 +429,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
     hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
-    timing_mark(stream, 7);
+    timing_mark(stream, 8);
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
@@ -438,7 +439,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
     HIP_TRY(hipGetLastError());
-    timing_mark(stream, 8);
+    timing_mark(stream, 9);
   }
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
@@ -730,6 +731,13 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
   all.insert(all.end(), ints, ints + 6);
   for (int i = 0; i < (int)all.size() && i < max; i++) counts[i] = all[i];
   return (int)all.size();
+}
+
+int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
+  if (!m || !read_write_bytes) return fail(-22, "null argument");
+  const int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, kernel, 1, &read_write_bytes[0], &read_write_bytes[1])
+                                     : mjh_kernel_io<float>(m->m32, kernel, 1, &read_write_bytes[0], &read_write_bytes[1]);
+  return rc == 0 ? 0 : -2;  // -2: this model's step does not launch that kernel
 }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }

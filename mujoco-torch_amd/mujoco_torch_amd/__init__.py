@@ -28,4 +28,12 @@ from .forward import forward, reset_where, step  # noqa: F401
 from .io import make_data  # noqa: F401
 from .types import Contact, Data, Model, Option, Statistic  # noqa: F401
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+
+def test_data_path(name: str = "") -> str:
+    """Path of a bundled model file (``mujoco_torch_amd/test_data/``: the reference's ``mujoco_torch/test_data`` models plus
+    the scenes of BASELINE.json's configs), e.g. ``test_data_path("humanoid.xml")``."""
+    import os
+
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_data", name)

@@ -233,6 +233,8 @@ def load_library(path: str | None = None):
     lib.mjh_model_lds_bytes.restype = ctypes.c_int
     lib.mjh_model_work_bytes.argtypes = [ctypes.c_void_p]
     lib.mjh_model_work_bytes.restype = ctypes.c_int64
+    lib.mjh_model_kernel_io.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.mjh_model_kernel_io.restype = ctypes.c_int
     lib.mjh_model_leaf_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     lib.mjh_model_leaf_counts.restype = ctypes.c_int
     for fn in ("mjh_last_error", "mjh_data_fields", "mjh_model_fields"):

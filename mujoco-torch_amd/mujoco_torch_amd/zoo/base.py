@@ -28,7 +28,7 @@ from .. import device_put, make_data, mjcf, reset_where, step
 from ._compat import Bounded, Composite, EnvBase, TensorDict, Unbounded  # noqa: F401
 
 _MODEL_DIR = os.environ.get(
-    "MJH_MODEL_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "..", "tests", "golden", "models")
+    "MJH_MODEL_DIR", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "test_data")
 )
 
 ENVS: dict = {}

@@ -206,7 +206,7 @@ def main(only=None):
         if only and case not in only:
             continue
         dtype = getattr(torch, dtype_s)
-        lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
+        lite = mjcf.from_xml_path(os.path.join(REPO, "mujoco-torch_amd", "mujoco_torch_amd", "test_data", xml + ".xml"))
         for k, v in overrides.items():
             setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
         has_convex = any(int(t) in (6, 7) for t in lite.geom_type) and not (int(lite.opt.disableflags) & (1 << 4))  # convex tables matter only with contacts on

@@ -40,7 +40,7 @@ def initial_state(lite, seed=7):
 def main():
     ref = ref_harness.load()
     for case, (xml, overrides, nsteps, every) in CASES.items():
-        lite = mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
+        lite = mjcf.from_xml_path(os.path.join(os.path.dirname(HERE), "mujoco-torch_amd", "mujoco_torch_amd", "test_data", xml + ".xml"))
         for k, v in overrides.items():
             setattr(lite.opt, k, v)
         m = ref_harness.put_model(ref, lite)

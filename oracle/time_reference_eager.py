@@ -17,7 +17,7 @@ from mujoco_torch_amd import mjcf  # noqa: E402
 
 ref = ref_harness.load()
 for name, overrides, nsteps in (("cartpole", {}, 50), ("humanoid", {"solver": 1}, 10)):
-    lite = mjcf.from_xml_path(os.path.join(os.path.dirname(HERE), "tests", "golden", "models", name + ".xml"))
+    lite = mjcf.from_xml_path(os.path.join(os.path.dirname(HERE), "mujoco-torch_amd", "mujoco_torch_amd", "test_data", name + ".xml"))
     for k, v in overrides.items():
         setattr(lite.opt, k, v)
     m = ref_harness.put_model(ref, lite)

@@ -1,0 +1,121 @@
+"""Seeded parity cases shared by tests/test_gpu_parity.py and tools/parity_survey.py.
+
+Each case: (xml, option overrides, dtype, batch) plus the bounds the HIP step must meet against the oracle on that batch:
+``tol_sol`` -- solver-dependent leaves on the accepted branch (relative to the leaf's max magnitude, see _util.rel_err);
+``max_alt`` -- largest fraction of environments allowed on a non-natural line-search branch (0: the natural oracle run must match).
+The bounds are measured ones (profiles/r02/parity_survey.json) with headroom, not wishes; north_star's bar for float64 is 1e-8.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+import mujoco_torch_amd as mt
+from _util import load_model
+
+F64, F32 = torch.float64, torch.float32
+TOL_PRE = {F64: 1e-9, F32: 2e-4}
+TOL_SOL = {F64: 1e-8, F32: 2e-3}
+
+# (xml, overrides, dtype, B, {bounds})
+SEEDED_CASES = [
+    ("humanoid", {"solver": 1}, F64, 256, dict(max_alt=0.35)),                  # BASELINE config 2: iterations=1 / ls_iterations=4 stop on the knife edge
+    ("humanoid", {}, F64, 64, dict(max_alt=0.35)),                              # ... Newton, same early stop
+    ("humanoid", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 64, dict(max_alt=0.0)),   # converged: branches re-converge
+    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 128, {}),          # BASELINE config 3
+    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F64, 64, dict(max_alt=0.0)),
+    ("ant", {}, F64, 64, dict(max_alt=0.0)),
+    ("cartpole", {}, F64, 64, dict(max_alt=0.0)),
+    ("mesh_contact", {}, F32, 256, {}),                                         # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
+    ("mesh_contact", {}, F64, 64, dict(max_alt=0.0)),
+    ("mesh_contact", {"solver": 1, "cone": 1}, F64, 32, dict(tol_sol=1e-5)),    # CG on 72 ill-conditioned rows: 100 iterations amplify rounding
+    ("convex_meshes", {}, F64, 32, dict(max_alt=0.0)),
+    ("convex_primitives", {}, F64, 32, dict(max_alt=0.0)),
+    ("convex_primitives", {}, F32, 32, {}),
+    ("sensor_rig", {}, F64, 64, dict(max_alt=0.0)),                             # sensors: IMU, rangefinders, joint sensors
+    ("sensor_rig", {"integrator": 1}, F32, 64, {}),                             # ... RK4, float32 (rays intersect in double)
+    ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, F64, 64, dict(max_alt=0.0)),  # fluid forces: density + viscosity + wind
+    ("ant_frictionloss", {}, F64, 64, dict(max_alt=0.0)),                       # dof frictionloss rows, Newton
+    ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG: 100 iterations on a piecewise-quadratic cost amplify rounding
+    ("halfcheetah", {}, F64, 64, dict(max_alt=0.0)),
+    ("hopper", {}, F64, 64, dict(tol_sol=1e-6)),
+    ("equality_loops", {}, F64, 64, dict(max_alt=0.0)),                         # equality rows: closed loop, weld, joint couplings
+    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-4)),  # RK4 + CG on the stiff always-active rows
+    ("equality", {}, F64, 32, dict(max_alt=0.0)),                               # bundled: site-form constraints carried inactive
+    ("ant", {"disableflags": 1 << 4}, F64, 32, dict(max_alt=0.0)),              # disable flags (test/constraint_test.py:148-200): contacts off
+    ("humanoid", {"disableflags": 1}, F64, 32, dict(max_alt=0.0)),              # ... every constraint off (nefc = 0)
+    ("ant", {"disableflags": (1 << 12) | (1 << 9) | (1 << 8)}, F64, 32, dict(max_alt=0.0)),  # ... refsafe, warm start and ctrl clamping off
+    ("hopper", {"disableflags": (1 << 7) | (1 << 11)}, F64, 32, dict(tol_sol=1e-6)),         # ... gravity and actuation off
+    ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, F64, 32, dict(max_alt=0.0)),      # ... springs (hence every passive force) and limits off
+    ("pendula", {}, F64, 64, dict(max_alt=0.0)),                                # bundled: every joint type, ball limits, gravcomp, mocap, tendons
+    ("tendon_fixed", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),
+]
+
+
+def case_id(c):
+    xml, ov, dt, B, _ = c
+    return f"{xml}-{'-'.join(f'{k}{v}' for k, v in ov.items()) or 'default'}-{str(dt)[6:]}-B{B}"
+
+
+def seeded_batch(xml, overrides, dtype, B):
+    """The bench's input recipe (make_data state, small random velocities, controls), with poses jittered where the scene would
+    otherwise be a single symmetric configuration."""
+    mx = load_model(xml, overrides, dtype)
+    rng = np.random.RandomState(42)
+    d = mt.make_data(mx).expand(B).clone()
+    d = d.replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(B, mx.nu)))
+    if any(p[0] >= 5 for p in mx.tables.pairs):  # convex pairs: free bodies resting on each other, jitter the poses too
+        q = d.qpos.clone()
+        for j in range(mx.njnt):
+            a = int(mx.jnt_qposadr[j])
+            if int(mx.jnt_type.data[j]) != 0:  # hinge / slide joints of mixed models: a small angle
+                q[:, a] += torch.tensor(0.05 * rng.randn(B))
+                continue
+            q[:, a : a + 3] += torch.tensor(0.01 * rng.randn(B, 3))
+            q[:, a + 3 : a + 7] += torch.tensor(0.03 * rng.randn(B, 4))
+        d = d.replace(qpos=q, qvel=torch.tensor(0.2 * rng.randn(B, mx.nv)))
+    if xml == "sensor_rig":  # move and spin the rover so every sensor reads something different per environment
+        q = d.qpos.clone()
+        q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))
+        q[:, 3:7] += torch.tensor(0.2 * rng.randn(B, 4))
+        q[:, 7:] += torch.tensor(0.3 * rng.randn(B, mx.nq - 7))
+        d = d.replace(qpos=q, qvel=torch.tensor(0.5 * rng.randn(B, mx.nv)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    return mx, d
+
+
+# the differential campaign of round 1 (tools/fuzz_parity.py): big perturbations, every input leaf randomised
+FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
+    ("humanoid", {"solver": 1}, F64, 1e-8), ("humanoid", {}, F64, 1e-8), ("humanoid", {"iterations": 20, "ls_iterations": 20}, F32, 5e-3),
+    ("ant", {}, F64, 1e-7), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 5e-3), ("ant", {"solver": 1, "cone": 1}, F64, 1e-5),
+    ("halfcheetah", {}, F64, 1e-8), ("hopper", {}, F64, 1e-8), ("walker2d", {"integrator": 1}, F64, 1e-8),
+    ("swimmer", {"viscosity": 0.05}, F64, 1e-8), ("cartpole", {}, F64, 1e-8), ("satellite_small", {}, F64, 1e-8),
+    ("sensor_rig", {}, F64, 1e-8), ("mesh_contact", {}, F64, 1e-8), ("mesh_contact", {"integrator": 1}, F64, 1e-8), ("convex_primitives", {}, F64, 1e-8),
+    ("equality_loops", {}, F64, 1e-8), ("equality", {}, F64, 1e-8), ("ball_limits", {}, F64, 1e-8),
+    ("tendon_fixed", {}, F64, 1e-8), ("gravcomp_arm", {}, F64, 1e-8), ("gravcomp_arm", {"integrator": 1}, F64, 1e-8), ("ball_free_actuators", {}, F64, 1e-8),
+    ("mocap_target", {}, F64, 1e-8), ("pendula", {}, F64, 1e-8), ("pendula", {"integrator": 1, "solver": 1}, F32, 5e-3),
+    ("frictionloss_dof", {}, F64, 1e-8), ("ant_frictionloss", {}, F64, 1e-8),
+]
+
+
+def fuzz_batch(xml, overrides, dtype, B):
+    mx = load_model(xml, overrides, dtype)
+    rng = np.random.RandomState(zlib.crc32(xml.encode()) % 1000)  # stable across processes (hash() is salted)
+    d = mt.make_data(mx).expand(B).clone()
+    q = d.qpos.clone()
+    scale = torch.tensor(rng.uniform(0.0, 0.5, size=(B, 1)))  # per-environment perturbation size, some environments stay at qpos0
+    q = q + scale * torch.tensor(rng.randn(B, mx.nq))
+    kw = dict(qpos=q, qvel=torch.tensor(rng.randn(B, mx.nv)) * scale * 4, ctrl=torch.tensor(rng.uniform(-1.2, 1.2, size=(B, mx.nu))),
+              qfrc_applied=torch.tensor(0.5 * rng.randn(B, mx.nv)), xfrc_applied=torch.tensor(0.5 * rng.randn(B, mx.nbody, 6)),
+              qacc_warmstart=torch.tensor(rng.randn(B, mx.nv)) * scale)
+    if mx.nmocap:
+        kw["mocap_pos"] = d.mocap_pos + 0.1 * torch.tensor(rng.randn(B, mx.nmocap, 3))
+        kw["mocap_quat"] = d.mocap_quat + 0.3 * torch.tensor(rng.randn(B, mx.nmocap, 4))
+    if mx.neq:
+        kw["eq_active"] = torch.tensor(rng.randint(0, 2, size=(B, mx.neq)), dtype=torch.int32) * d.eq_active.clamp(max=1) + d.eq_active * 0
+        kw["eq_active"] = torch.where(torch.tensor(rng.rand(B, mx.neq) < 0.3), torch.zeros_like(d.eq_active), d.eq_active)
+    d = d.replace(**kw)
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    return mx, d

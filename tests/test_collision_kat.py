@@ -109,7 +109,7 @@ def test_hull_topology():
 
     t = convex.tables_from_points(np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], dtype=float) * [0.1, 0.2, 0.3])
     assert t["vert"].shape == (8, 3) and t["face"].shape == (6, 4) and t["edge"].shape == (12, 2)
-    lite = mt.mjcf.from_xml_path(os.path.join(os.path.dirname(__file__), "golden", "models", "mesh_contact.xml"))
+    lite = mt.mjcf.from_xml_path(mt.test_data_path("mesh_contact.xml"))
     dod = convex.geom_convex_tables(lite)[2]
     assert dod["vert"].shape == (20, 3) and dod["face"].shape == (12, 5) and dod["edge"].shape == (30, 2)
     for tab in (t, dod):

@@ -1,8 +1,8 @@
 """HIP path (through the C ABI, via mujoco_torch_amd.step) against golden vectors and the CPU oracle.
 
-Tolerances (relative to the leaf's max magnitude):
-  float64: 1e-9 for leaves upstream of the solver, 1e-7 for solver-dependent leaves on the admissible
-           branch (see _util.check_against_oracle); north_star asks for < 1e-8 on the state.
+Tolerances (max-norm per leaf: |got - want|max / max(|want|max, floor) -- _util.rel_err; NOT element-wise):
+  float64: 1e-9 for leaves upstream of the solver, 1e-8 (north_star's bar) for solver-dependent leaves on the accepted
+           oracle branch, with the fraction of environments allowed on a non-natural branch bounded per case (tests/_cases.py);
   float32: 2e-4 / 2e-3.
 """
 import numpy as np
@@ -11,13 +11,11 @@ import torch
 
 import mujoco_torch_amd as mt
 import pyoracle
+from _cases import SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, seeded_batch
 from _util import (CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
 
 pytestmark = pytest.mark.gpu
-
-TOL_PRE = {torch.float64: 1e-9, torch.float32: 2e-4}
-TOL_SOL = {torch.float64: 1e-7, torch.float32: 2e-3}
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
@@ -30,7 +28,7 @@ def test_step_matches_reference_golden(case, oracle_lib):
     tol_pre, tol_sol = TOL_PRE[g.dtype], max(TOL_SOL[g.dtype], CASE_TOL_SOL.get(case, 0.0))
     via_oracle = 0
     for s in range(g.nsteps):
-        out = gpu_out_to_numpy(mt.step(mdev, d.to("cuda")))
+        out = gpu_out_to_numpy(mt.step(mdev, d.to("cuda"), fixed_iterations=g.fixed_iterations))
         want = lambda n: np.stack([g.expected(e, s, n) for e in range(g.nenv)])
         what = f"{case} step{s}"
         assert_ints_equal(lambda n: out[n], want, what=what)
@@ -41,72 +39,25 @@ def test_step_matches_reference_golden(case, oracle_lib):
                 # not the branch the reference's rounding took: it must still be an admissible outcome of the same
                 # algorithm (line-search noise candidates, narrow-phase index ties), which the oracle verifies
                 via_oracle += 1
-                check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, tol_pre, tol_sol, what=f"{what} env{e}")
+                check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, tol_pre, tol_sol, what=f"{what} env{e}", fixed_iterations=g.fixed_iterations)
         d = pyoracle.apply(d, {n: want(n) for n in REAL_LEAVES + INT_LEAVES})
     print(f"{case}: {via_oracle}/{g.nsteps * g.nenv} env-steps verified through an admissible oracle branch instead of the golden one")
 
 
-@pytest.mark.parametrize("xml,overrides,dtype,B", [
-    ("humanoid", {"solver": 1}, torch.float64, 256),
-    ("humanoid", {}, torch.float64, 64),
-    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 128),
-    ("ant", {}, torch.float64, 64),
-    ("cartpole", {}, torch.float64, 64),
-    ("mesh_contact", {}, torch.float32, 256),   # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
-    ("mesh_contact", {}, torch.float64, 64),
-    ("mesh_contact", {"solver": 1, "cone": 1, "_tol_sol": 1e-5}, torch.float64, 32),  # CG on 72 ill-conditioned rows: the iterates of 100 iterations amplify rounding
-    ("convex_meshes", {}, torch.float64, 32),
-    ("convex_primitives", {}, torch.float64, 32),
-    ("convex_primitives", {}, torch.float32, 32),
-    ("sensor_rig", {}, torch.float64, 64),                                         # sensors: IMU, rangefinders, joint sensors
-    ("sensor_rig", {"integrator": 1}, torch.float32, 64),                          # ... RK4, float32 (rays intersect in double)
-    ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, torch.float64, 64),  # fluid forces: density + viscosity + wind
-    ("ant_frictionloss", {}, torch.float64, 64),                                   # dof frictionloss rows, Newton
-    ("ant_frictionloss", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),      # ... CG (100 iterations on a piecewise-quadratic cost amplify rounding)
-    ("halfcheetah", {}, torch.float64, 64),
-    ("hopper", {"_tol_sol": 1e-6}, torch.float64, 64),
-    ("equality_loops", {}, torch.float64, 64),                                     # equality rows: closed loop, weld, joint couplings
-    ("equality_loops", {"integrator": 1, "solver": 1, "_tol_sol": 1e-4}, torch.float64, 32),  # RK4 + CG: 100 CG iterations on the stiff always-active rows amplify rounding (float32: golden equality_loops_rk4_f32)
-    ("equality", {}, torch.float64, 32),                                           # bundled: site-form constraints carried inactive
-    ("ant", {"disableflags": 1 << 4}, torch.float64, 32),                          # disable flags (test/constraint_test.py:148-200): contacts off
-    ("humanoid", {"disableflags": 1}, torch.float64, 32),                          # ... every constraint off (nefc = 0)
-    ("ant", {"disableflags": (1 << 12) | (1 << 9) | (1 << 8)}, torch.float64, 32), # ... refsafe, warm start and ctrl clamping off
-    ("hopper", {"disableflags": (1 << 7) | (1 << 11), "_tol_sol": 1e-6}, torch.float64, 32),  # ... gravity and actuation off
-    ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, torch.float64, 32),     # ... springs (hence every passive force) and limits off
-    ("pendula", {}, torch.float64, 64),                                            # bundled: every joint type, ball limits, gravcomp, mocap, tendons
-    ("tendon_fixed", {"solver": 1, "_tol_sol": 1e-5}, torch.float64, 64),
-])
-def test_step_matches_oracle_on_seeded_batch(xml, overrides, dtype, B, oracle_lib):
-    """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs."""
-    overrides = dict(overrides)
-    tol_sol = overrides.pop("_tol_sol", TOL_SOL[dtype])
-    mx = load_model(xml, overrides, dtype)
-    rng = np.random.RandomState(42)
-    d = mt.make_data(mx).expand(B).clone()
-    d = d.replace(qvel=torch.tensor(0.01 * rng.randn(B, mx.nv)), ctrl=torch.tensor(0.3 * rng.randn(B, mx.nu)))
-    if any(p[0] >= 5 for p in mx.tables.pairs):  # convex pairs: free bodies resting on each other, jitter the poses too
-        q = d.qpos.clone()
-        for j in range(mx.njnt):
-            a = int(mx.jnt_qposadr[j])
-            if int(mx.jnt_type.data[j]) != 0:  # hinge / slide joints of mixed models: a small angle
-                q[:, a] += torch.tensor(0.05 * rng.randn(B))
-                continue
-            q[:, a : a + 3] += torch.tensor(0.01 * rng.randn(B, 3))
-            q[:, a + 3 : a + 7] += torch.tensor(0.03 * rng.randn(B, 4))
-        d = d.replace(qpos=q, qvel=torch.tensor(0.2 * rng.randn(B, mx.nv)))
-    if xml == "sensor_rig":  # move and spin the rover so every sensor reads something different per environment
-        q = d.qpos.clone()
-        q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))
-        q[:, 3:7] += torch.tensor(0.2 * rng.randn(B, 4))
-        q[:, 7:] += torch.tensor(0.3 * rng.randn(B, mx.nq - 7))
-        d = d.replace(qpos=q, qvel=torch.tensor(0.5 * rng.randn(B, mx.nv)))
-    if dtype != torch.float64:
-        d = d.to(dtype)
+@pytest.mark.parametrize("case", SEEDED_CASES, ids=case_id)
+def test_step_matches_oracle_on_seeded_batch(case, oracle_lib):
+    """Seeded batch in the bench's input recipe, several steps; each step is checked on identical inputs against the oracle:
+    solver leaves within the case's tolerance (1e-8 in float64 unless the case states a measured reason), and no more than the
+    case's bound of environments on a non-natural line-search branch."""
+    xml, overrides, dtype, B, bounds = case
+    tol_sol = bounds.get("tol_sol", TOL_SOL[dtype])
+    mx, d = seeded_batch(xml, overrides, dtype, B)
     mdev = mx.to("cuda")
     dg = d.to("cuda")
     for s in range(3):
         og = mt.step(mdev, dg)
-        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4)
+        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4,
+                                           max_alt_frac=bounds.get("max_alt", 1.0), max_tie_frac=bounds.get("max_tie", 1.0))
         print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural line-search branch, worst solver rel err {worst:.2e}")
         dg = og
 
@@ -460,3 +411,108 @@ def test_two_leading_batch_dims_equal_the_flat_batch():
     assert tuple(got.qpos.shape) == (E, T, mx.nq) and tuple(got.contact.dist.shape)[:2] == (E, T)
     for n in ("qpos", "qvel", "qacc", "efc_J", "contact_frame", "xpos"):
         assert torch.equal(leaf(got, n).reshape(leaf(want, n).shape), leaf(want, n)), n
+
+
+def test_library_leaf_counts_and_kernel_io():
+    """mjh_model_leaf_counts (what the binding validates tensor sizes against) equals the per-leaf sizes of make_data, and
+    mjh_model_kernel_io accounts for no more than the leaves a kernel could touch."""
+    import ctypes
+
+    import _hostsim
+    from mujoco_torch_amd import native
+
+    for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32), ("pendula", {}, torch.float64), ("mesh_contact", {}, torch.float32)):
+        mx = load_model(xml, ov, dt)
+        nm = native.get_native_model(mx.to("cuda"), torch.device("cuda", 0), dt)
+        desc, keep = native.pack_model(mx, dt)
+        assert np.array_equal(nm.leaf_counts, _hostsim.leaf_counts(desc)), xml
+        d = mt.make_data(mx)
+        for n, c in zip(REAL_LEAVES + INT_LEAVES, nm.leaf_counts):
+            assert leaf(d, n).numel() == c, (xml, n)
+        total_r = total_w = 0
+        for k in range(10):
+            rw = (ctypes.c_int64 * 2)()
+            if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
+                assert rw[0] > 0 and rw[1] > 0, (xml, k)
+                total_r, total_w = total_r + rw[0], total_w + rw[1]
+        whole = sum(leaf(d, n).numel() * leaf(d, n).element_size() for n in REAL_LEAVES + INT_LEAVES) * (4 if dt == torch.float32 else 8) // 8
+        assert total_w <= 1.2 * whole and total_r <= 1.2 * whole, (xml, total_r, total_w, whole)
+
+
+def test_model_edits_after_device_put_reach_the_kernels(oracle_lib):
+    """mx.replace(...) / mx.tree_replace(...) after device_put (reference test/smooth_test.py:204) must step
+    the edited values; checked against the oracle run on the edited model."""
+    mx = load_model("hopper")
+    B = 16
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.1 * np.random.RandomState(0).randn(B, mx.nv)))
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    base = mt.step(mdev, dg)
+    for edit in (lambda m: m.replace(body_mass=m.body_mass * 2.0), lambda m: m.tree_replace({"opt.timestep": m.opt.timestep * 0.5}),
+                 lambda m: m.tree_replace({"opt.disableflags": m.opt.disableflags | mt.DisableBit.GRAVITY}), lambda m: m.replace(dof_damping=m.dof_damping + 0.5)):
+        m2 = edit(mdev)
+        got = mt.step(m2, dg)
+        assert not torch.equal(got.qpos, base.qpos)
+        check_against_oracle(edit(mx), d, gpu_out_to_numpy(got), 1e-9, 1e-8, what="edited model", max_alt_frac=0.0)
+    assert torch.equal(mt.step(mdev, dg).qpos, base.qpos)   # the original model still steps its own values
+    m3 = mdev.replace(body_mass=mdev.body_mass.clone())
+    assert torch.equal(mt.step(m3, dg).qpos, base.qpos)
+    m3.body_mass[2] *= 3.0                                   # in-place edit of a model leaf that has been stepped already
+    assert not torch.equal(mt.step(m3, dg).qpos, base.qpos)
+    with pytest.raises(NotImplementedError, match="device_put again"):
+        mt.step(mdev.tree_replace({"opt.cone": mt.ConeType.ELLIPTIC}), dg)
+
+
+def test_bad_leaf_sizes_and_destinations_are_rejected_on_the_device_path():
+    mx = load_model("humanoid", {"solver": 1})
+    B = 8
+    dg = mt.make_data(mx).expand(B).clone().to("cuda")
+    mdev = mx.to("cuda")
+    with pytest.raises(ValueError, match="ctrl holds"):
+        mt.step(mdev, dg.replace(ctrl=torch.zeros(mx.nu, dtype=torch.float64, device="cuda")))
+    with pytest.raises(ValueError, match="holds"):
+        mt.step(mdev, dg, out=dg[:4].clone())
+    with pytest.raises(ValueError, match="not contiguous"):
+        mt.step(mdev, dg, out=mt.make_data(mx).to("cuda").expand(B))
+    with pytest.raises(ValueError, match="shares storage"):
+        mt.step(mdev, dg, out=dg.clone().replace(qvel=dg.qvel))
+    with pytest.raises(RuntimeError, match="is on cpu"):
+        mt.step(mdev, dg.replace(ctrl=torch.zeros(B, mx.nu, dtype=torch.float64)))
+    assert torch.isfinite(mt.step(mdev, dg).qpos).all()
+
+
+def test_two_ranks_on_one_device_step_the_product():
+    """N > 1 path on the HIP library: two gloo ranks share cuda:0, each steps its contiguous shard with mt.step, the gathered
+    state equals the unsharded step bit for bit (tests/mp_worker.py)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", MJH_MP_DEVICE="cuda", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "tests", "mp_worker.py")]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "MP_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_config4_batch_properties():
+    """BASELINE config 4's per-GPU share (humanoid, B = 32768, float64): size-independent properties -- tiled environments are
+    bit-identical to their B = 64 twins after two steps through the drop-in call, outputs finite, unit quaternions."""
+    mx = load_model("humanoid", {"solver": 1})
+    B, U = 32768, 64
+    rng = np.random.RandomState(0)
+    base = mt.make_data(mx).expand(U).clone().replace(qvel=torch.tensor(0.01 * rng.randn(U, mx.nv)))
+    idx = torch.arange(B) % U
+    mdev = mx.to("cuda")
+    small = mt.step(mdev, mt.step(mdev, base.to("cuda")))
+    big = mt.step(mdev, mt.step(mdev, base[idx].clone().to("cuda")))
+    idx = idx.to("cuda")
+    for n in ("qpos", "qvel", "qacc", "efc_force", "efc_J", "contact_frame", "qM", "qLD", "cvel", "contact_geom"):
+        a, b = leaf(big, n), leaf(small, n)
+        assert torch.equal(a, b[idx]), f"{n}: tiled environments differ"
+        if a.is_floating_point():
+            assert torch.isfinite(a).all(), n
+    q = big.qpos[:, 3:7]
+    assert torch.allclose(q.norm(dim=-1), torch.ones(B, dtype=q.dtype, device=q.device), atol=1e-12)
+    del big
+    torch.cuda.empty_cache()

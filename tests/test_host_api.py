@@ -71,7 +71,7 @@ def mx_path(name):
 
     from _util import GOLD
 
-    return os.path.join(GOLD, "models", name + ".xml")
+    return mt.test_data_path(name + ".xml")
 
 
 def test_container_semantics():
@@ -142,7 +142,7 @@ def test_device_put_data_and_device_get_into_roundtrip():
     """`device_put(MjData)` / `device_get_into(MjData | list, Data)` (reference device.py:1011-1205) on duck-typed MjData objects."""
     from types import SimpleNamespace
 
-    lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", "hopper.xml"))
+    lite = mt.mjcf.from_xml_path(mt.test_data_path("hopper.xml"))
     mx = mt.device_put(lite)
     nq, nv, nu, nb = mx.nq, mx.nv, mx.nu, mx.nbody
 
@@ -206,7 +206,7 @@ def test_disable_flags_shrink_the_constraint_sizes():
     from mujoco_torch_amd import DisableBit
 
     def sizes(xml, flag):
-        lite = mt.mjcf.from_xml_path(os.path.join(ROOT, "tests", "golden", "models", xml + ".xml"))
+        lite = mt.mjcf.from_xml_path(mt.test_data_path(xml + ".xml"))
         lite.opt.disableflags = int(lite.opt.disableflags) | int(flag)
         return mt.device_put(lite).constraint_sizes_py
 

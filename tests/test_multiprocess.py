@@ -23,7 +23,7 @@ def test_shard_ranges_partition_the_batch():
 
 
 def test_two_rank_gloo_sharded_step_matches_unsharded(oracle_lib):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", MJH_MP_DEVICE="cpu")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "tests", "mp_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)

@@ -120,7 +120,7 @@ def test_patched_models_compile():
 
 
 def test_container_masked_assignment_touches_only_masked_rows():
-    mx = mt.device_put(mt.mjcf.from_xml_path(os.path.join(GOLD, "models", "hopper.xml")))
+    mx = mt.device_put(mt.mjcf.from_xml_path(mt.test_data_path("hopper.xml")))
     d = mt.make_data(mx).expand(5).clone()
     d.qpos.copy_(torch.arange(5.0).reshape(5, 1).expand(5, mx.nq))
     fresh = mt.make_data(mx).expand(2).clone()
@@ -134,7 +134,7 @@ def test_container_masked_assignment_touches_only_masked_rows():
 
 
 def test_native_entry_points_refuse_cpu_tensors():
-    mx = mt.device_put(mt.mjcf.from_xml_path(os.path.join(GOLD, "models", "hopper.xml")))
+    mx = mt.device_put(mt.mjcf.from_xml_path(mt.test_data_path("hopper.xml")))
     d = mt.make_data(mx).expand(3).clone()
     with pytest.raises(RuntimeError, match="HIP device"):
         mt.reset_where(mx, d, mt.make_data(mx), torch.ones(3, dtype=torch.bool))
@@ -218,7 +218,7 @@ def _leaf_items(d):
 @pytest.mark.gpu
 @pytest.mark.parametrize("xml,dtype", [("humanoid", torch.float64), ("ant", torch.float32), ("mesh_contact", torch.float32)])
 def test_reset_where_equals_masked_index_assignment(xml, dtype):
-    lite = mt.mjcf.from_xml_path(os.path.join(GOLD, "models", xml + ".xml"))
+    lite = mt.mjcf.from_xml_path(mt.test_data_path(xml + ".xml"))
     mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype).to("cuda")
     B = 37
     g = torch.Generator().manual_seed(5)
