@@ -261,6 +261,7 @@ def main(args):
     mdev = mx.to(device)
     # different seeds per rank: independent environments, no collective on the data path
     loop = Loop(mdev, build_inputs(mx, B, dtype, device, seed=42 + rank))
+    loop.bufs, loop.cur = [loop.d.clone(), loop.d.clone()], 0   # the out= loop starts from the same state (solver work depends on it)
 
     loop.dropin(args.warmup)
     elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)

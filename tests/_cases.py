@@ -19,8 +19,10 @@ TOL_SOL = {F64: 1e-8, F32: 2e-3}
 
 # (xml, overrides, dtype, B, {bounds})
 SEEDED_CASES = [
-    ("humanoid", {"solver": 1}, F64, 256, dict(max_alt=0.35)),                  # BASELINE config 2: iterations=1 / ls_iterations=4 stop on the knife edge
-    ("humanoid", {}, F64, 64, dict(max_alt=0.35)),                              # ... Newton, same early stop
+    # BASELINE config 2: iterations=1 / ls_iterations=4 stop the line search on its knife edge: measured 28.5 % of the
+    # environments on a non-natural branch (worst error on the accepted branch 1e-13), Newton 55 % (profiles/r02/parity_survey_first.log)
+    ("humanoid", {"solver": 1}, F64, 256, dict(max_alt=0.40)),
+    ("humanoid", {}, F64, 64, dict(max_alt=0.65)),
     ("humanoid", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 64, dict(max_alt=0.0)),   # converged: branches re-converge
     ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 128, {}),          # BASELINE config 3
     ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F64, 64, dict(max_alt=0.0)),
@@ -28,7 +30,11 @@ SEEDED_CASES = [
     ("cartpole", {}, F64, 64, dict(max_alt=0.0)),
     ("mesh_contact", {}, F32, 256, {}),                                         # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
     ("mesh_contact", {}, F64, 64, dict(max_alt=0.0)),
-    ("mesh_contact", {"solver": 1, "cone": 1}, F64, 32, dict(tol_sol=1e-5)),    # CG on 72 ill-conditioned rows: 100 iterations amplify rounding
+    # CG stops on the reference's own tolerance (1e-8 of the scaled gradient / improvement, solver.py:501-508): two correct
+    # implementations may stop an iteration apart and CG's iterate error at that point is O(tolerance x cond(M^-1 H)); measured
+    # cond = 3.2e2 and a worst error of 5.8e-7 here.  The same scene with the tolerance out of the way must meet 1e-8:
+    ("mesh_contact", {"solver": 1, "cone": 1}, F64, 32, dict(tol_sol=1e-5)),
+    ("mesh_contact", {"solver": 1, "cone": 1, "tolerance": 1e-14, "iterations": 300}, F64, 32, {}),
     ("convex_meshes", {}, F64, 32, dict(max_alt=0.0)),
     ("convex_primitives", {}, F64, 32, dict(max_alt=0.0)),
     ("convex_primitives", {}, F32, 32, {}),
@@ -36,19 +42,21 @@ SEEDED_CASES = [
     ("sensor_rig", {"integrator": 1}, F32, 64, {}),                             # ... RK4, float32 (rays intersect in double)
     ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, F64, 64, dict(max_alt=0.0)),  # fluid forces: density + viscosity + wind
     ("ant_frictionloss", {}, F64, 64, dict(max_alt=0.0)),                       # dof frictionloss rows, Newton
-    ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG: 100 iterations on a piecewise-quadratic cost amplify rounding
+    ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG stopping on its tolerance across frictionloss zone switches (measured 8.1e-7)
+    ("ant_frictionloss", {"solver": 1, "tolerance": 1e-14, "iterations": 300}, F64, 64, {}),
     ("halfcheetah", {}, F64, 64, dict(max_alt=0.0)),
-    ("hopper", {}, F64, 64, dict(tol_sol=1e-6)),
+    ("hopper", {}, F64, 64, dict(max_alt=0.0)),
     ("equality_loops", {}, F64, 64, dict(max_alt=0.0)),                         # equality rows: closed loop, weld, joint couplings
-    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-4)),  # RK4 + CG on the stiff always-active rows
+    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-4)),  # RK4 + CG stopping on its tolerance in each of four solves, stiff always-active rows (cond 2.5e2, measured 6e-5)
+    ("equality_loops", {"integrator": 1, "solver": 1, "tolerance": 1e-14, "iterations": 300}, F64, 32, {}),
     ("equality", {}, F64, 32, dict(max_alt=0.0)),                               # bundled: site-form constraints carried inactive
     ("ant", {"disableflags": 1 << 4}, F64, 32, dict(max_alt=0.0)),              # disable flags (test/constraint_test.py:148-200): contacts off
     ("humanoid", {"disableflags": 1}, F64, 32, dict(max_alt=0.0)),              # ... every constraint off (nefc = 0)
     ("ant", {"disableflags": (1 << 12) | (1 << 9) | (1 << 8)}, F64, 32, dict(max_alt=0.0)),  # ... refsafe, warm start and ctrl clamping off
-    ("hopper", {"disableflags": (1 << 7) | (1 << 11)}, F64, 32, dict(tol_sol=1e-6)),         # ... gravity and actuation off
+    ("hopper", {"disableflags": (1 << 7) | (1 << 11)}, F64, 32, dict(max_alt=0.0)),         # ... gravity and actuation off
     ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, F64, 32, dict(max_alt=0.0)),      # ... springs (hence every passive force) and limits off
     ("pendula", {}, F64, 64, dict(max_alt=0.0)),                                # bundled: every joint type, ball limits, gravcomp, mocap, tendons
-    ("tendon_fixed", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),
+    ("tendon_fixed", {"solver": 1}, F64, 64, dict(max_alt=0.0)),
 ]
 
 
