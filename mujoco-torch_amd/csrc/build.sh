@@ -12,10 +12,10 @@ LOG="$(mktemp)"
   -Rpass-analysis=kernel-resource-usage "$@" -o "$HERE/../lib/libmjhip.so" "$HERE/mjhip.hip" 2> "$LOG" || { cat "$LOG"; exit 1; }
 grep -E "error|warning: " "$LOG" || true
 NFUNC=$(grep -c "Function Name:" "$LOG" || true)
-NKERN=$(grep "Function Name:" "$LOG" | grep -cE "mjh_phase_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" || true)
+NKERN=$(grep "Function Name:" "$LOG" | grep -cE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" || true)
 if [ "$NFUNC" != "$NKERN" ]; then
   echo "build.sh: device functions were not inlined into the kernels:" >&2
-  grep "Function Name:" "$LOG" | grep -vE "mjh_phase_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" >&2
+  grep "Function Name:" "$LOG" | grep -vE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" >&2
   exit 1
 fi
 grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" "$LOG" | sed 's/.*remark: *//' | paste - - - - | sed 's/\[-Rpass[^]]*\]//g' > "$HERE/../lib/resource_usage.txt"

@@ -41,10 +41,14 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 #define PH_CON 4   /* collision + make_constraint               */
 #define PH_VEL 8   /* transmission, _velocity, _actuation, _acceleration */
 #define PH_SOL 16  /* solve + Euler / RK4 bookkeeping           */
+#define PH_SOL2 32   /* register solver (mjh_sol2_kernel): the part of its arena that lives while the solve runs ...            */
+#define PH_SOL2T 64  /* ... and the arrays of the integrator tail, carved over it once the constraint rows are dead           */
+#define PH_SOL2P 128 /* ... after the state the tail integrates, which is parked for the whole phase                           */
 #define MJH_NPHASE 5
+#define MJH_NARENA 6  /* arenas carved per model: the five phases + the register solver */
 #define MJH_LDS_ARRAYS(X, m)                                                                                   \
-  X(qpos, m.nq, PH_KIN | PH_VEL | PH_SOL) X(qpos_con, m.con_general ? m.nq : 0, PH_CON) /* general constraint phase only */ X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL)                     \
-  X(act, m.na, PH_VEL | PH_SOL)                                                                                \
+  X(qpos, m.nq, PH_KIN | PH_VEL | PH_SOL | PH_SOL2P) X(qpos_con, m.con_general ? m.nq : 0, PH_CON) /* general constraint phase only */ X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL | PH_SOL2P)                     \
+  X(act, m.na, PH_VEL | PH_SOL | PH_SOL2P)                                                                                \
   X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, 9 * m.nbody, PH_KIN)                      \
   X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
   X(xanchor, 3 * m.njnt, PH_KIN) X(xaxis, 3 * m.njnt, PH_KIN)                                                  \
@@ -60,27 +64,29 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(qLDp, m.nv * (m.nv + 1) / 2, PH_SOL) /* lower triangle, packed rows */                                      \
   X(qMs, m.sol_qm_lds ? m.nv * m.nv : 0, PH_SOL) /* only when the solver iterates enough to amortise the copy */ \
   X(qLD_inv, m.nv, PH_SOL)                                                                            \
-  X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL)                 \
-  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
-  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
+  X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL | PH_SOL2T)                 \
+  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL | PH_SOL2T) /* packed lower rows */ \
+  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL | PH_SOL2T)              \
   X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
   X(efc_J, (m.con_general ? m.nefc : m.nefc - m.nl) * m.nv, PH_CON) X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
-  X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL) /* dense rows of the contacts */                                   \
+  X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
   X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.con_general ? m.ne + m.nf + m.nlb + m.nl + m.nlt : 0, PH_CON) /* plain: equal to efc_pos for slide / hinge limits */ X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL) X(ten_len, m.ntendon, PH_VEL) X(ten_frc, m.ntendon, PH_VEL)                         \
-  X(act_dot, m.na, PH_VEL | PH_SOL)                                                                            \
+  X(act_dot, m.na, PH_VEL | PH_SOL | PH_SOL2P)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
-  X(qfrc_smooth, m.nv, PH_VEL | PH_SOL) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
-  X(qacc_warm, m.nv, PH_SOL) X(qacc, m.nv, PH_SOL) X(qfrc_constraint, m.nv, PH_SOL)                            \
-  X(s_qacc, m.nv, PH_SOL) X(s_qfrc, m.nv, PH_SOL) X(s_Ma, m.nv, PH_SOL) X(s_grad, m.nv, PH_SOL)                \
-  X(s_Mgrad, m.nv, PH_SOL) X(s_search, m.nv, PH_SOL) X(s_mv, m.nv, PH_SOL) X(s_pgrad, m.nv, PH_SOL)            \
-  X(s_pMgrad, m.nv, PH_SOL) X(tmp_nv, m.nv, PH_SOL) X(tmp_nv2, m.nv, PH_SOL)                                   \
+  X(qfrc_smooth, m.nv, PH_VEL | PH_SOL | PH_SOL2T) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
+  X(qacc_warm, m.nv, PH_SOL) X(qacc, m.nv, PH_SOL | PH_SOL2T) X(qfrc_constraint, m.nv, PH_SOL | PH_SOL2T)                            \
+  X(s_qacc, m.nv, PH_SOL) X(s_qfrc, m.nv, PH_SOL) X(s_Ma, m.nv, PH_SOL) X(s_grad, m.nv, PH_SOL | PH_SOL2T)                \
+  X(s_Mgrad, m.nv, PH_SOL | PH_SOL2T) X(s_search, m.nv, PH_SOL) X(s_mv, m.nv, PH_SOL | PH_SOL2T) X(s_pgrad, m.nv, PH_SOL | PH_SOL2T)            \
+  X(s_pMgrad, m.nv, PH_SOL) X(tmp_nv, m.nv, PH_SOL | PH_SOL2T) X(tmp_nv2, m.nv, PH_SOL | PH_SOL2T)                                   \
   X(s_Jaref, m.nefc, PH_SOL) X(s_force, m.nefc, PH_SOL) X(s_jv, m.nefc, PH_SOL) X(s_quad, 3 * m.nefc, PH_SOL)  \
-  X(tmp_nq, m.nq, PH_SOL)
+  X(tmp_nq, m.nq, PH_SOL | PH_SOL2T)                                                                                        \
+  X(r_vs, m.nv, PH_SOL2) X(r_vs2, m.nv, PH_SOL2) /* register solver: vectors staged for broadcast reads */     \
+  X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, m.nefc, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
 
 struct LdsOff {
 #define X(n, c, p) int n;
@@ -213,11 +219,29 @@ __device__ __forceinline__ bool sub_any(bool p) {
   const int sh = (int)(threadIdx.x & ~(W - 1));
   return ((m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1))) != 0;
 }
-// value of lane k OF THIS ENVIRONMENT's lane group (k uniform): v_readlane for a whole wave, a bpermute otherwise
+// value of lane k OF THIS ENVIRONMENT's lane group (k wave-uniform): v_readlane for a whole wave; for two 32-lane environments
+// one v_readlane per half and a select -- scalar broadcasts on the VALU / SALU, where a bpermute would be an LDS-pipe round trip
+// in the middle of the triangular solves' dependent chains
 template <int W, typename T>
 __device__ __forceinline__ T sub_read(T v, int k) {
   if (W == MJH_WAVE) return read_lane(v, k);
+  if (W == 32) {
+    const T a = read_lane(v, k), b = read_lane(v, 32 + k);
+    return threadIdx.x < 32 ? a : b;
+  }
   return __shfl(v, (int)(threadIdx.x & ~(W - 1)) + k, MJH_WAVE);
+}
+// sum over the lanes of this environment's group, every lane of the group ends with the same bits.  W = 32: the DPP steps leave
+// each 16-lane row's sum in all its lanes; rows 0 + 1 serve the first environment, rows 2 + 3 the second.
+template <int W, typename T>
+__device__ __forceinline__ T sub_sum(T v) {
+  if (W == MJH_WAVE) return wave_sum(v);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  const T a = read_lane(v, 0) + read_lane(v, 16), b = read_lane(v, 32) + read_lane(v, 48);
+  return threadIdx.x < 32 ? a : b;
 }
 
 // ---- small-vector math, reference math.py ------------------------------------------------------------------

@@ -41,6 +41,25 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
     if (n3 + n9 <= nj) { o.geom_xpos = o.efc_J; o.geom_xmat = o.efc_J + n3; }
     else { o.geom_xpos = off; o.geom_xmat = off + n3; off += n3 + n9; }
   }
+  if (phase_bit == PH_SOL2) {
+    // [parked state | solve arrays]; the integrator tail starts once the solve is over: its arrays are carved again over the solve arrays
+    LdsOff a, t;
+    int p0 = 0;
+#define X(n, c, p) a.n = p0; if ((p) & PH_SOL2P) p0 += (((c) + 1) & ~1);
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    int o1 = p0, o2 = p0;
+#define X(n, c, p) if ((p) & PH_SOL2P) o.n = a.n; else { o.n = o1; if ((p) & PH_SOL2) o1 += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+#define X(n, c, p) t.n = o2; if ((p) & PH_SOL2T) o2 += (((c) + 1) & ~1);
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+#define X(n, c, p) if ((p) & PH_SOL2T) o.n = t.n;
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    off = o1 > o2 ? o1 : o2;
+  }
   if (phase_bit == PH_CRB) {
     // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
     // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
@@ -348,6 +367,33 @@ __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, 
     const REAL xk = sub_read<W>(s * T.inv, k);
     if (i == k) s = xk;
     else if (i < k) s = s - T.col[k] * xk;
+  }
+  return s;
+}
+
+// Row i AND column i of a lower-triangular factor in ONE register array: lane i only ever needs L[i][k] for k <= i (forward
+// substitution) and L[k][i] for k >= i (backward), and the two index ranges meet at the diagonal -- t[k] = k <= i ? L[i][k] : L[k][i].
+template <typename REAL, int NMAX>
+struct TriPack {
+  REAL t[NMAX];
+  REAL inv;  // 1 / L[i][i]
+};
+// x = (L L^T)^-1 b, one element per lane (same step order as tri_solve / math.small_cholesky_solve :132-168)
+template <int W, typename REAL, int NMAX>
+__device__ __forceinline__ REAL tri_solve(const TriPack<REAL, NMAX>& T, REAL bi, int n) {
+  const int i = sub_lane<W>();
+  REAL s = (i < n) ? bi : (REAL)0;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) {
+    const REAL yk = sub_read<W>(s * T.inv, k);
+    if (i == k) s = yk;
+    else if (i > k) s = s - T.t[k] * yk;
+  }
+#pragma unroll
+  for (int k = NMAX - 1; k >= 0; k--) {
+    const REAL xk = sub_read<W>(s * T.inv, k);
+    if (i == k) s = xk;
+    else if (i < k) s = s - T.t[k] * xk;
   }
   return s;
 }
@@ -2287,6 +2333,14 @@ struct Env {
     } else {
       solve();
     }
+    integrate_tail();
+  }
+
+  // the integrator on the solved accelerations: _euler :313-328, or one stage of _rungekutta4 :331-370.  Reads S.qacc / qpos / qvel /
+  // act / act_dot / qfrc_smooth / qfrc_constraint from the arena (both solver kernels leave them there).
+  __device__ __forceinline__ void integrate_tail() {
+    const int l = lane();
+    const int nq = M.nq, nv = M.nv, na = M.na;
     if (!KA.do_step) return;
     const REAL dt = M.timestep;
     const REAL time0 = in.time ? in.time[e] : (REAL)0;
@@ -2353,6 +2407,350 @@ struct Env {
     wave_sync();
     advance(S.qpos(), S.s_pgrad(), S.act(), time0, S.act_dot(), S.s_mv(), S.tmp_nv2());
   }
+
+  // =====================================================================================================================================================
+  // Register solver (mjh_sol2_kernel): the solver phase of CG models with nv <= NMAX <= 28 dofs, slide / hinge limit rows and contact rows only, TWO
+  // ENVIRONMENTS PER WAVEFRONT (32 lanes each).  What the LDS solver above keeps in ~40 small arena arrays lives in registers here:
+  //   lane d < nv      every nv-vector (one element per lane), row d and column d of the Cholesky factor (TriReg);
+  //   lane r < nl      the single-column limit row r: its one Jacobian entry, D, aref, Jaref, jv, force;
+  //   lane l, slot j   the dense (contact) row l + 32 j, j < RPL: D, aref, Jaref, jv, force.
+  // LDS holds only the contact rows of efc_J and three small staging vectors (a vector that every lane must read in full is written once and
+  // read back as broadcasts), 7.8 KB per humanoid environment instead of 18.6 -- with two environments per wavefront a CU keeps 16 environments
+  // in flight, the whole B = 4096 batch in one round (the LDS solver: 8, two rounds).  The arithmetic follows solver.py:244-553 like the LDS
+  // solver; summation orders differ (register partials), which the 1e-8 parity bar leaves free.  The two environments of a wavefront branch
+  // independently (warm-start pick, line-search and iteration counts): plain divergent control flow, every cross-lane primitive used here
+  // (sub_sum / sub_read / sub_any) stays inside a 32-lane half.
+  // =====================================================================================================================================================
+  template <int NMAX>
+  __device__ __forceinline__ REAL tri_solve2(const TriPack<REAL, NMAX>& T, REAL bi) const {
+    return tri_solve<W, REAL, NMAX>(T, bi, M.nv);
+  }
+
+  template <int NMAX, int RPL>
+  __device__ __forceinline__ void run_sol2() {
+    static_assert(W == 32, "two environments per wavefront");
+    const int l = lane();
+    const int nq = M.nq, nv = M.nv, na = M.na, nefc = M.nefc, nl = M.nl, nd = nefc - nl;
+    const bool dof = l < nv, lim = l < nl;
+    const bool solving = (KA.stages & 0x40) != 0;
+    const bool from_in = !KA.state_from_cur;
+    // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
+    const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
+    TriPack<REAL, NMAX> T;
+    {
+      const REAL* gL = out.qLD + e * nv * nv;
+#pragma unroll
+      for (int k = 0; k < NMAX; k++) T.t[k] = (dof && k < nv) ? (k <= l ? gL[l * nv + k] : gL[k * nv + l]) : (REAL)0;
+    }
+    REAL qp0 = 0, qp1 = 0, qv = 0, ac = 0, ad = 0, warm = 0;
+    REAL Dl = 0, arl = 0, Jl = 0, Dd[RPL], ard[RPL];
+    int ldof = 0, limrow = -1;
+#pragma unroll
+    for (int j = 0; j < RPL; j++) { Dd[j] = 0; ard[j] = 0; }
+    if (solving) {
+      const REAL* gq = KA.cur.qpos + e * nq;
+      qp0 = l < nq ? gq[l] : (REAL)0;
+      qp1 = l + 32 < nq ? gq[l + 32] : (REAL)0;
+      if (dof) qv = (from_in ? in.qvel : KA.cur.qvel)[e * nv + l];
+      if (from_in && KA.do_step) qv = checked(qv, (REAL)0);  // _check_state
+      if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; ac = ga ? ga[e * na + l] : (REAL)0; ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
+      // the state only feeds the integrator tail: parked in the arena (its own slots, not under the constraint rows)
+      if (l < nq) S.qpos()[l] = qp0;
+      if (l + 32 < nq) S.qpos()[l + 32] = qp1;
+      if (dof) S.qvel()[l] = qv;
+      if (l < na) { S.act()[l] = ac; S.act_dot()[l] = ad; }
+      if (nefc > 0) {
+        const REAL* gJ = out.efc_J + e * nefc * nv;
+        if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
+        if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
+        if (dof) limrow = M.dof_limrow[2 * l];
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+          const int r = nl + l + 32 * j;
+          if (r < nefc) { Dd[j] = out.efc_D[e * nefc + r]; ard[j] = out.efc_aref[e * nefc + r]; }
+        }
+        // contact rows of efc_J -> LDS, eight requests in flight per trip
+        const int n = nd * nv;
+        const REAL* src = gJ + nl * nv;
+        REAL* dstJ = S.efc_Jc();
+        int i = l;
+        for (; i + 7 * W < n; i += 8 * W) {
+          REAL t[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) t[q] = src[i + q * W];
+#pragma unroll
+          for (int q = 0; q < 8; q++) dstJ[i + q * W] = t[q];
+        }
+        for (; i < n; i += W) dstJ[i] = src[i];
+      }
+    }
+    {  // T.row[l] with a lane-dependent index would spill the triangle: pick the diagonal with a compile-time scan instead
+      REAL dg = 1;
+#pragma unroll
+      for (int k = 0; k < NMAX; k++) dg = (k == l) ? T.t[k] : dg;
+      T.inv = dof ? 1 / dg : (REAL)0;
+    }
+    // ---- _acceleration: qacc_smooth = M^-1 qfrc_smooth (forward.py:222-228) -----------------------------------------------------------------------
+    const REAL qs = tri_solve2<NMAX>(T, f);
+    if (dof && out.qacc_smooth) out.qacc_smooth[e * nv + l] = qs;
+    if (!solving) return;
+    REAL qacc = qs, qfrc = 0;
+    if (nefc > 0) {
+      const REAL* gM = out.qM + e * nv * nv;
+      const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
+      const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
+      REAL* vs = S.r_vs();
+      REAL* vs2 = S.r_vs2();
+      REAL* fs = S.r_fs();
+      const REAL* Jc = S.efc_Jc();
+      // o1 = M a, o2 = M b for vectors staged in LDS (lane d: element d; qM is symmetric: row d is read as column d, coalesced)
+      auto mul_M2 = [&](const REAL* a, const REAL* b, REAL& o1, REAL& o2, bool two) {
+        REAL s1 = 0, s2 = 0;
+        if (dof) {
+          int k = 0;
+          for (; k + 9 <= nv; k += 9) {  // nine rows in flight per round trip (three trips cover the humanoid's 27)
+            REAL m[9];
+#pragma unroll
+            for (int t = 0; t < 9; t++) m[t] = gM[(k + t) * nv + l];
+#pragma unroll
+            for (int t = 0; t < 9; t++) { s1 += m[t] * a[k + t]; if (two) s2 += m[t] * b[k + t]; }
+          }
+          for (; k + 4 <= nv; k += 4) {
+            REAL m[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) m[t] = gM[(k + t) * nv + l];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { s1 += m[t] * a[k + t]; if (two) s2 += m[t] * b[k + t]; }
+          }
+          for (; k < nv; k++) { const REAL m = gM[k * nv + l]; s1 += m * a[k]; if (two) s2 += m * b[k]; }
+        }
+        o1 = s1; o2 = s2;
+      };
+      // dense rows: (J a)[r], (J b)[r] for the rows of this lane, terms in column order
+      auto mul_J2 = [&](const REAL* a, const REAL* b, REAL (&o1)[RPL], REAL (&o2)[RPL], bool two) {
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+          const int r = l + 32 * j;
+          REAL s1 = 0, s2 = 0;
+          if (r < nd) {
+            const REAL* row = Jc + r * nv;
+            int k = 0;
+            for (; k + 4 <= nv; k += 4) {
+              const REAL j0 = row[k], j1 = row[k + 1], j2 = row[k + 2], j3 = row[k + 3];
+              const REAL a0 = a[k], a1 = a[k + 1], a2 = a[k + 2], a3 = a[k + 3];
+              s1 += j0 * a0; s1 += j1 * a1; s1 += j2 * a2; s1 += j3 * a3;
+              if (two) { s2 += j0 * b[k]; s2 += j1 * b[k + 1]; s2 += j2 * b[k + 2]; s2 += j3 * b[k + 3]; }
+            }
+            for (; k < nv; k++) { s1 += row[k] * a[k]; if (two) s2 += row[k] * b[k]; }
+          }
+          o1[j] = s1; o2[j] = s2;
+        }
+      };
+      // _update_constraint :320-357 on register rows: forces, cost; returns (cost sum over rows, gauss term)
+      REAL frl = 0, frd[RPL];
+      auto constraint_cost = [&](REAL jal, const REAL (&jad)[RPL], REAL Ma, REAL qa, REAL& gauss) -> REAL {
+        REAL part = 0;
+        {
+          const REAL act = (REAL)(lim && jal < 0);
+          frl = Dl * -jal * act;
+          part += Dl * jal * jal * act;
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; j++) {
+          const REAL act = (REAL)((l + 32 * j < nd) && jad[j] < 0);
+          frd[j] = Dd[j] * -jad[j] * act;
+          part += Dd[j] * jad[j] * jad[j] * act;
+        }
+        const REAL gpart = dof ? (Ma - f) * (qa - qs) : (REAL)0;
+        const REAL csum = sub_sum<W>(part), g = sub_sum<W>(gpart);
+        gauss = (REAL)0.5 * g;
+        return ((REAL)0.5 * csum + gauss) + 0;
+      };
+      // qfrc_constraint = J^T efc_force (rows in index order: the single-column rows first), from the forces in frl / frd
+      auto constraint_qfrc = [&]() -> REAL {
+#pragma unroll
+        for (int j = 0; j < RPL; j++) if (l + 32 * j < nd) fs[l + 32 * j] = frd[j];
+        if (lim) fs[nd + l] = Jl * frl;
+        wave_sync();
+        REAL s = 0;
+        if (dof) {
+          if (limrow >= 0) s += fs[nd + limrow];
+          int r = 0;
+          for (; r + 8 <= nd; r += 8) {
+            REAL jj[8], ff[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) { jj[t] = Jc[(r + t) * nv + l]; ff[t] = fs[r + t]; }
+#pragma unroll
+            for (int t = 0; t < 8; t++) s += jj[t] * ff[t];
+          }
+          for (; r < nd; r++) s += Jc[r * nv + l] * fs[r];
+        }
+        wave_sync();
+        return s;
+      };
+      // ---- contexts of qacc_smooth and qacc_warmstart in one pass over efc_J and qM (solver.py:293-318, :526-531) ---------------------------------
+      const bool warm_on = !(M.disableflags & DSBL_WARMSTART);
+      if (dof) { vs[l] = qs; vs2[l] = warm; }
+      wave_sync();
+      REAL Ma_s, Ma_w, jal_s, jal_w, jad_s[RPL], jad_w[RPL];
+      mul_M2(vs, vs2, Ma_s, Ma_w, warm_on);
+      mul_J2(vs, vs2, jad_s, jad_w, warm_on);
+      {
+        const REAL a = lim ? vs[ldof] : (REAL)0, b = lim ? vs2[ldof] : (REAL)0;
+        jal_s = Jl * a - arl; jal_w = Jl * b - arl;
+      }
+#pragma unroll
+      for (int j = 0; j < RPL; j++) { jad_s[j] = jad_s[j] - ard[j]; jad_w[j] = jad_w[j] - ard[j]; }
+      wave_sync();
+      REAL Ma = Ma_s, jal = jal_s, jad[RPL];
+#pragma unroll
+      for (int j = 0; j < RPL; j++) jad[j] = jad_s[j];
+      REAL gauss = 0, cost = 0, prev_cost = (REAL)INFINITY;
+      if (warm_on) {
+        REAL g_s, g_w;
+        const REAL cost_s = constraint_cost(jal_s, jad_s, Ma_s, qs, g_s);
+        const REAL cost_w = constraint_cost(jal_w, jad_w, Ma_w, warm, g_w);
+        const bool use_warm = cost_w < cost_s;
+        if (use_warm) {
+          qacc = warm; Ma = Ma_w; jal = jal_w;
+#pragma unroll
+          for (int j = 0; j < RPL; j++) jad[j] = jad_w[j];
+        }
+      }
+      cost = constraint_cost(jal, jad, Ma, qacc, gauss);  // leaves the forces of the chosen context in frl / frd
+      qfrc = constraint_qfrc();
+      REAL grad = dof ? (Ma - f) - qfrc : (REAL)0;
+      REAL Mgrad = tri_solve2<NMAX>(T, grad);
+      REAL search = -Mgrad;
+      REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step: only read when another iteration follows
+      int it = 0, niter = 0;
+      for (;;) {
+        if (M.iterations == 1) { if (it >= 1) break; }
+        else if (fixed) { if (it >= M.iterations) break; }
+        else {  // cond :501-508
+          const REAL gg = sub_sum<W>(grad * grad);
+          const REAL improvement = (prev_cost - cost) / scale;
+          const REAL gradient = r_sqrt<REAL>(gg) / scale;
+          bool done = niter >= M.iterations;
+          done |= improvement < (REAL)M.tolerance;
+          done |= gradient < (REAL)M.tolerance;
+          if (done) break;
+        }
+        const bool need_grad = !(it + 1 >= M.iterations);
+        // ---- _linesearch :378-497 -----------------------------------------------------------------------------------------------------------------
+        {
+          if (dof) vs[l] = search;
+          wave_sync();
+          REAL mv, unused, jvd[RPL], unused_d[RPL];
+          mul_M2(vs, vs, mv, unused, false);
+          mul_J2(vs, vs, jvd, unused_d, false);
+          const REAL jvl = lim ? Jl * vs[ldof] : (REAL)0;
+          wave_sync();
+          const REAL ss = sub_sum<W>(dof ? search * search : (REAL)0);
+          const bool nz = sub_any<W>(dof && search != 0);
+          const REAL snorm = nz ? r_sqrt<REAL>(ss) : (REAL)0;
+          const REAL gtol = (REAL)(M.tolerance * M.ls_tolerance) * (snorm * scale);
+          const REAL a = sub_sum<W>(dof ? search * Ma : (REAL)0), b = sub_sum<W>(dof ? search * f : (REAL)0), cc = sub_sum<W>(dof ? search * mv : (REAL)0);
+          const REAL qg0 = gauss, qg1 = a - b, qg2 = (REAL)0.5 * cc;
+          // per-row quadratic coefficients (:386-394)
+          const REAL ql0 = ((REAL)0.5 * jal * jal) * Dl, ql1 = (jvl * jal) * Dl, ql2 = ((REAL)0.5 * jvl * jvl) * Dl;
+          REAL qd0[RPL], qd1[RPL], qd2[RPL];
+#pragma unroll
+          for (int j = 0; j < RPL; j++) { qd0[j] = ((REAL)0.5 * jad[j] * jad[j]) * Dd[j]; qd1[j] = (jvd[j] * jad[j]) * Dd[j]; qd2[j] = ((REAL)0.5 * jvd[j] * jvd[j]) * Dd[j]; }
+          auto point = [&](REAL alpha) -> LSPoint {  // point_fn :396-422
+            REAL q0 = 0, q1 = 0, q2 = 0;
+            {
+              const REAL x = jal + alpha * jvl;
+              const REAL act = (REAL)(lim && x < 0);
+              q0 += ql0 * act; q1 += ql1 * act; q2 += ql2 * act;
+            }
+#pragma unroll
+            for (int j = 0; j < RPL; j++) {
+              const REAL x = jad[j] + alpha * jvd[j];
+              const REAL act = (REAL)((l + 32 * j < nd) && x < 0);
+              q0 += qd0[j] * act; q1 += qd1[j] * act; q2 += qd2[j] * act;
+            }
+            q0 = sub_sum<W>(q0); q1 = sub_sum<W>(q1); q2 = sub_sum<W>(q2);
+            const REAL t0 = (qg0 + q0) + 0, t1 = (qg1 + q1) + 0, t2 = (qg2 + q2) + 0;
+            LSPoint p;
+            p.alpha = alpha;
+            p.cost = alpha * alpha * t2 + alpha * t1 + t0;
+            p.d0 = 2 * alpha * t2 + t1;
+            p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
+            return p;
+          };
+          const LSPoint p0 = point(0);
+          const LSPoint p1 = point(p0.alpha - p0.d0 / p0.d1);
+          const bool early = r_abs(p1.d0) < gtol;
+          LSPoint lo, hi;
+          if (p1.d0 < p0.d0) { hi = p0; lo = p1; } else { hi = p1; lo = p0; }
+          bool swap = !early;
+          int ls_iter = 0;
+          for (;;) {
+            if (fixed) { if (ls_iter >= M.ls_iterations) break; }
+            else {
+              bool done = ls_iter >= M.ls_iterations;
+              done |= !swap;
+              done |= (lo.d0 < 0) && (lo.d0 > -gtol);
+              done |= (hi.d0 > 0) && (hi.d0 < gtol);
+              if (done) break;
+            }
+            const LSPoint lo_next = point(lo.alpha - lo.d0 / lo.d1);
+            const LSPoint hi_next = point(hi.alpha - hi.d0 / hi.d1);
+            const LSPoint mid = point((REAL)0.5 * (lo.alpha + hi.alpha));
+            const bool nb = (lo.d0 < 0) == (hi.d0 < 0);
+            const bool s1 = ls_swap(lo.d0, lo_next.d0, nb); if (s1) lo = lo_next;
+            const bool s2 = ls_swap(lo.d0, mid.d0, nb); if (s2) lo = mid;
+            const bool s3 = ls_swap(lo.d0, hi_next.d0, nb); if (s3) lo = hi_next;
+            const bool s4 = ls_swap(hi.d0, hi_next.d0, nb); if (s4) hi = hi_next;
+            const bool s5 = ls_swap(hi.d0, mid.d0, nb); if (s5) hi = mid;
+            const bool s6 = ls_swap(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
+            swap = s1 | s2 | s3 | s4 | s5 | s6;
+            ls_iter++;
+          }
+          const REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
+          const REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+          qacc = qacc + improved * search * alpha;
+          Ma = Ma + improved * mv * alpha;
+          jal = jal + improved * jvl * alpha;
+#pragma unroll
+          for (int j = 0; j < RPL; j++) jad[j] = jad[j] + improved * jvd[j] * alpha;
+        }
+        if (need_grad && dof) { pg[l] = grad; pg[nv + l] = Mgrad; }
+        prev_cost = cost;
+        cost = constraint_cost(jal, jad, Ma, qacc, gauss);
+        qfrc = constraint_qfrc();
+        if (need_grad) {  // _update_gradient :359-376 (CG) and the Polak-Ribiere direction :519-523
+          grad = dof ? (Ma - f) - qfrc : (REAL)0;
+          Mgrad = tri_solve2<NMAX>(T, grad);
+          const REAL pgrad = dof ? pg[l] : (REAL)0, pMgrad = dof ? pg[nv + l] : (REAL)0;  // written by this lane
+          const REAL num = sub_sum<W>(grad * (Mgrad - pMgrad)), den = sub_sum<W>(pgrad * pMgrad);
+          REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+          beta = beta > 0 ? beta : (REAL)0;
+          search = -Mgrad + beta * search;
+        }
+        niter++; it++;
+      }
+      if (dof) {
+        if (out.qacc) out.qacc[e * nv + l] = qacc;
+        if (out.qacc_warmstart) out.qacc_warmstart[e * nv + l] = qacc;
+        if (out.qfrc_constraint) out.qfrc_constraint[e * nv + l] = qfrc;
+      }
+      if (out.efc_force) {
+        if (lim) out.efc_force[e * nefc + l] = frl;
+#pragma unroll
+        for (int j = 0; j < RPL; j++) if (l + 32 * j < nd) out.efc_force[e * nefc + nl + l + 32 * j] = frd[j];
+      }
+    } else {
+      if (dof && out.qacc) out.qacc[e * nv + l] = qacc;
+    }
+    if (!KA.do_step) return;
+    // ---- integrator tail on arena arrays carved over the (dead) constraint rows ----------------------------------------------------------------
+    wave_sync();
+    if (dof) { S.qacc()[l] = qacc; S.qfrc_smooth()[l] = f; S.qfrc_constraint()[l] = qfrc; }
+    wave_sync();
+    integrate_tail();
+  }
 };
 
 #undef M
@@ -2366,6 +2764,23 @@ struct Env {
 // (profiles/r01/notes.md).  The float32 solver, packed kinematics / velocity and CRB kernels sit just above an occupancy
 // step (197 / 181 / 185 -> 168 VGPRs = 3 waves, 132 -> 128 = 4 waves) and spill only 5-24 dwords to get under it; with
 // 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
+// The register solver's kernel: two environments per wavefront; an odd last environment leaves the second half of its wave idle.
+template <typename REAL, int NMAX, int RPL>
+__global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const KArgs<REAL>& K = kargs<REAL>();
+  const int sub = (int)(threadIdx.x >> 5);
+  REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
+  for (int64_t blk = blockIdx.x; blk * 2 < K.env_count; blk += gridDim.x) {
+    const int64_t idx = blk * 2 + sub;
+    if (idx < K.env_count) {
+      Env<REAL, 32, false> E(lds, K.env_begin + idx, K.flags);
+      E.template run_sol2<NMAX, RPL>();
+    }
+    wave_sync();
+  }
+}
+
 template <typename REAL, int PHASE, int W>
 __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W == 32))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W == 32 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? 4 : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];

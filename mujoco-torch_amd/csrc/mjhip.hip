@@ -44,8 +44,9 @@ struct mjhModel {
   int dtype;
   void* blob;          // device allocation holding every table
   size_t blob_bytes;
-  LdsOff off[MJH_NPHASE];
-  int lds_bytes[MJH_NPHASE];
+  LdsOff off[MJH_NARENA];
+  int lds_bytes[MJH_NARENA];
+  int sol2_nmax = 0, sol2_rpl = 0;         // register solver (mjh_sol2_kernel) instantiation serving this model, 0 = not eligible
   int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
   // hipGraph replay: the launch sequence of a (buffers, batch, flags) combination is captured once on a private stream and
   // replayed with one hipGraphLaunch on the caller's stream -- a step is 6 launches (24 with RK4) with ~3.6 KB of kernel
@@ -347,9 +348,19 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   out->cvx_lds_bytes = (cvx_reals + 8) * (int)sizeof(REAL);
   if (out->cvx_lds_bytes > 64 * 1024) return fail(-12, "convex hull too large for the pair kernel's LDS scratch");
 
-  for (int p = 0; p < MJH_NPHASE; p++) {
+  for (int p = 0; p < MJH_NARENA; p++) {
     out->lds_bytes[p] = lds_carve(M, 1 << p, out->off[p]) * (int)sizeof(REAL);
-    if (out->lds_bytes[p] > 160 * 1024) return fail(-12, "model does not fit the 160 KiB LDS of one CU");
+    if (p < MJH_NPHASE && out->lds_bytes[p] > 160 * 1024) return fail(-12, "model does not fit the 160 KiB LDS of one CU");
+  }
+  {  // register solver: CG, slide / hinge limit rows + contact rows only, one dof per lane of a 32-lane half
+    static const bool off = [] { const char* e = getenv("MJH_SOL2"); return e && e[0] == '0'; }();
+    const int nd = d->nefc - d->nf - d->nl;
+    const bool general = d->nf > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0;
+    out->sol2_nmax = out->sol2_rpl = 0;
+    if (!off && d->solver == SOL_CG && !general && d->nv <= 28 && nd <= 64 && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
+      out->sol2_nmax = d->nv <= 16 ? 16 : 28;
+      out->sol2_rpl = nd <= 32 ? 1 : 2;
+    }
   }
   out->leaf_count = leaf_counts(d);
   out->work_reals = 0;
@@ -389,6 +400,11 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
   if (out->pack2[3]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[3]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
+  if (out->sol2_nmax) {
+#define SET_SOL2(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[5]));
+    SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(28, 1) SET_SOL2(28, 2)
+#undef SET_SOL2
+  }
   return 0;
 }
 
@@ -418,6 +434,24 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   return launch_range<REAL, P, MJH_WAVE>(m, a, 0, a.B, stream);
 }
 
+// the solver phase through the register solver: two environments per wavefront
+template <typename REAL>
+int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  a.off = m->off[5];
+  a.env_begin = 0; a.env_count = a.B;
+  a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
+  const int64_t blocks = (a.B + 1) / 2;
+  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
+  const size_t lds = (size_t)(2 * m->lds_bytes[5]);
+#define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
+  if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else GO(16, 2); }
+  else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
+#undef GO
+  HIP_TRY(hipGetLastError());
+  timing_mark(stream, 4);
+  return 0;
+}
+
 // one forward pass = the phases selected by `stages`
 template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
@@ -441,6 +475,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     timing_mark(stream, 9);
   }
+  if ((st & 0x60) && m->sol2_nmax) return launch_sol2<REAL>(m, a, stream);
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
@@ -741,7 +776,7 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
 }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
-int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NPHASE) ? m->lds_bytes[phase] : 0; }
+int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0;  // 5: the register solver (0 when the model is not served by it) }
 const char* mjh_last_error(void) { return g_err.c_str(); }
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
 

@@ -273,7 +273,7 @@ class NativeModel:
         self.device = device
         self.dtype = dtype
         self.work_bytes = int(self.lib.mjh_model_work_bytes(handle))
-        self.lds_bytes = [int(self.lib.mjh_model_lds_bytes(handle, p)) for p in range(5)]
+        self.lds_bytes = [int(self.lib.mjh_model_lds_bytes(handle, p)) for p in range(6)]  # five phases + the register solver's arena
         n = len(DATA_PATH)
         buf = (ctypes.c_int64 * n)()
         got = int(self.lib.mjh_model_leaf_counts(handle, buf, n))
