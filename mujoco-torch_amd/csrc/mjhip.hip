@@ -776,7 +776,7 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
 }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
-int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0;  // 5: the register solver (0 when the model is not served by it) }
+int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0; }  // phase 5: the register solver's arena
 const char* mjh_last_error(void) { return g_err.c_str(); }
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
 
