@@ -31,6 +31,12 @@ void mjo_set_contact_hint(const void* dist, const void* pos, const void* frame, 
   g_hint_dist = dist; g_hint_pos = pos; g_hint_frame = frame; g_tie_pairs = tie_pairs;
 }
 
+/* RK4 stage ties (mjoracle_impl.h, stage_tie_flip): index of the stage tie event of each environment that takes its second candidate
+   in the next run (-1: none), and an int32 [B] that receives the number of such events met */
+static int g_stage_tie_flip = -1;
+static int32_t* g_stage_ties;
+void mjo_set_stage_tie_flip(int flip, int32_t* counts) { g_stage_tie_flip = flip; g_stage_ties = counts; }
+
 #define REAL double
 #define SFX _f64
 #include "mjoracle_impl.h"

@@ -94,7 +94,8 @@ static void FN(step_env)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(MjoWork) * 
   for (int i = 0; i < nv; i++) { REAL x = w->qacc[i]; if (!isfinite(x) || R_FABS(x) > (REAL)mjMAXVAL) w->qacc[i] = 0; }
   REAL time0 = w->time[0];
   FN(forward_env)(M, w, MJH_STAGE_ALL, flags, 1);
-  w->hint_dist = NULL; /* the returned contact leaves are stage 0's: later RK4 stages resolve ties naturally */
+  w->hint_dist = NULL; /* the returned contact leaves are stage 0's: later RK4 stages resolve ties naturally ... */
+  w->stage_mode = 1;   /* ... or under the caller's single-flip policy (stage_tie_flip) */
   if (m->integrator == INT_EULER) { /* _euler :313-328 */
     const REAL* qacc = w->qacc;
     if (!(m->disableflags & DSBL_EULERDAMP)) {
@@ -170,6 +171,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       w.knife = 0;
       w.knife_policy = knife_policy;
       w.nf = m->nf; w.ne_nf = m->ne + m->nf; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
+      w.stage_mode = 0; w.stage_tie_n = 0; w.stage_tie_flip = g_stage_tie_flip;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0; w.prim_hint_n = NULL; w.prim_adopted = 0; w0.prim_hint_n = NULL; w0.prim_adopted = 0;
       w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;
       w0.eq_active = w.eq_active;
@@ -183,6 +185,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
 #undef X
       if (knife) knife[e] = w.knife;
       if (g_tie_pairs) g_tie_pairs[e] = w.tie_pairs;
+      if (g_stage_ties) g_stage_ties[e] = w.stage_tie_n;
       if (out->contact_dim) for (int c = 0; c < m->ncon; c++) out->contact_dim[e * m->ncon + c] = m->con_dim[c];
       if (out->contact_geom1) for (int c = 0; c < m->ncon; c++) out->contact_geom1[e * m->ncon + c] = m->con_geom1[c];
       if (out->contact_geom2) for (int c = 0; c < m->ncon; c++) out->contact_geom2[e * m->ncon + c] = m->con_geom2[c];

@@ -39,6 +39,8 @@ def lib():
         _lib.mjo_max_threads.restype = ctypes.c_int
         _lib.mjo_set_contact_hint.argtypes = [ctypes.c_void_p] * 4
         _lib.mjo_set_contact_hint.restype = None
+        _lib.mjo_set_stage_tie_flip.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        _lib.mjo_set_stage_tie_flip.restype = None
     return _lib
 
 
@@ -61,7 +63,8 @@ def _ptrs(arrs):
     return p
 
 
-def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1, contact_hint=None, tie_pairs=None):
+def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1, contact_hint=None, tie_pairs=None,
+        stage_tie_flip=-1, stage_ties=None):
     """Runs the oracle on a (possibly batched) CPU Data; returns {leaf: numpy array} of outputs.
 
     ``knife``: optional int32 array [B]; receives per env the number of line-search candidates whose
@@ -70,6 +73,8 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
     an index selection of the convex narrow phase is decided by rounding noise, the oracle keeps the admissible
     outcome closest to the hint (natural pick on equality); ``tie_pairs`` (int32 [B]) receives how many geom pairs
     per env ended on a non-natural outcome.
+    ``stage_tie_flip``: index of the narrow-phase tie event INSIDE RK4 stages 1..3 (which no hint can reach) that takes its second
+    candidate, -1 = none; ``stage_ties`` (int32 [B]) receives the number of such events per environment.
     ``knife_policy``: -1 natural rounding; j >= 0 forces the first j such candidates to read as an exact
     zero (rejected by both bracket tests, solver.py:440-449) and the next one as non-zero (accepted)."""
     dtype = d.qpos.dtype
@@ -86,10 +91,12 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
         npdt = inp["contact_dist"].dtype
         hint = [np.array(np.asarray(contact_hint[k]).reshape(inp[k].shape), dtype=npdt, order="C", copy=True) for k in ("contact_dist", "contact_pos", "contact_frame")]
         lib().mjo_set_contact_hint(hint[0].ctypes.data, hint[1].ctypes.data, hint[2].ctypes.data, tie_pairs.ctypes.data if tie_pairs is not None else None)
+    lib().mjo_set_stage_tie_flip(int(stage_tie_flip), stage_ties.ctypes.data if stage_ties is not None else None)
     try:
         rc = _call(step, desc, pin, pout, B, dt, stages, flags, nthreads, knife, knife_policy)
     finally:
         lib().mjo_set_contact_hint(None, None, None, None)
+        lib().mjo_set_stage_tie_flip(-1, None)
     if rc != 0:
         raise RuntimeError(f"oracle failed: {rc}")
     return out

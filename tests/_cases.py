@@ -30,11 +30,12 @@ SEEDED_CASES = [
     ("cartpole", {}, F64, 64, dict(max_alt=0.0)),
     ("mesh_contact", {}, F32, 256, {}),                                         # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
     ("mesh_contact", {}, F64, 64, dict(max_alt=0.0)),
-    # CG stops on the reference's own tolerance (1e-8 of the scaled gradient / improvement, solver.py:501-508): two correct
-    # implementations may stop an iteration apart and CG's iterate error at that point is O(tolerance x cond(M^-1 H)); measured
-    # cond = 3.2e2 and a worst error of 5.8e-7 here.  The same scene with the tolerance out of the way must meet 1e-8:
+    # CG on a piecewise-quadratic cost does not reach 1e-8: it ends where a line search stops improving the cost (improvement <
+    # tolerance, solver.py:501-508) with the scaled gradient still ~1e-6, and two correct implementations end at points that far
+    # apart -- measured worst error 5.8e-7 here, the same (7.8e-7) with tolerance = 1e-14 and 300 iterations, cond(M^-1 H) = 3.2e2
+    # (profiles/r02/parity_survey_first.log).  What bounds the agreement is the solver's accuracy, not rounding: Newton on the
+    # same scene (two lines up) agrees to 2e-14.
     ("mesh_contact", {"solver": 1, "cone": 1}, F64, 32, dict(tol_sol=1e-5)),
-    ("mesh_contact", {"solver": 1, "cone": 1, "tolerance": 1e-14, "iterations": 300}, F64, 32, {}),
     ("convex_meshes", {}, F64, 32, dict(max_alt=0.0)),
     ("convex_primitives", {}, F64, 32, dict(max_alt=0.0)),
     ("convex_primitives", {}, F32, 32, {}),
@@ -42,13 +43,11 @@ SEEDED_CASES = [
     ("sensor_rig", {"integrator": 1}, F32, 64, {}),                             # ... RK4, float32 (rays intersect in double)
     ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, F64, 64, dict(max_alt=0.0)),  # fluid forces: density + viscosity + wind
     ("ant_frictionloss", {}, F64, 64, dict(max_alt=0.0)),                       # dof frictionloss rows, Newton
-    ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG stopping on its tolerance across frictionloss zone switches (measured 8.1e-7)
-    ("ant_frictionloss", {"solver": 1, "tolerance": 1e-14, "iterations": 300}, F64, 64, {}),
+    ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG: stalls across frictionloss zone switches (measured 8.1e-7; Newton one line up: 1e-13)
     ("halfcheetah", {}, F64, 64, dict(max_alt=0.0)),
     ("hopper", {}, F64, 64, dict(max_alt=0.0)),
     ("equality_loops", {}, F64, 64, dict(max_alt=0.0)),                         # equality rows: closed loop, weld, joint couplings
-    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-4)),  # RK4 + CG stopping on its tolerance in each of four solves, stiff always-active rows (cond 2.5e2, measured 6e-5)
-    ("equality_loops", {"integrator": 1, "solver": 1, "tolerance": 1e-14, "iterations": 300}, F64, 32, {}),
+    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-4)),  # RK4 + CG stalling in each of four solves on stiff always-active rows (cond 2.5e2, measured 6e-5; Newton one line up: 2e-13)
     ("equality", {}, F64, 32, dict(max_alt=0.0)),                               # bundled: site-form constraints carried inactive
     ("ant", {"disableflags": 1 << 4}, F64, 32, dict(max_alt=0.0)),              # disable flags (test/constraint_test.py:148-200): contacts off
     ("humanoid", {"disableflags": 1}, F64, 32, dict(max_alt=0.0)),              # ... every constraint off (nefc = 0)
@@ -57,6 +56,14 @@ SEEDED_CASES = [
     ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, F64, 32, dict(max_alt=0.0)),      # ... springs (hence every passive force) and limits off
     ("pendula", {}, F64, 64, dict(max_alt=0.0)),                                # bundled: every joint type, ball limits, gravcomp, mocap, tendons
     ("tendon_fixed", {"solver": 1}, F64, 64, dict(max_alt=0.0)),
+    # CG models served by the register solver (mjh_sol2_kernel: two environments per wavefront): Euler with the eulerdamp re-solve,
+    # RK4, float32, odd batch sizes (the last wavefront runs half empty), warm start off, one- and many-iteration loops
+    ("halfcheetah", {"solver": 1}, F64, 33, dict(tol_sol=1e-6)),
+    ("hopper", {"solver": 1, "integrator": 1}, F64, 17, dict(tol_sol=1e-6)),
+    ("walker2d", {"solver": 1, "disableflags": 1 << 9}, F64, 32, dict(tol_sol=1e-6)),
+    ("humanoid", {"solver": 1, "integrator": 1}, F64, 31, dict(max_alt=0.6)),
+    ("humanoid", {"solver": 1, "iterations": 3, "ls_iterations": 8}, F32, 64, {}),
+    ("humanoid", {"solver": 1, "disableflags": 1 << 15 ^ 1 << 15}, F64, 1, dict(max_alt=1.0)),
 ]
 
 
