@@ -31,11 +31,11 @@ void mjo_set_contact_hint(const void* dist, const void* pos, const void* frame, 
   g_hint_dist = dist; g_hint_pos = pos; g_hint_frame = frame; g_tie_pairs = tie_pairs;
 }
 
-/* RK4 stage ties (mjoracle_impl.h, stage_tie_flip): index of the stage tie event of each environment that takes its second candidate
-   in the next run (-1: none), and an int32 [B] that receives the number of such events met */
-static int g_stage_tie_flip = -1;
+/* RK4 stage ties (mjoracle_impl.h, stage_tie_flip): bit mask of the stage tie events (per environment, first 32) that take their
+   second candidate in the next run (0: none), and an int32 [B] that receives the number of such events met */
+static unsigned g_stage_tie_flip = 0;
 static int32_t* g_stage_ties;
-void mjo_set_stage_tie_flip(int flip, int32_t* counts) { g_stage_tie_flip = flip; g_stage_ties = counts; }
+void mjo_set_stage_tie_flip(unsigned mask, int32_t* counts) { g_stage_tie_flip = mask; g_stage_ties = counts; }
 
 #define REAL double
 #define SFX _f64

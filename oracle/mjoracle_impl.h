@@ -121,9 +121,9 @@ typedef struct FN(MjoWork) {
   const REAL *hint_dist, *hint_pos, *hint_frame; /* this env's expected contact leaves or NULL */
   int tie_pairs; /* pairs whose kept outcome is not the natural one */
   /* ties inside RK4 stages 1..3 cannot be hinted (those contacts are never returned): there tie_on == 2 counts the events of the
-     environment's step in stage_tie_n, and the event whose index equals stage_tie_flip takes its second candidate instead of the
-     natural one -- callers enumerate single flips (tests/_util.oracle_alternatives) */
-  int stage_mode, stage_tie_n, stage_tie_flip;
+     environment's step in stage_tie_n, and the events whose bit is set in stage_tie_flip (first 32 events) take their second
+     candidate instead of the natural one -- callers enumerate single and double flips (tests/_util.oracle_alternatives) */
+  int stage_mode, stage_tie_n; unsigned stage_tie_flip;
   const REAL* prim_hint_n; /* hinted normal of the primitive pair being evaluated (coincident-centre case of sphere_sphere_), or NULL */
   int prim_adopted;
   const int32_t* eq_active; /* this env's Data.eq_active (input leaf, types.py:1103) */
@@ -620,7 +620,7 @@ static int FN(pick)(FN(MjoWork) * w, const REAL* x, int n, int sgn, REAL scale, 
     if (!dup) cand[nc++] = i;
   }
   if (nc == 1) return b;
-  if (w->tie_on == 2) { int ev = w->stage_tie_n++; return cand[ev == w->stage_tie_flip ? 1 : 0]; }
+  if (w->tie_on == 2) { int ev = w->stage_tie_n++; return cand[(ev < 32 && ((w->stage_tie_flip >> ev) & 1u)) ? 1 : 0]; }
   int e = w->tie_n++;
   if (e >= MJO_MAX_TIE) return b;
   w->tie_count[e] = nc;

@@ -39,7 +39,7 @@ def lib():
         _lib.mjo_max_threads.restype = ctypes.c_int
         _lib.mjo_set_contact_hint.argtypes = [ctypes.c_void_p] * 4
         _lib.mjo_set_contact_hint.restype = None
-        _lib.mjo_set_stage_tie_flip.argtypes = [ctypes.c_int, ctypes.c_void_p]
+        _lib.mjo_set_stage_tie_flip.argtypes = [ctypes.c_uint, ctypes.c_void_p]
         _lib.mjo_set_stage_tie_flip.restype = None
     return _lib
 
@@ -64,7 +64,7 @@ def _ptrs(arrs):
 
 
 def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthreads=1, knife=None, knife_policy=-1, contact_hint=None, tie_pairs=None,
-        stage_tie_flip=-1, stage_ties=None):
+        stage_tie_flip=0, stage_ties=None):
     """Runs the oracle on a (possibly batched) CPU Data; returns {leaf: numpy array} of outputs.
 
     ``knife``: optional int32 array [B]; receives per env the number of line-search candidates whose
@@ -73,8 +73,8 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
     an index selection of the convex narrow phase is decided by rounding noise, the oracle keeps the admissible
     outcome closest to the hint (natural pick on equality); ``tie_pairs`` (int32 [B]) receives how many geom pairs
     per env ended on a non-natural outcome.
-    ``stage_tie_flip``: index of the narrow-phase tie event INSIDE RK4 stages 1..3 (which no hint can reach) that takes its second
-    candidate, -1 = none; ``stage_ties`` (int32 [B]) receives the number of such events per environment.
+    ``stage_tie_flip``: bit mask of the narrow-phase tie events INSIDE RK4 stages 1..3 (which no hint can reach; per environment,
+    in order of occurrence) that take their second candidate, 0 = none; ``stage_ties`` (int32 [B]) receives the number of such events.
     ``knife_policy``: -1 natural rounding; j >= 0 forces the first j such candidates to read as an exact
     zero (rejected by both bracket tests, solver.py:440-449) and the next one as non-zero (accepted)."""
     dtype = d.qpos.dtype
@@ -96,7 +96,7 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
         rc = _call(step, desc, pin, pout, B, dt, stages, flags, nthreads, knife, knife_policy)
     finally:
         lib().mjo_set_contact_hint(None, None, None, None)
-        lib().mjo_set_stage_tie_flip(-1, None)
+        lib().mjo_set_stage_tie_flip(0, None)
     if rc != 0:
         raise RuntimeError(f"oracle failed: {rc}")
     return out

@@ -63,7 +63,7 @@ SEEDED_CASES = [
     ("walker2d", {"solver": 1, "disableflags": 1 << 9}, F64, 32, dict(tol_sol=1e-6)),
     ("humanoid", {"solver": 1, "integrator": 1}, F64, 31, dict(max_alt=0.6)),
     ("humanoid", {"solver": 1, "iterations": 3, "ls_iterations": 8}, F32, 64, {}),
-    ("humanoid", {"solver": 1, "disableflags": 1 << 15 ^ 1 << 15}, F64, 1, dict(max_alt=1.0)),
+    ("humanoid", {"solver": 1, "disableflags": 0}, F64, 1, dict(max_alt=1.0)),     # eulerdamp on (the XML disables it), a single environment
 ]
 
 

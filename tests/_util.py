@@ -15,6 +15,7 @@ REAL_LEAVES = native.LISTS["MJH_DATA_REALS"]
 INT_LEAVES = native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
 
+OUTLIER_CASES = sorted(f[:-4] for f in os.listdir(os.path.join(GOLD, "outliers")) if f.endswith(".npz")) if os.path.isdir(os.path.join(GOLD, "outliers")) else []
 GOLDEN_CASES = sorted(f[:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and not f.startswith(("traj_", "env_")))
 ENV_CASES = sorted(f[4:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("env_"))
 TRAJECTORY_CASES = sorted(f[5:-4] for f in os.listdir(GOLD) if f.endswith(".npz") and f.startswith("traj_"))
@@ -107,6 +108,7 @@ def assert_ints_equal(get_got, get_want, what=""):
 
 SOLVER_LEAVES = ["qacc", "qacc_warmstart", "efc_force", "qfrc_constraint", "qpos", "qvel", "act", "time"]
 MAX_KNIFE_POLICIES = 14
+MAX_STAGE_TIE_PAIRS = 16
 
 
 HINT_LEAVES = ("contact_dist", "contact_pos", "contact_frame")
@@ -137,6 +139,17 @@ def oracle_alternatives(model, d, step=True, hint=None, knife_out=None, **kw):
         outs.append(pyoracle.run(model, d, step=step, knife=knife, knife_policy=pol, **kw))
         if int(knife.max()) <= pol:  # fewer noise candidates than the policy index: every one was rejected
             break
+    if step and int(model.opt.integrator) == 1 and any(p[0] >= 5 for p in model.tables.pairs):
+        # narrow-phase ties inside RK4 stages 1..3: those contacts are never returned, so no hint reaches them -- enumerate the
+        # single flips of the (few) tie events of a step, and the double flips when there are not many
+        ties = np.zeros(B, dtype=np.int32)
+        pyoracle.run(model, d, step=step, stage_ties=ties, **kw)
+        n = min(int(ties.max()), 32)
+        masks = [1 << i for i in range(n)]
+        if n <= MAX_STAGE_TIE_PAIRS:
+            masks += [(1 << i) | (1 << j) for i in range(n) for j in range(i + 1, n)]
+        for mk in masks:
+            outs.append(pyoracle.run(model, d, step=step, stage_tie_flip=mk, **kw))
     return outs
 
 
@@ -202,3 +215,32 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
         tied = int((c["tie_pairs"] > 0).sum())
         assert tied / B <= max_tie_frac, f"{what}: {tied}/{B} envs needed a non-natural narrow-phase tie outcome (bound {max_tie_frac})"
     return need_alt / B, float(c["err_best"].max())
+
+
+def load_outlier(name, extra_overrides=None):
+    """tests/golden/outliers/<name>.npz: the full input Data of ONE environment that the round-1 differential campaign could not
+    match to a single-policy oracle branch -> (model, unbatched Data on CPU, meta)."""
+    z = np.load(os.path.join(GOLD, "outliers", name + ".npz"))
+    meta = json.loads(str(z["meta"]))
+    mx = load_model(meta["xml"], dict(meta["overrides"], **(extra_overrides or {})))
+    d = mt.make_data(mx)
+    top, con = {}, {}
+    for n in REAL_LEAVES + INT_LEAVES:
+        path = native.DATA_PATH[n]
+        (con if len(path) == 2 else top)[path[-1]] = torch.from_numpy(z["in/" + n].copy())
+    d = d.replace(**top)
+    return mx, d.replace(contact=d.contact.replace(**con)), meta
+
+
+def policy_spread(model, d, **kw):
+    """How far apart the oracle's OWN admissible outcomes of one step are (max over the line-search knife policies of the
+    solver-leaf difference to the natural run): the size of the reference's implementation-defined band at this state."""
+    import pyoracle
+
+    knife = np.zeros(1, dtype=np.int32)
+    nat = pyoracle.run(model, d, knife=knife, **kw)
+    spread = 0.0
+    for pol in range(MAX_KNIFE_POLICIES):
+        o = pyoracle.run(model, d, knife_policy=pol, **kw)
+        spread = max(spread, max(rel_err(o[n], nat[n], SOLVER_FLOOR) for n in SOLVER_LEAVES))
+    return spread, int(knife[0])

@@ -12,7 +12,7 @@ import torch
 import mujoco_torch_amd as mt
 import pyoracle
 from _cases import SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, seeded_batch
-from _util import (CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+from _util import (OUTLIER_CASES, compare_with_oracle, load_outlier, policy_spread, CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
 
 pytestmark = pytest.mark.gpu
@@ -516,3 +516,27 @@ def test_config4_batch_properties():
     assert torch.allclose(q.norm(dim=-1), torch.ones(B, dtype=q.dtype, device=q.device), atol=1e-12)
     del big
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name", OUTLIER_CASES)
+def test_pinned_campaign_outliers(name, oracle_lib):
+    """The environments of the round-1 differential campaign that matched no oracle branch (profiles/r01/fuzz_parity.txt), pinned:
+
+    * RK4 + convex contacts (mesh_contact, gravcomp_arm): the difference was a narrow-phase tie INSIDE stages 1..3, which no hint
+      reaches; the oracle now enumerates single / double flips of those events and the step must match one outcome at 1e-8;
+    * Euler, Newton capped at 10 iterations (convex_primitives): the oracle's own admissible outcomes are 1e-6 .. 1e-1 apart at
+      these states (test_oracle_golden.py::test_iteration_capped_newton_states_are_implementation_defined); the step must agree
+      on every pre-solver leaf, lie inside that band, and match at 1e-8 once the same solve is allowed to converge."""
+    mx, d, meta = load_outlier(name)
+    got = gpu_out_to_numpy(mt.step(mx.to("cuda"), d.to("cuda")))
+    if "_rk4_" in name:
+        check_against_oracle(mx, d, got, 1e-9, 1e-8, what=name)
+        return
+    c = compare_with_oracle(mx, d, got)
+    assert c["pre_worst"] <= 1e-9 and c["ints_ok"], c["pre"]
+    spread, knife = policy_spread(mx, d)
+    assert knife >= 10
+    assert c["err_best"].max() <= max(spread, 1e-8), (c["err_best"].max(), spread)
+    mx2, d2, _ = load_outlier(name, dict(iterations=100, ls_iterations=50, tolerance=1e-12))
+    got2 = gpu_out_to_numpy(mt.step(mx2.to("cuda"), d2.to("cuda")))
+    check_against_oracle(mx2, d2, got2, 1e-9, 1e-8, what=name + " converged")

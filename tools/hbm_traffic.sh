@@ -20,6 +20,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if r["Counter_Name"] == c and "mjh_" in r["Kernel_Name"]:
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     res[c] = {k: (sum(v) / len(v), len(v)) for k, v in per.items()}
+import hashlib, os, subprocess
+def lib_fingerprint():
+    h = hashlib.sha256()
+    csrc = "/root/repo/mujoco-torch_amd/csrc"
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 line = json.loads([x for x in open(f"/tmp/pmc_{w}_WRITE_SIZE.log").read().splitlines() if x.startswith('{"metric"')][-1])
 steps_total = line["steps"] + line["warmup"] + min(line["steps"], 50)  # + the per-kernel timing pass of bench.py
 # per-step launches of each kernel = dispatches / steps (RK4 launches each phase four times per step)
@@ -27,6 +35,8 @@ fetch_kb = sum(m * n for m, n in res["FETCH_SIZE"].values()) / steps_total
 write_kb = sum(m * n for m, n in res["WRITE_SIZE"].values()) / steps_total
 out = {
     "config": line["config"]["workload"],
+    "lib_fingerprint": lib_fingerprint(),  # sha256 of csrc/*.h, *.hip the counters were collected on (bench.py drops the figures when the kernels changed)
+    "git_commit": (subprocess.run(["git", "-C", "/root/repo", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("MJH_GIT_COMMIT")),
     "kernels": {k: {"FETCH_SIZE_KB_raw_mean": res["FETCH_SIZE"].get(k, (0, 0))[0], "WRITE_SIZE_KB_mean": res["WRITE_SIZE"].get(k, (0, 0))[0], "dispatches_per_step": n / steps_total} for k, (m, n) in res["WRITE_SIZE"].items()},
     "FETCH_SIZE_KB_raw_per_step": fetch_kb, "WRITE_SIZE_KB_per_step": write_kb,
     "fetch_bytes_corrected": 2 * 1024 * fetch_kb, "write_bytes": 1024 * write_kb,
