@@ -31,7 +31,7 @@ CONFIGS = {
 }
 out = {"reference": "CPU oracle (oracle/mjoracle.c), pinned bit-for-bit-reproducibly by goldens recorded from the reference's own Python step; MJX parity unpinned (no jax / mujoco offline)",
        "metric": "max-norm relative error per leaf, |got - want|max / max(|want|max, floor); floor 1e-6 (1e-3 for solver leaves and float32)",
-       "git_commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None,
+       "git_commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or os.environ.get("MJH_GIT_COMMIT"),
        "configs": {}, "summary": {}}
 for name, (xml, ov, dt, B) in CONFIGS.items():
     mx, d = seeded_batch(xml, ov, dt, B)
