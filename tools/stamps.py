@@ -18,7 +18,8 @@ import mujoco_torch_amd as mt
 from _util import load_model
 which = sys.argv[1] if len(sys.argv) > 1 else "humanoid"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-cfg = {"humanoid": ("humanoid", {"solver": 1}, torch.float64), "ant": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32)}[which]
+cfg = {"humanoid": ("humanoid", {"solver": 1}, torch.float64), "ant": ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
+       "mesh": ("mesh_contact", {}, torch.float32)}[which]
 mx = load_model(*cfg)
 d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.01 * np.random.RandomState(42).randn(B, mx.nv)))
 if cfg[2] != torch.float64: d = d.to(cfg[2])
@@ -35,15 +36,13 @@ names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, 
          19: "CON start", 20: "load geoms + narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
          30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
          50: "SOL start", 51: "all loads issued + waited", 52: "inv_diag + chol_solve (qacc_smooth)", 53: "store qacc_smooth", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
-last = {}
+names.update({63: "newton: H build", 64: "newton: factor H", 65: "newton: solve", 66: "update_constraint + J^T force"})
+# every slot holds the cycles ACCUMULATED in the section that ends at that stamp (loops add up), summed over RK stages
 for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 79)]:
-    prev = None; tot = 0
+    tot = 0
     for k in range(lo, hi + 1):
-        if st[:, k].max() == 0: continue
-        if prev is not None:
-            dlt = (st[:, k] - st[:, prev]).mean(); tot += dlt
-            print(f"  [{k:2d}] {names.get(k, ''):40s} {dlt:10.0f} cycles")
-        else:
-            print(f"phase @{k}: {names.get(k, '')}")
-        prev = k
+        v = st[:, k].mean()
+        if v == 0: continue
+        tot += v
+        print(f"  [{k:2d}] {names.get(k, ''):40s} {v:10.0f} cycles   (max {st[:, k].max():10.0f})")
     print(f"  phase total {tot:10.0f} cycles")
