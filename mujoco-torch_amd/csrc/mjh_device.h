@@ -72,6 +72,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
+  X(i_row_src, m.nefc - m.ne - m.nf - m.nl - m.nlb - m.nlt, PH_SOL) X(i_row_dst, m.nefc - m.ne - m.nf - m.nl - m.nlb - m.nlt, PH_SOL) /* active-contact row tables (ints) */ \
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
   X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.con_general ? m.ne + m.nf + m.nlb + m.nl + m.nlt : 0, PH_CON) /* plain: equal to efc_pos for slide / hinge limits */ X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \

@@ -1235,7 +1235,11 @@ struct Env {
       const REAL* cpos = S.con_pos() + 3 * c;
       const REAL* fric = M.con_friction + 5 * c;
       const REAL dist = S.con_dist()[c] - M.con_includemargin[c];
-      const REAL active = (REAL)(dist < 0);
+      if (!(dist < 0)) {  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+        const int rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
+        for (int r = 0; r < rows; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = 0;
+        continue;
+      }
       REAL jp1[3], jr1[3], jp2[3], jr2[3];
       jac_dof(cpos, b2, d, jp2, jr2);
       jac_dof(cpos, b1, d, jp1, jr1);
@@ -1248,15 +1252,15 @@ struct Env {
         diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
       }
       if (dim == 1) {
-        S.efc_J()[(row0 - jrow0) * nv + d] = diff[0] * active;
+        S.efc_J()[(row0 - jrow0) * nv + d] = diff[0];
       } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
         const int nedge = 2 * (dim - 1);
         for (int ed = 0; ed < nedge; ed++) {
           const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
-          S.efc_J()[(row0 - jrow0 + ed) * nv + d] = (diff[0] + diff[1 + (ed >> 1)] * f) * active;
+          S.efc_J()[(row0 - jrow0 + ed) * nv + d] = diff[0] + diff[1 + (ed >> 1)] * f;
         }
       } else {  // _instantiate_contact_elliptic :519-583
-        for (int r = 0; r < dim; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = diff[r] * active;
+        for (int r = 0; r < dim; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = diff[r];
       }
     }
     wave_sync();
@@ -1727,6 +1731,13 @@ struct Env {
   struct LSPoint { REAL alpha, cost, d0, d1; };
   struct Ctx { REAL gauss, cost, prev_cost; int niter; };
 
+  // rows the solver iterates on: every non-contact row + the rows of the contacts that are ACTIVE in this environment.  A contact
+  // with dist >= includemargin has an all-zero Jacobian row and aref == 0 (constraint.py:440-451, :507-515, :552-561), so Jaref, jv,
+  // force and every sum it enters stay exact zeros: those rows are left out of the arena instead of being carried through every
+  // product, reduction and line-search point (the ant keeps 4 - 8 of its 60 contacts active)
+  int nrow_;
+  __device__ __forceinline__ int* row_src_lds() const { return reinterpret_cast<int*>(S.i_row_src()); }   // compact contact row -> Data row
+  __device__ __forceinline__ int* row_dst_lds() const { return reinterpret_cast<int*>(S.i_row_dst()); }   // Data contact row - first contact row -> compact row, -1 = inactive
   __device__ __forceinline__ int* lim_dof_lds() const { return reinterpret_cast<int*>(S.i_lim_dof()); }
   __device__ __forceinline__ int* dof_limrow_lds() const { return reinterpret_cast<int*>(S.i_dof_limrow()); }
 
@@ -1765,7 +1776,7 @@ struct Env {
   // exact zeros, so the single term is the same value.
   __device__ __forceinline__ void mul_J(const REAL* v, REAL* o, const REAL* sub) {
     const int nv = M.nv, nl = nf_() + M.nl;  // single-column rows (frictionloss, joint limits) come first
-    for (int r = lane(); r < M.nefc; r += W) {
+    for (int r = lane(); r < nrow_; r += W) {
       const REAL s = r < nl ? S.efc_Jl()[r] * v[lim_dof_lds()[r]] : dot_seq(S.efc_Jc() + (r - nl) * nv, 1, v, 1, nv);
       o[r] = sub ? s - sub[r] : s;
     }
@@ -1773,7 +1784,7 @@ struct Env {
 
   __device__ __forceinline__ void update_constraint(Ctx& c) {  // :320-357
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc;
+    const int nv = M.nv, nefc = nrow_;
     REAL part = 0, fneg = 0, fpos = 0;
     const int nf = nf_();
     for (int r = l; r < nefc; r += W) {
@@ -1821,7 +1832,7 @@ struct Env {
   // returned -- the cost-only contexts of the warm-start choice (:526-531) never read it.
   __device__ __forceinline__ void constraint_qfrc() {
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc;
+    const int nv = M.nv, nefc = nrow_;
     {  // rows in index order; rows whose force is exactly zero add +-0 and are skipped
       REAL s = 0;
       const int nl = nf_() + M.nl;
@@ -1850,7 +1861,7 @@ struct Env {
 
   __device__ __forceinline__ void update_gradient() {  // :359-376
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc;
+    const int nv = M.nv, nefc = nrow_;
     for (int d = l; d < nv; d += W) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
     wave_sync();
     if (M.solver == SOL_CG) {
@@ -1898,7 +1909,7 @@ struct Env {
     REAL q0 = 0, q1 = 0, q2 = 0;
     REAL f0n = 0, f0p = 0, f1n = 0, f1p = 0;
     const int nf = nf_();
-    for (int r = lane(); r < M.nefc; r += W) {
+    for (int r = lane(); r < nrow_; r += W) {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
       const REAL x = ja + alpha * jv;
       bool act = (x < 0) || is_eq_row(r);
@@ -1940,7 +1951,7 @@ struct Env {
     REAL q0[3] = {0, 0, 0}, q1[3] = {0, 0, 0}, q2[3] = {0, 0, 0};
     REAL f0n[3] = {0, 0, 0}, f0p[3] = {0, 0, 0}, f1n[3] = {0, 0, 0}, f1p[3] = {0, 0, 0};
     const int nf = nf_();
-    for (int r = lane(); r < M.nefc; r += W) {
+    for (int r = lane(); r < nrow_; r += W) {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
       const REAL u0 = S.s_quad()[3 * r], u1 = S.s_quad()[3 * r + 1], u2 = S.s_quad()[3 * r + 2];
       const bool eq = is_eq_row(r);
@@ -1987,7 +1998,7 @@ struct Env {
 
   __device__ __forceinline__ void linesearch(Ctx& c) {  // :378-497
     const int l = lane();
-    const int nv = M.nv, nefc = M.nefc;
+    const int nv = M.nv, nefc = nrow_;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     REAL ss = 0;
     bool nz = false;
@@ -2066,13 +2077,11 @@ struct Env {
     const int l = lane(), nv = M.nv;
     if (solving) {  // the small vectors of the phase in one batch of loads (one L2 round trip instead of eight)
       const bool from_in = !KA.state_from_cur;
-      const bool perm = ne_() > 0 || nlim_rows() > 0;  // permuted row order: efc_D / efc_aref are gathered in load_solver_inputs
-      const int nrow = (M.nefc > 0 && !perm) ? M.nefc : 0;
-      REAL* const dst[8] = {S.qfrc_smooth(), S.qpos(), S.qvel(), S.act(), S.act_dot(), S.qacc_warm(), S.efc_D(), S.efc_aref()};
-      const REAL* const src[8] = {out.qfrc_smooth, KA.cur.qpos, from_in ? in.qvel : KA.cur.qvel, KA.state_from_cur ? KA.cur.act : in.act,
-                                  out.act_dot, KA.warm_src, out.efc_D, out.efc_aref};
-      const int cnt[8] = {nv, M.nq, nv, M.na, M.na, M.nefc > 0 ? nv : 0, nrow, nrow};
-      multi_load<W, 8, 1>(dst, src, cnt, e);
+      REAL* const dst[6] = {S.qfrc_smooth(), S.qpos(), S.qvel(), S.act(), S.act_dot(), S.qacc_warm()};  // (efc_D / efc_aref are gathered row by row in load_solver_inputs)
+      const REAL* const src[6] = {out.qfrc_smooth, KA.cur.qpos, from_in ? in.qvel : KA.cur.qvel, KA.state_from_cur ? KA.cur.act : in.act,
+                                  out.act_dot, KA.warm_src};
+      const int cnt[6] = {nv, M.nq, nv, M.na, M.na, M.nefc > 0 ? nv : 0};
+      multi_load<W, 6, 1>(dst, src, cnt, e);
       if (from_in && KA.do_step) for (int i = l; i < nv; i += W) S.qvel()[i] = checked(S.qvel()[i], (REAL)0);  // _check_state (same lane wrote it)
     } else {
       row_load<W>(S.qfrc_smooth(), out.qfrc_smooth, nv, e);
@@ -2124,33 +2133,64 @@ struct Env {
           if (c) dof_limrow_lds()[r] = lr;
         }
       }
+      const int nlim = FRIC ? M.nlb + M.nlt : 0;  // dense limit rows: gathered row by row
+      const int c0 = nl + ne + nlim;              // first contact row (the contact rows close both row orders)
+      int nact = 0;
+      {  // active contacts -> compact row tables.  One contact per lane, exclusive prefix sum of the active contacts' row counts.
+        const int ncon = M.ncon;
+        const bool elliptic = M.cone == CONE_ELLIPTIC;
+        for (int base = 0; base < ncon; base += W) {
+          const int c = base + l;
+          const bool valid = c < ncon;
+          int rows = 0, start = 0;
+          bool act = false;
+          if (valid) {
+            const int dim = M.con_dim[c];
+            rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
+            start = M.con_efc_address[c] - c0;
+            act = (out.contact_dist[e * ncon + c] - M.con_includemargin[c]) < 0;
+          }
+          int x = act ? rows : 0;
+          for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
+          const int excl = x - (act ? rows : 0) + nact;
+          for (int k = 0; k < rows; k++) {
+            row_dst_lds()[start + k] = act ? excl + k : -1;
+            if (act) row_src_lds()[excl + k] = c0 + start + k;
+          }
+          nact += __builtin_amdgcn_readlane(x, W - 1);
+        }
+      }
+      nrow_ = c0 + nact;
+      wave_sync();
       {
-        const int nlim = FRIC ? M.nlb + M.nlt : 0;  // dense limit rows: gathered row by row
         for (int i = l; i < (ne + nlim) * nv; i += W) {
           int k, c;
           split_index(i, nv, M.inv_nv, k, c);
           S.efc_Jc()[i] = gJ[ext_row(nl + k) * nv + c];
         }
-        const int n = (nefc - nl - ne - nlim) * nv;  // the contact rows are contiguous in both orders
-        const REAL* src = gJ + (nl + ne + nlim) * nv;
+        // the rows of the active contacts, in row order (the rows of one contact are adjacent in memory: runs of rows * nv elements)
+        const int n = nact * nv;
         REAL* dstJ = S.efc_Jc() + (ne + nlim) * nv;
         int i = l;
-        for (; i + 7 * W < n; i += 8 * W) {  // eight requests in flight per trip: this copy is most of the phase's input bytes
-          REAL t[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) t[q] = src[i + q * W];
-#pragma unroll
-          for (int q = 0; q < 8; q++) dstJ[i + q * W] = t[q];
-        }
         for (; i + 3 * W < n; i += 4 * W) {
-          const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
+          int r0, k0, r1, k1, r2, k2, r3, k3;
+          split_index(i, nv, M.inv_nv, r0, k0); split_index(i + W, nv, M.inv_nv, r1, k1);
+          split_index(i + 2 * W, nv, M.inv_nv, r2, k2); split_index(i + 3 * W, nv, M.inv_nv, r3, k3);
+          const REAL a = gJ[row_src_lds()[r0] * nv + k0], b = gJ[row_src_lds()[r1] * nv + k1];
+          const REAL c = gJ[row_src_lds()[r2] * nv + k2], d = gJ[row_src_lds()[r3] * nv + k3];
           dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
         }
-        for (; i < n; i += W) dstJ[i] = src[i];
+        for (; i < n; i += W) {
+          int r, k;
+          split_index(i, nv, M.inv_nv, r, k);
+          dstJ[i] = gJ[row_src_lds()[r] * nv + k];
+        }
       }
-      if (ne > 0 || nlim_rows() > 0) {
-        for (int r = l; r < nefc; r += W) { const int x = ext_row(r); S.efc_D()[r] = out.efc_D[e * nefc + x]; S.efc_aref()[r] = out.efc_aref[e * nefc + x]; }
-      }  // (the unpermuted efc_D / efc_aref and the warm start came with the batch in load_factor_and_accelerate)
+      for (int r = l; r < nrow_; r += W) {
+        const int x = r < c0 ? ext_row(r) : row_src_lds()[r - c0];
+        S.efc_D()[r] = out.efc_D[e * nefc + x];
+        S.efc_aref()[r] = out.efc_aref[e * nefc + x];
+      }
     }
   }
 
@@ -2245,8 +2285,11 @@ struct Env {
     wave_sync();
     STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
-    if (ne_() > 0 || nlim_rows() > 0) { if (out.efc_force) for (int r = l; r < nefc; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r]; }
-    else put(out.efc_force, S.s_force(), nefc);
+    if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
+      const int c0 = nf_() + M.nl + ne_() + nlim_rows();
+      for (int r = l; r < c0; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r];
+      for (int r = l; r < nefc - c0; r += W) { const int q = row_dst_lds()[r]; out.efc_force[e * nefc + c0 + r] = q >= 0 ? S.s_force()[c0 + q] : (REAL)0; }
+    }
     STAMP(62);
   }
 

@@ -105,7 +105,8 @@ std::vector<int64_t> leaf_counts(const mjhModelDesc* m) {
 // frames that no later phase reads)
 const char* const kStageLeaves[] = {
     "qpos", "qvel", "act", "qacc_warmstart", "qacc", "act_dot", "xipos", "geom_xpos", "geom_xmat", "subtree_com", "cdof",
-    "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint"};
+    "cinert", "qM", "qLD", "efc_J", "efc_D", "efc_aref", "qfrc_smooth", "qacc_smooth", "qfrc_constraint",
+    "contact_dist" /* the solver phase picks the active contacts' rows by it */};
 // ... plus, for models with convex pairs, the contact leaves the convex kernel hands to the constraint phase
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
 const char* const kEqStageLeaves[] = {"xpos", "xquat", "xmat"};  // body frames read by the equality rows (constraint.py:116-212)
@@ -500,6 +501,7 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
   a.stamps = g_stamps;
   if (!a.in.qpos || !a.in.qvel) return fail(-22, "in.qpos and in.qvel are required");
   if ((a.stages & 0x60) && !(fin.qM && fin.qLD && fin.qfrc_smooth)) return fail(-22, "the solver phase reads out.qM / out.qLD: both leaves are required");
+  if (M.ncon > 0 && M.nefc > 0 && (a.stages & 0x40) && !fin.contact_dist) return fail(-22, "the solver phase reads out.contact_dist (active-contact row compaction): the leaf is required");
   if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(fin.contact_dist && fin.contact_pos && fin.contact_frame && fin.geom_xpos && fin.geom_xmat))
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
