@@ -282,6 +282,11 @@ def test_vmap_idiom_is_one_native_batch():
     assert torch.equal(got.qvel, want.qvel)
     with pytest.raises(NotImplementedError):
         torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))
+    # the reference's published mode, benchmarks/bench_compile.py:39-43: compile(vmap(step)) -- Dynamo finds nothing to fuse and hands
+    # the call to the same native batch
+    compiled = torch.compile(torch.vmap(lambda x: mt.step(mdev, x)))
+    got = compiled(dg)
+    assert torch.equal(got.qpos, mt.step(mdev, dg).qpos) and torch.equal(compiled(got).qvel, mt.step(mdev, mt.step(mdev, dg)).qvel)
 
 
 @pytest.mark.parametrize("scale,batch,nsteps", [(2.0, 64, 500), (50.0, 16, 200)])

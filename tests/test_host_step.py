@@ -238,3 +238,17 @@ def test_cpu_tensors_are_still_rejected_without_the_test_backend():
         mt.step(mx, mt.make_data(mx))
     with pytest.raises(RuntimeError, match="HIP device"):
         mt.forward(mx, mt.make_data(mx))
+
+
+def test_compile_and_vmap_wrappers_run_the_native_step(sim):
+    """The reference's published modes -- `torch.compile(torch.vmap(lambda d: step(mx, d)))` (benchmarks/bench_compile.py:39-43,
+    zoo/base.py compile_step=True) and plain `torch.vmap` -- wrapped around this package's step: there is nothing for a tracing
+    compiler to fuse (the step is one native launch sequence), so Dynamo's graph breaks hand the call to the same batched native
+    step; results equal the direct call and the returned container feeds the next call."""
+    mx = load_model("hopper")
+    d = seeded(mx, 4)
+    want = mt.step(mx, d)
+    for wrap in (torch.vmap(lambda x: mt.step(mx, x)), torch.compile(torch.vmap(lambda x: mt.step(mx, x))), torch.compile(lambda x: mt.step(mx, x))):
+        got = wrap(d)
+        assert tuple(got.batch_size) == (4,) and torch.equal(got.qpos, want.qpos) and torch.equal(got.contact.dist, want.contact.dist)
+        assert torch.equal(wrap(got).qpos, mt.step(mx, want).qpos)
