@@ -87,7 +87,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(s_Jaref, m.nefc, PH_SOL) X(s_force, m.nefc, PH_SOL) X(s_jv, m.nefc, PH_SOL) X(s_quad, 3 * m.nefc, PH_SOL)  \
   X(tmp_nq, m.nq, PH_SOL | PH_SOL2T)                                                                                        \
   X(r_vs, m.nv, PH_SOL2) X(r_vs2, m.nv, PH_SOL2) /* register solver: vectors staged for broadcast reads */     \
-  X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, m.nefc, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
+  X(r_src, m.nefc - m.nl, PH_SOL2) X(r_dst, m.nefc - m.nl, PH_SOL2) /* active-contact row tables (ints) */ X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, m.nefc, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
 
 struct LdsOff {
 #define X(n, c, p) int n;
@@ -180,6 +180,7 @@ __device__ __forceinline__ double dpp_move(double v) {
 __device__ __forceinline__ float read_lane(float v, int lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+__device__ __forceinline__ int read_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ double read_lane(double v, int lane) {
   unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   int lo = __builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane);

@@ -2484,11 +2484,13 @@ struct Env {
   template <int NMAX, int RPL>
   __device__ __forceinline__ void run_sol2() {
     static_assert(W == 32, "two environments per wavefront");
+    constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na, nefc = M.nefc, nl = M.nl, nd = nefc - nl;
     const bool dof = l < nv, lim = l < nl;
     const bool solving = (KA.stages & 0x40) != 0;
     const bool from_in = !KA.state_from_cur;
+    const bool newton = NEWT && M.solver == SOL_NEWTON;
     // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
     const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
     TriPack<REAL, NMAX> T;
@@ -2497,11 +2499,20 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < NMAX; k++) T.t[k] = (dof && k < nv) ? (k <= l ? gL[l * nv + k] : gL[k * nv + l]) : (REAL)0;
     }
+    REAL mrow[NEWT ? NMAX : 1];  // row d of qM (Newton models: nv <= 16): M products and the Hessian start from registers
+    if (NEWT) {
+      const REAL* gM = out.qM + e * nv * nv;
+#pragma unroll
+      for (int k = 0; k < (NEWT ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[l * nv + k] : (REAL)0;
+    }
     REAL qp0 = 0, qp1 = 0, qv = 0, ac = 0, ad = 0, warm = 0;
     REAL Dl = 0, arl = 0, Jl = 0, Dd[RPL], ard[RPL];
     int ldof = 0, limrow = -1;
+    int nda = 0;  // dense rows of the ACTIVE contacts of this environment (the rows of inactive contacts are exact zeros throughout, see Env::nrow_)
 #pragma unroll
     for (int j = 0; j < RPL; j++) { Dd[j] = 0; ard[j] = 0; }
+    int* rsrc = reinterpret_cast<int*>(S.r_src());  // compact dense row -> Data row
+    int* rdst = reinterpret_cast<int*>(S.r_dst());  // Data row - nl -> compact dense row, -1 = inactive
     if (solving) {
       const REAL* gq = KA.cur.qpos + e * nq;
       qp0 = l < nq ? gq[l] : (REAL)0;
@@ -2519,27 +2530,55 @@ struct Env {
         if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
         if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
         if (dof) limrow = M.dof_limrow[2 * l];
+        {  // active contacts -> compact row tables: one contact per lane, exclusive prefix sum of the active contacts' row counts
+          const int ncon = M.ncon;
+          const bool elliptic = M.cone == CONE_ELLIPTIC;
+          for (int base = 0; base < ncon; base += W) {
+            const int c = base + l;
+            const bool valid = c < ncon;
+            int rows = 0, start = 0;
+            bool act = false;
+            if (valid) {
+              const int dim = M.con_dim[c];
+              rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
+              start = M.con_efc_address[c] - nl;
+              act = (out.contact_dist[e * ncon + c] - M.con_includemargin[c]) < 0;
+            }
+            int x = act ? rows : 0;
+            for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
+            const int excl = x - (act ? rows : 0) + nda;
+            for (int k = 0; k < rows; k++) {
+              rdst[start + k] = act ? excl + k : -1;
+              if (act) rsrc[excl + k] = nl + start + k;
+            }
+            nda += sub_read<W>(x, W - 1);
+          }
+        }
+        wave_sync();
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-          const int r = nl + l + 32 * j;
-          if (r < nefc) { Dd[j] = out.efc_D[e * nefc + r]; ard[j] = out.efc_aref[e * nefc + r]; }
+          const int r = l + 32 * j;
+          if (r < nda) { const int x = rsrc[r]; Dd[j] = out.efc_D[e * nefc + x]; ard[j] = out.efc_aref[e * nefc + x]; }
         }
-        // contact rows of efc_J -> LDS, eight requests in flight per trip
-        const int n = nd * nv;
-        const REAL* src = gJ + nl * nv;
+        // rows of the active contacts of efc_J -> LDS, four requests in flight per trip
+        const int n = nda * nv;
         REAL* dstJ = S.efc_Jc();
         int i = l;
-        for (; i + 7 * W < n; i += 8 * W) {
-          REAL t[8];
-#pragma unroll
-          for (int q = 0; q < 8; q++) t[q] = src[i + q * W];
-#pragma unroll
-          for (int q = 0; q < 8; q++) dstJ[i + q * W] = t[q];
+        for (; i + 3 * W < n; i += 4 * W) {
+          int r0, k0, r1, k1, r2, k2, r3, k3;
+          split_index(i, nv, M.inv_nv, r0, k0); split_index(i + W, nv, M.inv_nv, r1, k1);
+          split_index(i + 2 * W, nv, M.inv_nv, r2, k2); split_index(i + 3 * W, nv, M.inv_nv, r3, k3);
+          const REAL a = gJ[rsrc[r0] * nv + k0], b = gJ[rsrc[r1] * nv + k1], c = gJ[rsrc[r2] * nv + k2], d = gJ[rsrc[r3] * nv + k3];
+          dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
         }
-        for (; i < n; i += W) dstJ[i] = src[i];
+        for (; i < n; i += W) {
+          int r, k;
+          split_index(i, nv, M.inv_nv, r, k);
+          dstJ[i] = gJ[rsrc[r] * nv + k];
+        }
       }
     }
-    {  // T.row[l] with a lane-dependent index would spill the triangle: pick the diagonal with a compile-time scan instead
+    {  // T.t[l] with a lane-dependent index would spill the triangle: pick the diagonal with a compile-time scan instead
       REAL dg = 1;
 #pragma unroll
       for (int k = 0; k < NMAX; k++) dg = (k == l) ? T.t[k] : dg;
@@ -2558,12 +2597,17 @@ struct Env {
       REAL* vs2 = S.r_vs2();
       REAL* fs = S.r_fs();
       const REAL* Jc = S.efc_Jc();
-      // o1 = M a, o2 = M b for vectors staged in LDS (lane d: element d; qM is symmetric: row d is read as column d, coalesced)
+      // o1 = M a, o2 = M b for vectors staged in LDS (lane d: element d).  Newton models: row d of qM is in registers; otherwise qM is
+      // read from L2 -- it is symmetric, so row d is read as column d, coalesced -- nine rows in flight per trip.  Terms in column order.
       auto mul_M2 = [&](const REAL* a, const REAL* b, REAL& o1, REAL& o2, bool two) {
         REAL s1 = 0, s2 = 0;
-        if (dof) {
+        if (NEWT) {
+#pragma unroll
+          for (int k = 0; k < (NEWT ? NMAX : 1); k++)
+            if (k < nv) { s1 += mrow[k] * a[k]; if (two) s2 += mrow[k] * b[k]; }
+        } else if (dof) {
           int k = 0;
-          for (; k + 9 <= nv; k += 9) {  // nine rows in flight per round trip (three trips cover the humanoid's 27)
+          for (; k + 9 <= nv; k += 9) {
             REAL m[9];
 #pragma unroll
             for (int t = 0; t < 9; t++) m[t] = gM[(k + t) * nv + l];
@@ -2579,7 +2623,7 @@ struct Env {
           }
           for (; k < nv; k++) { const REAL m = gM[k * nv + l]; s1 += m * a[k]; if (two) s2 += m * b[k]; }
         }
-        o1 = s1; o2 = s2;
+        o1 = dof ? s1 : (REAL)0; o2 = dof ? s2 : (REAL)0;
       };
       // dense rows: (J a)[r], (J b)[r] for the rows of this lane, terms in column order
       auto mul_J2 = [&](const REAL* a, const REAL* b, REAL (&o1)[RPL], REAL (&o2)[RPL], bool two) {
@@ -2587,7 +2631,7 @@ struct Env {
         for (int j = 0; j < RPL; j++) {
           const int r = l + 32 * j;
           REAL s1 = 0, s2 = 0;
-          if (r < nd) {
+          if (r < nda) {
             const REAL* row = Jc + r * nv;
             int k = 0;
             for (; k + 4 <= nv; k += 4) {
@@ -2612,7 +2656,7 @@ struct Env {
         }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-          const REAL act = (REAL)((l + 32 * j < nd) && jad[j] < 0);
+          const REAL act = (REAL)((l + 32 * j < nda) && jad[j] < 0);
           frd[j] = Dd[j] * -jad[j] * act;
           part += Dd[j] * jad[j] * jad[j] * act;
         }
@@ -2624,21 +2668,21 @@ struct Env {
       // qfrc_constraint = J^T efc_force (rows in index order: the single-column rows first), from the forces in frl / frd
       auto constraint_qfrc = [&]() -> REAL {
 #pragma unroll
-        for (int j = 0; j < RPL; j++) if (l + 32 * j < nd) fs[l + 32 * j] = frd[j];
+        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = frd[j];
         if (lim) fs[nd + l] = Jl * frl;
         wave_sync();
         REAL s = 0;
         if (dof) {
           if (limrow >= 0) s += fs[nd + limrow];
           int r = 0;
-          for (; r + 8 <= nd; r += 8) {
+          for (; r + 8 <= nda; r += 8) {
             REAL jj[8], ff[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) { jj[t] = Jc[(r + t) * nv + l]; ff[t] = fs[r + t]; }
 #pragma unroll
             for (int t = 0; t < 8; t++) s += jj[t] * ff[t];
           }
-          for (; r < nd; r++) s += Jc[r * nv + l] * fs[r];
+          for (; r < nda; r++) s += Jc[r * nv + l] * fs[r];
         }
         wave_sync();
         return s;
@@ -2674,8 +2718,61 @@ struct Env {
       }
       cost = constraint_cost(jal, jad, Ma, qacc, gauss);  // leaves the forces of the chosen context in frl / frd
       qfrc = constraint_qfrc();
+      // M^-1 grad (CG) or H^-1 grad with H = M + J^T diag(D active) J factorised in registers (Newton, solver.py:359-376)
+      auto precondition = [&](REAL grad) -> REAL {
+        if (!newton) return tri_solve2<NMAX>(T, grad);
+        TriPack<REAL, NMAX> H;
+        // weights of the rows in the quadratic set, staged for broadcast reads (fs is rewritten by the next constraint_qfrc)
+#pragma unroll
+        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = jad[j] < 0 ? Dd[j] : (REAL)0;
+        if (lim) fs[nd + l] = jal < 0 ? (Jl * Dl * (REAL)1) * Jl : (REAL)0;
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) H.t[k] = (NEWT && k <= l) ? mrow[NEWT ? k : 0] : (REAL)0;
+        REAL acc[NMAX];
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) acc[k] = 0;
+        if (dof && limrow >= 0) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
+#pragma unroll
+          for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[nd + limrow];
+        }
+        for (int r = 0; r < nda; r++) {
+          const REAL w = fs[r];
+          if (w != 0 && dof) {
+            const REAL* jr = Jc + r * nv;
+            const REAL ji = jr[l] * w * (REAL)1;
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) if (k < nv) acc[k] += ji * jr[k];  // only k <= l is read back
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NMAX; k++) H.t[k] = (k <= l) ? H.t[k] + acc[k] : (REAL)0;
+        wave_sync();
+        // register Cholesky (math.small_cholesky :117-127, pivots clamped at 1e-12) leaving row AND column l of L in lane l
+#pragma unroll
+        for (int j = 0; j < NMAX; j++) {
+          if (j < nv) {
+            const REAL sj = sub_read<W>(H.t[j], j);
+            const REAL dj = r_sqrt<REAL>(sj > (REAL)1e-12 ? sj : (REAL)1e-12);
+            const REAL lij = (l == j) ? dj : ((l > j && dof) ? H.t[j] / dj : (REAL)0);
+            if (l >= j) H.t[j] = lij;
+#pragma unroll
+            for (int k = j + 1; k < NMAX; k++) {
+              const REAL lkj = sub_read<W>(lij, k);
+              H.t[k] = (l == j) ? lkj : ((l > j) ? H.t[k] - lij * lkj : H.t[k]);
+            }
+          }
+        }
+        {
+          REAL dg = 1;
+#pragma unroll
+          for (int k = 0; k < NMAX; k++) dg = (k == l) ? H.t[k] : dg;
+          H.inv = dof ? 1 / dg : (REAL)0;
+        }
+        return tri_solve2<NMAX>(H, grad);
+      };
       REAL grad = dof ? (Ma - f) - qfrc : (REAL)0;
-      REAL Mgrad = tri_solve2<NMAX>(T, grad);
+      REAL Mgrad = precondition(grad);
       REAL search = -Mgrad;
       REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step: only read when another iteration follows
       int it = 0, niter = 0;
@@ -2722,7 +2819,7 @@ struct Env {
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
               const REAL x = jad[j] + alpha * jvd[j];
-              const REAL act = (REAL)((l + 32 * j < nd) && x < 0);
+              const REAL act = (REAL)((l + 32 * j < nda) && x < 0);
               q0 += qd0[j] * act; q1 += qd1[j] * act; q2 += qd2[j] * act;
             }
             q0 = sub_sum<W>(q0); q1 = sub_sum<W>(q1); q2 = sub_sum<W>(q2);
@@ -2771,30 +2868,38 @@ struct Env {
 #pragma unroll
           for (int j = 0; j < RPL; j++) jad[j] = jad[j] + improved * jvd[j] * alpha;
         }
-        if (need_grad && dof) { pg[l] = grad; pg[nv + l] = Mgrad; }
+        if (need_grad && !newton && dof) { pg[l] = grad; pg[nv + l] = Mgrad; }
         prev_cost = cost;
         cost = constraint_cost(jal, jad, Ma, qacc, gauss);
         qfrc = constraint_qfrc();
-        if (need_grad) {  // _update_gradient :359-376 (CG) and the Polak-Ribiere direction :519-523
+        if (need_grad) {  // _update_gradient :359-376 and the next direction: Newton -H^-1 grad, CG Polak-Ribiere :519-523
           grad = dof ? (Ma - f) - qfrc : (REAL)0;
-          Mgrad = tri_solve2<NMAX>(T, grad);
-          const REAL pgrad = dof ? pg[l] : (REAL)0, pMgrad = dof ? pg[nv + l] : (REAL)0;  // written by this lane
-          const REAL num = sub_sum<W>(grad * (Mgrad - pMgrad)), den = sub_sum<W>(pgrad * pMgrad);
-          REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
-          beta = beta > 0 ? beta : (REAL)0;
-          search = -Mgrad + beta * search;
+          Mgrad = precondition(grad);
+          if (newton) {
+            search = -Mgrad;
+          } else {
+            const REAL pgrad = dof ? pg[l] : (REAL)0, pMgrad = dof ? pg[nv + l] : (REAL)0;  // written by this lane
+            const REAL num = sub_sum<W>(grad * (Mgrad - pMgrad)), den = sub_sum<W>(pgrad * pMgrad);
+            REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+            beta = beta > 0 ? beta : (REAL)0;
+            search = -Mgrad + beta * search;
+          }
         }
         niter++; it++;
+      }
+      if (newton) {  // the Hessian weights overwrote the staged forces: stage the final ones for the row-order store below
+#pragma unroll
+        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = frd[j];
+        wave_sync();
       }
       if (dof) {
         if (out.qacc) out.qacc[e * nv + l] = qacc;
         if (out.qacc_warmstart) out.qacc_warmstart[e * nv + l] = qacc;
         if (out.qfrc_constraint) out.qfrc_constraint[e * nv + l] = qfrc;
       }
-      if (out.efc_force) {
+      if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
         if (lim) out.efc_force[e * nefc + l] = frl;
-#pragma unroll
-        for (int j = 0; j < RPL; j++) if (l + 32 * j < nd) out.efc_force[e * nefc + nl + l + 32 * j] = frd[j];
+        for (int r = l; r < nd; r += W) { const int q = rdst[r]; out.efc_force[e * nefc + nl + r] = q >= 0 ? fs[q] : (REAL)0; }
       }
     } else {
       if (dof && out.qacc) out.qacc[e * nv + l] = qacc;

@@ -358,9 +358,15 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     const int nd = d->nefc - d->nf - d->nl;
     const bool general = d->nf > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0;
     out->sol2_nmax = out->sol2_rpl = 0;
-    if (!off && d->solver == SOL_CG && !general && d->nv <= 28 && nd <= 64 && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
-      out->sol2_nmax = d->nv <= 16 ? 16 : 28;
-      out->sol2_rpl = nd <= 32 ? 1 : 2;
+    const int nmax = d->nv <= 16 ? 16 : 28, rpl = nd <= 32 ? 1 : (nd <= 64 ? 2 : (nd <= 128 ? 4 : 8));
+    // Newton (Hessian built and factorised in registers): two environments per wavefront run until BOTH have converged, which pays
+    // when the solves are short -- measured on MI355X: ant (nv 8, 1 - 3 iterations) solver phase 229 -> 175 us, mesh scene (nv 12, up to
+    // 100 iterations x 50 line-search steps, very uneven across environments) 548 -> 691 us.  MJH_SOL2_NEWTON_NV moves the cut.
+    static const int newton_nv = [] { const char* e = getenv("MJH_SOL2_NEWTON_NV"); return e ? atoi(e) : 8; }();
+    const bool solver_ok = d->solver == SOL_CG || (d->solver == SOL_NEWTON && nmax == 16 && d->nv <= newton_nv);
+    if (!off && solver_ok && !general && d->nv <= 28 && nd <= 32 * (nmax == 16 ? 8 : 2) && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
+      out->sol2_nmax = nmax;
+      out->sol2_rpl = rpl;
     }
   }
   out->leaf_count = leaf_counts(d);
@@ -403,7 +409,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   if (out->sol2_nmax) {
 #define SET_SOL2(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[5]));
-    SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(28, 1) SET_SOL2(28, 2)
+    SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(16, 4) SET_SOL2(16, 8) SET_SOL2(28, 1) SET_SOL2(28, 2)
 #undef SET_SOL2
   }
   return 0;
@@ -445,7 +451,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   const size_t lds = (size_t)(2 * m->lds_bytes[5]);
 #define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
-  if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else GO(16, 2); }
+  if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
   else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
 #undef GO
   HIP_TRY(hipGetLastError());
