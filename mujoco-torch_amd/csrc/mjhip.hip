@@ -400,7 +400,11 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     out->pack2[P] = 1;                                                                                                       \
   }
   SET_PACK(0) SET_PACK(3)
-  if (sizeof(REAL) == 4 && d->nv <= 16) { SET_PACK(1) }  // float32 CRB of small models: register-bound at 4 waves/SIMD, two environments per wave double the residents
+  // CRB: the register Cholesky keeps one matrix row per lane, so nv <= 32 would fit a 32-lane half too; measured on the float64
+  // humanoid (nv 27) two per wavefront is SLOWER, 50.2 vs 39.9 us (132 VGPRs: 3 waves / SIMD instead of 4, and every broadcast of the
+  // factorisation becomes two v_readlane + a select): opt-in only (MJH_CRB_PACK=1).  float32 small models: +13 % on the ant (round 1).
+  static const bool crb_pack = [] { const char* e = getenv("MJH_CRB_PACK"); return e && e[0] == '1'; }();
+  if ((sizeof(REAL) == 4 && d->nv <= 16) || (crb_pack && d->nv <= 32 && d->nv > 16)) { SET_PACK(1) }
 #undef SET_PACK
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 7, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));
