@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 9
+#define MJH_ABI_VERSION 10
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -68,7 +68,7 @@ extern "C" {
 /* int32 scalars */
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
-  X(ne) X(nf) X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(nefc) X(npair) X(nconvex) \
+  X(ne) X(nf) /* dof-frictionloss rows */ X(nft) /* tendon-frictionloss rows (dense; they follow the dof ones) */ X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(nefc) X(npair) X(nconvex) \
   X(ntendon) /* fixed tendons = length of the ten_length / ten_velocity leaves */ X(nwrapj) /* joint terms of all tendons (entries of ten_dof / ten_qposadr / ten_coef) */ \
   X(neq) /* equality constraints of the model = length of the eq_active leaf */ X(neqtab) /* entries of the eq_* tables (0 when equality rows are disabled) */ \
   X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
@@ -134,6 +134,7 @@ extern "C" {
   X(eq_row)         /* neqtab: first efc row */                                                  \
   X(eq_jadr)        /* neqtab*4: joint couplings: dofadr1, dofadr2, qposadr1, qposadr2 (device.py:310-314; a missing second joint reads the LAST joint, as the reference's jnt_dofadr[-1] does) */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
+  X(fric_tendon)    /* nft: tendon id of each tendon-frictionloss row (constraint.py:230-234) */ \
   X(ten_adr)        /* ntendon+1: CSR of the joint terms of each fixed tendon (smooth.py:470-497) */ \
   X(ten_dof)        /* nwrapj: dof of the term */                                                \
   X(ten_qposadr)    /* nwrapj: qpos address of the term */                                       \
@@ -195,6 +196,7 @@ extern "C" {
   X(tendon_solimp_lim) /* ntendon*5 */                                                           \
   X(tendon_stiffness) /* ntendon */                                                              \
   X(tendon_damping) /* ntendon */                                                                \
+  X(tendon_frictionloss) /* ntendon */ X(tendon_solref_fri) /* ntendon*2 */ X(tendon_solimp_fri) /* ntendon*5 */ \
   X(tendon_lengthspring) /* ntendon*2: the spring is slack between the two lengths (passive.py:121-127) */ \
   X(body_gravcomp)  /* nbody: fraction of the body's weight compensated (passive.py:148-156); all zero = none */ \
   X(body_invweight0_rot) /* nbody (rotational component; weld rows 3..5, constraint.py:193-194) */         \

@@ -71,11 +71,11 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(efc_J, (m.con_general ? m.nefc : m.nefc - m.nl) * m.nv, PH_CON) X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
-  X(efc_fl, m.nf, PH_SOL) /* frictionloss of the dof-friction rows */                \
-  X(i_row_src, m.nefc - m.ne - m.nf - m.nl - m.nlb - m.nlt, PH_SOL) X(i_row_dst, m.nefc - m.ne - m.nf - m.nl - m.nlb - m.nlt, PH_SOL) /* active-contact row tables (ints) */ \
+  X(efc_fl, m.nf + m.nft, PH_SOL) /* frictionloss of the dof- and tendon-friction rows */                \
+  X(i_row_src, m.nefc - m.ne - m.nf - m.nft - m.nl - m.nlb - m.nlt, PH_SOL) X(i_row_dst, m.nefc - m.ne - m.nf - m.nft - m.nl - m.nlb - m.nlt, PH_SOL) /* active-contact row tables (ints) */ \
   X(i_lim_dof, m.nf + m.nl, PH_SOL) X(i_dof_limrow, (m.nf + m.nl) ? 2 * m.nv : 0, PH_SOL) /* int copies of the model tables: lane-indexed reads stay on chip */ \
   X(efc_aref, m.nefc, PH_SOL)                                                                                  \
-  X(efc_pos, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.con_general ? m.ne + m.nf + m.nlb + m.nl + m.nlt : 0, PH_CON) /* plain: equal to efc_pos for slide / hinge limits */ X(efc_invweight, m.ne + m.nf + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
+  X(efc_pos, m.ne + m.nf + m.nft + m.nlb + m.nl + m.nlt, PH_CON) X(efc_pos_norm, m.con_general ? m.ne + m.nf + m.nft + m.nlb + m.nl + m.nlt : 0, PH_CON) /* plain: equal to efc_pos for slide / hinge limits */ X(efc_invweight, m.ne + m.nf + m.nft + m.nlb + m.nl + m.nlt, PH_CON) /* contact rows recompute theirs */ \
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL) X(ten_len, m.ntendon, PH_VEL) X(ten_frc, m.ntendon, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL | PH_SOL2P)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \

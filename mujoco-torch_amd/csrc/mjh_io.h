@@ -16,7 +16,7 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
   const int64_t nsingle = m.nf + m.nl;             // single-column rows (dof frictionloss, slide / hinge limits)
   const int64_t ndense = nefc - nsingle;           // dense rows (equality, ball / tendon limits, contacts)
   const int64_t tri = nv * (nv + 1) / 2;
-  const bool general_con = m.con_general != 0, general_sol = (m.nf > 0 || m.ne > 0 || m.nlb > 0 || m.nlt > 0);
+  const bool general_con = m.con_general != 0, general_sol = (m.nf > 0 || m.nft > 0 || m.ne > 0 || m.nlb > 0 || m.nlt > 0);
   const bool opt_vel = (m.has_fluid || m.has_gravcomp || m.ntendon > 0);
   int64_t rd = 0, wr = 0;
   switch (kernel) {

@@ -501,20 +501,25 @@ struct Env {
   // [frictionloss | joint limits | equality | contacts]: single-column rows first, dense rows after them; the Data leaves
   // use the reference's order [equality | frictionloss | limits | contacts] and ext_row() maps one to the other.
   __device__ __forceinline__ static int ne_() { return FRIC ? M.ne : 0; }
+  // tendon-frictionloss rows (constraint.py:230-234): dense rows with the frictionloss cost; they lead the solver's dense block
+  __device__ __forceinline__ static int nft_() { return FRIC ? M.nft : 0; }
+  __device__ __forceinline__ static bool is_dfric(int r) { return FRIC && (unsigned)(r - (nf_() + M.nl)) < (unsigned)M.nft; }
+  __device__ __forceinline__ static bool is_fric(int r) { return FRIC && (r < nf_() || is_dfric(r)); }
+  __device__ __forceinline__ static int fric_index(int r) { return r < nf_() ? r : r - M.nl; }  // slot of a friction row in efc_fl: dof rows, then tendon rows
   __device__ __forceinline__ static int nlim_rows() { return FRIC ? M.nlb + M.nlt : 0; }
-  __device__ __forceinline__ static bool is_eq_row(int r) { return FRIC && (unsigned)(r - (nf_() + M.nl)) < (unsigned)M.ne; }
+  __device__ __forceinline__ static bool is_eq_row(int r) { return FRIC && (unsigned)(r - (nf_() + M.nl + nft_())) < (unsigned)M.ne; }
   // dense limit rows (ball joints, tendons) sit between the equality rows and the contacts in the solver's dense block:
-  //   solver order  [frictionloss | slide-hinge limits || equality | ball limits | tendon limits | contacts]
-  //   Data order    [equality | frictionloss | ball limits | slide-hinge limits | tendon limits | contacts]
+  //   solver order  [dof frictionloss | slide-hinge limits || tendon frictionloss | equality | ball limits | tendon limits | contacts]
+  //   Data order    [equality | dof frictionloss | tendon frictionloss | ball limits | slide-hinge limits | tendon limits | contacts]
   __device__ __forceinline__ static int ext_row(int r) {
     if (!FRIC) return r;
-    const int nf = nf_(), s1 = nf + M.nl, ne = M.ne, nlb = M.nlb, nlt = M.nlt;
+    const int nf = nf_(), nft = M.nft, s1 = nf + M.nl, s2 = s1 + nft, ne = M.ne, nlb = M.nlb;
     if (r < nf) return ne + r;
-    if (r < s1) return ne + nlb + r;
-    if (r < s1 + ne) return r - s1;
-    if (r < s1 + ne + nlb) return r - s1 + nf;          // ne + nf + (r - s1 - ne)
-    if (r < s1 + ne + nlb + nlt) return r;              // ne + nf + nlb + nl + (r - s1 - ne - nlb), and s1 = nf + nl
-    return r;
+    if (r < s1) return ne + nft + nlb + r;              // ne + nf + nft + nlb + (r - nf)
+    if (r < s2) return ne + nf + (r - s1);
+    if (r < s2 + ne) return r - s2;
+    if (r < s2 + ne + nlb) return r - s2 + nf + nft;    // ne + nf + nft + (r - s2 - ne)
+    return r;                                           // tendon limits and contacts sit at the same index in both orders
   }
   LdsView<REAL> S;
   int64_t e;      // environment index
@@ -1074,7 +1079,7 @@ struct Env {
     const int l = lane();
     // FRIC = false: the plain instantiation (slide / hinge limits and contacts only); equality, frictionloss, ball- and tendon-limit
     // rows compile away and cost the headline kernel no registers
-    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = FRIC ? M.nf : 0, ne = FRIC ? M.ne : 0, nlb = FRIC ? M.nlb : 0, nlt = FRIC ? M.nlt : 0;
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = FRIC ? M.nf : 0, nft = FRIC ? M.nft : 0, nfa = nf + nft, ne = FRIC ? M.ne : 0, nlb = FRIC ? M.nlb : 0, nlt = FRIC ? M.nlt : 0;
     if (nefc == 0) return;
     // plain instantiation: the slide / hinge limit rows have one non-zero each -- they go straight to global memory and the LDS copy
     // of efc_J holds the contact rows only (4.5 KB less for the humanoid); qpos is read from global by the few lanes that need it
@@ -1089,7 +1094,7 @@ struct Env {
       multi_load<W, 3, 3>(dst, src, cnt, e);
       if (from_in && KA.do_step) for (int i = l; i < nv; i += W) S.qvel()[i] = checked(S.qvel()[i], (REAL)0);  // _check_state (same lane wrote it)
     }
-    if (FRIC) for (int w = l; w < (ne + nf + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
+    if (FRIC) for (int w = l; w < (ne + nfa + nlb + nl + nlt) * nv; w += W) S.efc_J()[w] = 0;
     wave_sync();
     STAMP(23);
     // equality rows (constraint.py:116-212, 254-296): one lane per (constraint, dof) column of a connect / weld, one lane per
@@ -1181,8 +1186,16 @@ struct Env {
       S.efc_pos_norm()[r] = 0;
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
-    for (int r0 = l; r0 < nlb; r0 += W) {  // _instantiate_limit_ball :299-335
+    for (int r0 = l; r0 < nft; r0 += W) {  // _instantiate_friction :215-251 (tendon rows: J = ten_J[t], a model constant for fixed tendons)
       const int r = ne + nf + r0;
+      const int t = M.fric_tendon[r0];
+      for (int d = 0; d < nv; d++) S.efc_J()[r * nv + d] = M.ten_J0[t * nv + d];
+      S.efc_pos()[r] = 0;
+      S.efc_pos_norm()[r] = 0;
+      S.efc_invweight()[r] = M.tendon_invweight0[t];
+    }
+    for (int r0 = l; r0 < nlb; r0 += W) {  // _instantiate_limit_ball :299-335
+      const int r = ne + nfa + r0;
       const int j = M.lim_ball_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q[4] = {S.qpos_con()[qa], S.qpos_con()[qa + 1], S.qpos_con()[qa + 2], S.qpos_con()[qa + 3]};
       REAL axis[3], angle;
@@ -1197,7 +1210,7 @@ struct Env {
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
     for (int r0 = l; r0 < nlt; r0 += W) {  // _instantiate_limit_tendon :375-405
-      const int r = ne + nf + nlb + nl + r0;
+      const int r = ne + nfa + nlb + nl + r0;
       const int t = M.lim_tendon[r0];
       REAL len = 0;
       for (int q = M.ten_adr[t]; q < M.ten_adr[t + 1]; q++) len += M.ten_coef[q] * S.qpos_con()[M.ten_qposadr[q]];
@@ -1211,7 +1224,7 @@ struct Env {
       S.efc_invweight()[r] = M.tendon_invweight0[t];
     }
     for (int r0 = l; r0 < nl; r0 += W) {  // _instantiate_limit_slide_hinge :338-372
-      const int r = ne + nf + nlb + r0;
+      const int r = ne + nfa + nlb + r0;
       const int j = M.lim_jnt[r0], qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       const REAL q = FRIC ? S.qpos_con()[qa] : gq[qa];
       const REAL dist_min = q - M.jnt_range[2 * j], dist_max = M.jnt_range[2 * j + 1] - q;
@@ -1265,7 +1278,7 @@ struct Env {
     }
     wave_sync();
     STAMP(25);
-    const int ns = ne + nf + nlb + nl + nlt;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
+    const int ns = ne + nfa + nlb + nl + nlt;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
@@ -1278,12 +1291,16 @@ struct Env {
         const int da = M.fric_dof[r - ne];
         solref[0] = M.dof_solref[2 * da]; solref[1] = M.dof_solref[2 * da + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.dof_solimp[5 * da + i];
-      } else if (r < ne + nf + nlb + nl) {
-        const int j = r < ne + nf + nlb ? M.lim_ball_jnt[r - ne - nf] : M.lim_jnt[r - ne - nf - nlb];
+      } else if (r < ne + nfa) {
+        const int t = M.fric_tendon[r - ne - nf];
+        solref[0] = M.tendon_solref_fri[2 * t]; solref[1] = M.tendon_solref_fri[2 * t + 1];
+        for (int i = 0; i < 5; i++) solimp[i] = M.tendon_solimp_fri[5 * t + i];
+      } else if (r < ne + nfa + nlb + nl) {
+        const int j = r < ne + nfa + nlb ? M.lim_ball_jnt[r - ne - nfa] : M.lim_jnt[r - ne - nfa - nlb];
         solref[0] = M.jnt_solref[2 * j]; solref[1] = M.jnt_solref[2 * j + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * j + i];
       } else if (r < ns) {
-        const int t = M.lim_tendon[r - ne - nf - nlb - nl];
+        const int t = M.lim_tendon[r - ne - nfa - nlb - nl];
         solref[0] = M.tendon_solref_lim[2 * t]; solref[1] = M.tendon_solref_lim[2 * t + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.tendon_solimp_lim[5 * t + i];
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
@@ -1333,7 +1350,7 @@ struct Env {
       for (int w = l; w < (nefc - nl) * nv; w += W) gJ[nl * nv + w] = S.efc_J()[w];
     }
     STAMP(27);
-    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : (REAL)0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : ((r >= ne + nf && r < ne + nfa) ? M.tendon_frictionloss[M.fric_tendon[r - ne - nf]] : (REAL)0);
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
@@ -1791,9 +1808,9 @@ struct Env {
       const REAL ja = S.s_Jaref()[r];
       bool act = (ja < 0) || is_eq_row(r);
       REAL floss_force = 0;
-      if (nf > 0 && r < nf) {
+      if (is_fric(r)) {
         act = true;  // frictionloss row: quadratic inside |Jaref| < R f, linear (saturated force) outside (solver.py:326-342)
-        const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+        const REAL fl = S.efc_fl()[fric_index(r)], D = S.efc_D()[r];
         const REAL rr = 1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL);
         const bool lin_neg = (ja <= -rr * fl) && (fl > 0), lin_pos = (ja >= rr * fl) && (fl > 0);
         act = act && !lin_neg && !lin_pos;
@@ -1806,9 +1823,10 @@ struct Env {
       part += S.efc_D()[r] * ja * ja * active;
     }
     REAL floss_cost = 0;
-    if (nf > 0) {  // the two frictionloss cost sums, rows in index order (nf <= nv <= 64: one row per lane)
+    if (nf > 0 || nft_() > 0) {  // the two frictionloss cost sums, rows in index order (every friction row sits in the first 64 rows: one per lane)
       REAL sn = 0, sp = 0;
       for (int r = 0; r < nf; r++) { sn += read_lane(fneg, r); sp += read_lane(fpos, r); }
+      for (int r = nf + M.nl; r < nf + M.nl + nft_(); r++) { sn += read_lane(fneg, r); sp += read_lane(fpos, r); }
       floss_cost = sn + sp;
     }
     REAL gpart = 0;
@@ -1819,6 +1837,12 @@ struct Env {
     c.prev_cost = c.cost;
     c.cost = ((REAL)0.5 * csum + c.gauss) + floss_cost;
     wave_sync();
+  }
+  // whether the dense (tendon) frictionloss row r is in its quadratic zone
+  __device__ __forceinline__ bool dfric_quadratic(int r) const {
+    const REAL ja = S.s_Jaref()[r], fl = S.efc_fl()[fric_index(r)], D = S.efc_D()[r];
+    const REAL rr = 1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL);
+    return !((ja <= -rr * fl) && (fl > 0)) && !((ja >= rr * fl) && (fl > 0));
   }
   // whether row r (a single-column row: frictionloss first, then joint limits) is in the quadratic (active) set
   __device__ __forceinline__ bool crow_active(int r) const {
@@ -1884,7 +1908,7 @@ struct Env {
         }
         for (int base = nl; base < nefc; base += W) {
           const int r = base + l;
-          unsigned long long mask = __ballot(r < nefc && (S.s_Jaref()[r] < 0 || is_eq_row(r)));
+          unsigned long long mask = __ballot(r < nefc && (is_dfric(r) ? dfric_quadratic(r) : (S.s_Jaref()[r] < 0 || is_eq_row(r))));
           while (mask) {
             const int row = base + __ffsll((long long)mask) - 1;
             mask &= mask - 1;
@@ -1913,9 +1937,9 @@ struct Env {
       const REAL ja = S.s_Jaref()[r], jv = S.s_jv()[r];
       const REAL x = ja + alpha * jv;
       bool act = (x < 0) || is_eq_row(r);
-      if (nf > 0 && r < nf) {  // frictionloss row (solver.py:404-416): active unless in a linear zone
+      if (is_fric(r)) {  // frictionloss row (solver.py:404-416): active unless in a linear zone
         act = true;
-        const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+        const REAL fl = S.efc_fl()[fric_index(r)], D = S.efc_D()[r];
         const REAL rf = (1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL)) * fl;
         const bool ln = (x <= -rf) && (fl > 0), lp = (x >= rf) && (fl > 0);
         f0n = (REAL)ln * fl * ((REAL)-0.5 * rf - ja);
@@ -1931,9 +1955,10 @@ struct Env {
     }
     q0 = wave_sum(q0); q1 = wave_sum(q1); q2 = wave_sum(q2);
     REAL fa0 = 0, fa1 = 0;
-    if (nf > 0) {  // frictionloss adjustments, rows in index order (one row per lane)
+    if (nf > 0 || nft_() > 0) {  // frictionloss adjustments, rows in index order (one row per lane)
       REAL s0n = 0, s0p = 0, s1n = 0, s1p = 0;
       for (int r = 0; r < nf; r++) { s0n += read_lane(f0n, r); s0p += read_lane(f0p, r); s1n += read_lane(f1n, r); s1p += read_lane(f1p, r); }
+      for (int r = nf + M.nl; r < nf + M.nl + nft_(); r++) { s0n += read_lane(f0n, r); s0p += read_lane(f0p, r); s1n += read_lane(f1n, r); s1p += read_lane(f1p, r); }
       fa0 = s0n + s0p; fa1 = s1n + s1p;
     }
     const REAL t0 = (qg[0] + q0) + fa0, t1 = (qg[1] + q1) + fa1, t2 = (qg[2] + q2) + 0;
@@ -1959,9 +1984,9 @@ struct Env {
       for (int k = 0; k < 3; k++) {
         const REAL x = ja + alpha[k] * jv;
         bool act = (x < 0) || eq;
-        if (nf > 0 && r < nf) {
+        if (is_fric(r)) {
           act = true;
-          const REAL fl = S.efc_fl()[r], D = S.efc_D()[r];
+          const REAL fl = S.efc_fl()[fric_index(r)], D = S.efc_D()[r];
           const REAL rf = (1 / (D + (REAL)(D == 0) * (REAL)(float)mjMINVAL)) * fl;
           const bool ln = (x <= -rf) && (fl > 0), lp = (x >= rf) && (fl > 0);
           f0n[k] = (REAL)ln * fl * ((REAL)-0.5 * rf - ja);
@@ -1979,9 +2004,10 @@ struct Env {
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       REAL fa0 = 0, fa1 = 0;
-      if (nf > 0) {
+      if (nf > 0 || nft_() > 0) {
         REAL s0n = 0, s0p = 0, s1n = 0, s1p = 0;
         for (int r = 0; r < nf; r++) { s0n += read_lane(f0n[k], r); s0p += read_lane(f0p[k], r); s1n += read_lane(f1n[k], r); s1p += read_lane(f1p[k], r); }
+        for (int r = nf + M.nl; r < nf + M.nl + nft_(); r++) { s0n += read_lane(f0n[k], r); s0p += read_lane(f0p[k], r); s1n += read_lane(f1n[k], r); s1p += read_lane(f1p[k], r); }
         fa0 = s0n + s0p; fa1 = s1n + s1p;
       }
       const REAL t0 = (qg[0] + q0[k]) + fa0, t1 = (qg[1] + q1[k]) + fa1, t2 = (qg[2] + q2[k]) + 0;
@@ -2132,9 +2158,11 @@ struct Env {
           if (b) S.efc_fl()[r] = fl;
           if (c) dof_limrow_lds()[r] = lr;
         }
+        for (int j = l; j < nft_(); j += W) S.efc_fl()[nfr + j] = M.tendon_frictionloss[M.fric_tendon[j]];
       }
       const int nlim = FRIC ? M.nlb + M.nlt : 0;  // dense limit rows: gathered row by row
-      const int c0 = nl + ne + nlim;              // first contact row (the contact rows close both row orders)
+      const int ndense0 = nft_() + ne + nlim;     // dense rows ahead of the contacts: tendon frictionloss, equality, ball / tendon limits
+      const int c0 = nl + ndense0;                // first contact row (the contact rows close both row orders)
       int nact = 0;
       {  // active contacts -> compact row tables.  One contact per lane, exclusive prefix sum of the active contacts' row counts.
         const int ncon = M.ncon;
@@ -2163,14 +2191,14 @@ struct Env {
       nrow_ = c0 + nact;
       wave_sync();
       {
-        for (int i = l; i < (ne + nlim) * nv; i += W) {
+        for (int i = l; i < ndense0 * nv; i += W) {
           int k, c;
           split_index(i, nv, M.inv_nv, k, c);
           S.efc_Jc()[i] = gJ[ext_row(nl + k) * nv + c];
         }
         // the rows of the active contacts, in row order (the rows of one contact are adjacent in memory: runs of rows * nv elements)
         const int n = nact * nv;
-        REAL* dstJ = S.efc_Jc() + (ne + nlim) * nv;
+        REAL* dstJ = S.efc_Jc() + ndense0 * nv;
         int i = l;
         for (; i + 3 * W < n; i += 4 * W) {
           int r0, k0, r1, k1, r2, k2, r3, k3;
@@ -2286,7 +2314,7 @@ struct Env {
     STAMP(61);
     put(out.qacc, S.qacc(), nv); put(out.qacc_warmstart, S.qacc(), nv); put(out.qfrc_constraint, S.qfrc_constraint(), nv);
     if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
-      const int c0 = nf_() + M.nl + ne_() + nlim_rows();
+      const int c0 = nf_() + M.nl + nft_() + ne_() + nlim_rows();
       for (int r = l; r < c0; r += W) out.efc_force[e * nefc + ext_row(r)] = S.s_force()[r];
       for (int r = l; r < nefc - c0; r += W) { const int q = row_dst_lds()[r]; out.efc_force[e * nefc + c0 + r] = q >= 0 ? S.s_force()[c0 + q] : (REAL)0; }
     }

@@ -133,7 +133,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
   M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M.has_gravcomp = 0;
-  M.con_general = (d->nf > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0) ? 1 : 0;
+  M.con_general = (d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0) ? 1 : 0;
+  if (d->nft > 0 && d->nf + d->nl + d->nft > 64) return fail(-38, "frictionloss rows beyond the first 64 solver rows are not supported");
   for (int b = 0; b < d->nbody; b++) if (d->body_gravcomp[b] != 0) M.has_gravcomp = 1;
   M.gravity[0] = (REAL)d->gravity_x; M.gravity[1] = (REAL)d->gravity_y; M.gravity[2] = (REAL)d->gravity_z;
   M.meaninertia = d->meaninertia; M.tolerance = d->tolerance; M.ls_tolerance = d->ls_tolerance;
@@ -356,7 +357,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   {  // register solver: CG, slide / hinge limit rows + contact rows only, one dof per lane of a 32-lane half
     static const bool off = [] { const char* e = getenv("MJH_SOL2"); return e && e[0] == '0'; }();
     const int nd = d->nefc - d->nf - d->nl;
-    const bool general = d->nf > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0;
+    const bool general = d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0;
     out->sol2_nmax = out->sol2_rpl = 0;
     const int nmax = d->nv <= 16 ? 16 : 28, rpl = nd <= 32 ? 1 : (nd <= 64 ? 2 : (nd <= 128 ? 4 : 8));
     // Newton (Hessian built and factorised in registers): two environments per wavefront run until BOTH have converged, which pays
@@ -487,7 +488,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     timing_mark(stream, 9);
   }
   if ((st & 0x60) && m->sol2_nmax) return launch_sol2<REAL>(m, a, stream);
-  if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
+  if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.nft > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
 }
 

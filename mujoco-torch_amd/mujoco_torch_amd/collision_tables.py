@@ -162,7 +162,7 @@ def constraint_sizes(m, dims) -> tuple:
         return (0, 0, 0, 0, 0)
     et = np.asarray(getattr(m, "eq_type", np.zeros(0, dtype=np.int32)))
     ne = 0 if flags & DisableBit.EQUALITY else int(3 * (et == 0).sum() + 6 * (et == 1).sum() + (et == 2).sum())
-    nf = 0 if flags & DisableBit.FRICTIONLOSS else int((np.asarray(m.dof_frictionloss) > 0).sum())
+    nf = 0 if flags & DisableBit.FRICTIONLOSS else int((np.asarray(m.dof_frictionloss) > 0).sum()) + int((np.asarray(getattr(m, "tendon_frictionloss", np.zeros(0))) > 0).sum())
     nl = 0 if flags & DisableBit.LIMIT else int(np.asarray(m.jnt_limited).sum()) + int(np.asarray(getattr(m, "tendon_limited", np.zeros(0))).sum())
     if flags & DisableBit.CONTACT:
         ncon, nc = 0, 0

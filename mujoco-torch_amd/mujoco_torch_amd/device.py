@@ -79,8 +79,6 @@ def _validate(m):
     if int(_get(m, "ntendon", 0)):
         if np.any(np.asarray(_get(m, "wrap_type", lambda: np.ones(0))) != 1):
             raise NotImplementedError("only fixed tendons (joint wraps) are supported; spatial tendons are a 'next' item.")
-        if np.any(np.asarray(_get(m, "tendon_frictionloss", lambda: np.zeros(0))) > 0):
-            raise NotImplementedError("tendon frictionloss rows are a 'next' item (SURVEY section 8f).")
         if np.any(np.asarray(_get(m, "tendon_armature", lambda: np.zeros(0))) != 0):
             raise NotImplementedError("tendon armature is not supported by the native stepper yet.")
     et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))
@@ -245,7 +243,11 @@ def _build_tables(m, dtype) -> StaticTables:
     if not (flags & (DisableBit.CONSTRAINT | DisableBit.FRICTIONLOSS)):
         fric = [d for d in range(int(m.nv)) if float(np.asarray(m.dof_frictionloss)[d]) > 0]
     T.fric_dof = np.array(fric, dtype=np.int32)
-    assert len(fric) == nf, (len(fric), nf)
+    fric_t = []
+    if not (flags & (DisableBit.CONSTRAINT | DisableBit.FRICTIONLOSS)) and int(_get(m, "ntendon", 0)):
+        fric_t = [t for t in range(int(m.ntendon)) if float(np.asarray(m.tendon_frictionloss)[t]) > 0]
+    T.fric_tendon = np.array(fric_t, dtype=np.int32)  # tendon-frictionloss rows follow the dof ones (constraint.py:215-251)
+    assert len(fric) + len(fric_t) == nf, (len(fric), len(fric_t), nf)
     T.eq = _equality_tables(m, flags)
     assert T.eq["nrow"] == ne, (T.eq["nrow"], ne)
     T.sensors = _sensor_tables(m)

@@ -90,6 +90,10 @@ CASES = {
     # fixed tendons: lengths, limit rows, springs / dampers, tendon transmissions (smooth.py:470-497, constraint.py:375-405, passive.py:119-144)
     "tendon_fixed_f64": ("tendon_fixed", {}, "float64", 3, 3, "tendon"),
     "tendon_fixed_cg_rk4_f32": ("tendon_fixed", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
+    # tendon frictionloss rows (constraint.py:230-234) next to dof frictionloss, tendon limits and a contact
+    "tendon_friction_f64": ("tendon_friction", {}, "float64", 3, 3, "tendon"),
+    "tendon_friction_cg_f64": ("tendon_friction", {"solver": 1}, "float64", 2, 2, "tendon"),
+    "tendon_friction_rk4_f32": ("tendon_friction", {"integrator": 1}, "float32", 2, 2, "tendon"),
     # the last bundled model: every joint type stacked, ball limits, gravity compensation, mocap bodies, fixed tendons, motors on
     # ball / free joints, camera modes (contacts disabled in the XML)
     "pendula_f64": ("pendula", {}, "float64", 3, 3, "pendula"),

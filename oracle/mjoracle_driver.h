@@ -170,7 +170,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       memcpy(w.in_subtree_com, w.subtree_com, sizeof(REAL) * 3 * m->nbody);
       w.knife = 0;
       w.knife_policy = knife_policy;
-      w.nf = m->nf; w.ne_nf = m->ne + m->nf; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
+      w.nf = m->nf + m->nft; w.ne_nf = m->ne + m->nf + m->nft; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
       w.stage_mode = 0; w.stage_tie_n = 0; w.stage_tie_flip = g_stage_tie_flip;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0; w.prim_hint_n = NULL; w.prim_adopted = 0; w0.prim_hint_n = NULL; w0.prim_adopted = 0;
       w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;

@@ -1281,6 +1281,16 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
     for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->dof_solref[2 * da + i];
     for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->dof_solimp[5 * da + i];
   }
+  for (int f = 0; f < m->nft; f++, row++) { /* _instantiate_friction :215-251 (tendon rows: J = ten_J[t]) */
+    int t = m->fric_tendon[f];
+    for (int q = m->ten_adr[t]; q < m->ten_adr[t + 1]; q++) w->efc_J[row * nv + m->ten_dof[q]] = M->ten_coef[q]; /* last term wins, smooth.py:492-494 */
+    w->efc_pos[row] = 0;
+    w->efc_pos_norm[row] = 0;
+    w->efc_invweight[row] = M->tendon_invweight0[t];
+    w->efc_frictionloss[row] = M->tendon_frictionloss[t];
+    for (int i = 0; i < 2; i++) w->efc_solref[2 * row + i] = M->tendon_solref_fri[2 * t + i];
+    for (int i = 0; i < 5; i++) w->efc_solimp[5 * row + i] = M->tendon_solimp_fri[5 * t + i];
+  }
   for (int l = 0; l < m->nlb; l++, row++) { /* _instantiate_limit_ball :299-335 */
     int j = m->lim_ball_jnt[l], qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
     REAL q[4] = {w->qpos[qa], w->qpos[qa + 1], w->qpos[qa + 2], w->qpos[qa + 3]}, axis[3], angle;
@@ -1704,12 +1714,12 @@ static void FN(update_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(So
   const mjhModelDesc* m = M->d;
   int nv = m->nv, nefc = m->nefc;
   REAL csum = 0, fneg = 0, fpos = 0;
-  int ne_nf = m->ne + m->nf;
+  int ne_nf = m->ne + m->nf + m->nft;
   for (int r = 0; r < nefc; r++) {
     REAL ja = w->s_Jaref[r];
     int active = (ja < 0) || (r < ne_nf);
     REAL floss_force = 0;
-    if (m->nf > 0) { /* quadratic inside |Jaref| < R f, linear outside (solver.py:326-342) */
+    if (m->nf + m->nft > 0) { /* quadratic inside |Jaref| < R f, linear outside (solver.py:326-342) */
       REAL fl = w->efc_frictionloss[r];
       REAL rr = 1 / (w->efc_D[r] + (REAL)(w->efc_D[r] == 0) * (REAL)(float)mjMINVAL);
       int lin_neg = (ja <= -rr * fl) && (fl > 0), lin_pos = (ja >= rr * fl) && (fl > 0);

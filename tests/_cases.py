@@ -56,6 +56,8 @@ SEEDED_CASES = [
     ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, F64, 32, dict(max_alt=0.0)),      # ... springs (hence every passive force) and limits off
     ("pendula", {}, F64, 64, dict(max_alt=0.0)),                                # bundled: every joint type, ball limits, gravcomp, mocap, tendons
     ("tendon_fixed", {"solver": 1}, F64, 64, dict(max_alt=0.0)),
+    ("tendon_friction", {}, F64, 64, dict(max_alt=0.0)),                         # tendon + dof frictionloss rows, Newton
+    ("tendon_friction", {"solver": 1, "integrator": 1}, F64, 32, dict(tol_sol=1e-5)),  # ... CG (stall accuracy, see above), RK4
     # CG models served by the register solver (mjh_sol2_kernel: two environments per wavefront): Euler with the eulerdamp re-solve,
     # RK4, float32, odd batch sizes (the last wavefront runs half empty), warm start off, one- and many-iteration loops
     ("halfcheetah", {"solver": 1}, F64, 33, dict(tol_sol=1e-6)),
