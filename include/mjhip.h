@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 10
+#define MJH_ABI_VERSION 11
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -68,7 +68,7 @@ extern "C" {
 /* int32 scalars */
 #define MJH_MODEL_INTS(X)                                                                        \
   X(nq) X(nv) X(nu) X(na) X(nbody) X(njnt) X(ngeom) X(nsite) X(ncam) X(nlight) X(nmocap)         \
-  X(ne) X(nf) /* dof-frictionloss rows */ X(nft) /* tendon-frictionloss rows (dense; they follow the dof ones) */ X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(nefc) X(npair) X(nconvex) \
+  X(ne) X(nf) /* dof-frictionloss rows */ X(nft) /* tendon-frictionloss rows (dense; they follow the dof ones) */ X(nl) /* slide / hinge limit rows (single-column) */ X(nlb) /* ball-joint limit rows */ X(nlt) /* tendon limit rows */ X(ncon) X(ncand) /* candidate contacts the narrow phase computes: == ncon unless max_contact_points keeps the ncon closest (collision_driver.py:822-840) */ X(topk) /* 1: that selection is on; the con_* tables are then in candidate order, ncand long */ X(nefc) X(npair) X(nconvex) \
   X(ntendon) /* fixed tendons = length of the ten_length / ten_velocity leaves */ X(nwrapj) /* joint terms of all tendons (entries of ten_dof / ten_qposadr / ten_coef) */ \
   X(neq) /* equality constraints of the model = length of the eq_active leaf */ X(neqtab) /* entries of the eq_* tables (0 when equality rows are disabled) */ \
   X(nsensor) /* sensors the stepper computes (sns_* tables) */ X(nsensordata) /* length of the sensordata leaf */ \
@@ -134,6 +134,7 @@ extern "C" {
   X(eq_row)         /* neqtab: first efc row */                                                  \
   X(eq_jadr)        /* neqtab*4: joint couplings: dofadr1, dofadr2, qposadr1, qposadr2 (device.py:310-314; a missing second joint reads the LAST joint, as the reference's jnt_dofadr[-1] does) */ \
   X(fric_dof)       /* nf: dof of each dof-frictionloss row, reference row order (constraint.py:215-251) */ \
+  X(topk_slot)      /* ncon (top-k only): final contact slot of the t-th closest candidate (the unstable argsort of the kept contacts' equal condims, collision_driver.py:828) */ \
   X(fric_tendon)    /* nft: tendon id of each tendon-frictionloss row (constraint.py:230-234) */ \
   X(ten_adr)        /* ntendon+1: CSR of the joint terms of each fixed tendon (smooth.py:470-497) */ \
   X(ten_dof)        /* nwrapj: dof of the term */                                                \

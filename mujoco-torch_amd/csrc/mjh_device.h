@@ -67,7 +67,8 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL | PH_SOL2T)                 \
   X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL | PH_SOL2T) /* packed lower rows */ \
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL | PH_SOL2T)              \
-  X(con_dist, m.ncon, PH_CON) X(con_pos, 3 * m.ncon, PH_CON) X(con_frame, 9 * m.ncon, PH_CON)                  \
+  X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
+  X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
   X(efc_J, (m.con_general ? m.nefc : m.nefc - m.nl) * m.nv, PH_CON) X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \

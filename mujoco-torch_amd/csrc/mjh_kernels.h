@@ -1010,6 +1010,36 @@ struct Env {
     }
     wave_sync();
     STAMP(20);
+    if (M.topk) {
+      // max_contact_points (collision_driver.py:822-840): keep the ncon candidates with the smallest dist -- torch.topk(-dist): closest
+      // first; equal distances are ordered by candidate index here (torch leaves that order to its partial sort) -- then the static
+      // permutation of the argsort over their (equal) condims.  One candidate per lane, rank by counting.
+      const int nk = M.ncon, ncand = M.ncand;
+      for (int q = l; q < ncand; q += W) {
+        const REAL dq = S.con_dist()[q];
+        int rank = 0;
+        for (int q2 = 0; q2 < ncand; q2++) { const REAL d2 = S.con_dist()[q2]; rank += (d2 < dq) || (d2 == dq && q2 < q); }
+        if (rank < nk) con_src_lds()[M.topk_slot[rank]] = q;
+      }
+      wave_sync();
+      for (int c = l; c < nk; c += W) {  // every contact leaf is per environment now: gathered through the kept candidate
+        const int q = con_src_lds()[c];
+        if (out.contact_dist) out.contact_dist[e * nk + c] = S.con_dist()[q];
+        for (int i = 0; i < 3; i++) if (out.contact_pos) out.contact_pos[(e * nk + c) * 3 + i] = S.con_pos()[3 * q + i];
+        for (int i = 0; i < 9; i++) if (out.contact_frame) out.contact_frame[(e * nk + c) * 9 + i] = S.con_frame()[9 * q + i];
+        if (out.contact_includemargin) out.contact_includemargin[e * nk + c] = M.con_includemargin[q];
+        for (int i = 0; i < 5; i++) if (out.contact_friction) out.contact_friction[(e * nk + c) * 5 + i] = M.con_friction[5 * q + i];
+        for (int i = 0; i < 2; i++) if (out.contact_solref) out.contact_solref[(e * nk + c) * 2 + i] = M.con_solref[2 * q + i];
+        for (int i = 0; i < 2; i++) if (out.contact_solreffriction) out.contact_solreffriction[(e * nk + c) * 2 + i] = M.con_solreffriction[2 * q + i];
+        for (int i = 0; i < 5; i++) if (out.contact_solimp) out.contact_solimp[(e * nk + c) * 5 + i] = M.con_solimp[5 * q + i];
+        if (out.contact_dim) out.contact_dim[e * nk + c] = M.con_dim[q];
+        if (out.contact_geom1) out.contact_geom1[e * nk + c] = M.con_geom1[q];
+        if (out.contact_geom2) out.contact_geom2[e * nk + c] = M.con_geom2[q];
+        if (out.contact_geom) { out.contact_geom[(e * nk + c) * 2] = M.con_geom1[q]; out.contact_geom[(e * nk + c) * 2 + 1] = M.con_geom2[q]; }
+        if (out.contact_efc_address) out.contact_efc_address[e * nk + c] = M.con_efc_address[c];
+      }
+      return;
+    }
     {
       const int nc = M.ncon;
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
@@ -1029,6 +1059,9 @@ struct Env {
       }
     }
   }
+  __device__ __forceinline__ int* con_src_lds() const { return reinterpret_cast<int*>(S.i_con_src()); }
+  // candidate behind contact slot c: the slot itself unless max_contact_points selected per environment
+  __device__ __forceinline__ int con_src(int c) const { return M.topk ? con_src_lds()[c] : c; }
 
   // ---- constraint rows (constraint.py:600-768) ---------------------------------------------------------------------------------------------------
   // support.jac :138-153 restricted to one dof: jacp / jacr of `point` on `body`, masked to ancestor dofs
@@ -1242,12 +1275,13 @@ struct Env {
     for (int w = l; w < M.ncon * nv; w += W) {
       int c, d;
       split_index(w, nv, M.inv_nv, c, d);
-      const int dim = M.con_dim[c], row0 = M.con_efc_address[c];
-      const int b1 = M.geom_bodyid[M.con_geom1[c]], b2 = M.geom_bodyid[M.con_geom2[c]];
-      const REAL* fr = S.con_frame() + 9 * c;
-      const REAL* cpos = S.con_pos() + 3 * c;
-      const REAL* fric = M.con_friction + 5 * c;
-      const REAL dist = S.con_dist()[c] - M.con_includemargin[c];
+      const int cq = con_src(c);  // candidate behind the slot (the per-contact tables and the narrow-phase results are indexed by it)
+      const int dim = M.con_dim[cq], row0 = M.con_efc_address[c];
+      const int b1 = M.geom_bodyid[M.con_geom1[cq]], b2 = M.geom_bodyid[M.con_geom2[cq]];
+      const REAL* fr = S.con_frame() + 9 * cq;
+      const REAL* cpos = S.con_pos() + 3 * cq;
+      const REAL* fric = M.con_friction + 5 * cq;
+      const REAL dist = S.con_dist()[cq] - M.con_includemargin[cq];
       if (!(dist < 0)) {  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
         const int rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
         for (int r = 0; r < rows; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = 0;
@@ -1304,7 +1338,8 @@ struct Env {
         solref[0] = M.tendon_solref_lim[2 * t]; solref[1] = M.tendon_solref_lim[2 * t + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.tendon_solimp_lim[5 * t + i];
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
-        const int c = M.efc_row_con[r], sub = r - M.con_efc_address[c];
+        const int cs = M.efc_row_con[r], sub = r - M.con_efc_address[cs];
+        const int c = con_src(cs);
         const REAL* sr = M.con_solref + 2 * c;
         solref[0] = sr[0]; solref[1] = sr[1];
         const int dim = M.con_dim[c];
@@ -2176,7 +2211,7 @@ struct Env {
             const int dim = M.con_dim[c];
             rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
             start = M.con_efc_address[c] - c0;
-            act = (out.contact_dist[e * ncon + c] - M.con_includemargin[c]) < 0;
+            act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
           }
           int x = act ? rows : 0;
           for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
@@ -2570,7 +2605,7 @@ struct Env {
               const int dim = M.con_dim[c];
               rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
               start = M.con_efc_address[c] - nl;
-              act = (out.contact_dist[e * ncon + c] - M.con_includemargin[c]) < 0;
+              act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
             }
             int x = act ? rows : 0;
             for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }

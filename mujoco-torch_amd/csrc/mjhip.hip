@@ -110,7 +110,8 @@ const char* const kStageLeaves[] = {
 // ... plus, for models with convex pairs, the contact leaves the convex kernel hands to the constraint phase
 const char* const kConvexStageLeaves[] = {"contact_dist", "contact_pos", "contact_frame"};
 const char* const kEqStageLeaves[] = {"xpos", "xquat", "xmat"};  // body frames read by the equality rows (constraint.py:116-212)
-bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid, bool has_eq) {
+bool is_stage_leaf(const char* name, bool has_convex, bool has_fluid, bool has_eq, bool topk) {
+  if (topk && !strcmp(name, "contact_includemargin")) return true;  // per environment once max_contact_points selects: the solver phase reads it
   if (!strcmp(name, "qfrc_gravcomp") || !strncmp(name, "ten_", 4)) return false;  // tendon quantities are recomputed from qpos where they are used  // staged in LDS inside the velocity phase; the leaf itself is written by stage 0 only
   if (has_eq) for (const char* s : kEqStageLeaves) if (!strcmp(s, name)) return true;
   for (const char* s : kStageLeaves) if (!strcmp(s, name)) return true;
@@ -379,7 +380,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
     };
     for (size_t i = 0; i < out->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0)) out->work_reals += out->leaf_count[i];
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
 
@@ -531,7 +532,7 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
 #undef X
     };
     for (size_t i = 0; i < m->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
   }
   a.W.qvel0 = w; w += (int64_t)M.nv * B;
   a.W.kqvel = w; w += (int64_t)M.nv * B;

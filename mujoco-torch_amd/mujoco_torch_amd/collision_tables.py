@@ -142,7 +142,20 @@ def ordered_pairs(cands):
     return out
 
 
+def max_contact_points(m) -> int:
+    """The custom numeric `max_contact_points`, -1 when absent (reference collision_driver.py:571-578)."""
+    names = getattr(m, "names", b"")
+    if isinstance(names, str):
+        names = names.encode("utf-8")
+    for i in range(int(getattr(m, "nnumeric", 0) or 0)):
+        name = bytes(names[int(m.name_numericadr[i]):]).decode("utf-8").split("\x00", 1)[0]
+        if name == "max_contact_points":
+            return int(np.asarray(m.numeric_data)[int(m.numeric_adr[i])])
+    return -1
+
+
 def make_condim(m, cands) -> list:
+    """Per-contact condim, ascending, capped at max_contact_points (reference collision_driver.py:618-644)."""
     if int(m.opt.disableflags) & DisableBit.CONTACT:
         return []
     dims = []
@@ -152,7 +165,11 @@ def make_condim(m, cands) -> list:
             continue
         for c in lst:
             dims.extend([c.dim] * fn[1])
-    return sorted(dims)
+    dims = sorted(dims)
+    cap = max_contact_points(m)
+    if cap > -1 and len(dims) > cap:
+        dims = dims[:cap]
+    return dims
 
 
 def constraint_sizes(m, dims) -> tuple:

@@ -213,7 +213,25 @@ def _build_tables(m, dtype) -> StaticTables:
             dims_unsorted.append(c.dim)
             src_pair.append(pi)
             src_k.append(kk)
-    perm = ct.contact_order(dims_unsorted)  # final slot s holds pre-sort contact perm[s]
+    # max_contact_points (collision_driver.py:822-840): every candidate contact is computed, the `ncon` with the smallest dist are
+    # kept per environment (torch.topk(-dist)) and re-ordered by the (unstable) argsort of their condims.  The per-contact tables then
+    # stay in CANDIDATE (pre-sort) order and the kernels pick by a per-environment source index; `topk_slot[t]` is the final slot of
+    # the t-th closest contact.
+    cap = ct.max_contact_points(m)
+    T.topk = bool(ncon > 0 and cap > -1 and len(dims_unsorted) > cap)
+    if T.topk:
+        if len(set(dims_unsorted)) != 1:
+            raise NotImplementedError("max_contact_points with mixed condims is not supported (the reference sizes its row groups from the "
+                                      "smallest condims, collision_driver.py:618-644, whatever the selected contacts' condims are)")
+        if any(p[0] >= 5 for p in pairs):
+            raise NotImplementedError("max_contact_points with box / mesh pairs is not supported by the native stepper")
+        order = ct.contact_order([dims_unsorted[0]] * ncon)  # final slot s holds the order[s]-th closest contact
+        T.topk_slot = np.empty(ncon, dtype=np.int32)
+        T.topk_slot[order] = np.arange(ncon)
+        perm = np.arange(len(dims_unsorted))
+    else:
+        T.topk_slot = np.zeros(0, dtype=np.int32)
+        perm = ct.contact_order(dims_unsorted)  # final slot s holds pre-sort contact perm[s]
     T.contact_perm = perm
     inv = np.empty_like(perm)
     inv[perm] = np.arange(len(perm))
@@ -228,7 +246,7 @@ def _build_tables(m, dtype) -> StaticTables:
     T.con_pair = con_pair
     elliptic = int(m.opt.cone) == ConeType.ELLIPTIC
     ns = ne + nf + nl
-    rows = [1 if d == 1 else (d if elliptic else 2 * (d - 1)) for d in T.con_dim]
+    rows = [1 if d == 1 else (d if elliptic else 2 * (d - 1)) for d in T.con_dim[:ncon]]  # (top-k: uniform condim, one entry per kept contact)
     T.con_rows = np.array(rows, dtype=np.int32)
     T.con_efc_address = (ns + np.concatenate([[0], np.cumsum(rows)[:-1]])).astype(np.int32) if ncon else np.zeros(0, dtype=np.int32)
     # the address collision() writes first (pyramidal-style, collision_driver.py:847-850) is
@@ -457,7 +475,7 @@ def device_put(value, *, dtype: torch.dtype | None = None):
         constraint_sizes_py=T.constraint_sizes,
         condim_counts_py=T.condim_counts,
         condim_tensor_py=torch.tensor(sorted(int(d) for d in T.con_dim), dtype=torch.long),
-        collision_max_cp_py=-1,
+        collision_max_cp_py=int(ct.max_contact_points(value)),
         collision_total_contacts_py=int(T.total_contacts),
         cache_id=next(_cache_id_counter),
         body_rootid_t=L(value.body_rootid),

@@ -52,6 +52,10 @@ def make_data(m: Model) -> Data:
     st = static_contact_fields(model_float_leaves(m, mdtype), T, mdtype)
     g1 = torch.as_tensor(T.con_geom1, dtype=torch.int64)
     g2 = torch.as_tensor(T.con_geom2, dtype=torch.int64)
+    con_dim = torch.as_tensor(T.con_dim, dtype=torch.int32)
+    if getattr(T, "topk", False):  # max_contact_points: which contacts are kept is decided per step, nothing to bake (collision_driver.py:709-713)
+        st = {k: torch.zeros((ncon,) + tuple(v.shape[1:]), dtype=v.dtype) for k, v in st.items()}
+        g1, g2, con_dim = torch.zeros(ncon, dtype=torch.int64), torch.zeros(ncon, dtype=torch.int64), con_dim[:ncon]
     contact = Contact(
         dist=z(ncon), pos=z(ncon, 3), frame=z(ncon, 3, 3),
         includemargin=st["includemargin"].to(DEFAULT_DTYPE),
@@ -59,7 +63,7 @@ def make_data(m: Model) -> Data:
         solref=st["solref"].to(DEFAULT_DTYPE),
         solreffriction=st["solreffriction"].to(DEFAULT_DTYPE),
         solimp=st["solimp"].to(DEFAULT_DTYPE),
-        contact_dim=torch.as_tensor(T.con_dim, dtype=torch.int32).clone(),
+        contact_dim=con_dim.clone(),
         geom1=g1, geom2=g2, geom=torch.stack([g1, g2], dim=-1) if ncon else torch.zeros((0, 2), dtype=torch.int64),
         efc_address=torch.as_tensor(T.con_efc_address, dtype=torch.int64).clone(),
         batch_size=[ncon],

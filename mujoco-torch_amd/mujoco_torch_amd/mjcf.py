@@ -1423,12 +1423,25 @@ class _Compiler:
         m.wrap_prm = np.array(wrap_prm, dtype=np.float64)
 
     def _build_empty_sections(self, m):
-        m.nnumeric = 0
+        """<custom><numeric name=.. data=.. [size=..]/>: MuJoCo's user numerics (the reference reads `max_contact_points` from them,
+        collision_driver.py:571-578).  `names` holds only the numerics' names, null-terminated, as MuJoCo's name buffer would."""
+        nums = [n for cn in self.root.findall("custom") for n in cn.findall("numeric")]
+        m.nnumeric = len(nums)
         m.nuserdata = 0
-        m.numeric_adr = np.zeros(0, dtype=np.int32)
-        m.numeric_data = np.zeros(0)
-        m.name_numericadr = np.zeros(0, dtype=np.int32)
-        m.names = b""
+        adr, data, nadr, names = [], [], [], b""
+        for n in nums:
+            vals = _floats(n.get("data", "0"))
+            size = int(n.get("size", len(vals)))
+            vals = (list(vals) + [0.0] * size)[:size]
+            adr.append(len(data))
+            data.extend(vals)
+            nadr.append(len(names))
+            names += n.get("name", "").encode("utf-8") + b"\x00"
+        m.numeric_adr = np.array(adr, dtype=np.int32)
+        m.numeric_size = np.array([int(n.get("size", len(_floats(n.get("data", "0"))))) for n in nums], dtype=np.int32)
+        m.numeric_data = np.array(data, dtype=np.float64)
+        m.name_numericadr = np.array(nadr, dtype=np.int32)
+        m.names = names
 
     def _build_keyframes(self, m):
         keys = [k for kn in self.root.findall("keyframe") for k in kn.findall("key")]

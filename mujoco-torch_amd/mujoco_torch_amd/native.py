@@ -93,7 +93,7 @@ def pack_model(m, dtype: torch.dtype):
     ne, nf, nl, ncon, nefc = m.constraint_sizes_py
     ints = dict(
         nq=m.nq, nv=m.nv, nu=m.nu, na=m.na, nbody=m.nbody, njnt=m.njnt, ngeom=m.ngeom, nsite=m.nsite,
-        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=len(T.fric_dof), nft=len(T.fric_tendon), nl=len(T.lim_jnt), nlb=len(T.lim_ball_jnt), nlt=int(T.nlt), ncon=ncon, nefc=nefc, neq=int(m.neq), neqtab=len(T.eq['kind']), ntendon=int(m.ntendon), nwrapj=len(T.tendon['dof']),
+        ncam=m.ncam, nlight=m.nlight, nmocap=m.nmocap, ne=ne, nf=len(T.fric_dof), nft=len(T.fric_tendon), nl=len(T.lim_jnt), nlb=len(T.lim_ball_jnt), nlt=int(T.nlt), ncon=ncon, ncand=len(T.con_dim), topk=int(T.topk), nefc=nefc, neq=int(m.neq), neqtab=len(T.eq['kind']), ntendon=int(m.ntendon), nwrapj=len(T.tendon['dof']),
         npair=len(T.pairs), nconvex=0, nsensor=len(T.sensors["type"]), nsensordata=int(getattr(m, "nsensordata", 0) or 0), integrator=int(m.opt.integrator), solver=int(m.opt.solver),
         cone=int(m.opt.cone), disableflags=int(m.opt.disableflags), iterations=int(m.opt.iterations),
         ls_iterations=int(m.opt.ls_iterations),
@@ -129,7 +129,7 @@ def pack_model(m, dtype: torch.dtype):
         sns_rootid=i32(T.sensors["rootid"]), sns_datatype=i32(T.sensors["datatype"]), sns_rfadr=i32(T.sensors["rfadr"]),
         rf_geom=i32(T.sensors["rf_geom"]), slot_sensor=i32(T.sensors["slot"]),
         eq_kind=i32(T.eq['kind']), eq_id=i32(T.eq['id']), eq_obj1=i32(T.eq['obj1']), eq_obj2=i32(T.eq['obj2']), eq_row=i32(T.eq['row']), eq_jadr=i32(T.eq['jadr']),
-        fric_dof=i32(T.fric_dof), fric_tendon=i32(T.fric_tendon), ten_adr=i32(T.tendon['adr']), ten_dof=i32(T.tendon['dof']), ten_qposadr=i32(T.tendon['qpos']), lim_tendon=i32(T.tendon['lim']), act_trnid=i32([x[1] for x in info]),
+        topk_slot=i32(T.topk_slot), fric_dof=i32(T.fric_dof), fric_tendon=i32(T.fric_tendon), ten_adr=i32(T.tendon['adr']), ten_dof=i32(T.tendon['dof']), ten_qposadr=i32(T.tendon['qpos']), lim_tendon=i32(T.tendon['lim']), act_trnid=i32([x[1] for x in info]),
         lim_ball_jnt=i32(T.lim_ball_jnt), lim_jnt=i32(T.lim_jnt), pair_fn=i32([p[0] for p in T.pairs]), pair_geom1=i32([p[2].geom1 for p in T.pairs]),
         pair_geom2=i32([p[2].geom2 for p in T.pairs]), pair_ncon=i32([p[1] for p in T.pairs]), pair_dst=i32(T.pair_dst),
         con_dim=i32(T.con_dim), con_geom1=i32(T.con_geom1), con_geom2=i32(T.con_geom2), con_efc_address=i32(T.con_efc_address),
@@ -174,7 +174,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 10
+    desc.abi_version = 11
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

@@ -94,6 +94,12 @@ CASES = {
     "tendon_friction_f64": ("tendon_friction", {}, "float64", 3, 3, "tendon"),
     "tendon_friction_cg_f64": ("tendon_friction", {"solver": 1}, "float64", 2, 2, "tendon"),
     "tendon_friction_rk4_f32": ("tendon_friction", {"integrator": 1}, "float32", 2, 2, "tendon"),
+    # max_contact_points (collision_driver.py:822-840): 13 candidate contacts, the 5 closest kept per environment
+    # (every environment jittered: at the XML pose several candidates are at exactly equal distance and torch.topk orders equal
+    # values by the internals of its partial sort -- [10, 7, 8, 9, 6] for thirteen equal values -- which is not a property of the
+    # algorithm; this build orders ties by candidate index)
+    "capsules_topk_f64": ("capsules_topk", {}, "float64", 4, 3, "topk"),
+    "capsules_topk_ell_rk4_f32": ("capsules_topk", {"integrator": 1, "cone": 1}, "float32", 3, 2, "topk"),
     # the last bundled model: every joint type stacked, ball limits, gravity compensation, mocap bodies, fixed tendons, motors on
     # ball / free joints, camera modes (contacts disabled in the XML)
     "pendula_f64": ("pendula", {}, "float64", 3, 3, "pendula"),
@@ -139,6 +145,14 @@ def make_inputs(recipe, lite, env):
                 q[a + 3 : a + 7] += 0.03 * rng.randn(4)  # un-normalised on purpose
         out["qpos"] = q
         out["qvel"] = 0.2 * rng.randn(nv)
+    elif recipe == "topk":  # free bodies, every environment jittered (no two candidate contacts at exactly the same distance)
+        q = lite.qpos0.copy()
+        for j in range(lite.njnt):
+            a = int(lite.jnt_qposadr[j])
+            q[a : a + 3] += 0.02 * rng.randn(3)
+            q[a + 3 : a + 7] += 0.05 * rng.randn(4)
+        out["qpos"] = q
+        out["qvel"] = 0.3 * rng.randn(nv)
     elif recipe == "sensor_rig":
         q = lite.qpos0.copy()
         q[:3] += 0.1 * rng.randn(3) * (env > 0)

@@ -65,6 +65,8 @@ static void FN(work_init)(FN(MjoWork) * w, const mjhModelDesc* m) {
   w->rk_qpos0 = FN(ralloc)(nq); w->rk_qvel0 = FN(ralloc)(nv); w->rk_act0 = FN(ralloc)(m->na); w->rk_qvel = FN(ralloc)(nv);
   w->rk_qacc = FN(ralloc)(nv); w->rk_actdot = FN(ralloc)(m->na); w->rk_kqvel = FN(ralloc)(nv);
   w->in_subtree_com = FN(ralloc)(nb * 3);
+  w->cand_dist = FN(ralloc)(m->ncand); w->cand_pos = FN(ralloc)(3 * (size_t)m->ncand); w->cand_frame = FN(ralloc)(9 * (size_t)m->ncand);
+  w->con_src = (int*)calloc((size_t)m->ncon + 8, sizeof(int));
 }
 static void FN(work_free)(FN(MjoWork) * w) {
 #define X(n) free(w->n);
@@ -76,6 +78,7 @@ static void FN(work_free)(FN(MjoWork) * w) {
   free(w->s_force); free(w->s_Ma); free(w->s_grad); free(w->s_Mgrad); free(w->s_search); free(w->s_mv); free(w->s_jv);
   free(w->s_quad); free(w->s_prev_grad); free(w->s_prev_Mgrad); free(w->s_active); free(w->rk_qpos0); free(w->rk_qvel0);
   free(w->rk_act0); free(w->rk_qvel); free(w->rk_qacc); free(w->rk_actdot); free(w->rk_kqvel); free(w->in_subtree_com);
+  free(w->cand_dist); free(w->cand_pos); free(w->cand_frame); free(w->con_src);
 }
 
 /* snapshot of the leaves a forward() pass writes, used to keep stage-0 results across RK4 stages */
@@ -83,6 +86,7 @@ static void FN(copy_work_outputs)(const mjhModelDesc* m, FN(MjoWork) * dst, cons
 #define X(n) memcpy(dst->n, src->n, sizeof(REAL) * (size_t)FN(field_count)(m, #n));
   MJH_DATA_REALS(X)
 #undef X
+  memcpy(dst->con_src, src->con_src, sizeof(int) * (size_t)m->ncon);
 }
 
 static void FN(step_env)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(MjoWork) * w0, int flags) {
@@ -186,10 +190,11 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       if (knife) knife[e] = w.knife;
       if (g_tie_pairs) g_tie_pairs[e] = w.tie_pairs;
       if (g_stage_ties) g_stage_ties[e] = w.stage_tie_n;
-      if (out->contact_dim) for (int c = 0; c < m->ncon; c++) out->contact_dim[e * m->ncon + c] = m->con_dim[c];
-      if (out->contact_geom1) for (int c = 0; c < m->ncon; c++) out->contact_geom1[e * m->ncon + c] = m->con_geom1[c];
-      if (out->contact_geom2) for (int c = 0; c < m->ncon; c++) out->contact_geom2[e * m->ncon + c] = m->con_geom2[c];
-      if (out->contact_geom) for (int c = 0; c < m->ncon; c++) { out->contact_geom[(e * m->ncon + c) * 2] = m->con_geom1[c]; out->contact_geom[(e * m->ncon + c) * 2 + 1] = m->con_geom2[c]; }
+      const int* cs = w.con_src; /* (RK4: restored to stage 0's with the other returned leaves) */
+      if (out->contact_dim) for (int c = 0; c < m->ncon; c++) out->contact_dim[e * m->ncon + c] = m->con_dim[cs[c]];
+      if (out->contact_geom1) for (int c = 0; c < m->ncon; c++) out->contact_geom1[e * m->ncon + c] = m->con_geom1[cs[c]];
+      if (out->contact_geom2) for (int c = 0; c < m->ncon; c++) out->contact_geom2[e * m->ncon + c] = m->con_geom2[cs[c]];
+      if (out->contact_geom) for (int c = 0; c < m->ncon; c++) { out->contact_geom[(e * m->ncon + c) * 2] = m->con_geom1[cs[c]]; out->contact_geom[(e * m->ncon + c) * 2 + 1] = m->con_geom2[cs[c]]; }
       if (out->contact_efc_address) for (int c = 0; c < m->ncon; c++) out->contact_efc_address[e * m->ncon + c] = m->con_efc_address[c];
     }
     FN(work_free)(&w);

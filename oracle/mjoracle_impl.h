@@ -127,6 +127,9 @@ typedef struct FN(MjoWork) {
   const REAL* prim_hint_n; /* hinted normal of the primitive pair being evaluated (coincident-centre case of sphere_sphere_), or NULL */
   int prim_adopted;
   const int32_t* eq_active; /* this env's Data.eq_active (input leaf, types.py:1103) */
+  /* max_contact_points (collision_driver.py:822-840): candidate contacts of the step and the candidate kept in each contact slot */
+  REAL *cand_dist, *cand_pos, *cand_frame;
+  int* con_src;
 } FN(MjoWork);
 
 /* ---- small vector math (math.py) ------------------------------------------------------------ */
@@ -1121,17 +1124,36 @@ static void FN(collision)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* collisio
     }
     for (int q = 0; q < k; q++) {
       int c = m->pair_dst[p * MJH_MAX_PAIR_CONTACTS + q];
-      w->contact_dist[c] = dist[q];
-      for (int i = 0; i < 3; i++) w->contact_pos[3 * c + i] = pos[q][i];
-      for (int i = 0; i < 9; i++) w->contact_frame[9 * c + i] = frame[q][i];
+      REAL *cd = m->topk ? w->cand_dist : w->contact_dist, *cp = m->topk ? w->cand_pos : w->contact_pos, *cf = m->topk ? w->cand_frame : w->contact_frame;
+      cd[c] = dist[q];
+      for (int i = 0; i < 3; i++) cp[3 * c + i] = pos[q][i];
+      for (int i = 0; i < 9; i++) cf[9 * c + i] = frame[q][i];
     }
   }
+  if (m->topk) {
+    /* torch.topk(-dist, k = ncon): the ncon closest candidates, closest first (equal distances by candidate index: torch leaves
+       their order to its partial sort), then contact[argsort(contact_dim)] over equal condims = the static permutation topk_slot */
+    for (int q = 0; q < m->ncand; q++) {
+      int rank = 0;
+      for (int q2 = 0; q2 < m->ncand; q2++) rank += (w->cand_dist[q2] < w->cand_dist[q]) || (w->cand_dist[q2] == w->cand_dist[q] && q2 < q);
+      if (rank < m->ncon) w->con_src[m->topk_slot[rank]] = q;
+    }
+    for (int c = 0; c < m->ncon; c++) {
+      int q = w->con_src[c];
+      w->contact_dist[c] = w->cand_dist[q];
+      for (int i = 0; i < 3; i++) w->contact_pos[3 * c + i] = w->cand_pos[3 * q + i];
+      for (int i = 0; i < 9; i++) w->contact_frame[9 * c + i] = w->cand_frame[9 * q + i];
+    }
+  } else {
+    for (int c = 0; c < m->ncon; c++) w->con_src[c] = c;
+  }
   for (int c = 0; c < m->ncon; c++) {
-    w->contact_includemargin[c] = M->con_includemargin[c];
-    for (int i = 0; i < 5; i++) w->contact_friction[5 * c + i] = M->con_friction[5 * c + i];
-    for (int i = 0; i < 2; i++) w->contact_solref[2 * c + i] = M->con_solref[2 * c + i];
-    for (int i = 0; i < 2; i++) w->contact_solreffriction[2 * c + i] = M->con_solreffriction[2 * c + i];
-    for (int i = 0; i < 5; i++) w->contact_solimp[5 * c + i] = M->con_solimp[5 * c + i];
+    int q = w->con_src[c];
+    w->contact_includemargin[c] = M->con_includemargin[q];
+    for (int i = 0; i < 5; i++) w->contact_friction[5 * c + i] = M->con_friction[5 * q + i];
+    for (int i = 0; i < 2; i++) w->contact_solref[2 * c + i] = M->con_solref[2 * q + i];
+    for (int i = 0; i < 2; i++) w->contact_solreffriction[2 * c + i] = M->con_solreffriction[2 * q + i];
+    for (int i = 0; i < 5; i++) w->contact_solimp[5 * c + i] = M->con_solimp[5 * q + i];
   }
 }
 
@@ -1335,8 +1357,9 @@ static void FN(make_constraint)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* :6
   }
   int elliptic = m->cone == CONE_ELLIPTIC;
   for (int c = 0; c < m->ncon; c++) {
-    int dim = m->con_dim[c];
-    int b1 = m->geom_bodyid[m->con_geom1[c]], b2 = m->geom_bodyid[m->con_geom2[c]];
+    int cq = w->con_src[c];
+    int dim = m->con_dim[cq];
+    int b1 = m->geom_bodyid[m->con_geom1[cq]], b2 = m->geom_bodyid[m->con_geom2[cq]];
     const REAL* fr = w->contact_frame + 9 * c;
     const REAL* cpos = w->contact_pos + 3 * c;
     const REAL* fric = w->contact_friction + 5 * c;
