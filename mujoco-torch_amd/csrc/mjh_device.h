@@ -239,6 +239,7 @@ __device__ __forceinline__ T sub_read(T v, int k) {
 template <int W, typename T>
 __device__ __forceinline__ T sub_sum(T v) {
   if (W == MJH_WAVE) return wave_sum(v);
+  if (W == 16) { v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v); return v; }  // one 16-lane DPP row per environment
   v += dpp_move<0xB1>(v);
   v += dpp_move<0x4E>(v);
   v += dpp_move<0x141>(v);

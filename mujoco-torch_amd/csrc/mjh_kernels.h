@@ -3006,7 +3006,7 @@ __global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args)
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W == 32))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W == 32 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? 4 : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? 4 : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each

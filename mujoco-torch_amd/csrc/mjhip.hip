@@ -48,6 +48,7 @@ struct mjhModel {
   int lds_bytes[MJH_NARENA];
   int sol2_nmax = 0, sol2_rpl = 0;         // register solver (mjh_sol2_kernel) instantiation serving this model, 0 = not eligible
   int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
+  int pack4[MJH_NPHASE];                   // ... or four (16 lanes each): small models only
   // hipGraph replay: the launch sequence of a (buffers, batch, flags) combination is captured once on a private stream and
   // replayed with one hipGraphLaunch on the caller's stream -- a step is 6 launches (24 with RK4) with ~3.6 KB of kernel
   // arguments each, which costs more host time than a small batch takes on the device
@@ -360,13 +361,13 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     const int nd = d->nefc - d->nf - d->nl;
     const bool general = d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0;
     out->sol2_nmax = out->sol2_rpl = 0;
-    const int nmax = d->nv <= 16 ? 16 : 28, rpl = nd <= 32 ? 1 : (nd <= 64 ? 2 : (nd <= 128 ? 4 : 8));
+    const int nmax = d->nv <= 8 ? 8 : (d->nv <= 16 ? 16 : 28), rpl = nd <= 32 ? 1 : (nd <= 64 ? 2 : (nd <= 128 ? 4 : 8));
     // Newton (Hessian built and factorised in registers): two environments per wavefront run until BOTH have converged, which pays
     // when the solves are short -- measured on MI355X: ant (nv 8, 1 - 3 iterations) solver phase 229 -> 175 us, mesh scene (nv 12, up to
     // 100 iterations x 50 line-search steps, very uneven across environments) 548 -> 691 us.  MJH_SOL2_NEWTON_NV moves the cut.
     static const int newton_nv = [] { const char* e = getenv("MJH_SOL2_NEWTON_NV"); return e ? atoi(e) : 8; }();
-    const bool solver_ok = d->solver == SOL_CG || (d->solver == SOL_NEWTON && nmax == 16 && d->nv <= newton_nv);
-    if (!off && solver_ok && !general && d->nv <= 28 && nd <= 32 * (nmax == 16 ? 8 : 2) && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
+    const bool solver_ok = d->solver == SOL_CG || (d->solver == SOL_NEWTON && nmax <= 16 && d->nv <= newton_nv);
+    if (!off && solver_ok && !general && d->nv <= 28 && nd <= 32 * (nmax <= 16 ? 8 : 2) && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
       out->sol2_nmax = nmax;
       out->sol2_rpl = rpl;
     }
@@ -395,7 +396,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef SET_ATTR
   // phases that are register-bound (not LDS-bound) run two environments per wavefront, 32 lanes each: the same
   // VGPR budget then keeps twice as many environments in flight (mjh_kernels.h, Env<REAL, W>)
-  for (int p = 0; p < MJH_NPHASE; p++) out->pack2[p] = 0;
+  for (int p = 0; p < MJH_NPHASE; p++) out->pack2[p] = out->pack4[p] = 0;
 #define SET_PACK(P)                                                                                                          \
   if (2 * out->lds_bytes[P] <= 64 * 1024) {                                                                                  \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[P])); \
@@ -408,6 +409,20 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   static const bool crb_pack = [] { const char* e = getenv("MJH_CRB_PACK"); return e && e[0] == '1'; }();
   if ((sizeof(REAL) == 4 && d->nv <= 16) || (crb_pack && d->nv <= 32 && d->nv > 16)) { SET_PACK(1) }
 #undef SET_PACK
+  // small models (every per-body / per-joint / per-dof loop fits 16 lanes): FOUR environments per wavefront in the packed phases.
+  // These phases are bound by the number of dependent chains a SIMD can interleave (registers cap the waves), so the same waves
+  // carrying twice the environments is close to twice the throughput -- measured on the ant (B = 16384, 64 environments per CU):
+  // see profiles/r02/notes.md.  MJH_PACK4=0 turns it off.
+  static const bool pack4 = [] { const char* e = getenv("MJH_PACK4"); return !(e && e[0] == '0'); }();
+  if (pack4 && d->nbody <= 16 && d->njnt <= 16 && d->nv <= 16) {
+#define SET_PACK4(P, Q)                                                                                                      \
+    if (out->pack2[Q] && 4 * out->lds_bytes[Q] <= 64 * 1024) {                                                               \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, P, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_bytes[Q])); \
+      if (P == Q) out->pack4[Q] = 1;                                                                                         \
+    }
+    SET_PACK4(0, 0) SET_PACK4(1, 1) SET_PACK4(3, 3) SET_PACK4(5, 3)
+#undef SET_PACK4
+  }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 7, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
@@ -415,7 +430,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   if (out->sol2_nmax) {
 #define SET_SOL2(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[5]));
-    SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(16, 4) SET_SOL2(16, 8) SET_SOL2(28, 1) SET_SOL2(28, 2)
+    SET_SOL2(8, 1) SET_SOL2(8, 2) SET_SOL2(8, 4) SET_SOL2(8, 8) SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(16, 4) SET_SOL2(16, 8) SET_SOL2(28, 1) SET_SOL2(28, 2)
 #undef SET_SOL2
   }
   return 0;
@@ -438,11 +453,17 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  if ((P == 0 || P == 1 || P == 3 || P == 5) && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // pairs of environments, then the odd one on its own
-    const int64_t even = a.B & ~(int64_t)1;
-    int rc = launch_range<REAL, P, ((P == 0 || P == 1 || P == 3 || P == 5) ? 32 : MJH_WAVE)>(m, a, 0, even, stream);
-    if (rc) return rc;
-    return launch_range<REAL, P, MJH_WAVE>(m, a, even, a.B - even, stream);
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5);
+  if (PACKABLE && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
+    int64_t done = 0;
+    int rc = 0;
+    if (m->pack4[P == 5 ? 3 : P] && a.B >= 4) {
+      done = a.B & ~(int64_t)3;
+      if ((rc = launch_range<REAL, P, (PACKABLE ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
+    }
+    const int64_t even = (a.B - done) & ~(int64_t)1;
+    if ((rc = launch_range<REAL, P, (PACKABLE ? 32 : MJH_WAVE)>(m, a, done, even, stream))) return rc;
+    return launch_range<REAL, P, MJH_WAVE>(m, a, done + even, a.B - done - even, stream);
   }
   return launch_range<REAL, P, MJH_WAVE>(m, a, 0, a.B, stream);
 }
@@ -457,7 +478,8 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   const size_t lds = (size_t)(2 * m->lds_bytes[5]);
 #define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
-  if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
+  if (m->sol2_nmax == 8) { if (m->sol2_rpl == 1) GO(8, 1); else if (m->sol2_rpl == 2) GO(8, 2); else if (m->sol2_rpl == 4) GO(8, 4); else GO(8, 8); }
+  else if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
   else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
 #undef GO
   HIP_TRY(hipGetLastError());
