@@ -69,7 +69,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL | PH_SOL2T)              \
   X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
   X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
-  X(efc_J, (m.con_general ? m.nefc : m.nefc - m.nl) * m.nv, PH_CON) X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
+  X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf + m.nft, PH_SOL) /* frictionloss of the dof- and tendon-friction rows */                \
@@ -143,6 +143,7 @@ struct DevModel {
   const REAL* act_ent_coef;
   const int* act_ent_rot;
   const REAL* ten_J0;                      // ntendon*nv: the constant Jacobian of the fixed tendons (ten_J[t, dof] = coef, last term wins: smooth.py:492-494)
+  int con_direct;                          // plain constraint phase of a small model: contact rows written straight to the efc_J leaf, two environments per wavefront
   int con_general;                         // equality / frictionloss / ball- or tendon-limit rows present: constraint phase kernel 7
   int act_simple;                          // every actuator drives a slide / hinge joint
   int act_has_rot;                         // some JOINTINPARENT transmission on a ball / free joint (moment depends on qpos)

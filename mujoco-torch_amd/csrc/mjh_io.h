@@ -29,8 +29,8 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
       rd = 10 * nb + 6 * nv;
       wr = nv * nv + 10 * nb + nv * nv;
       break;
-    case 2: case 7: {  // collision() + make_constraint()
-      if ((kernel == 7) != general_con) return -1;
+    case 2: case 7: case 8: {  // collision() + make_constraint() (8: small models, contact rows straight to the leaf)
+      if ((kernel == 7) != general_con || (kernel == 8) != (m.con_direct != 0)) return -1;
       if (ncon > 0) { rd += 12 * ng; if (m.ncvxpair > 0) rd += 13 * ncon; }
       if (nefc > 0) {
         rd += nv + 3 * nb + 6 * nv + (general_con ? nq : (int64_t)m.nl);   // qvel, subtree_com, cdof, qpos (plain: one entry per limit row)
@@ -64,12 +64,12 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
       }
       if (do_step) { rd += 1; wr += nq + nv + na + 1; if (!(m.disableflags & DSBL_EULERDAMP) && m.integrator == INT_EULER) rd += tri; }
       break;
-    case 8:  // mjh_convex_kernel: the two geom frames of every convex pair in, its (up to four) contacts out
+    case 10:  // mjh_convex_kernel: the two geom frames of every convex pair in, its (up to four) contacts out
       if (m.ncvxpair == 0) return -1;
       rd = 24 * (int64_t)m.ncvxpair;
       wr = 13 * 4 * (int64_t)m.ncvxpair;
       break;
-    case 9:  // mjh_sensor_kernel: site frames of the sensors, geom frames for the rays, cvel / subtree_com of the IMU bodies, joint state
+    case 11:  // mjh_sensor_kernel: site frames of the sensors, geom frames for the rays, cvel / subtree_com of the IMU bodies, joint state
       if (m.nsensor == 0) return -1;
       rd = 12 * (int64_t)m.nsensor + 12 * ng + 9 * (int64_t)m.nsensor + (int64_t)m.nsensordata;
       wr = (int64_t)m.nsensordata;

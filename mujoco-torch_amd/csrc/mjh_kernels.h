@@ -37,7 +37,7 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
   if (phase_bit == PH_CON) {
     // the geom frames are only read by the narrow phase, the dense efc_J only written after it: they share storage
     // (unless the frames are the larger of the two, then they get their own)
-    const int n3 = ((3 * m.ngeom + 1) & ~1), n9 = ((9 * m.ngeom + 1) & ~1), nj = (((m.con_general ? m.nefc : m.nefc - m.nl) * m.nv + 1) & ~1);
+    const int n3 = ((3 * m.ngeom + 1) & ~1), n9 = ((9 * m.ngeom + 1) & ~1), nj = (((m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv)) + 1) & ~1);
     if (n3 + n9 <= nj) { o.geom_xpos = o.efc_J; o.geom_xmat = o.efc_J + n3; }
     else { o.geom_xpos = off; o.geom_xmat = off + n3; off += n3 + n9; }
   }
@@ -491,7 +491,9 @@ __device__ __forceinline__ REAL dot_seq(const REAL* a, int sa, const REAL* b, in
 }
 
 // =====================================================================================================================
-template <typename REAL, int W = 64, bool FRIC = false>
+// FRIC: the general constraint / solver instantiations (equality, frictionloss, dense limit rows; also max_contact_points);
+// DIRECT: the constraint phase of small models that writes its contact rows straight to the efc_J leaf (kernel 8)
+template <typename REAL, int W = 64, bool FRIC = false, bool DIRECT = false>
 struct Env {
   __device__ __forceinline__ static int lane() { return sub_lane<W>(); }
   // dof-frictionloss rows of the SOLVER phase: its frictionloss-free instantiation (kernel 4) carries none of their code,
@@ -1010,7 +1012,7 @@ struct Env {
     }
     wave_sync();
     STAMP(20);
-    if (M.topk) {
+    if (FRIC && M.topk) {  // (models with max_contact_points run the general constraint kernel)
       // max_contact_points (collision_driver.py:822-840): keep the ncon candidates with the smallest dist -- torch.topk(-dist): closest
       // first; equal distances are ordered by candidate index here (torch leaves that order to its partial sort) -- then the static
       // permutation of the argsort over their (equal) condims.  One candidate per lane, rank by counting.
@@ -1061,7 +1063,7 @@ struct Env {
   }
   __device__ __forceinline__ int* con_src_lds() const { return reinterpret_cast<int*>(S.i_con_src()); }
   // candidate behind contact slot c: the slot itself unless max_contact_points selected per environment
-  __device__ __forceinline__ int con_src(int c) const { return M.topk ? con_src_lds()[c] : c; }
+  __device__ __forceinline__ int con_src(int c) const { return (FRIC && M.topk) ? con_src_lds()[c] : c; }
 
   // ---- constraint rows (constraint.py:600-768) ---------------------------------------------------------------------------------------------------
   // support.jac :138-153 restricted to one dof: jacp / jacr of `point` on `body`, masked to ancestor dofs
@@ -1276,7 +1278,11 @@ struct Env {
       int c, d;
       split_index(w, nv, M.inv_nv, c, d);
       const int cq = con_src(c);  // candidate behind the slot (the per-contact tables and the narrow-phase results are indexed by it)
-      const int dim = M.con_dim[cq], row0 = M.con_efc_address[c];
+      // small models (con_direct): the rows go straight to the efc_J leaf (lanes of one contact write runs of nv elements) and the
+      // aref loop below reads them back through L2 -- without the dense copy this phase's arena fits two environments per wavefront
+      constexpr bool direct = DIRECT;
+      REAL* const Jdst = direct ? out.efc_J + e * nefc * nv : S.efc_J();
+      const int dim = M.con_dim[cq], row0 = M.con_efc_address[c] - (direct ? 0 : jrow0);
       const int b1 = M.geom_bodyid[M.con_geom1[cq]], b2 = M.geom_bodyid[M.con_geom2[cq]];
       const REAL* fr = S.con_frame() + 9 * cq;
       const REAL* cpos = S.con_pos() + 3 * cq;
@@ -1284,7 +1290,7 @@ struct Env {
       const REAL dist = S.con_dist()[cq] - M.con_includemargin[cq];
       if (!(dist < 0)) {  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
         const int rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
-        for (int r = 0; r < rows; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = 0;
+        for (int r = 0; r < rows; r++) Jdst[(row0 + r) * nv + d] = 0;
         continue;
       }
       REAL jp1[3], jr1[3], jp2[3], jr2[3];
@@ -1299,15 +1305,15 @@ struct Env {
         diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
       }
       if (dim == 1) {
-        S.efc_J()[(row0 - jrow0) * nv + d] = diff[0];
+        Jdst[row0 * nv + d] = diff[0];
       } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
         const int nedge = 2 * (dim - 1);
         for (int ed = 0; ed < nedge; ed++) {
           const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
-          S.efc_J()[(row0 - jrow0 + ed) * nv + d] = diff[0] + diff[1 + (ed >> 1)] * f;
+          Jdst[(row0 + ed) * nv + d] = diff[0] + diff[1 + (ed >> 1)] * f;
         }
       } else {  // _instantiate_contact_elliptic :519-583
-        for (int r = 0; r < dim; r++) S.efc_J()[(row0 - jrow0 + r) * nv + d] = diff[r];
+        for (int r = 0; r < dim; r++) Jdst[(row0 + r) * nv + d] = diff[r];
       }
     }
     wave_sync();
@@ -1316,6 +1322,7 @@ struct Env {
     for (int r = l; r < nefc; r += W) {  // :683-693
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
+      bool con_row_active = false;
       if (r < ns) { pos = S.efc_pos()[r]; pos_norm = FRIC ? S.efc_pos_norm()[r] : pos; invweight = S.efc_invweight()[r]; }
       if (r < ne) {
         const int id = M.eq_id[M.efc_row_eq[r]];
@@ -1352,6 +1359,7 @@ struct Env {
         const REAL* fric = M.con_friction + 5 * c;
         const REAL dist = S.con_dist()[c] - M.con_includemargin[c];
         const REAL active = (REAL)(dist < 0);
+        con_row_active = dist < 0;
         const REAL t = M.body_invweight0[M.geom_bodyid[M.con_geom1[c]]] + M.body_invweight0[M.geom_bodyid[M.con_geom2[c]]];
         if (dim == 1) {
           pos = dist * active; pos_norm = dist * active; invweight = t;
@@ -1369,7 +1377,25 @@ struct Env {
       kbi(solref, solimp, pos_norm, k, b, imp);
       REAL rr = invweight * (1 - imp) / imp;
       rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
-      const REAL jv = (!FRIC && r < nl) ? (0 + S.efc_jl()[r] * S.qvel()[M.jnt_dofadr[M.lim_jnt[r]]]) : dot_seq(S.efc_J() + (r - jrow0) * nv, 1, S.qvel(), 1, nv);
+      REAL jv;
+      if (FRIC) jv = dot_seq(S.efc_J() + r * nv, 1, S.qvel(), 1, nv);
+      else if (r < nl) jv = 0 + S.efc_jl()[r] * S.qvel()[M.jnt_dofadr[M.lim_jnt[r]]];
+      else if (!DIRECT) jv = dot_seq(S.efc_J() + (r - jrow0) * nv, 1, S.qvel(), 1, nv);
+      else if (!con_row_active) jv = 0;  // the row is all zeros
+      else {
+        // this wave stored the row above and the barrier drained the stores to L2.  Agent-scope loads read L2 past the CU's L1,
+        // where a line shared with a neighbouring environment's rows could have been cached before this wave's stores landed.
+        const REAL* jr = out.efc_J + (e * nefc + r) * nv;
+        REAL s = 0;
+        int k = 0;
+        for (; k + 4 <= nv; k += 4) {
+          const REAL a0 = __hip_atomic_load(jr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(jr + k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const REAL a2 = __hip_atomic_load(jr + k + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a3 = __hip_atomic_load(jr + k + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s += a0 * S.qvel()[k]; s += a1 * S.qvel()[k + 1]; s += a2 * S.qvel()[k + 2]; s += a3 * S.qvel()[k + 3];
+        }
+        for (; k < nv; k++) s += __hip_atomic_load(jr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * S.qvel()[k];
+        jv = s;
+      }
       if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
       if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
     }
@@ -1382,7 +1408,7 @@ struct Env {
         split_index(w, nv, M.inv_nv, r, d);
         gJ[w] = (d == M.jnt_dofadr[M.lim_jnt[r]]) ? S.efc_jl()[r] : (REAL)0;
       }
-      for (int w = l; w < (nefc - nl) * nv; w += W) gJ[nl * nv + w] = S.efc_J()[w];
+      if (!DIRECT) for (int w = l; w < (nefc - nl) * nv; w += W) gJ[nl * nv + w] = S.efc_J()[w];
     }
     STAMP(27);
     if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : ((r >= ne + nf && r < ne + nfa) ? M.tendon_frictionloss[M.fric_tendon[r - ne - nf]] : (REAL)0);
@@ -3013,10 +3039,10 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 |
   const int sub = (W == MJH_WAVE) ? 0 : (int)(threadIdx.x / W);  // folded away for a whole-wave environment: everything stays scalar
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
-    Env<REAL, W, PHASE == 6 || PHASE == 7> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
+    Env<REAL, W, PHASE == 6 || PHASE == 7, PHASE == 8> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
     if (PHASE == 0) E.run_kin();
     else if (PHASE == 1) E.run_crb();
-    else if (PHASE == 2 || PHASE == 7) E.run_con();  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
+    else if (PHASE == 2 || PHASE == 7 || PHASE == 8) E.run_con();  // 8: plain constraint phase of small models, contact rows straight to the leaf  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows

@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static struct {
   bool on = false;
   int n = 0;                          // launches recorded by the last call
-  int id[MJH_TIMING_MAX];             // 0..7 phase-kernel ids, 8 convex narrow phase, 9 sensors
+  int id[MJH_TIMING_MAX];             // 0..8 phase-kernel ids, 10 convex narrow phase, 11 sensors
   hipEvent_t ev[MJH_TIMING_MAX + 1];  // ev[i] .. ev[i + 1] brackets launch i
 } g_timing;
 static inline void timing_begin(hipStream_t s) { if (g_timing.on) { g_timing.n = 0; (void)hipEventRecord(g_timing.ev[0], s); } }
@@ -135,9 +135,15 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
   M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M.has_gravcomp = 0;
-  M.con_general = (d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0) ? 1 : 0;
+  M.con_general = (d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0 || d->topk) ? 1 : 0;
   if (d->nft > 0 && d->nf + d->nl + d->nft > 64) return fail(-38, "frictionloss rows beyond the first 64 solver rows are not supported");
   for (int b = 0; b < d->nbody; b++) if (d->body_gravcomp[b] != 0) M.has_gravcomp = 1;
+  {
+    // measured on MI355X (profiles/r02/notes.md): ant (nv 8) constraint phase 127 -> 112 us, mesh scene 58 -> 54 us; the humanoid (nv 27) is
+    // slower that way (43 -> 59 us: every (contact, dof) lane re-reads 27-wide rows through L2) and keeps the dense copy in LDS
+    static const int direct_nv = [] { const char* e = getenv("MJH_CON_DIRECT_NV"); return e ? atoi(e) : 16; }();
+    M.con_direct = (d->nv <= direct_nv && !(d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0 || d->topk)) ? 1 : 0;
+  }
   M.gravity[0] = (REAL)d->gravity_x; M.gravity[1] = (REAL)d->gravity_y; M.gravity[2] = (REAL)d->gravity_z;
   M.meaninertia = d->meaninertia; M.tolerance = d->tolerance; M.ls_tolerance = d->ls_tolerance;
 #define X(n) fix.push_back({(const void**)&M.n, bb.add(d->n, sizeof(int32_t) * (size_t)d->len_##n)});
@@ -403,6 +409,12 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     out->pack2[P] = 1;                                                                                                       \
   }
   SET_PACK(0) SET_PACK(3)
+  static const bool con_pack = [] { const char* e = getenv("MJH_CON_PACK"); return !(e && e[0] == '0'); }();
+  if (con_pack && M.con_direct && 2 * out->lds_bytes[2] <= 64 * 1024) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[2]));
+    out->pack2[2] = 1;
+  }
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 8, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));  // plain constraint phase: its contact rows go straight to the leaf, the arena is small enough for two per wavefront
   // CRB: the register Cholesky keeps one matrix row per lane, so nv <= 32 would fit a 32-lane half too; measured on the float64
   // humanoid (nv 27) two per wavefront is SLOWER, 50.2 vs 39.9 us (132 VGPRs: 3 waves / SIMD instead of 4, and every broadcast of the
   // factorisation becomes two v_readlane + a select): opt-in only (MJH_CRB_PACK=1).  float32 small models: +13 % on the ant (round 1).
@@ -440,7 +452,7 @@ template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
-  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : (P == 7 ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
+  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : ((P == 7 || P == 8) ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
   a.off = m->off[A];
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = m->lds_bytes[A] / (int)sizeof(REAL);
@@ -453,13 +465,13 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5);
-  if (PACKABLE && m->pack2[P == 5 ? 3 : P] && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8);
+  if (PACKABLE && m->pack2[P == 5 ? 3 : (P == 8 ? 2 : P)] && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
     int64_t done = 0;
     int rc = 0;
-    if (m->pack4[P == 5 ? 3 : P] && a.B >= 4) {
+    if (P != 8 && m->pack4[P == 5 ? 3 : P] && a.B >= 4) {
       done = a.B & ~(int64_t)3;
-      if ((rc = launch_range<REAL, P, (PACKABLE ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
+      if ((rc = launch_range<REAL, P, ((PACKABLE && P != 8) ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
     }
     const int64_t even = (a.B - done) & ~(int64_t)1;
     if ((rc = launch_range<REAL, P, (PACKABLE ? 32 : MJH_WAVE)>(m, a, done, even, stream))) return rc;
@@ -498,17 +510,17 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
     hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
-    timing_mark(stream, 8);
+    timing_mark(stream, 10);
   }
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
-      (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream))) return rc;
+      (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
   if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
     HIP_TRY(hipGetLastError());
-    timing_mark(stream, 9);
+    timing_mark(stream, 11);
   }
   if ((st & 0x60) && m->sol2_nmax) return launch_sol2<REAL>(m, a, stream);
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.nft > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
