@@ -3009,6 +3009,9 @@ struct Env {
 #undef STAMP
 #undef STAMP0
 
+#ifndef MJH_CON64_WAVES
+#define MJH_CON64_WAVES 4  /* float64 plain constraint phase: 128 VGPRs + ~108 B of scratch buys the fourth wave per SIMD (16 environments per CU) */
+#endif
 // Occupancy bounds (second launch-bound argument = waves per SIMD the allocator must fit): float64 kernels are left alone --
 // capping them at 128 VGPRs was measured 3-11 % slower than ~180-230 VGPRs at 2 waves/SIMD, their spills are twice as wide
 // (profiles/r01/notes.md).  The float32 solver, packed kinematics / velocity and CRB kernels sit just above an occupancy
@@ -3032,7 +3035,7 @@ __global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args)
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? 4 : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
