@@ -103,7 +103,8 @@ def algorithmic_bytes_per_env_step(mx, dtype):
 KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kernel<{r}, 1, W> (crb / factor)", 2: "mjh_phase_kernel<{r}, 2, W> (collision / constraint)",
                3: "mjh_phase_kernel<{r}, 3, W> (velocity)", 4: "mjh_phase_kernel<{r}, 4, W> (solve / integrate)", 5: "mjh_phase_kernel<{r}, 5, W> (velocity + fluid)",
                6: "mjh_phase_kernel<{r}, 6, 64> (solve / integrate, general rows)", 7: "mjh_phase_kernel<{r}, 7, 64> (collision / constraint, general rows)",
-               8: "mjh_phase_kernel<{r}, 8, W> (collision / constraint, rows straight to the leaf)", 10: "mjh_convex_kernel<{r}>", 11: "mjh_sensor_kernel<{r}>"}
+               8: "mjh_phase_kernel<{r}, 8, W> (collision / constraint, rows straight to the leaf)",
+               9: "mjh_sol2_kernel<{r}, NMAX, RPL> (solve / integrate: register solver, two environments per wavefront)", 10: "mjh_convex_kernel<{r}>", 11: "mjh_sensor_kernel<{r}>"}
 
 
 def kernel_algorithmic_bytes(nm):
@@ -312,8 +313,11 @@ def main(args):
                     "measured_in_this_run": False, "kernels_changed_since": stale}
             if not stale:
                 traffic = tj.get("hbm_bytes_per_step")
+                best_disp = 0
                 for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
-                    if f"Li{dom['id']}E" in name or dom["kernel"].split(" (")[0].replace(" ", "").replace("W>", "") in name.replace(" ", ""):
+                    pat = "mjh_sol2_kernel<" if dom["id"] == 9 else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
+                    if pat in name and v.get("dispatches_per_step", 0) >= best_disp:  # (the packed variant, not the odd-tail launch)
+                        best_disp = v.get("dispatches_per_step", 0)
                         ktraffic = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,

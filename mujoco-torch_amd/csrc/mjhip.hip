@@ -27,7 +27,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static struct {
   bool on = false;
   int n = 0;                          // launches recorded by the last call
-  int id[MJH_TIMING_MAX];             // 0..8 phase-kernel ids, 10 convex narrow phase, 11 sensors
+  int id[MJH_TIMING_MAX];             // 0..8 phase-kernel ids, 9 register solver, 10 convex narrow phase, 11 sensors
   hipEvent_t ev[MJH_TIMING_MAX + 1];  // ev[i] .. ev[i + 1] brackets launch i
 } g_timing;
 static inline void timing_begin(hipStream_t s) { if (g_timing.on) { g_timing.n = 0; (void)hipEventRecord(g_timing.ev[0], s); } }
@@ -495,7 +495,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
 #undef GO
   HIP_TRY(hipGetLastError());
-  timing_mark(stream, 4);
+  timing_mark(stream, 9);
   return 0;
 }
 
@@ -818,8 +818,10 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
 
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   if (!m || !read_write_bytes) return fail(-22, "null argument");
-  const int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, kernel, 1, &read_write_bytes[0], &read_write_bytes[1])
-                                     : mjh_kernel_io<float>(m->m32, kernel, 1, &read_write_bytes[0], &read_write_bytes[1]);
+  if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
+  const int k = kernel == 9 ? 4 : kernel;  // the register solver moves the same leaves as the plain LDS solver
+  const int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 1, &read_write_bytes[0], &read_write_bytes[1])
+                                     : mjh_kernel_io<float>(m->m32, k, 1, &read_write_bytes[0], &read_write_bytes[1]);
   return rc == 0 ? 0 : -2;  // -2: this model's step does not launch that kernel
 }
 
