@@ -69,7 +69,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL | PH_SOL2T)              \
   X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
   X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
-  X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(efc_D, m.nefc, PH_SOL)                                            \
+  X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(i_con_act, m.con_direct ? m.ncon : 0, PH_CON) X(i_crow_act, m.con_direct ? m.nefc - m.nl : 0, PH_CON) /* small models: compact list of the active contacts, per-row activity (ints) */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf + m.nft, PH_SOL) /* frictionloss of the dof- and tendon-friction rows */                \
@@ -151,6 +151,13 @@ struct DevModel {
   const int* dof_limrow;                   // 2*nv: the (up to two: frictionloss, then joint limit) single-column rows of dof d, -1 = none
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
+  // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
+  // everything a row needs with ONE table read indexed by its own row number instead of a chain row -> contact -> geom -> body
+  const REAL* crow_par;                    // 9 * ncrow, parameter-major [k * ncrow + q]: solref (2, friction rows of elliptic cones resolved), solimp (5), invweight, includemargin of contact row q
+  const int* crow_info;                    // ncrow: contact | (row within the contact) << 16 | (elliptic cone and condim > 1) << 24
+  int ncrow;                               // contact rows = nefc - (rows ahead of the contacts)
+  const int* con_body;                     // 4 * ncon: body1, body2, root body of body1, of body2
+  const unsigned long long* con_dmask;     // 2 * ncon: body_dofmask of body1, body2
   const int* cvx_pairs;                    // ncvxpair: indices (into pair_*) of the pairs with a convex pair function
   int ncvxpair;
 };

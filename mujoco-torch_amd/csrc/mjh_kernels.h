@@ -233,6 +233,25 @@ template <bool PACKED>
 __device__ __forceinline__ int tri_at(int i, int k, int n) { return PACKED ? (i * (i + 1)) / 2 + k : i * n + k; }
 
 // inverse of the packed index: w = i (i + 1) / 2 + j, 0 <= j <= i
+// ---- 16x16x4 matrix-core tiles (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64) ------------------------------------------------------------
+// The Newton Hessian H = M + J^T diag(D) J (solver.py:366-370) and qfrc_constraint = J^T efc_force are the only contractions of the step with a
+// long summed index (the constraint rows); for nv <= 16 one tile holds the whole result.  Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of a
+// 16x4 . 4x16 block, i.e. ONE element J[row 4 b + (l >> 4)][column l & 15] feeds both operands.  The instruction accumulates in k order with one
+// rounding per term (a fused-multiply-add chain): the rows are summed in index order like the scalar loops they replace.
+typedef float mjh_f32x4 __attribute__((ext_vector_type(4)));
+typedef double mjh_f64x4 __attribute__((ext_vector_type(4)));
+template <typename REAL> struct MfmaTile;
+template <> struct MfmaTile<float> {
+  typedef mjh_f32x4 Acc;
+  static __device__ __forceinline__ Acc mac(float a, float b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }  // C/D: column = lane & 15
+};
+template <> struct MfmaTile<double> {
+  typedef mjh_f64x4 Acc;
+  static __device__ __forceinline__ Acc mac(double a, double b, Acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int reg) { return (lane >> 4) + 4 * reg; }  // the f64 form has its own C/D map
+};
+
 __device__ __forceinline__ void tri_unpack(int w, int& i, int& j) {
   int r = (int)((__builtin_sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
   if ((r * (r + 1)) / 2 > w) r--;
@@ -1078,6 +1097,17 @@ struct Env {
     for (int i = 0; i < 3; i++) { jp[i] = (cd[3 + i] + c[i]) * on; jr[i] = cd[i] * on; }
   }
 
+  // the same with the body's root and its dof-mask bit already looked up (DevModel::con_body / con_dmask)
+  __device__ __forceinline__ void jac_dof_root(const REAL* point, int root, REAL on, int dof, REAL* jp, REAL* jr) const {
+    const REAL* rc = S.subtree_com() + 3 * root;
+    const REAL off[3] = {point[0] - rc[0], point[1] - rc[1], point[2] - rc[2]};
+    const REAL* cd = S.cdof() + 6 * dof;
+    REAL c[3];
+    cross3(cd, off, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { jp[i] = (cd[3 + i] + c[i]) * on; jr[i] = cd[i] * on; }
+  }
+
   __device__ __forceinline__ void kbi(const REAL* solref, const REAL* solimp, REAL pos, REAL& k, REAL& b, REAL& imp) const {  // :69-113
     REAL timeconst = solref[0], dampratio = solref[1];
     if (!(M.disableflags & DSBL_REFSAFE)) {
@@ -1273,6 +1303,75 @@ struct Env {
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
     const bool elliptic = M.cone == CONE_ELLIPTIC;
+    if constexpr (!FRIC && DIRECT) {
+      // Small models (rows straight to the leaf).  (A) one lane per contact: which contacts are active, as a compact list and as a per-row flag; (B) the rows of the
+      // inactive contacts are zeroed by a straight loop over the block (no table reads); (C) one lane per (ACTIVE contact, dof) forms the
+      // Jacobian entries, everything it needs about the contact coming from two table reads indexed by the contact.  Walking all
+      // (contact, dof) pairs cost every lane a chain of dependent table reads per pair -- 15 trips per lane for the ant, which keeps 4 - 8 of
+      // its 60 contacts active.  (The float64 instantiation that keeps the rows in LDS -- the humanoid's -- is slower with this loop
+      // structure, 43 -> 56 us: its register allocation sits at the 128-VGPR bound; it keeps the (contact, dof) walk below.)
+      int* const act_list = reinterpret_cast<int*>(S.i_con_act());
+      int* const row_act = reinterpret_cast<int*>(S.i_crow_act());
+      const int ncon = M.ncon, nd = nefc - nl;
+      int nact = 0;
+      for (int base = 0; base < ncon; base += W) {
+        const int c = base + l;
+        bool act = false;
+        int rows = 0, row0 = 0;
+        if (c < ncon) {
+          const int dim = M.con_dim[c];
+          rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
+          row0 = M.con_efc_address[c] - nl;
+          act = (S.con_dist()[c] - M.con_includemargin[c]) < 0;
+        }
+        int x = act ? 1 : 0;
+        for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
+        if (act) act_list[nact + x - 1] = c;
+        for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
+        nact += sub_read<W>(x, W - 1);
+      }
+      wave_sync();
+      REAL* const Jdst = out.efc_J + (e * nefc + nl) * nv;  // row 0 = first contact row
+      for (int w = l; w < nd * nv; w += W) {
+        int q, d;
+        split_index(w, nv, M.inv_nv, q, d);
+        if (!row_act[q]) Jdst[w] = 0;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+      }
+      for (int w = l; w < nact * nv; w += W) {
+        int a, d;
+        split_index(w, nv, M.inv_nv, a, d);
+        const int c = act_list[a];
+        const int dim = M.con_dim[c], row0 = M.con_efc_address[c] - nl;
+        const int* cb = M.con_body + 4 * c;
+        const int root1 = cb[2], root2 = cb[3];
+        const REAL on1 = (REAL)((M.con_dmask[2 * c] >> d) & 1ull), on2 = (REAL)((M.con_dmask[2 * c + 1] >> d) & 1ull);
+        const REAL* fr = S.con_frame() + 9 * c;
+        const REAL* cpos = S.con_pos() + 3 * c;
+        const REAL* fric = M.con_friction + 5 * c;
+        REAL jp1[3], jr1[3], jp2[3], jr2[3];
+        jac_dof_root(cpos, root2, on2, d, jp2, jr2);
+        jac_dof_root(cpos, root1, on1, d, jp1, jr1);
+        const REAL dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]};
+        const REAL dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
+        REAL diff[6];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          diff[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2];
+          diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
+        }
+        if (dim == 1) {
+          Jdst[row0 * nv + d] = diff[0];
+        } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
+          const int nedge = 2 * (dim - 1);
+          for (int ed = 0; ed < nedge; ed++) {
+            const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
+            Jdst[(row0 + ed) * nv + d] = diff[0] + diff[1 + (ed >> 1)] * f;
+          }
+        } else {  // _instantiate_contact_elliptic :519-583
+          for (int r = 0; r < dim; r++) Jdst[(row0 + r) * nv + d] = diff[r];
+        }
+      }
+    } else
     // contact rows: one lane per (contact, dof) column entry; all rows of the contact for that dof
     for (int w = l; w < M.ncon * nv; w += W) {
       int c, d;
@@ -1344,6 +1443,20 @@ struct Env {
         const int t = M.lim_tendon[r - ne - nfa - nlb - nl];
         solref[0] = M.tendon_solref_lim[2 * t]; solref[1] = M.tendon_solref_lim[2 * t + 1];
         for (int i = 0; i < 5; i++) solimp[i] = M.tendon_solimp_lim[5 * t + i];
+      } else if (!FRIC && DIRECT) {  // contact row, small models: every static scalar of the row from ONE table column read indexed by the row
+        const int q = r - ns, ncr = M.ncrow;
+        const int info = M.crow_info[q];
+        const REAL* P = M.crow_par + q;
+        solref[0] = P[0]; solref[1] = P[ncr];
+#pragma unroll
+        for (int i = 0; i < 5; i++) solimp[i] = P[(2 + i) * ncr];
+        invweight = P[7 * ncr];
+        const int c = info & 0xffff, sub = (info >> 16) & 0xff;
+        const REAL dist = S.con_dist()[c] - P[8 * ncr];
+        const REAL active = (REAL)(dist < 0);
+        con_row_active = dist < 0;
+        if (!(info >> 24)) { pos = dist * active; pos_norm = dist * active; }
+        else { pos = (sub == 0 ? dist : (REAL)0) * active; pos_norm = dist; }
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
         const int cs = M.efc_row_con[r], sub = r - M.con_efc_address[cs];
         const int c = con_src(cs);
@@ -1918,9 +2031,48 @@ struct Env {
   __device__ __forceinline__ void constraint_qfrc() {
     const int l = lane();
     const int nv = M.nv, nefc = nrow_;
-    {  // rows in index order; rows whose force is exactly zero add +-0 and are skipped
+    const int nl = nf_() + M.nl;
+    if constexpr (W == 64) {
+      if (nv <= 16) {  // one matrix-core tile: C[i][*] = sum_rows J[row][i] * force[row], rows in index order (every column of C carries the same vector)
+        typedef MfmaTile<REAL> MT;
+        const int c = l & 15, kq = l >> 4, nd = nefc - nl;
+        typename MT::Acc acc = {0, 0, 0, 0};
+        if (nl > 0) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch dof i
+          const int nslot = nf_() > 0 ? 2 : 1;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = MT::row(l, r);
+            REAL s0 = 0;
+            for (int q = 0; q < nslot; q++) {
+              const int lr = i < nv ? dof_limrow_lds()[2 * i + q] : -1;
+              if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s0 += S.efc_Jl()[lr] * f; }
+            }
+            acc[r] = s0;
+          }
+        }
+        // out-of-range lanes read a clamped address and select 0 afterwards: unconditional LDS reads that pipeline across the unrolled blocks
+        const REAL* jc = S.efc_Jc() + (c < nv ? c : 0);
+        const REAL* fr = S.s_force() + nl;
+        for (int k0 = 0; k0 < nd; k0 += 16) {  // four tiles per trip, unrolled by hand (the compiler does not unroll a loop around the intrinsic): eight reads in flight
+          REAL jl[4], fl[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) { const int row = k0 + 4 * t + kq, rc = row < nd ? row : nd - 1; jl[t] = jc[rc * nv]; fl[t] = fr[rc]; }
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int row = k0 + 4 * t + kq;
+            acc = MT::mac((row < nd && c < nv) ? jl[t] : (REAL)0, row < nd ? fl[t] : (REAL)0, acc);  // a tile past the last row adds exact zeros
+          }
+        }
+        if (c == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) { const int i = MT::row(l, r); if (i < nv) S.s_qfrc()[i] = acc[r]; }
+        }
+        wave_sync();
+        return;
+      }
+    }
+    {  // rows in index order
       REAL s = 0;
-      const int nl = nf_() + M.nl;
       if (nl > 0 && l < nv) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch column l
         const int nslot = nf_() > 0 ? 2 : 1;  // without frictionloss rows the second slot of every dof is empty
         for (int q = 0; q < nslot; q++) {
@@ -1928,16 +2080,13 @@ struct Env {
           if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
         }
       }
-      for (int base = nl; base < nefc; base += W) {
-        const int r = base + l;
-        const REAL f = (r < nefc) ? S.s_force()[r] : (REAL)0;
-        unsigned long long mask = __ballot(f != 0);
-        while (mask) {
-          const int bit = __ffsll((long long)mask) - 1;
-          mask &= mask - 1;
-          const REAL fr = read_lane(f, bit);
-          if (l < nv) s += S.efc_Jc()[(base - nl + bit) * nv + l] * fr;
-        }
+      // a counted loop over the compacted rows: the loads of consecutive rows pipeline (the force is one broadcast read), where
+      // picking the non-zero forces out of a ballot made every row a dependent round trip; rows with a zero force add +-0
+      if (l < nv) {
+        const REAL* jc = S.efc_Jc() + l;
+        const REAL* fr = S.s_force();
+#pragma unroll 8
+        for (int r = nl; r < nefc; r++) s += jc[(r - nl) * nv] * fr[r];
       }
       if (l < nv) S.s_qfrc()[l] = s;
     }
@@ -1955,29 +2104,82 @@ struct Env {
       // H = M + J^T diag(D active) J (solver.py:366-370); inactive rows contribute exact zeros and are skipped
       // only the lower triangle is ever read by the factorisation: one lane per packed entry (i, j <= i)
       const int np = (nv * (nv + 1)) / 2, nl = nf_() + M.nl;
-      for (int w0 = 0; w0 < np; w0 += W) {
-        const int w = w0 + l;
-        int i, j;
-        tri_unpack(w < np ? w : 0, i, j);
-        REAL s = 0;
-        if (nl > 0 && i == j) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
+      // weight of every dense row: D where the row is in the quadratic set, else 0 (the line search's quad buffer is dead here).
+      // The row loop below is then a plain counted loop whose LDS reads pipeline; an inactive row adds (J * 0) * J = +-0.
+      REAL* hw = S.s_quad();
+      for (int r = nl + l; r < nefc; r += W) hw[r] = (is_dfric(r) ? dfric_quadratic(r) : (S.s_Jaref()[r] < 0 || is_eq_row(r))) ? S.efc_D()[r] : (REAL)0;
+      wave_sync();
+      bool tiled = false;
+      if constexpr (W == 64) {
+        if (nv <= 16) {  // one matrix-core tile: C = J^T diag(hw) J over the dense rows, started from the single-column rows' diagonal terms
+          typedef MfmaTile<REAL> MT;
+          tiled = true;
+          const int c = l & 15, kq = l >> 4, nd = nefc - nl;
+          typename MT::Acc acc = {0, 0, 0, 0};
+          if (nl > 0) {
+            const int nslot = nf_() > 0 ? 2 : 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const int i = MT::row(l, r);
+              REAL s0 = 0;
+              if (i == c && i < nv) {
+                for (int q = 0; q < nslot; q++) {
+                  const int lr = dof_limrow_lds()[2 * i + q];
+                  if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; s0 += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+                }
+              }
+              acc[r] = s0;
+            }
+          }
+          const REAL* jc = S.efc_Jc() + (c < nv ? c : 0);  // clamped addresses, selected to 0 afterwards: the LDS reads pipeline
+          const REAL* hd = hw + nl;
+          for (int k0 = 0; k0 < nd; k0 += 16) {  // four tiles per trip, unrolled by hand: eight reads in flight
+            REAL jl[4], dl[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const int row = k0 + 4 * t + kq, rc = row < nd ? row : nd - 1; jl[t] = jc[rc * nv]; dl[t] = hd[rc]; }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const int row = k0 + 4 * t + kq;
+              const REAL jv = (row < nd && c < nv) ? jl[t] : (REAL)0;
+              acc = MT::mac(jv * (row < nd ? dl[t] : (REAL)0) * (REAL)1, jv, acc);  // a tile past the last row adds exact zeros
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int i = MT::row(l, r);
+            if (i < nv && c <= i) S.H()[(i * (i + 1)) / 2 + c] = (M.sol_qm_lds ? S.qMs()[i * nv + c] : out.qM[e * nv * nv + i * nv + c]) + acc[r];
+          }
+        }
+      }
+      if (!tiled)
+      for (int w0 = 0; w0 < np; w0 += 2 * W) {  // two packed entries per lane and pass (nv = 12: 78 entries, one pass)
+        const int wa = w0 + l, wb = w0 + W + l;
+        int ia, ja, ib, jb;
+        tri_unpack(wa < np ? wa : 0, ia, ja);
+        tri_unpack(wb < np ? wb : 0, ib, jb);
+        REAL sa = 0, sb = 0;
+        if (nl > 0) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
           const int nslot = nf_() > 0 ? 2 : 1;
           for (int q = 0; q < nslot; q++) {
-            const int lr = dof_limrow_lds()[2 * i + q];
-            if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; s += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+            if (ia == ja) {
+              const int lr = dof_limrow_lds()[2 * ia + q];
+              if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; sa += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+            }
+            if (ib == jb) {
+              const int lr = dof_limrow_lds()[2 * ib + q];
+              if (lr >= 0 && crow_active(lr)) { const REAL jl = S.efc_Jl()[lr]; sb += (jl * S.efc_D()[lr] * (REAL)1) * jl; }
+            }
           }
         }
-        for (int base = nl; base < nefc; base += W) {
-          const int r = base + l;
-          unsigned long long mask = __ballot(r < nefc && (is_dfric(r) ? dfric_quadratic(r) : (S.s_Jaref()[r] < 0 || is_eq_row(r))));
-          while (mask) {
-            const int row = base + __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const REAL* jr = S.efc_Jc() + (row - nl) * nv;
-            s += (jr[i] * S.efc_D()[row] * (REAL)1) * jr[j];
-          }
+        const REAL* jr = S.efc_Jc();
+#pragma unroll 4
+        for (int row = nl; row < nefc; row++, jr += nv) {
+          const REAL dw = hw[row];
+          sa += (jr[ia] * dw * (REAL)1) * jr[ja];
+          sb += (jr[ib] * dw * (REAL)1) * jr[jb];
         }
-        if (w < np) S.H()[w] = (M.sol_qm_lds ? S.qMs()[i * nv + j] : out.qM[e * nv * nv + i * nv + j]) + s;
+        if (wa < np) S.H()[wa] = (M.sol_qm_lds ? S.qMs()[ia * nv + ja] : out.qM[e * nv * nv + ia * nv + ja]) + sa;
+        if (wb < np) S.H()[wb] = (M.sol_qm_lds ? S.qMs()[ib * nv + jb] : out.qM[e * nv * nv + ib * nv + jb]) + sb;
       }
       wave_sync();
       STAMP(63);
@@ -2198,6 +2400,26 @@ struct Env {
     STAMP(52);
     put(out.qacc_smooth, S.qacc_smooth(), nv);
   }
+  // rows `src[r]` (an LDS table of Data row numbers) of the efc_J leaf -> consecutive rows of an LDS block, DEPTH requests per lane in flight per
+  // round trip.  The whole copy is two trips for the humanoid's 32 x 27 block; at four per trip it was seven dependent ones, the longest
+  // section of the solver phase.  Lanes past the end read a clamped address (no exec-masked branches between the loads) and skip the store.
+  template <int DEPTH>
+  __device__ __forceinline__ void gather_rows(REAL* dstJ, const REAL* gJ, const int* src, int n) const {
+    const int nv = M.nv;
+    for (int i = lane(); i < n; i += DEPTH * W) {
+      REAL v[DEPTH];
+#pragma unroll
+      for (int t = 0; t < DEPTH; t++) {
+        const int idx = i + t * W, idc = idx < n ? idx : n - 1;
+        int r, k;
+        split_index(idc, nv, M.inv_nv, r, k);
+        v[t] = gJ[src[r] * nv + k];
+      }
+#pragma unroll
+      for (int t = 0; t < DEPTH; t++) { const int idx = i + t * W; if (idx < n) dstJ[idx] = v[t]; }
+    }
+  }
+
   __device__ __forceinline__ void load_solver_inputs() {
     const int nv = M.nv, nefc = M.nefc;
     if (M.sol_qm_lds) row_load<W>(S.qMs(), out.qM, nv * nv, e);
@@ -2258,22 +2480,7 @@ struct Env {
           S.efc_Jc()[i] = gJ[ext_row(nl + k) * nv + c];
         }
         // the rows of the active contacts, in row order (the rows of one contact are adjacent in memory: runs of rows * nv elements)
-        const int n = nact * nv;
-        REAL* dstJ = S.efc_Jc() + ndense0 * nv;
-        int i = l;
-        for (; i + 3 * W < n; i += 4 * W) {
-          int r0, k0, r1, k1, r2, k2, r3, k3;
-          split_index(i, nv, M.inv_nv, r0, k0); split_index(i + W, nv, M.inv_nv, r1, k1);
-          split_index(i + 2 * W, nv, M.inv_nv, r2, k2); split_index(i + 3 * W, nv, M.inv_nv, r3, k3);
-          const REAL a = gJ[row_src_lds()[r0] * nv + k0], b = gJ[row_src_lds()[r1] * nv + k1];
-          const REAL c = gJ[row_src_lds()[r2] * nv + k2], d = gJ[row_src_lds()[r3] * nv + k3];
-          dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
-        }
-        for (; i < n; i += W) {
-          int r, k;
-          split_index(i, nv, M.inv_nv, r, k);
-          dstJ[i] = gJ[row_src_lds()[r] * nv + k];
-        }
+        gather_rows<8>(S.efc_Jc() + ndense0 * nv, gJ, row_src_lds(), nact * nv);
       }
       for (int r = l; r < nrow_; r += W) {
         const int x = r < c0 ? ext_row(r) : row_src_lds()[r - c0];
@@ -2348,7 +2555,9 @@ struct Env {
         for (int d = l; d < nv; d += W) { S.s_grad()[d] = 0; S.s_Mgrad()[d] = 0; S.s_search()[d] = 0; }
         wave_sync();
       }
+      STAMP(68);
       if (do_ls || do_init) update_constraint(c);
+      STAMP(67);
       if (ph >= P_START) constraint_qfrc();
       STAMP(66);
       if (do_grad) {
@@ -2580,6 +2789,7 @@ struct Env {
     const bool solving = (KA.stages & 0x40) != 0;
     const bool from_in = !KA.state_from_cur;
     const bool newton = NEWT && M.solver == SOL_NEWTON;
+    STAMP0();
     // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
     const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
     TriPack<REAL, NMAX> T;
@@ -2649,24 +2859,11 @@ struct Env {
           const int r = l + 32 * j;
           if (r < nda) { const int x = rsrc[r]; Dd[j] = out.efc_D[e * nefc + x]; ard[j] = out.efc_aref[e * nefc + x]; }
         }
-        // rows of the active contacts of efc_J -> LDS, four requests in flight per trip
-        const int n = nda * nv;
-        REAL* dstJ = S.efc_Jc();
-        int i = l;
-        for (; i + 3 * W < n; i += 4 * W) {
-          int r0, k0, r1, k1, r2, k2, r3, k3;
-          split_index(i, nv, M.inv_nv, r0, k0); split_index(i + W, nv, M.inv_nv, r1, k1);
-          split_index(i + 2 * W, nv, M.inv_nv, r2, k2); split_index(i + 3 * W, nv, M.inv_nv, r3, k3);
-          const REAL a = gJ[rsrc[r0] * nv + k0], b = gJ[rsrc[r1] * nv + k1], c = gJ[rsrc[r2] * nv + k2], d = gJ[rsrc[r3] * nv + k3];
-          dstJ[i] = a; dstJ[i + W] = b; dstJ[i + 2 * W] = c; dstJ[i + 3 * W] = d;
-        }
-        for (; i < n; i += W) {
-          int r, k;
-          split_index(i, nv, M.inv_nv, r, k);
-          dstJ[i] = gJ[rsrc[r] * nv + k];
-        }
+        // rows of the active contacts of efc_J -> LDS
+        gather_rows<16>(S.efc_Jc(), gJ, rsrc, nda * nv);
       }
     }
+    STAMP(70);
     {  // T.t[l] with a lane-dependent index would spill the triangle: pick the diagonal with a compile-time scan instead
       REAL dg = 1;
 #pragma unroll
@@ -2676,6 +2873,7 @@ struct Env {
     // ---- _acceleration: qacc_smooth = M^-1 qfrc_smooth (forward.py:222-228) -----------------------------------------------------------------------
     const REAL qs = tri_solve2<NMAX>(T, f);
     if (dof && out.qacc_smooth) out.qacc_smooth[e * nv + l] = qs;
+    STAMP(71);
     if (!solving) return;
     REAL qacc = qs, qfrc = 0;
     if (nefc > 0) {
@@ -2807,6 +3005,7 @@ struct Env {
       }
       cost = constraint_cost(jal, jad, Ma, qacc, gauss);  // leaves the forces of the chosen context in frl / frd
       qfrc = constraint_qfrc();
+      STAMP(72);
       // M^-1 grad (CG) or H^-1 grad with H = M + J^T diag(D active) J factorised in registers (Newton, solver.py:359-376)
       auto precondition = [&](REAL grad) -> REAL {
         if (!newton) return tri_solve2<NMAX>(T, grad);
@@ -2825,18 +3024,30 @@ struct Env {
 #pragma unroll
           for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[nd + limrow];
         }
-        for (int r = 0; r < nda; r++) {
-          const REAL w = fs[r];
-          if (w != 0 && dof) {
-            const REAL* jr = Jc + r * nv;
-            const REAL ji = jr[l] * w * (REAL)1;
+        // The 32 lanes of the environment split into G = 32 / NMAX groups of NMAX: lane (g, i) sums row i of J^T diag(w) J over the rows
+        // r = g, g + G, ... (a counted loop whose LDS reads pipeline; a row outside the quadratic set has weight 0 and adds (J * 0) * J = +-0),
+        // then the groups' partial sums are added across lanes.  One lane per dof walking every row was a quarter of the lanes doing
+        // four times the trips.
+        {
+          constexpr int G = NEWT ? 32 / NMAX : 1;
+          const int hi = NEWT ? (l & (NMAX - 1)) : l, hg = NEWT ? l / NMAX : 0;
+          const REAL* jr = Jc + hg * nv;
+#pragma unroll 2
+          for (int r = hg; r < nda; r += G, jr += G * nv) {
+            const REAL ji = (hi < nv ? jr[hi] : (REAL)0) * fs[r] * (REAL)1;
 #pragma unroll
             for (int k = 0; k < NMAX; k++) if (k < nv) acc[k] += ji * jr[k];  // only k <= l is read back
+          }
+#pragma unroll
+          for (int o = NMAX; o < 32; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) acc[k] += __shfl_xor(acc[k], o, 32);
           }
         }
 #pragma unroll
         for (int k = 0; k < NMAX; k++) H.t[k] = (k <= l) ? H.t[k] + acc[k] : (REAL)0;
         wave_sync();
+        STAMP(73);
         // register Cholesky (math.small_cholesky :117-127, pivots clamped at 1e-12) leaving row AND column l of L in lane l
 #pragma unroll
         for (int j = 0; j < NMAX; j++) {
@@ -2858,7 +3069,10 @@ struct Env {
           for (int k = 0; k < NMAX; k++) dg = (k == l) ? H.t[k] : dg;
           H.inv = dof ? 1 / dg : (REAL)0;
         }
-        return tri_solve2<NMAX>(H, grad);
+        STAMP(74);
+        const REAL hx = tri_solve2<NMAX>(H, grad);
+        STAMP(75);
+        return hx;
       };
       REAL grad = dof ? (Ma - f) - qfrc : (REAL)0;
       REAL Mgrad = precondition(grad);
@@ -2887,6 +3101,7 @@ struct Env {
           mul_J2(vs, vs, jvd, unused_d, false);
           const REAL jvl = lim ? Jl * vs[ldof] : (REAL)0;
           wave_sync();
+          STAMP(76);
           const REAL ss = sub_sum<W>(dof ? search * search : (REAL)0);
           const bool nz = sub_any<W>(dof && search != 0);
           const REAL snorm = nz ? r_sqrt<REAL>(ss) : (REAL)0;
@@ -2956,11 +3171,13 @@ struct Env {
           jal = jal + improved * jvl * alpha;
 #pragma unroll
           for (int j = 0; j < RPL; j++) jad[j] = jad[j] + improved * jvd[j] * alpha;
+          STAMP(77);
         }
         if (need_grad && !newton && dof) { pg[l] = grad; pg[nv + l] = Mgrad; }
         prev_cost = cost;
         cost = constraint_cost(jal, jad, Ma, qacc, gauss);
         qfrc = constraint_qfrc();
+        STAMP(78);
         if (need_grad) {  // _update_gradient :359-376 and the next direction: Newton -H^-1 grad, CG Polak-Ribiere :519-523
           grad = dof ? (Ma - f) - qfrc : (REAL)0;
           Mgrad = precondition(grad);
@@ -2993,6 +3210,7 @@ struct Env {
     } else {
       if (dof && out.qacc) out.qacc[e * nv + l] = qacc;
     }
+    STAMP(79);
     if (!KA.do_step) return;
     // ---- integrator tail on arena arrays carved over the (dead) constraint rows ----------------------------------------------------------------
     wave_sync();

@@ -220,6 +220,49 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       row_con[row] = c;
     }
   }
+  {  // per-row / per-contact tables of the plain constraint phase (DevModel::crow_par ...).  The arithmetic is the kernel's own, in REAL, in
+     // the same order (constraint.py:440-451, 480-487, 547-561): the values are bit-identical to what each lane used to recompute.
+    const int first = d->nefc - [&] { int n = 0; for (int r = 0; r < d->nefc; r++) n += row_con[r] >= 0; return n; }();
+    int ncrow = d->nefc - first;
+    for (int r = first; r < d->nefc; r++) if (row_con[r] < 0) ncrow = -1;  // contact rows must close the row order
+    if (ncrow < 0 || d->topk) ncrow = 0;
+    M.ncrow = ncrow;
+    const bool elliptic = d->cone == CONE_ELLIPTIC;
+    std::vector<REAL> par((size_t)9 * (ncrow > 0 ? ncrow : 1), (REAL)0);
+    std::vector<int> info((size_t)(ncrow > 0 ? ncrow : 1), 0);
+    for (int q = 0; q < ncrow; q++) {
+      const int c = row_con[first + q], sub = first + q - d->con_efc_address[c], dim = d->con_dim[c];
+      REAL sr0 = (REAL)d->con_solref[2 * c], sr1 = (REAL)d->con_solref[2 * c + 1];
+      if (elliptic && dim > 1 && sub > 0) {
+        const REAL sf0 = (REAL)d->con_solreffriction[2 * c], sf1 = (REAL)d->con_solreffriction[2 * c + 1];
+        const REAL none = (REAL)(!((sf0 != 0) || (sf1 != 0)));
+        sr0 = sf0 + sr0 * none; sr1 = sf1 + sr1 * none;
+      }
+      REAL fric[5];
+      for (int i = 0; i < 5; i++) fric[i] = (REAL)d->con_friction[5 * c + i];
+      const REAL t = (REAL)d->body_invweight0[d->geom_bodyid[d->con_geom1[c]]] + (REAL)d->body_invweight0[d->geom_bodyid[d->con_geom2[c]]];
+      REAL invweight;
+      if (dim == 1) invweight = t;
+      else if (!elliptic) { const REAL mu = fric[0]; invweight = (t + mu * mu * t) * 2 * mu * mu / M.impratio; }
+      else { const REAL iwf = t / M.impratio; invweight = (sub == 0) ? t : (sub == 1 ? iwf : iwf * ((fric[0] * fric[0]) / (fric[sub - 1] * fric[sub - 1]))); }
+      par[(size_t)0 * ncrow + q] = sr0; par[(size_t)1 * ncrow + q] = sr1;
+      for (int i = 0; i < 5; i++) par[(size_t)(2 + i) * ncrow + q] = (REAL)d->con_solimp[5 * c + i];
+      par[(size_t)7 * ncrow + q] = invweight;
+      par[(size_t)8 * ncrow + q] = (REAL)d->con_includemargin[c];
+      info[q] = c | (sub << 16) | ((elliptic && dim > 1) ? (1 << 24) : 0);
+    }
+    fix.push_back({(const void**)&M.crow_par, bb.add(par.data(), sizeof(REAL) * par.size())});
+    fix.push_back({(const void**)&M.crow_info, bb.add(info.data(), sizeof(int) * info.size())});
+    std::vector<int> cbody((size_t)4 * (d->ncon > 0 ? d->ncon : 1), 0);
+    std::vector<unsigned long long> cmask((size_t)2 * (d->ncon > 0 ? d->ncon : 1), 0ull);
+    for (int c = 0; c < d->ncon; c++) {
+      const int b1 = d->geom_bodyid[d->con_geom1[c]], b2 = d->geom_bodyid[d->con_geom2[c]];
+      cbody[4 * c] = b1; cbody[4 * c + 1] = b2; cbody[4 * c + 2] = d->body_rootid[b1]; cbody[4 * c + 3] = d->body_rootid[b2];
+      cmask[2 * c] = body_dofmask[b1]; cmask[2 * c + 1] = body_dofmask[b2];
+    }
+    fix.push_back({(const void**)&M.con_body, bb.add(cbody.data(), sizeof(int) * cbody.size())});
+    fix.push_back({(const void**)&M.con_dmask, bb.add(cmask.data(), sizeof(unsigned long long) * cmask.size())});
+  }
   {
     int max_jnt = 1;
     for (int b = 0; b < nb; b++) if (d->body_jntnum[b] > max_jnt) max_jnt = d->body_jntnum[b];

@@ -37,6 +37,11 @@ static unsigned g_stage_tie_flip = 0;
 static int32_t* g_stage_ties;
 void mjo_set_stage_tie_flip(unsigned mask, int32_t* counts) { g_stage_tie_flip = mask; g_stage_ties = counts; }
 
+/* work counters of the next run (diagnostics for the solver kernels' load balance): int32 [B, 4] = solver calls, solver iterations,
+   line-search iterations, non-trivial constraint rows summed over the calls; NULL = off */
+static int32_t* g_work_stats;
+void mjo_set_work_stats(int32_t* stats) { g_work_stats = stats; }
+
 #define REAL double
 #define SFX _f64
 #include "mjoracle_impl.h"

@@ -176,6 +176,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       w.knife_policy = knife_policy;
       w.nf = m->nf + m->nft; w.ne_nf = m->ne + m->nf + m->nft; w0.nf = w.nf; w0.ne_nf = w.ne_nf;
       w.stage_mode = 0; w.stage_tie_n = 0; w.stage_tie_flip = g_stage_tie_flip;
+      w.stat_solves = w.stat_niter = w.stat_ls = w.stat_rows = 0;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0; w.prim_hint_n = NULL; w.prim_adopted = 0; w0.prim_hint_n = NULL; w0.prim_adopted = 0;
       w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;
       w0.eq_active = w.eq_active;
@@ -190,6 +191,7 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       if (knife) knife[e] = w.knife;
       if (g_tie_pairs) g_tie_pairs[e] = w.tie_pairs;
       if (g_stage_ties) g_stage_ties[e] = w.stage_tie_n;
+      if (g_work_stats) { g_work_stats[4 * e] = w.stat_solves; g_work_stats[4 * e + 1] = w.stat_niter; g_work_stats[4 * e + 2] = w.stat_ls; g_work_stats[4 * e + 3] = w.stat_rows; }
       const int* cs = w.con_src; /* (RK4: restored to stage 0's with the other returned leaves) */
       if (out->contact_dim) for (int c = 0; c < m->ncon; c++) out->contact_dim[e * m->ncon + c] = m->con_dim[cs[c]];
       if (out->contact_geom1) for (int c = 0; c < m->ncon; c++) out->contact_geom1[e * m->ncon + c] = m->con_geom1[cs[c]];

@@ -124,6 +124,7 @@ typedef struct FN(MjoWork) {
      environment's step in stage_tie_n, and the events whose bit is set in stage_tie_flip (first 32 events) take their second
      candidate instead of the natural one -- callers enumerate single and double flips (tests/_util.oracle_alternatives) */
   int stage_mode, stage_tie_n; unsigned stage_tie_flip;
+  int stat_solves, stat_niter, stat_ls, stat_rows; /* work counters of the step (diagnostics: solver calls, solver iterations, line-search iterations, active contact rows) */
   const REAL* prim_hint_n; /* hinted normal of the primitive pair being evaluated (coincident-centre case of sphere_sphere_), or NULL */
   int prim_adopted;
   const int32_t* eq_active; /* this env's Data.eq_active (input leaf, types.py:1103) */
@@ -1885,6 +1886,7 @@ static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx)
       done |= (hi.d0 > 0) && (hi.d0 < gtol);
       if (done) break;
     }
+    w->stat_ls++;
     FN(LSPoint) lo_next = FN(ls_point)(w, nefc, qg, lo.alpha - lo.d0 / lo.d1);
     FN(LSPoint) hi_next = FN(ls_point)(w, nefc, qg, hi.alpha - hi.d0 / hi.d1);
     FN(LSPoint) mid = FN(ls_point)(w, nefc, qg, (REAL)0.5 * (lo.alpha + hi.alpha));
@@ -1941,6 +1943,8 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
   }
   for (int d = 0; d < nv; d++) w->tmp_nv[d] = start[d];
   FN(create_context)(M, w, &c, w->tmp_nv, 1);
+  w->stat_solves++;
+  for (int r = 0; r < nefc; r++) w->stat_rows += w->efc_D[r] != 0 && w->efc_aref[r] != 0;
   for (int it = 0;; it++) {
     if (m->iterations == 1) { if (it >= 1) break; }
     else if (fixed_iterations) { if (it >= m->iterations) break; }
@@ -1954,6 +1958,7 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
       if (done) break;
     }
     /* body :510-524 */
+    w->stat_niter++;
     FN(linesearch)(M, w, &c, fixed_iterations);
     for (int d = 0; d < nv; d++) { w->s_prev_grad[d] = w->s_grad[d]; w->s_prev_Mgrad[d] = w->s_Mgrad[d]; }
     FN(update_constraint)(M, w, &c);
