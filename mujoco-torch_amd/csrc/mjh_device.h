@@ -41,6 +41,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
 #define PH_CON 4   /* collision + make_constraint               */
 #define PH_VEL 8   /* transmission, _velocity, _actuation, _acceleration */
 #define PH_SOL 16  /* solve + Euler / RK4 bookkeeping           */
+#define MJH_JC_ROWS(m) ((m.sol2_row_cap > 0 && m.sol2_row_cap < m.nefc - m.nf - m.nl) ? m.sol2_row_cap : m.nefc - m.nf - m.nl)
 #define PH_SOL2 32   /* register solver (mjh_sol2_kernel): the part of its arena that lives while the solve runs ...            */
 #define PH_SOL2T 64  /* ... and the arrays of the integrator tail, carved over it once the constraint rows are dead           */
 #define PH_SOL2P 128 /* ... after the state the tail integrates, which is parked for the whole phase                           */
@@ -70,7 +71,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
   X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
   X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
   X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(i_con_act, m.con_direct ? m.ncon : 0, PH_CON) X(i_crow_act, m.con_direct ? m.nefc - m.nl : 0, PH_CON) /* small models: compact list of the active contacts, per-row activity (ints) */ X(efc_D, m.nefc, PH_SOL)                                            \
-  X(efc_Jc, (m.nefc - m.nf - m.nl) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts */                                   \
+  X(efc_Jc, MJH_JC_ROWS(m) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts (sol2_row_cap: the register solver's first tier keeps 32 of them) */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf + m.nft, PH_SOL) /* frictionloss of the dof- and tendon-friction rows */                \
   X(i_row_src, m.nefc - m.ne - m.nf - m.nft - m.nl - m.nlb - m.nlt, PH_SOL) X(i_row_dst, m.nefc - m.ne - m.nf - m.nft - m.nl - m.nlb - m.nlt, PH_SOL) /* active-contact row tables (ints) */ \
@@ -151,6 +152,7 @@ struct DevModel {
   const int* dof_limrow;                   // 2*nv: the (up to two: frictionloss, then joint limit) single-column rows of dof d, -1 = none
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
+  int sol2_row_cap;                        // only while the arena of the register solver's first tier is carved (mjhip.hip): dense rows it keeps; 0 otherwise
   // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
   // everything a row needs with ONE table read indexed by its own row number instead of a chain row -> contact -> geom -> body
   const REAL* crow_par;                    // 9 * ncrow, parameter-major [k * ncrow + q]: solref (2, friction rows of elliptic cones resolved), solimp (5), invweight, includemargin of contact row q

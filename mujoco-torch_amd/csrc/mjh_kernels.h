@@ -119,6 +119,7 @@ struct KArgs {
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
+  int row_lo, row_hi;   // register solver tiers: this launch serves the environments with row_lo < (dense rows of their active contacts) <= row_hi
   unsigned long long* stamps;  // diagnostic builds (-DMJH_STAMPS): [B, 128] s_memtime stamps, else unused
 };
 template <typename REAL>
@@ -420,6 +421,52 @@ __device__ __forceinline__ REAL tri_solve(const TriPack<REAL, NMAX>& T, REAL bi,
     else if (i < k) s = s - T.t[k] * xk;
   }
   return s;
+}
+
+// Cholesky of the symmetric matrix A (LDS, packed lower rows, n <= NMAX <= 16) straight into a TriPack: lane i starts from row i of A; the
+// column scale L[k][j] of step j is broadcast to every lane for the trailing update anyway, and lane j keeps it as its column entry -- row AND
+// column of the factor end up in registers without the round trip through an n x n LDS image (store, reciprocal diagonal, reload) that a separate
+// factorisation and substitution pay.  math.small_cholesky :117-127 (pivots clamped at 1e-12), same operation order as chol_factor_reg.
+template <int W, typename REAL, int NMAX>
+__device__ __forceinline__ void chol_factor_pack(const REAL* A, TriPack<REAL, NMAX>& T, int n) {
+  const int i = sub_lane<W>();
+  const bool valid = i < n;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) T.t[k] = (k < n && valid && k <= i) ? A[(i * (i + 1)) / 2 + k] : (REAL)0;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      const REAL sj = sub_read<W>(T.t[j], j);
+      const REAL dj = r_sqrt<REAL>(sj > (REAL)1e-12 ? sj : (REAL)1e-12);
+      const REAL lij = (i == j) ? dj : ((i > j && valid) ? T.t[j] / dj : (REAL)0);
+      if (i >= j) T.t[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < NMAX; k++) {
+        const REAL lkj = sub_read<W>(lij, k);  // L[k][j]: lane j keeps it (its column), lanes below update their rows
+        T.t[k] = (i == j) ? lkj : ((i > j) ? T.t[k] - lij * lkj : T.t[k]);
+      }
+    }
+  }
+  REAL dg = 1;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) dg = (k == i) ? T.t[k] : dg;
+  T.inv = valid ? 1 / dg : (REAL)0;
+}
+// x = (A)^-1 b for a symmetric positive matrix in LDS (packed lower rows), n <= 16: factor and substitute in registers
+template <int W, typename REAL, int NMAX>
+__device__ __forceinline__ void chol_factor_solve_n(const REAL* A, const REAL* b, REAL* x, int n) {
+  TriPack<REAL, NMAX> T;
+  chol_factor_pack<W, REAL, NMAX>(A, T, n);
+  const int i = sub_lane<W>();
+  const REAL xi = tri_solve<W, REAL, NMAX>(T, i < n ? b[i] : (REAL)0, n);
+  if (i < n) x[i] = xi;
+  wave_sync();
+}
+template <int W, typename REAL>
+__device__ __forceinline__ void chol_factor_solve(const REAL* A, const REAL* b, REAL* x, int n) {
+  if (n <= 8) chol_factor_solve_n<W, REAL, 8>(A, b, x, n);
+  else if (n <= 12) chol_factor_solve_n<W, REAL, 12>(A, b, x, n);
+  else chol_factor_solve_n<W, REAL, 16>(A, b, x, n);
 }
 
 // Cholesky of the symmetric matrix A (LDS, n x n) into L (LDS, lower triangle, zeros above)
@@ -2183,12 +2230,17 @@ struct Env {
       }
       wave_sync();
       STAMP(63);
-      chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
-      chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
-      wave_sync();
-      STAMP(64);
-      chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
-      STAMP(65);
+      if (nv <= 16) {
+        chol_factor_solve<W, REAL>(S.H(), S.s_grad(), S.s_Mgrad(), nv);
+        STAMP(64);
+      } else {
+        chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
+        chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
+        wave_sync();
+        STAMP(64);
+        chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+        STAMP(65);
+      }
     }
   }
 
@@ -2709,10 +2761,14 @@ struct Env {
         }
         for (int d = l; d < nv; d += W) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
-        chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
-        chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
-        wave_sync();
-        chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+        if (nv <= 16) {
+          chol_factor_solve<W, REAL>(S.H(), S.s_grad(), S.s_Mgrad(), nv);
+        } else {
+          chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
+          chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
+          wave_sync();
+          chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+        }
         qacc = S.s_Mgrad();
       }
       advance(S.qpos(), S.qvel(), S.act(), time0, S.act_dot(), qacc, nullptr);
@@ -2794,16 +2850,19 @@ struct Env {
     const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
     TriPack<REAL, NMAX> T;
     {
+      // (staging the leaf through LDS with contiguous loads was measured: the strided section shrinks 21 k -> 3 k cycles but the wait only moves
+      // to the next load -- this phase's loads are bound by the bytes, 79 MB at B = 4096 -- and the extra registers cost the float32 tier its third wave)
       const REAL* gL = out.qLD + e * nv * nv;
 #pragma unroll
       for (int k = 0; k < NMAX; k++) T.t[k] = (dof && k < nv) ? (k <= l ? gL[l * nv + k] : gL[k * nv + l]) : (REAL)0;
     }
     REAL mrow[NEWT ? NMAX : 1];  // row d of qM (Newton models: nv <= 16): M products and the Hessian start from registers
-    if (NEWT) {
+    if (NEWT) {  // qM is exactly symmetric: row d is read as column d, one coalesced load per term
       const REAL* gM = out.qM + e * nv * nv;
 #pragma unroll
-      for (int k = 0; k < (NEWT ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[l * nv + k] : (REAL)0;
+      for (int k = 0; k < (NEWT ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[k * nv + l] : (REAL)0;
     }
+    STAMP(80);
     REAL qp0 = 0, qp1 = 0, qv = 0, ac = 0, ad = 0, warm = 0;
     REAL Dl = 0, arl = 0, Jl = 0, Dd[RPL], ard[RPL];
     int ldof = 0, limrow = -1;
@@ -2829,6 +2888,7 @@ struct Env {
         if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
         if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
         if (dof) limrow = M.dof_limrow[2 * l];
+        STAMP(81);
         {  // active contacts -> compact row tables: one contact per lane, exclusive prefix sum of the active contacts' row counts
           const int ncon = M.ncon;
           const bool elliptic = M.cone == CONE_ELLIPTIC;
@@ -2853,12 +2913,23 @@ struct Env {
             nda += sub_read<W>(x, W - 1);
           }
         }
+      }
+    }
+    // Tiers: the first launch is the instantiation with ONE row slot per lane (32 dense rows: fewer registers -- three waves per SIMD instead of
+    // two -- and none of the eight-slot loops) and serves the environments whose active contacts fit it; a second launch of the full-width
+    // instantiation picks up the rest (the ant keeps 4 - 8 of its 60 contacts active: almost none).  Each environment is integrated by exactly one.
+    STAMP(82);
+    if (!(nda > KA.row_lo && nda <= KA.row_hi)) return;
+    if (solving) {
+      if (nefc > 0) {
+        const REAL* gJ = out.efc_J + e * nefc * nv;
         wave_sync();
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
           const int r = l + 32 * j;
           if (r < nda) { const int x = rsrc[r]; Dd[j] = out.efc_D[e * nefc + x]; ard[j] = out.efc_aref[e * nefc + x]; }
         }
+        STAMP(83);
         // rows of the active contacts of efc_J -> LDS
         gather_rows<16>(S.efc_Jc(), gJ, rsrc, nda * nv);
       }

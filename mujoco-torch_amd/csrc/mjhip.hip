@@ -47,6 +47,9 @@ struct mjhModel {
   LdsOff off[MJH_NARENA];
   int lds_bytes[MJH_NARENA];
   int sol2_nmax = 0, sol2_rpl = 0;         // register solver (mjh_sol2_kernel) instantiation serving this model, 0 = not eligible
+  int sol2_tiers = 0;                      // 1: a first launch with ONE row slot per lane serves the environments whose active contacts fit 32 dense rows
+  LdsOff off_tier;                         // ... from an arena of its own (32 rows of efc_J instead of all of them)
+  int lds_tier = 0;
   int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
   int pack4[MJH_NPHASE];                   // ... or four (16 lanes each): small models only
   // hipGraph replay: the launch sequence of a (buffers, batch, flags) combination is captured once on a private stream and
@@ -419,6 +422,14 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     if (!off && solver_ok && !general && d->nv <= 28 && nd <= 32 * (nmax <= 16 ? 8 : 2) && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
       out->sol2_nmax = nmax;
       out->sol2_rpl = rpl;
+      // measured on MI355X (profiles/r02/notes.md): ant solver phase 124 -> 114 us (the narrow tier runs three waves per SIMD).  MJH_SOL2_TIERS=0 keeps the single full-width launch.
+      static const bool tiers_off = [] { const char* e = getenv("MJH_SOL2_TIERS"); return e && e[0] == '0'; }();
+      if (rpl > 1 && !tiers_off) {
+        DevModel<REAL> Mc = M;
+        Mc.sol2_row_cap = 32;
+        out->lds_tier = lds_carve(Mc, PH_SOL2, out->off_tier) * (int)sizeof(REAL);
+        out->sol2_tiers = 1;
+      }
     }
   }
   out->leaf_count = leaf_counts(d);
@@ -526,19 +537,31 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 // the solver phase through the register solver: two environments per wavefront
 template <typename REAL>
 int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  a.off = m->off[5];
   a.env_begin = 0; a.env_count = a.B;
-  a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  const size_t lds = (size_t)(2 * m->lds_bytes[5]);
 #define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
+  if (m->sol2_tiers) {  // first tier: one row slot per lane, its own (smaller) arena
+    a.off = m->off_tier;
+    a.lds_reals = m->lds_tier / (int)sizeof(REAL);
+    a.row_lo = -1; a.row_hi = 32;
+    const size_t lds = (size_t)(2 * m->lds_tier);
+    if (m->sol2_nmax == 8) GO(8, 1); else if (m->sol2_nmax == 16) GO(16, 1); else GO(28, 1);
+    HIP_TRY(hipGetLastError());
+    a.row_lo = 32;
+  } else {
+    a.row_lo = -1;
+  }
+  a.row_hi = 0x7fffffff;
+  a.off = m->off[5];
+  a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
+  const size_t lds = (size_t)(2 * m->lds_bytes[5]);
   if (m->sol2_nmax == 8) { if (m->sol2_rpl == 1) GO(8, 1); else if (m->sol2_rpl == 2) GO(8, 2); else if (m->sol2_rpl == 4) GO(8, 4); else GO(8, 8); }
   else if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
   else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
 #undef GO
   HIP_TRY(hipGetLastError());
-  timing_mark(stream, 9);
+  timing_mark(stream, 9);  // both tiers under one mark: the solver phase
   return 0;
 }
 

@@ -545,3 +545,44 @@ def test_pinned_campaign_outliers(name, oracle_lib):
     mx2, d2, _ = load_outlier(name, dict(iterations=100, ls_iterations=50, tolerance=1e-12))
     got2 = gpu_out_to_numpy(mt.step(mx2.to("cuda"), d2.to("cuda")))
     check_against_oracle(mx2, d2, got2, 1e-9, 1e-8, what=name + " converged")
+
+
+@pytest.mark.parametrize("dtype,overrides", [(torch.float64, {"integrator": 1, "solver": 2, "cone": 1}), (torch.float32, {"integrator": 1, "solver": 2, "cone": 1}),
+                                             (torch.float64, {"solver": 1, "cone": 1, "iterations": 100, "ls_iterations": 50})])
+def test_register_solver_row_tiers(dtype, overrides, oracle_lib):
+    """The register solver runs as two launches when a model has more than 32 contact rows: environments whose ACTIVE contacts fit one row
+    slot per lane (32 rows) go through the narrow instantiation, the rest through the full-width one.  Crumpled ants (random joint angles,
+    torso at the floor) put 4 .. 13 of the 60 contacts in contact, i.e. 12 .. 39 rows at three rows per elliptic contact: the batch must hold
+    environments of both tiers, and every one of them must match the oracle like any other step."""
+    mx = load_model("ant", overrides, dtype)
+    B = 256
+    rng = np.random.RandomState(1)
+    d = mt.make_data(mx).expand(B).clone()
+    q = d.qpos.clone()
+    q[:, 2] = torch.tensor(rng.uniform(0.0, 0.1, B))
+    q[:, 7:] += torch.tensor(3.0 * rng.randn(B, mx.nq - 7))
+    q[:, 3:7] += torch.tensor(0.8 * rng.randn(B, 4))
+    d = d.replace(qpos=q, qvel=torch.tensor(0.05 * rng.randn(B, mx.nv)))
+    if dtype != torch.float64:
+        d = d.to(dtype)
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    og = mt.step(mdev, dg)
+    out = gpu_out_to_numpy(og)
+    rows = 3 * (out["contact_dist"] < 0).sum(1)  # condim 3, elliptic: three rows per active contact (margin 0)
+    assert (rows > 32).sum() >= 1 and (rows <= 32).sum() >= 2, f"the batch must exercise both tiers: rows per environment {np.bincount(rows)}"
+    cg = overrides.get("solver") == 1
+    tol_sol = (1e-5 if cg else 1e-8) if dtype == torch.float64 else 5e-3  # CG stalls at ~1e-6 on these costs (tests/_cases.py)
+    if dtype == torch.float64:
+        frac, worst = check_against_oracle(mx, d, out, TOL_PRE[dtype], tol_sol, what="crumpled ants", nthreads=4)
+    else:
+        # float32: the four always-penetrating leg pairs of this model carry forces of 3.5e5 that cancel in qfrc_constraint to ~5e-3 of rounding
+        # residue -- where no other contact is active that leaf is all residue, so the leaves are compared on the scale of the forces instead
+        nat = pyoracle.run(mx, d, step=True, nthreads=4)
+        frac, worst = 0.0, 0.0
+        for n in ("qpos", "qvel", "qacc", "efc_force", "qfrc_constraint"):
+            scale = np.abs(nat["efc_force"]).max(axis=1, keepdims=True) if n == "qfrc_constraint" else np.maximum(np.abs(nat[n]).max(axis=1, keepdims=True), 1e-3)
+            worst = max(worst, float((np.abs(out[n].astype(np.float64) - nat[n]) / scale).max()))
+        assert worst <= tol_sol, f"float32 crumpled ants: worst error {worst:.2e}"
+    print(f"rows per environment: max {rows.max()}, {int((rows > 32).sum())} environments in the wide tier; worst solver rel err {worst:.2e}, {frac:.1%} on a non-natural branch")
+    lone = mt.step(mdev, dg[rows.argmax() : rows.argmax() + 1].clone())  # a wide-tier environment alone in its launch: same bits
+    assert torch.equal(lone.qpos[0], og.qpos[int(rows.argmax())]) and torch.equal(lone.efc_force[0], og.efc_force[int(rows.argmax())])

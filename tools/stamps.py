@@ -40,8 +40,9 @@ names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, 
          19: "CON start", 20: "load geoms + narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
          30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
          50: "SOL start", 51: "all loads issued + waited", 52: "inv_diag + chol_solve (qacc_smooth)", 53: "store qacc_smooth", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
-names.update({70: "sol2: loads + row compaction + J copy", 71: "sol2: qacc_smooth solve", 72: "sol2: contexts (mulM2, mulJ2, costs, qfrc)", 73: "sol2: H build", 74: "sol2: H Cholesky",
+names.update({70: "sol2: J rows gather (+ rest of the loads)", 71: "sol2: qacc_smooth solve", 72: "sol2: contexts (mulM2, mulJ2, costs, qfrc)", 73: "sol2: H build", 74: "sol2: H Cholesky",
               75: "sol2: tri solve (M or H)", 76: "sol2 LS: mulM, mulJ", 77: "sol2 LS: dots, points, loop", 78: "sol2: cost + J^T force", 79: "sol2: stores"})
+names.update({80: "sol2 loads: qfrc_smooth, factor rows (T.t), qM rows", 81: "sol2 loads: state, limit rows", 82: "sol2 loads: contact_dist + compaction", 83: "sol2 loads: D / aref of the dense rows"})
 names.update({63: "newton: H build", 64: "newton: factor H", 65: "newton: solve", 66: "J^T force", 67: "update_constraint", 68: "context init (mulJ, mulM) / loop head"})
 # every slot holds the cycles ACCUMULATED in the section that ends at that stamp (loops add up), summed over RK stages
 for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 89)]:
