@@ -386,7 +386,8 @@ int mjh_debug_phase_times(float* ms, int* kernel_ids, int max);
 
 /* global-memory bytes ONE launch of kernel `kernel` (ids as above) reads and writes per environment in a step: the library's own
  * account of its loads / stores through the Data leaves (csrc/mjh_io.h) -- the per-kernel "algorithmic bytes" of the roofline.
- * read_write_bytes[0] = read, [1] = written.  Returns 0, or -2 when this model's step does not launch that kernel. */
+ * read_write_bytes[0] = read, [1] = written.  RK4 models: the mean over the four stage launches of a step (stages 1..3 write a private
+ * workspace holding only the leaves a later phase reads).  Returns 0, or -2 when this model's step does not launch that kernel. */
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes);
 
 /* last error message of the calling thread ("" if none) */

@@ -152,6 +152,7 @@ struct DevModel {
   const int* dof_limrow;                   // 2*nv: the (up to two: frictionloss, then joint limit) single-column rows of dof d, -1 = none
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
+  int con_rows;                            // constraint rows of every contact when they all have the same number (one condim), else 0
   int sol2_row_cap;                        // only while the arena of the register solver's first tier is carved (mjhip.hip): dense rows it keeps; 0 otherwise
   // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
   // everything a row needs with ONE table read indexed by its own row number instead of a chain row -> contact -> geom -> body
@@ -231,6 +232,16 @@ __device__ __forceinline__ bool sub_any(bool p) {
   const unsigned long long m = __ballot(p);
   const int sh = (int)(threadIdx.x & ~(W - 1));
   return ((m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1))) != 0;
+}
+// number of lanes below this one in the environment's lane group whose predicate holds, and the group's total: one ballot and two
+// population counts, where a shuffle-based prefix sum is log2(W) dependent LDS-pipe round trips
+template <int W>
+__device__ __forceinline__ int sub_prefix_count(bool p, int& total) {
+  const unsigned long long m = __ballot(p);
+  const int sh = (int)(threadIdx.x & ~(W - 1)), l = (int)(threadIdx.x & (W - 1));
+  const unsigned long long g = (m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1));
+  total = __popcll(g);
+  return __popcll(g & ((1ull << l) - 1ull));
 }
 // value of lane k OF THIS ENVIRONMENT's lane group (k wave-uniform): v_readlane for a whole wave; for two 32-lane environments
 // one v_readlane per half and a select -- scalar broadcasts on the VALU / SALU, where a bpermute would be an LDS-pipe round trip

@@ -3,8 +3,10 @@
 // This is the "algorithmic bytes" account behind bench.py's per-kernel roofline (mjh_model_kernel_io): it lives next to the
 // kernels and restates, load by load and store by store, what their code moves through the Data leaves -- the PACKED triangle
 // of the factor (not the whole qLD leaf), the contact rows of efc_J plus ONE entry per single-column row (not the dense leaf),
-// qM once per solve, and so on.  Model constants (tens of KB, L2-resident) are not counted.  The figures are for a plain
-// forward / Euler step launch (stage 0 of an RK4 step); RK stages 1..3 move the same leaves minus the camera / light frames.
+// qM once per solve, and so on.  Model constants (tens of KB, L2-resident) are not counted.  `do_step` = 1: a plain forward / Euler step
+// launch (stage 0 of an RK4 step, which writes the returned Data in full); `do_step` = 2: a launch of RK4 stages 1..3, which write a private
+// workspace Data holding only the leaves a later phase of the same stage reads (mjhip.hip: kStageLeaves) -- and, in the small-model constraint
+// phase, only the rows of the active contacts (data dependent: counted as zero, the figure is a lower bound there).
 // tools/hbm_traffic.sh measures the PMC counterpart; profiles/r02/notes.md compares the two.
 #pragma once
 #include "mjh_device.h"
@@ -19,15 +21,18 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
   const bool general_con = m.con_general != 0, general_sol = (m.nf > 0 || m.nft > 0 || m.ne > 0 || m.nlb > 0 || m.nlt > 0);
   const bool opt_vel = (m.has_fluid || m.has_gravcomp || m.ntendon > 0);
   int64_t rd = 0, wr = 0;
+  const bool scratch = do_step == 2;  // RK4 stage 1..3
   switch (kernel) {
     case 0:  // kinematics + com_pos: load_qpos; kinematics() stores; com_pos() stores
       rd = nq + 7 * (int64_t)m.nmocap;
       wr = nq + (3 + 4 + 9 + 3 + 9) * nb + 6 * nj + 12 * ng + 12 * (int64_t)m.nsite + 12 * (int64_t)m.ncam + 6 * (int64_t)m.nlight
            + 3 * nb + 10 * nb + 6 * nv;
+      if (scratch) wr = nq + 3 * nb /* xipos */ + 12 * ng + 3 * nb + 10 * nb + 6 * nv;
       break;
     case 1:  // crb_factor(): multi_load cinert, cdof; stores qM (full symmetric), crb, qLD (full, zeros above the diagonal)
       rd = 10 * nb + 6 * nv;
       wr = nv * nv + 10 * nb + nv * nv;
+      if (scratch) wr = 2 * nv * nv;
       break;
     case 2: case 7: case 8: {  // collision() + make_constraint() (8: small models, contact rows straight to the leaf)
       if ((kernel == 7) != general_con || (kernel == 8) != (m.con_direct != 0)) return -1;
@@ -38,8 +43,12 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
         wr += nefc * nv + 3 * nefc;                                          // efc_J, efc_D, efc_aref, efc_frictionloss
       }
       wr += (13 + 15) * ncon;                                                // dist / pos / frame + the five model-constant contact leaves
+      if (scratch) {
+        wr = ncon + (m.ncvxpair > 0 ? 12 * ncon : 0);                        // contact_dist (+ pos / frame where the convex kernel hands them over)
+        if (nefc > 0) wr += (kernel == 8) ? (int64_t)m.nl * (nv + 2) : nefc * (nv + 2);  // efc_J, efc_D, efc_aref (small models: limit rows + the active contacts' rows, the latter not counted)
+      }
       *read_bytes = rd * R + (general_con ? 4 * (int64_t)m.neq : 0);
-      *write_bytes = wr * R + 44 * ncon;                                     // contact_dim i32; geom1, geom2, geom[2], efc_address i64
+      *write_bytes = wr * R + (scratch ? 0 : 44 * ncon);                     // contact_dim i32; geom1, geom2, geom[2], efc_address i64
       return 0;
     }
     case 3: case 5:  // velocity<FLUID>() + actuation<FLUID>()
@@ -51,6 +60,7 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
         if (m.has_gravcomp) wr += nv;
         wr += (int64_t)m.ntendon * (2 + nv);                                       // ten_length, ten_velocity, ten_J
       }
+      if (scratch) wr = nv + na;                                                   // qfrc_smooth, act_dot
       break;
     case 4: case 6:  // load_factor_and_accelerate(), load_solver_inputs(), solve(), integrator
       if ((kernel == 6) != general_sol) return -1;
@@ -63,6 +73,8 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
         wr += nv /* qacc_warmstart */ + nv /* qfrc_constraint */ + nefc /* efc_force */;
       }
       if (do_step) { rd += 1; wr += nq + nv + na + 1; if (!(m.disableflags & DSBL_EULERDAMP) && m.integrator == INT_EULER) rd += tri; }
+      if (scratch) { wr -= (nefc > 0 ? nefc : 0); rd += 2 * nv + na; wr += 2 * nv + na; }  // no efc_force; the running sums of the tableau
+      if (m.integrator == INT_RK4 && do_step == 1) { rd += nv + na; wr += 3 * nv + 2 * na; }  // stage 0 starts the sums and keeps qvel0 / act0
       break;
     case 10:  // mjh_convex_kernel: the two geom frames of every convex pair in, its (up to four) contacts out
       if (m.ncvxpair == 0) return -1;

@@ -1371,14 +1371,18 @@ struct Env {
           row0 = M.con_efc_address[c] - nl;
           act = (S.con_dist()[c] - M.con_includemargin[c]) < 0;
         }
-        int x = act ? 1 : 0;
-        for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
-        if (act) act_list[nact + x - 1] = c;
+        int tot;
+        const int before = sub_prefix_count<W>(act, tot);
+        if (act) act_list[nact + before] = c;
         for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
-        nact += sub_read<W>(x, W - 1);
+        nact += tot;
       }
       wave_sync();
       REAL* const Jdst = out.efc_J + (e * nefc + nl) * nv;  // row 0 = first contact row
+      // RK4 stages 1..3 write a private workspace Data whose only reader is this stage's solver phase, and that gathers the rows of the ACTIVE
+      // contacts only (load_solver_inputs / run_sol2): the zero rows, and further down D / aref of the inactive rows, are not written there
+      const bool scratch_stage = KA.rk_stage > 0;
+      if (!scratch_stage)
       for (int w = l; w < nd * nv; w += W) {
         int q, d;
         split_index(w, nv, M.inv_nv, q, d);
@@ -1502,6 +1506,7 @@ struct Env {
         const REAL dist = S.con_dist()[c] - P[8 * ncr];
         const REAL active = (REAL)(dist < 0);
         con_row_active = dist < 0;
+        if (KA.rk_stage > 0 && !con_row_active) continue;  // workspace Data of an RK4 stage: nobody reads D / aref of an inactive row (see above)
         if (!(info >> 24)) { pos = dist * active; pos_norm = dist * active; }
         else { pos = (sub == 0 ? dist : (REAL)0) * active; pos_norm = dist; }
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
@@ -2513,14 +2518,21 @@ struct Env {
             start = M.con_efc_address[c] - c0;
             act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
           }
-          int x = act ? rows : 0;
-          for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
-          const int excl = x - (act ? rows : 0) + nact;
+          int excl, tot;
+          if (M.con_rows) {  // one condim: the prefix sum of the row counts is a population count times that count
+            excl = sub_prefix_count<W>(act, tot) * M.con_rows + nact;
+            tot *= M.con_rows;
+          } else {
+            int x = act ? rows : 0;
+            for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
+            excl = x - (act ? rows : 0) + nact;
+            tot = __builtin_amdgcn_readlane(x, W - 1);
+          }
           for (int k = 0; k < rows; k++) {
             row_dst_lds()[start + k] = act ? excl + k : -1;
             if (act) row_src_lds()[excl + k] = c0 + start + k;
           }
-          nact += __builtin_amdgcn_readlane(x, W - 1);
+          nact += tot;
         }
       }
       nrow_ = c0 + nact;
@@ -2903,14 +2915,21 @@ struct Env {
               start = M.con_efc_address[c] - nl;
               act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
             }
-            int x = act ? rows : 0;
-            for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
-            const int excl = x - (act ? rows : 0) + nda;
+            int excl, tot;
+            if (M.con_rows) {  // one condim: the prefix sum of the row counts is a population count times that count
+              excl = sub_prefix_count<W>(act, tot) * M.con_rows + nda;
+              tot *= M.con_rows;
+            } else {
+              int x = act ? rows : 0;
+              for (int o = 1; o < W; o <<= 1) { const int y = __shfl_up(x, o, W); if (l >= o) x += y; }
+              excl = x - (act ? rows : 0) + nda;
+              tot = sub_read<W>(x, W - 1);
+            }
             for (int k = 0; k < rows; k++) {
               rdst[start + k] = act ? excl + k : -1;
               if (act) rsrc[excl + k] = nl + start + k;
             }
-            nda += sub_read<W>(x, W - 1);
+            nda += tot;
           }
         }
       }

@@ -230,6 +230,11 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     for (int r = first; r < d->nefc; r++) if (row_con[r] < 0) ncrow = -1;  // contact rows must close the row order
     if (ncrow < 0 || d->topk) ncrow = 0;
     M.ncrow = ncrow;
+    M.con_rows = 0;
+    for (int c = 0; c < d->ncon; c++) {
+      const int dim = d->con_dim[c], rows = dim == 1 ? 1 : (d->cone == CONE_ELLIPTIC ? dim : 2 * (dim - 1));
+      if (c == 0) M.con_rows = rows; else if (rows != M.con_rows) { M.con_rows = 0; break; }
+    }
     const bool elliptic = d->cone == CONE_ELLIPTIC;
     std::vector<REAL> par((size_t)9 * (ncrow > 0 ? ncrow : 1), (REAL)0);
     std::vector<int> info((size_t)(ncrow > 0 ? ncrow : 1), 0);
@@ -886,8 +891,14 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
   if (!m || !read_write_bytes) return fail(-22, "null argument");
   if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
   const int k = kernel == 9 ? 4 : kernel;  // the register solver moves the same leaves as the plain LDS solver
-  const int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 1, &read_write_bytes[0], &read_write_bytes[1])
-                                     : mjh_kernel_io<float>(m->m32, k, 1, &read_write_bytes[0], &read_write_bytes[1]);
+  const bool rk4 = (m->dtype == MJH_F64 ? m->m64.integrator : m->m32.integrator) == INT_RK4;
+  int64_t a[2] = {0, 0}, b[2] = {0, 0};
+  int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 1, &a[0], &a[1]) : mjh_kernel_io<float>(m->m32, k, 1, &a[0], &a[1]);
+  if (rc == 0 && rk4 && k != 11) {  // the mean over the four stage launches of a step (the sensor kernel runs once)
+    rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 2, &b[0], &b[1]) : mjh_kernel_io<float>(m->m32, k, 2, &b[0], &b[1]);
+    a[0] = (a[0] + 3 * b[0]) / 4; a[1] = (a[1] + 3 * b[1]) / 4;
+  }
+  read_write_bytes[0] = a[0]; read_write_bytes[1] = a[1];
   return rc == 0 ? 0 : -2;  // -2: this model's step does not launch that kernel
 }
 
