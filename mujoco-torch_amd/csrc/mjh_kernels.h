@@ -239,6 +239,9 @@ __device__ __forceinline__ int tri_at(int i, int k, int n) { return PACKED ? (i 
 // long summed index (the constraint rows); for nv <= 16 one tile holds the whole result.  Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of a
 // 16x4 . 4x16 block, i.e. ONE element J[row 4 b + (l >> 4)][column l & 15] feeds both operands.  The instruction accumulates in k order with one
 // rounding per term (a fused-multiply-add chain): the rows are summed in index order like the scalar loops they replace.
+// Float64 instantiations only.  In float32 the Newton iteration of the mesh scene is sensitive to the last bit of H and of J^T f (its stopping
+// test works in rounding noise): the fused chain moved the HIP step 5.8e-5 -> 2.4e-3 away from the oracle's unfused sums on BASELINE config 5
+// (profiles/r02/notes.md), for 4 % of that solver phase -- float32 keeps the counted VALU loops, whose operation order is the oracle's.
 typedef float mjh_f32x4 __attribute__((ext_vector_type(4)));
 typedef double mjh_f64x4 __attribute__((ext_vector_type(4)));
 template <typename REAL> struct MfmaTile;
@@ -2084,7 +2087,7 @@ struct Env {
     const int l = lane();
     const int nv = M.nv, nefc = nrow_;
     const int nl = nf_() + M.nl;
-    if constexpr (W == 64) {
+    if constexpr (W == 64 && sizeof(REAL) == 8) {
       if (nv <= 16) {  // one matrix-core tile: C[i][*] = sum_rows J[row][i] * force[row], rows in index order (every column of C carries the same vector)
         typedef MfmaTile<REAL> MT;
         const int c = l & 15, kq = l >> 4, nd = nefc - nl;
@@ -2162,7 +2165,7 @@ struct Env {
       for (int r = nl + l; r < nefc; r += W) hw[r] = (is_dfric(r) ? dfric_quadratic(r) : (S.s_Jaref()[r] < 0 || is_eq_row(r))) ? S.efc_D()[r] : (REAL)0;
       wave_sync();
       bool tiled = false;
-      if constexpr (W == 64) {
+      if constexpr (W == 64 && sizeof(REAL) == 8) {
         if (nv <= 16) {  // one matrix-core tile: C = J^T diag(hw) J over the dense rows, started from the single-column rows' diagonal terms
           typedef MfmaTile<REAL> MT;
           tiled = true;
