@@ -60,6 +60,20 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
 #undef X
     off = o1 > o2 ? o1 : o2;
   }
+  if (phase_bit == PH_KINVEL) {
+    // fused kinematics + velocity kernel: what both phases use first (it stays resident across the two), then the frames only the kinematics
+    // touches and the spatial quantities only the velocity phase touches from one common offset -- the former are stored and dead when the
+    // latter are first written (a wave-wide sync separates the phases)
+    int s0 = 0;
+#define X(n, c, p) if (((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = s0; s0 += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    int ka = s0, va = s0;
+#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = va; va += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    off = ka > va ? ka : va;
+  }
   if (phase_bit == PH_CRB) {
     // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
     // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
@@ -1583,14 +1597,15 @@ struct Env {
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
-  template <bool FLUID>
+  template <bool FLUID, bool FUSED = false>
   __device__ __forceinline__ void velocity() {
     const int l = lane();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
-    load_qpos(false); load_qvel(); load_act();
-    row_load<W>(S.cdof(), out.cdof, 6 * nv, e);      // the two long arrays batch four loads per trip on their own; this phase has no
-    row_load<W>(S.cinert(), out.cinert, 10 * nb, e);  // registers to spare for holding more of them in flight
-    {
+    if (!FUSED) load_qpos(false);
+    load_qvel(); load_act();
+    if (!FUSED) {  // (fused with the kinematics: qpos, cdof, cinert, subtree_com and xipos are still in the arena)
+      row_load<W>(S.cdof(), out.cdof, 6 * nv, e);      // the two long arrays batch four loads per trip on their own; this phase has no
+      row_load<W>(S.cinert(), out.cinert, 10 * nb, e);  // registers to spare for holding more of them in flight
       REAL* const dst[2] = {S.subtree_com(), S.xipos()};
       const REAL* const src[2] = {out.subtree_com, out.xipos};
       const int cnt[2] = {3 * nb, 3 * nb};
@@ -2731,10 +2746,10 @@ struct Env {
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
-  template <bool FLUID>
+  template <bool FLUID, bool FUSED = false>
   __device__ __forceinline__ void run_vel() {
     STAMP0();
-    velocity<FLUID>();
+    velocity<FLUID, FUSED>();
     if (KA.stages & 0x60) actuation<FLUID>();
   }
 
@@ -3346,7 +3361,7 @@ __global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args)
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : 1)))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3 || PHASE == 12) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
@@ -3359,6 +3374,7 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 |
     else if (PHASE == 2 || PHASE == 7 || PHASE == 8) E.run_con();  // 8: plain constraint phase of small models, contact rows straight to the leaf  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
+    else if (PHASE == 12) { E.run_kin(); wave_sync(); E.template run_vel<false, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
     wave_sync();
   }

@@ -47,6 +47,9 @@ struct mjhModel {
   LdsOff off[MJH_NARENA];
   int lds_bytes[MJH_NARENA];
   int sol2_nmax = 0, sol2_rpl = 0;         // register solver (mjh_sol2_kernel) instantiation serving this model, 0 = not eligible
+  int fuse_kv = 0;                         // kinematics + velocity phases run as ONE kernel (12) from an arena of their own
+  LdsOff off_kv;
+  int lds_kv = 0;
   int sol2_tiers = 0;                      // 1: a first launch with ONE row slot per lane serves the environments whose active contacts fit 32 dense rows
   LdsOff off_tier;                         // ... from an arena of its own (32 rows of efc_J instead of all of them)
   int lds_tier = 0;
@@ -468,6 +471,16 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     out->pack2[P] = 1;                                                                                                       \
   }
   SET_PACK(0) SET_PACK(3)
+  {  // fused kinematics + velocity kernel (plain velocity phase only).  Measured on MI355X: profiles/r02/notes.md.  MJH_FUSE_KV=0 keeps two launches.
+    static const bool fuse_off = [] { const char* e = getenv("MJH_FUSE_KV"); return e && e[0] == '0'; }();
+    out->lds_kv = lds_carve(M, PH_KINVEL, out->off_kv) * (int)sizeof(REAL);
+    out->fuse_kv = (!fuse_off && !(M.has_fluid || M.has_gravcomp || M.ntendon > 0) && out->lds_kv <= 160 * 1024) ? 1 : 0;
+    if (out->fuse_kv) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kv));
+      if (2 * out->lds_kv <= 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_kv));
+      if (4 * out->lds_kv <= 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_kv));
+    }
+  }
   static const bool con_pack = [] { const char* e = getenv("MJH_CON_PACK"); return !(e && e[0] == '0'); }();
   if (con_pack && M.con_direct && 2 * out->lds_bytes[2] <= 64 * 1024) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[2]));
@@ -512,23 +525,27 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
   constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : ((P == 7 || P == 8) ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
-  a.off = m->off[A];
+  const int arena_bytes = P == 12 ? m->lds_kv : m->lds_bytes[P == 12 ? 0 : A];
+  a.off = P == 12 ? m->off_kv : m->off[P == 12 ? 0 : A];
   a.env_begin = begin; a.env_count = count;
-  a.lds_reals = m->lds_bytes[A] / (int)sizeof(REAL);
+  a.lds_reals = arena_bytes / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * m->lds_bytes[A]), stream, a);
+  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);
   HIP_TRY(hipGetLastError());
   timing_mark(stream, P);
   return 0;
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8);
-  if (PACKABLE && m->pack2[P == 5 ? 3 : (P == 8 ? 2 : P)] && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8 || P == 12);
+  constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : (P == 12 ? 0 : P)));  // index into the per-phase packing flags
+  const bool can2 = !PACKABLE ? false : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]);
+  const bool can4 = !PACKABLE ? false : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && m->pack4[PI]));
+  if (PACKABLE && can2 && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
     int64_t done = 0;
     int rc = 0;
-    if (P != 8 && m->pack4[P == 5 ? 3 : P] && a.B >= 4) {
+    if (can4 && a.B >= 4) {
       done = a.B & ~(int64_t)3;
       if ((rc = launch_range<REAL, P, ((PACKABLE && P != 8) ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
     }
@@ -575,7 +592,8 @@ template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
-  if ((st & 0x7f) && (rc = launch_phase<REAL, 0>(m, a, stream))) return rc;
+  const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
+  if ((st & 0x7f) && (rc = fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream))) return rc;
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
     const int64_t items = a.B * a.M.ncvxpair;
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
@@ -586,7 +604,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
-  if ((st & 0x70) && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
@@ -890,16 +908,31 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   if (!m || !read_write_bytes) return fail(-22, "null argument");
   if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
-  const int k = kernel == 9 ? 4 : kernel;  // the register solver moves the same leaves as the plain LDS solver
-  const bool rk4 = (m->dtype == MJH_F64 ? m->m64.integrator : m->m32.integrator) == INT_RK4;
-  int64_t a[2] = {0, 0}, b[2] = {0, 0};
-  int rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 1, &a[0], &a[1]) : mjh_kernel_io<float>(m->m32, k, 1, &a[0], &a[1]);
-  if (rc == 0 && rk4 && k != 11) {  // the mean over the four stage launches of a step (the sensor kernel runs once)
-    rc = m->dtype == MJH_F64 ? mjh_kernel_io<double>(m->m64, k, 2, &b[0], &b[1]) : mjh_kernel_io<float>(m->m32, k, 2, &b[0], &b[1]);
-    a[0] = (a[0] + 3 * b[0]) / 4; a[1] = (a[1] + 3 * b[1]) / 4;
+  if ((kernel == 12) != (m->fuse_kv != 0) && (kernel == 12 || kernel == 0 || kernel == 3)) return -2;  // kinematics + velocity: ONE kernel (12) or two (0, 3)
+  const bool f64 = m->dtype == MJH_F64;
+  const bool rk4 = (f64 ? m->m64.integrator : m->m32.integrator) == INT_RK4;
+  auto io_of = [&](int k, int64_t* a) -> int {  // RK4: the mean over the four stage launches of a step (the sensor kernel runs once)
+    int64_t b[2] = {0, 0};
+    int rc = f64 ? mjh_kernel_io<double>(m->m64, k, 1, &a[0], &a[1]) : mjh_kernel_io<float>(m->m32, k, 1, &a[0], &a[1]);
+    if (rc == 0 && rk4 && k != 11) {
+      rc = f64 ? mjh_kernel_io<double>(m->m64, k, 2, &b[0], &b[1]) : mjh_kernel_io<float>(m->m32, k, 2, &b[0], &b[1]);
+      a[0] = (a[0] + 3 * b[0]) / 4; a[1] = (a[1] + 3 * b[1]) / 4;
+    }
+    return rc;
+  };
+  int64_t a[2] = {0, 0};
+  if (kernel == 12) {  // the two accounts minus what stays in the arena between the phases: qpos, cdof, cinert, subtree_com, xipos are not read back
+    int64_t k0[2] = {0, 0}, k3[2] = {0, 0};
+    if (io_of(0, k0) != 0 || io_of(3, k3) != 0) return -2;
+    const int64_t R = f64 ? 8 : 4, nq = f64 ? m->m64.nq : m->m32.nq, nv = f64 ? m->m64.nv : m->m32.nv, nb = f64 ? m->m64.nbody : m->m32.nbody;
+    read_write_bytes[0] = k0[0] + k3[0] - (nq + 6 * nv + 10 * nb + 3 * nb + 3 * nb) * R;
+    read_write_bytes[1] = k0[1] + k3[1];
+    return 0;
   }
+  const int k = kernel == 9 ? 4 : kernel;  // the register solver moves the same leaves as the plain LDS solver
+  if (io_of(k, a) != 0) return -2;  // -2: this model's step does not launch that kernel
   read_write_bytes[0] = a[0]; read_write_bytes[1] = a[1];
-  return rc == 0 ? 0 : -2;  // -2: this model's step does not launch that kernel
+  return 0;
 }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }

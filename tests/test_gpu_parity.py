@@ -435,7 +435,7 @@ def test_library_leaf_counts_and_kernel_io():
         for n, c in zip(REAL_LEAVES + INT_LEAVES, nm.leaf_counts):
             assert leaf(d, n).numel() == c, (xml, n)
         total_r = total_w = 0
-        for k in range(12):
+        for k in range(13):
             rw = (ctypes.c_int64 * 2)()
             if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
                 assert rw[0] > 0 and rw[1] > 0, (xml, k)
