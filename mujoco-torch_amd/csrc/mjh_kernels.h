@@ -3335,6 +3335,12 @@ struct Env {
 #undef STAMP
 #undef STAMP0
 
+#ifndef MJH_SOL32_WAVES
+#define MJH_SOL32_WAVES 3  /* float32 LDS solver: 168 VGPRs + ~96 B of scratch; measured on the mesh scene: 2 waves (173 VGPRs, no scratch) 374 us, 3 waves 338 us, 4 waves (128 + 156 B) 362 us */
+#endif
+#ifndef MJH_KV32_WAVES
+#define MJH_KV32_WAVES 2  /* float32 fused kinematics + velocity kernel, packed: 256 VGPRs and no scratch; at 3 waves (168 VGPRs + ~300 B of scratch, twice the instructions) the ant ran it in 99.6 us instead of 86.3 */
+#endif
 #ifndef MJH_CON64_WAVES
 #define MJH_CON64_WAVES 4  /* float64 plain constraint phase: 128 VGPRs + ~108 B of scratch buys the fourth wave per SIMD (16 environments per CU) */
 #endif
@@ -3361,7 +3367,7 @@ __global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args)
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && (PHASE == 4 || PHASE == 6 || ((PHASE == 0 || PHASE == 3 || PHASE == 12) && W < 64))) ? 3 : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
