@@ -586,3 +586,27 @@ def test_register_solver_row_tiers(dtype, overrides, oracle_lib):
     print(f"rows per environment: max {rows.max()}, {int((rows > 32).sum())} environments in the wide tier; worst solver rel err {worst:.2e}, {frac:.1%} on a non-natural branch")
     lone = mt.step(mdev, dg[rows.argmax() : rows.argmax() + 1].clone())  # a wide-tier environment alone in its launch: same bits
     assert torch.equal(lone.qpos[0], og.qpos[int(rows.argmax())]) and torch.equal(lone.efc_force[0], og.efc_force[int(rows.argmax())])
+
+
+@pytest.mark.parametrize("xml,overrides,B", [("ant", {"integrator": 1, "solver": 2, "cone": 1}, 16384), ("mesh_contact", {}, 8192)])
+def test_configs_3_and_5_full_size_batch_properties(xml, overrides, B, oracle_lib):
+    """BASELINE configs 3 (ant, B = 16384, RK4 + Newton elliptic, float32) and 5 (mesh scene, B = 8192, Newton, float32) at their full sizes:
+    128 distinct states tiled over the batch give bit-identical results for every copy and equal the same states stepped as a B = 128 batch
+    (through the four-per-wavefront kernels, the two solver tiers and the odd-tail launches alike), outputs are finite, and the first 128
+    environments match the oracle within the float32 tolerances."""
+    dtype = torch.float32
+    mx, base = seeded_batch(xml, overrides, dtype, 128)
+    idx = torch.arange(B) % 128
+    mdev = mx.to("cuda")
+    small = mt.step(mdev, mt.step(mdev, base.to("cuda")))
+    big_in = base[idx].clone().to("cuda")
+    big = mt.step(mdev, mt.step(mdev, big_in))
+    idx = idx.to("cuda")
+    for n in REAL_LEAVES + INT_LEAVES:
+        a, b = leaf(big, n), leaf(small, n)
+        assert torch.equal(a, b[idx]), f"{n}: tiled environments differ"
+        if a.is_floating_point():
+            assert torch.isfinite(a).all(), n
+    first = mt.step(mdev, base.to("cuda"))
+    frac, worst = check_against_oracle(mx, base, gpu_out_to_numpy(first), TOL_PRE[dtype], TOL_SOL[dtype], what=f"{xml} full size", nthreads=4)
+    print(f"{xml} B={B}: worst solver rel err of the first 128 environments {worst:.2e}")
