@@ -2888,6 +2888,26 @@ struct Env {
     const bool from_in = !KA.state_from_cur;
     const bool newton = NEWT && M.solver == SOL_NEWTON;
     STAMP0();
+    if (KA.row_lo >= 0) {
+      // Second (full-width) tier: almost every environment was served by the first launch.  Count the rows of the active contacts before
+      // anything else is requested and leave -- the full prologue (factor rows, state, limit rows) cost the ant 21 us per launch for nothing.
+      int rows_active = 0;
+      if (solving && nefc > 0) {
+        const int ncon = M.ncon;
+        const bool elliptic = M.cone == CONE_ELLIPTIC;
+        for (int base = 0; base < ncon; base += W) {
+          const int c = base + l;
+          int rows = 0;
+          if (c < ncon) {
+            const int dim = M.con_dim[c];
+            const bool act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
+            rows = act ? (dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1))) : 0;
+          }
+          rows_active += (int)sub_sum<W>((float)rows);  // small integers: exact in float
+        }
+      }
+      if (!(rows_active > KA.row_lo && rows_active <= KA.row_hi)) return;
+    }
     // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
     const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
     TriPack<REAL, NMAX> T;
