@@ -47,8 +47,15 @@ __device__ __forceinline__ void lane_best(REAL& bv, int& bi, REAL v, int i) {
 }
 #define CVX_NONE 0x7fffffff
 
+#ifdef MJH_STAMPS
+#define CSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+    if (kargs<REAL>().stamps && l == 0) kargs<REAL>().stamps[e * 128 + (slot)] += t_ - cstamp_prev; cstamp_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CSTAMP(slot) do {} while (0)
+#endif
 template <typename REAL>
 struct CvxPair {
+  unsigned long long cstamp_prev = 0;
   REAL* L;       // this wave's LDS scratch
   int64_t e;
   int p, l;
@@ -360,6 +367,7 @@ struct CvxPair {
 
   // ---- convex_convex :805-856 with _sat_hull_hull :464-601 ------------------------------------------------------------------------
   __device__ __forceinline__ void convex_convex(const REAL* pos1, const REAL* mat1, CvxView<REAL> c1, const REAL* pos2, const REAL* mat2, CvxView<REAL> c2) {
+    CSTAMP(99);
     const int K = c1.nfv > c2.nfv ? c1.nfv : c2.nfv;
     const bool swapped = c1.nvert > c2.nvert;
     if (swapped) {
@@ -397,21 +405,46 @@ struct CvxPair {
     for (int i = l; i < 3 * V2; i += MJH_WAVE) v2[i] = c2.vert[i];
     for (int i = l; i < 3 * F2; i += MJH_WAVE) n2[i] = c2.norm[i];
     wave_sync();
+    CSTAMP(90);
     // separating axis test: lanes over axes
     const int NA = F1 + F2 + E1 * E2;
     REAL bd = 0; int ba = -1, bsign = 1;
     REAL baxis[3] = {0, 0, 0};
-    for (int a = l; a < NA; a += MJH_WAVE) {
-      REAL axis[3];
-      sat_axis(a, c1, c2, v1, n1, v2, n2, axis);
-      REAL amax = 0, amin = 0, bmax = 0, bmin = 0;
-      for (int v = 0; v < V1; v++) { const REAL s = dot3(axis, v1 + 3 * v); if (v == 0 || s > amax) amax = s; if (v == 0 || s < amin) amin = s; }
-      for (int v = 0; v < V2; v++) { const REAL s = dot3(axis, v2 + 3 * v); if (v == 0 || s > bmax) bmax = s; if (v == 0 || s < bmin) bmin = s; }
-      const REAL d1 = amax - bmin, d2 = bmax - amin;
-      REAL d = d1 < d2 ? d1 : d2;
-      if (axis[0] == 0 && axis[1] == 0 && axis[2] == 0) d = (REAL)1e6;
-      if (ba < 0 || d < bd) { bd = d; ba = a; bsign = d1 > d2 ? -1 : 1; baxis[0] = axis[0]; baxis[1] = axis[1]; baxis[2] = axis[2]; }
+    // two axes per lane and pass (a, a + 64): every vertex read from LDS serves both projections and the multiply-adds pair up into packed
+    // float32 operations; each projection is the same dot3 expression, and a lane still meets its axes in increasing index order
+    for (int a0 = l; a0 < NA; a0 += 2 * MJH_WAVE) {
+      const int a1 = a0 + MJH_WAVE;
+      const bool has1 = a1 < NA;
+      REAL ax0[3], ax1[3];
+      sat_axis(a0, c1, c2, v1, n1, v2, n2, ax0);
+      sat_axis(has1 ? a1 : a0, c1, c2, v1, n1, v2, n2, ax1);
+      // running extremes as hardware max / min from +-infinity (one instruction each; the same values as compare-and-keep for finite projections)
+      const REAL inf = (REAL)INFINITY;
+      REAL amax0 = -inf, amin0 = inf, bmax0 = -inf, bmin0 = inf, amax1 = -inf, amin1 = inf, bmax1 = -inf, bmin1 = inf;
+      for (int v = 0; v < V1; v++) {
+        const REAL x = v1[3 * v], y = v1[3 * v + 1], z = v1[3 * v + 2];
+        const REAL s0 = (ax0[0] * x + ax0[1] * y) + ax0[2] * z, s1 = (ax1[0] * x + ax1[1] * y) + ax1[2] * z;
+        amax0 = r_max(amax0, s0); amin0 = r_min(amin0, s0); amax1 = r_max(amax1, s1); amin1 = r_min(amin1, s1);
+      }
+      for (int v = 0; v < V2; v++) {
+        const REAL x = v2[3 * v], y = v2[3 * v + 1], z = v2[3 * v + 2];
+        const REAL s0 = (ax0[0] * x + ax0[1] * y) + ax0[2] * z, s1 = (ax1[0] * x + ax1[1] * y) + ax1[2] * z;
+        bmax0 = r_max(bmax0, s0); bmin0 = r_min(bmin0, s0); bmax1 = r_max(bmax1, s1); bmin1 = r_min(bmin1, s1);
+      }
+      {
+        const REAL d1 = amax0 - bmin0, d2 = bmax0 - amin0;
+        REAL d = d1 < d2 ? d1 : d2;
+        if (ax0[0] == 0 && ax0[1] == 0 && ax0[2] == 0) d = (REAL)1e6;
+        if (ba < 0 || d < bd) { bd = d; ba = a0; bsign = d1 > d2 ? -1 : 1; baxis[0] = ax0[0]; baxis[1] = ax0[1]; baxis[2] = ax0[2]; }
+      }
+      if (has1) {
+        const REAL d1 = amax1 - bmin1, d2 = bmax1 - amin1;
+        REAL d = d1 < d2 ? d1 : d2;
+        if (ax1[0] == 0 && ax1[1] == 0 && ax1[2] == 0) d = (REAL)1e6;
+        if (d < bd) { bd = d; ba = a1; bsign = d1 > d2 ? -1 : 1; baxis[0] = ax1[0]; baxis[1] = ax1[1]; baxis[2] = ax1[2]; }
+      }
     }
+    CSTAMP(91);
     if (ba < 0) { bd = (REAL)1e30; ba = CVX_NONE; }
     wave_argbest<-1>(bd, ba);
     const int owner = ba % MJH_WAVE;
@@ -435,6 +468,7 @@ struct CvxPair {
       subj_n[i] = best_sign > 0 ? n2[3 * b_min + i] : n1[3 * a_min + i];
       sep[i] = (REAL)(-best_sign) * best_axis[i];
     }
+    CSTAMP(92);
     // reference (clipping) and incident (subject) polygons
     for (int k = l; k < K; k += MJH_WAVE) {
       const REAL* rp = best_sign > 0 ? v1 + 3 * fv(c1, a_max, k) : v2 + 3 * fv(c2, b_max, k);
@@ -462,6 +496,7 @@ struct CvxPair {
       }
     }
     wave_sync();
+    CSTAMP(93);
     // clip: K subject edges against the clipping side planes, K projected clipping edges against the subject side planes
     for (int t = l; t < 2 * K; t += MJH_WAVE) {
       const bool first = t < K;
@@ -488,8 +523,10 @@ struct CvxPair {
       }
     }
     wave_sync();
+    CSTAMP(94);
     int best[4];
     manifold_points(ref, msk, P, clip_n, best);
+    CSTAMP(95);
     REAL ldist[4], lpos[4][3];
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -523,9 +560,13 @@ struct CvxPair {
         emit(q, ldist[q], pw, nw);
       }
     }
+    CSTAMP(96);
   }
 
   __device__ __forceinline__ void run() {
+#ifdef MJH_STAMPS
+    cstamp_prev = __builtin_amdgcn_s_memtime();
+#endif
     const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p];
     const int64_t ng = M.ngeom;
     const REAL *gp = out.geom_xpos + e * ng * 3, *gm = out.geom_xmat + e * ng * 9;

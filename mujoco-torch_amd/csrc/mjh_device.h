@@ -293,6 +293,10 @@ template <typename R> __device__ __forceinline__ R r_abs(R x) { return x < 0 ? -
 template <> __device__ __forceinline__ double r_abs<double>(double x) { return fabs(x); }
 template <> __device__ __forceinline__ float r_abs<float>(float x) { return fabsf(x); }
 template <typename R> __device__ __forceinline__ bool r_finite(R x) { return isfinite(x); }
+__device__ __forceinline__ float r_max(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ double r_max(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float r_min(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double r_min(double a, double b) { return __builtin_fmin(a, b); }
 
 template <typename R>
 __device__ __forceinline__ void cross3(const R* a, const R* b, R* o) {  // math.py:63-76

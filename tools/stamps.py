@@ -43,9 +43,10 @@ names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, 
 names.update({70: "sol2: J rows gather (+ rest of the loads)", 71: "sol2: qacc_smooth solve", 72: "sol2: contexts (mulM2, mulJ2, costs, qfrc)", 73: "sol2: H build", 74: "sol2: H Cholesky",
               75: "sol2: tri solve (M or H)", 76: "sol2 LS: mulM, mulJ", 77: "sol2 LS: dots, points, loop", 78: "sol2: cost + J^T force", 79: "sol2: stores"})
 names.update({80: "sol2 loads: qfrc_smooth, factor rows (T.t), qM rows", 81: "sol2 loads: state, limit rows", 82: "sol2 loads: contact_dist + compaction", 83: "sol2 loads: D / aref of the dense rows"})
+names.update({99: "convex pair: wave start -> convex_convex", 90: "convex_convex: frames into LDS", 91: "SAT axes", 92: "best axis, support faces", 93: "polygons, side planes", 94: "edge clipping, reference points", 95: "manifold points", 96: "contacts out"})
 names.update({63: "newton: H build", 64: "newton: factor H", 65: "newton: solve", 66: "J^T force", 67: "update_constraint", 68: "context init (mulJ, mulM) / loop head"})
 # every slot holds the cycles ACCUMULATED in the section that ends at that stamp (loops add up), summed over RK stages
-for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 89)]:
+for lo, hi in [(0, 9), (10, 18), (19, 29), (30, 49), (50, 89), (90, 99)]:
     tot = 0
     for k in range(lo, hi + 1):
         v = st[:, k].mean()
