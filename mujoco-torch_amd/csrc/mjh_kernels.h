@@ -3367,6 +3367,9 @@ struct Env {
 #undef STAMP
 #undef STAMP0
 
+#ifndef MJH_SOL2_T1_WAVES
+#define MJH_SOL2_T1_WAVES 4  /* float32 register solver, NMAX = 8, one row slot per lane (the ant's first tier): 128 VGPRs + 80 B of scratch at four waves per SIMD, 94 us; 164 VGPRs at three: 100.7 us */
+#endif
 #ifndef MJH_SOL32_WAVES
 #define MJH_SOL32_WAVES 3  /* float32 LDS solver: 168 VGPRs + ~96 B of scratch; measured on the mesh scene: 2 waves (173 VGPRs, no scratch) 374 us, 3 waves 338 us, 4 waves (128 + 156 B) 362 us */
 #endif
@@ -3383,7 +3386,7 @@ struct Env {
 // 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
 // The register solver's kernel: two environments per wavefront; an odd last environment leaves the second half of its wave idle.
 template <typename REAL, int NMAX, int RPL>
-__global__ void __launch_bounds__(MJH_WAVE, 2) mjh_sol2_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL == 1) ? MJH_SOL2_T1_WAVES : 2) mjh_sol2_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   const int sub = (int)(threadIdx.x >> 5);
