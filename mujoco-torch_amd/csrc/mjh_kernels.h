@@ -3367,6 +3367,9 @@ struct Env {
 #undef STAMP
 #undef STAMP0
 
+#ifndef MJH_CRB32P_WAVES
+#define MJH_CRB32P_WAVES 4  /* packed float32 CRB (two / four environments per wavefront): at four waves per SIMD the ant runs it in 27.1 us (three: 32.2), the mesh scene in 23.0 (20.7) */
+#endif
 #ifndef MJH_SOL2_T1_WAVES
 #define MJH_SOL2_T1_WAVES 4  /* float32 register solver, NMAX = 8, one row slot per lane (the ant's first tier): 128 VGPRs + 80 B of scratch at four waves per SIMD, 94 us; 164 VGPRs at three: 100.7 us */
 #endif
@@ -3402,7 +3405,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? 3 : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
