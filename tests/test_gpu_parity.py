@@ -610,3 +610,35 @@ def test_configs_3_and_5_full_size_batch_properties(xml, overrides, B, oracle_li
     first = mt.step(mdev, base.to("cuda"))
     frac, worst = check_against_oracle(mx, base, gpu_out_to_numpy(first), TOL_PRE[dtype], TOL_SOL[dtype], what=f"{xml} full size", nthreads=4)
     print(f"{xml} B={B}: worst solver rel err of the first 128 environments {worst:.2e}")
+
+
+def test_device_put_step_device_get_into_roundtrip_on_the_device(oracle_lib):
+    """The reference's host round trip (device.py:1011-1205) through the device: duck-typed MjData objects -> `device_put` -> one batched step on
+    the GPU -> `device_get_into` a list of MjData objects; every environment's host copy must equal the oracle's step of that MjData
+    (lazily carved leaves of the step's output slab included: device_get_into reads them through `items()`)."""
+    from types import SimpleNamespace
+
+    lite = mt.mjcf.from_xml_path(mt.test_data_path("hopper.xml"))
+    mx = mt.device_put(lite)
+    nq, nv, nu, nb = mx.nq, mx.nv, mx.nu, mx.nbody
+    ncon = int(mt.make_data(mx).ncon)
+    rng = np.random.RandomState(5)
+
+    def mjdata(seed):
+        r = np.random.RandomState(seed)
+        q = np.asarray(lite.qpos0, dtype=np.float64) + 0.05 * r.randn(nq)
+        return SimpleNamespace(model=lite, time=0.0, qpos=q, qvel=0.1 * r.randn(nv), act=np.zeros(0), ctrl=0.3 * r.randn(nu), qacc=np.zeros(nv),
+                               qacc_warmstart=np.zeros(nv), qfrc_applied=np.zeros(nv), xfrc_applied=np.zeros((nb, 6)), xpos=np.zeros((nb, 3)),
+                               cvel=np.zeros((nb, 6)), qfrc_constraint=np.zeros(nv), contact=SimpleNamespace(dist=np.zeros(ncon), pos=np.zeros((ncon, 3))))
+
+    hosts = [mjdata(s) for s in range(4)]
+    rows = [mt.device_put(h) for h in hosts]
+    batch = mt.make_data(mx).expand(4).clone().replace(**{n: torch.stack([getattr(r, n) for r in rows]) for n in ("qpos", "qvel", "ctrl")})
+    out = mt.step(mx.to("cuda"), batch.to("cuda"))
+    mt.device_get_into(hosts, out)
+    want = pyoracle.run(mx, batch, step=True)
+    for e, h in enumerate(hosts):
+        for name, key in (("qpos", "qpos"), ("qvel", "qvel"), ("qacc", "qacc"), ("xpos", "xpos"), ("cvel", "cvel"), ("qfrc_constraint", "qfrc_constraint")):
+            assert rel_err(np.asarray(getattr(h, name)).reshape(-1), want[key][e].reshape(-1), 1e-6) < 1e-8, (e, name)
+        assert rel_err(h.contact.dist, want["contact_dist"][e], 1e-6) < 1e-9 and rel_err(h.contact.pos.reshape(-1), want["contact_pos"][e].reshape(-1), 1e-6) < 1e-9
+        assert abs(float(h.time) - float(mx.opt.timestep)) < 1e-15
