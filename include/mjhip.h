@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 11
+#define MJH_ABI_VERSION 12
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -216,8 +216,10 @@ extern "C" {
   X(light_pos)      /* nlight*3 */                                                               \
   X(light_dir)      /* nlight*3 */                                                               \
   X(act_gear)       /* nu*6 */                                                                   \
-  X(act_gainprm)    /* nu*3 */                                                                   \
-  X(act_biasprm)    /* nu*3 */                                                                   \
+  X(act_gainprm)    /* nu*9 (muscle gains read all nine, support.py:246-272; fixed / affine the first three) */ \
+  X(act_biasprm)    /* nu*9 */                                                                   \
+  X(act_lengthrange) /* nu*2 (muscles) */                                                        \
+  X(act_acc0)       /* nu (muscles: force = scale / acc0 when gainprm[2] < 0) */                  \
   X(act_dynprm)     /* nu*3 */                                                                   \
   X(act_ctrlrange)  /* nu*2 */                                                                   \
   X(act_forcerange) /* nu*2 */                                                                   \

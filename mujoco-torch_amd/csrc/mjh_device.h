@@ -28,8 +28,8 @@ enum { DSBL_CONSTRAINT = 1 << 0, DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSB
        DSBL_EULERDAMP = 1 << 15 };
 enum { INT_EULER = 0, INT_RK4 = 1, SOL_CG = 1, SOL_NEWTON = 2, CONE_ELLIPTIC = 1 };
 enum { CAM_FIXED = 0, CAM_TRACK = 1, CAM_TRACKCOM = 2, CAM_TARGETBODY = 3, CAM_TARGETBODYCOM = 4 };
-enum { GAIN_FIXED = 0, GAIN_AFFINE = 1, BIAS_NONE = 0, BIAS_AFFINE = 1 };
-enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3 };
+enum { GAIN_FIXED = 0, GAIN_AFFINE = 1, GAIN_MUSCLE = 2, BIAS_NONE = 0, BIAS_AFFINE = 1, BIAS_MUSCLE = 2 };
+enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DYN_MUSCLE = 4 };
 #define INLINE_CHOL_MAX 16  // math.py:84
 
 // ---- LDS arenas ------------------------------------------------------------------------------------------

@@ -1903,6 +1903,62 @@ struct Env {
     STAMP(39);
   }
 
+  // ---- muscle actuators (support.py:197-296) ---------------------------------------------------------------------------------------------
+  static __device__ __forceinline__ REAL clamp_min(REAL x, REAL lo) { return x > lo ? x : lo; }
+  static __device__ __forceinline__ REAL sq(REAL x) { return x * x; }
+  static __device__ __forceinline__ REAL muscle_sigmoid(REAL x) {  // :197-202
+    REAL sol = x * x * x * (3 * x * (2 * x - 5) + 10);
+    sol = x <= 0 ? (REAL)0 : sol;
+    return x >= 1 ? (REAL)1 : sol;
+  }
+  static __device__ __forceinline__ REAL muscle_dynamics(REAL ctrl, REAL act, const REAL* prm) {  // :205-232
+    const REAL ctrlclamp = ctrl < 0 ? (REAL)0 : (ctrl > 1 ? (REAL)1 : ctrl), actclamp = act < 0 ? (REAL)0 : (act > 1 ? (REAL)1 : act);
+    const REAL tau_act = prm[0] * ((REAL)0.5 + (REAL)1.5 * actclamp), tau_deact = prm[1] / ((REAL)0.5 + (REAL)1.5 * actclamp), width = prm[2];
+    const REAL dctrl = ctrlclamp - act;
+    const REAL tau_hard = dctrl > 0 ? tau_act : tau_deact;
+    const REAL q = dctrl / (width + (width == 0 ? (REAL)(float)mjMINVAL : (REAL)0));  // math.safe_div
+    const REAL tau_smooth = tau_deact + (tau_act - tau_deact) * muscle_sigmoid(q + (REAL)0.5);
+    const REAL tau = width < (REAL)mjMINVAL ? tau_hard : tau_smooth;
+    return dctrl / clamp_min(tau, (REAL)mjMINVAL);
+  }
+  static __device__ __forceinline__ REAL muscle_gain_length(REAL len, REAL lmin, REAL lmax) {  // :235-249
+    const REAL a = (REAL)0.5 * (lmin + 1), b = (REAL)0.5 * (1 + lmax);
+    const REAL out0 = (REAL)0.5 * sq((len - lmin) / clamp_min(a - lmin, (REAL)mjMINVAL));
+    const REAL out1 = 1 - (REAL)0.5 * sq((1 - len) / clamp_min(1 - a, (REAL)mjMINVAL));
+    const REAL out2 = 1 - (REAL)0.5 * sq((len - 1) / clamp_min(b - 1, (REAL)mjMINVAL));
+    const REAL out3 = (REAL)0.5 * sq((lmax - len) / clamp_min(lmax - b, (REAL)mjMINVAL));
+    REAL o = len <= b ? out2 : out3;
+    o = len <= 1 ? out1 : o;
+    o = len <= a ? out0 : o;
+    return (lmin <= len && len <= lmax) ? o : (REAL)0;
+  }
+  static __device__ __forceinline__ REAL muscle_gain(REAL len, REAL vel, const REAL* lr, REAL acc0, const REAL* prm) {  // :252-278
+    REAL force = prm[2];
+    const REAL scale = prm[3], lmin = prm[4], lmax = prm[5], vmax = prm[6], fvmax = prm[8];
+    force = force < 0 ? scale / clamp_min(acc0, (REAL)mjMINVAL) : force;
+    const REAL L0 = (lr[1] - lr[0]) / clamp_min(prm[1] - prm[0], (REAL)mjMINVAL);
+    const REAL L = prm[0] + (len - lr[0]) / clamp_min(L0, (REAL)mjMINVAL);
+    const REAL V = vel / clamp_min(L0 * vmax, (REAL)mjMINVAL);
+    const REAL FL = muscle_gain_length(L, lmin, lmax);
+    const REAL y = fvmax - 1;
+    REAL FV = V <= y ? fvmax - sq(y - V) / clamp_min(y, (REAL)mjMINVAL) : fvmax;
+    FV = V <= 0 ? sq(V + 1) : FV;
+    FV = V <= -1 ? (REAL)0 : FV;
+    return -force * FL * FV;
+  }
+  static __device__ __forceinline__ REAL muscle_bias(REAL len, const REAL* lr, REAL acc0, const REAL* prm) {  // :281-296
+    REAL force = prm[2];
+    const REAL scale = prm[3], lmax = prm[5], fpmax = prm[7];
+    force = force < 0 ? scale / clamp_min(acc0, (REAL)mjMINVAL) : force;
+    const REAL L0 = (lr[1] - lr[0]) / clamp_min(prm[1] - prm[0], (REAL)mjMINVAL);
+    const REAL L = prm[0] + (len - lr[0]) / clamp_min(L0, (REAL)mjMINVAL);
+    const REAL b = (REAL)0.5 * (1 + lmax);
+    const REAL out1 = -force * fpmax * (REAL)0.5 * sq((L - 1) / clamp_min(b - 1, (REAL)mjMINVAL));
+    const REAL out2 = -force * fpmax * ((REAL)0.5 + (L - b) / clamp_min(b - 1, (REAL)mjMINVAL));
+    const REAL o = L <= b ? out1 : out2;
+    return L <= 1 ? (REAL)0 : o;
+  }
+
   // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
   template <bool FLUID>
   __device__ __forceinline__ void actuation() {
@@ -1925,6 +1981,7 @@ struct Env {
           const int a = M.act_actadr[i];
           const REAL act = S.act()[a];
           if (dyn == DYN_INTEGRATOR) S.act_dot()[a] = ctrl;
+          else if (dyn == DYN_MUSCLE) S.act_dot()[a] = muscle_dynamics(ctrl, act, M.act_dynprm + 3 * i);
           else {
             REAL tau = M.act_dynprm[3 * i];
             tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
@@ -1933,10 +1990,13 @@ struct Env {
           ctrl_act = S.act()[a + M.act_actnum[i] - 1];
         }
         const REAL len = S.act_length()[i], vel = S.act_velocity()[i];
-        const REAL* gp = M.act_gainprm + 3 * i;
-        const REAL* bp = M.act_biasprm + 3 * i;
-        const REAL gain = (M.act_gaintype[i] == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
-        const REAL bias = (M.act_biastype[i] == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : (REAL)0;
+        const REAL* gp = M.act_gainprm + 9 * i;
+        const REAL* bp = M.act_biasprm + 9 * i;
+        const int gt = M.act_gaintype[i], bt = M.act_biastype[i];
+        REAL gain = (gt == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
+        REAL bias = (bt == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : (REAL)0;
+        if (gt == GAIN_MUSCLE) gain = muscle_gain(len, vel, M.act_lengthrange + 2 * i, M.act_acc0[i], gp);
+        if (bt == BIAS_MUSCLE) bias = muscle_bias(len, M.act_lengthrange + 2 * i, M.act_acc0[i], bp);
         REAL force = gain * ctrl_act + bias;
         if (M.act_forcelimited[i]) {
           const REAL lo = M.act_forcerange[2 * i], hi = M.act_forcerange[2 * i + 1];

@@ -73,9 +73,9 @@ def _validate(m):
         raise NotImplementedError("Only condim=1, 3, 4 and 6 are supported.")
     for name, enum, ok in (
         ("actuator_trntype", TrnType, (TrnType.JOINT, TrnType.JOINTINPARENT, TrnType.TENDON)),
-        ("actuator_dyntype", DynType, (DynType.NONE, DynType.INTEGRATOR, DynType.FILTER, DynType.FILTEREXACT)),
-        ("actuator_gaintype", GainType, (GainType.FIXED, GainType.AFFINE)),
-        ("actuator_biastype", BiasType, (BiasType.NONE, BiasType.AFFINE)),
+        ("actuator_dyntype", DynType, (DynType.NONE, DynType.INTEGRATOR, DynType.FILTER, DynType.FILTEREXACT, DynType.MUSCLE)),
+        ("actuator_gaintype", GainType, (GainType.FIXED, GainType.AFFINE, GainType.MUSCLE)),
+        ("actuator_biastype", BiasType, (BiasType.NONE, BiasType.AFFINE, BiasType.MUSCLE)),
     ):
         for v in np.asarray(getattr(m, name)).reshape(-1):
             if int(v) not in [int(x) for x in ok]:

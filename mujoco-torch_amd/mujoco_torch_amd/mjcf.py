@@ -137,7 +137,7 @@ def _bool(s):
     return s.strip().lower() == "true"
 
 
-_ACT_TAGS = ("motor", "position", "velocity", "general", "intvelocity", "damper")
+_ACT_TAGS = ("motor", "position", "velocity", "general", "intvelocity", "damper", "muscle")
 
 
 class _Defaults:
@@ -1238,6 +1238,25 @@ class _Compiler:
                 m.actuator_gainprm[i, 0] = kv
                 m.actuator_biastype[i] = BiasType.AFFINE
                 m.actuator_biasprm[i, :3] = [0.0, 0.0, -kv]
+            elif tag == "muscle":
+                # <muscle> shortcut (MuJoCo XML reference): dyntype = gaintype = biastype = muscle; dynprm = timeconst (2), tausmooth;
+                # gainprm = biasprm = range (2), force, scale, lmin, lmax, vmax, fpmax, fvmax.  The length range must be given: the
+                # compiler's simulation-based mj_setLengthRange is not restated here.
+                if "lengthrange" not in a:
+                    raise NotImplementedError("<muscle> needs an explicit lengthrange (automatic length-range computation is not supported)")
+                m.actuator_dyntype[i] = DynType.MUSCLE
+                m.actuator_gaintype[i] = GainType.MUSCLE
+                m.actuator_biastype[i] = BiasType.MUSCLE
+                tc = _floats(a.get("timeconst", "0.01 0.04"))
+                m.actuator_dynprm[i, :] = 0
+                m.actuator_dynprm[i, :3] = [tc[0], tc[1], float(a.get("tausmooth", 0.0))]
+                rg = _floats(a.get("range", "0.75 1.05"))
+                prm = [rg[0], rg[1], float(a.get("force", -1.0)), float(a.get("scale", 200.0)), float(a.get("lmin", 0.5)), float(a.get("lmax", 1.6)),
+                       float(a.get("vmax", 1.5)), float(a.get("fpmax", 1.3)), float(a.get("fvmax", 1.2))]
+                m.actuator_gainprm[i, :] = 0
+                m.actuator_biasprm[i, :] = 0
+                m.actuator_gainprm[i, :9] = prm
+                m.actuator_biasprm[i, :9] = prm
             elif tag == "general":
                 dt = a.get("dyntype", "none")
                 m.actuator_dyntype[i] = {"none": DynType.NONE, "integrator": DynType.INTEGRATOR, "filter": DynType.FILTER, "filterexact": DynType.FILTEREXACT, "muscle": DynType.MUSCLE}[dt]
@@ -1262,6 +1281,8 @@ class _Compiler:
                     arr[i] = _floats(a[key])
                 lim = a.get(attr, "auto")
                 limarr[i] = (has and self.autolimits) if lim == "auto" else _bool(lim)
+            if "lengthrange" in a:
+                m.actuator_lengthrange[i] = _floats(a["lengthrange"])
             if m.actuator_dyntype[i] != DynType.NONE:
                 m.actuator_actadr[i] = na
                 m.actuator_actnum[i] = 1

@@ -167,14 +167,15 @@ def pack_model(m, dtype: torch.dtype):
         geom_size=f64(m.geom_size), site_pos=f64(m.site_pos), site_quat=f64(m.site_quat), cam_pos=f64(m.cam_pos),
         cam_quat=f64(m.cam_quat), cam_pos0=f64(m.cam_pos0), cam_mat0=f64(m.cam_mat0), light_pos=f64(m.light_pos),
         light_dir=f64(m.light_dir), act_gear=f64(m.actuator_gear) if nu else empty,
-        act_gainprm=f64(m.actuator_gainprm[:, :3]) if nu else empty, act_biasprm=f64(m.actuator_biasprm[:, :3]) if nu else empty,
+        act_gainprm=f64(m.actuator_gainprm[:, :9]) if nu else empty, act_biasprm=f64(m.actuator_biasprm[:, :9]) if nu else empty,
+        act_lengthrange=f64(m.actuator_lengthrange) if nu else empty, act_acc0=f64(m.actuator_acc0) if nu else empty,
         act_dynprm=f64(m.actuator_dynprm[:, :3]) if nu else empty, act_ctrlrange=f64(m.actuator_ctrlrange) if nu else empty,
         act_forcerange=f64(m.actuator_forcerange) if nu else empty, act_actrange=f64(m.actuator_actrange) if nu else empty,
         con_includemargin=f64(st["includemargin"]), con_friction=f64(st["friction"]), con_solref=f64(st["solref"]),
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 11
+    desc.abi_version = 12
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))

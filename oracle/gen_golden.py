@@ -98,6 +98,9 @@ CASES = {
     # (every environment jittered: at the XML pose several candidates are at exactly equal distance and torch.topk orders equal
     # values by the internals of its partial sort -- [10, 7, 8, 9, 6] for thirteen equal values -- which is not a property of the
     # algorithm; this build orders ties by candidate index)
+    # muscle actuators (support.py:197-296, forward.py:102-219; reference test/forward_test.py::test_muscle): <muscle> shortcut and <general> form
+    "muscle_arm_f64": ("muscle_arm", {}, "float64", 4, 4, "muscle"),
+    "muscle_arm_rk4_f32": ("muscle_arm", {"integrator": 1}, "float32", 3, 3, "muscle"),
     "capsules_topk_f64": ("capsules_topk", {}, "float64", 4, 3, "topk"),
     "capsules_topk_ell_rk4_f32": ("capsules_topk", {"integrator": 1, "cone": 1}, "float32", 3, 2, "topk"),
     # the last bundled model: every joint type stacked, ball limits, gravity compensation, mocap bodies, fixed tendons, motors on
@@ -136,6 +139,11 @@ def make_inputs(recipe, lite, env):
         out["qpos"] = lite.qpos0 + 0.2 * rng.randn(nq)
         out["qfrc_applied"] = 0.5 * rng.randn(nv)
         out["xfrc_applied"] = 0.5 * rng.randn(nb, 6)
+    elif recipe == "muscle":  # activations, controls beyond [0, 1] (clamped by the dynamics), joint angles and speeds across the force-length-velocity curves
+        out["qpos"] = lite.qpos0 + np.array([0.6, 0.9]) * rng.randn(nq)
+        out["qvel"] = 3.0 * rng.randn(nv)
+        out["ctrl"] = rng.uniform(-0.3, 1.3, nu)
+        out["act"] = rng.uniform(-0.1, 1.1, lite.na)
     elif recipe == "convex":  # free bodies resting on each other: jitter the poses (env 0 keeps the XML pose) and add velocity
         q = lite.qpos0.copy()
         for j in range(lite.njnt):

@@ -48,10 +48,13 @@
 #define GAIN_AFFINE 1
 #define BIAS_NONE 0
 #define BIAS_AFFINE 1
+#define GAIN_MUSCLE 2
+#define BIAS_MUSCLE 2
 #define DYN_NONE 0
 #define DYN_INTEGRATOR 1
 #define DYN_FILTER 2
 #define DYN_FILTEREXACT 3
+#define DYN_MUSCLE 4
 #define INLINE_CHOL_MAX 16 /* math.py:84 */
 #define MJO_MAX_TIE 16
 #define MJO_MAX_TIE_RUNS 512
@@ -1657,6 +1660,60 @@ static void FN(velocity)(const FN(MjoModel) * M, FN(MjoWork) * w) {
 }
 
 /* ---- actuation + acceleration (forward.py:102-228) ---------------------------------------------- */
+/* ---- muscle actuators (support.py:197-296) ---- */
+static REAL FN(clamp_min)(REAL x, REAL lo) { return x > lo ? x : lo; }
+static REAL FN(sq)(REAL x) { return x * x; }
+static REAL FN(muscle_sigmoid)(REAL x) { /* :197-202 */
+  REAL sol = x * x * x * (3 * x * (2 * x - 5) + 10);
+  sol = x <= 0 ? (REAL)0 : sol;
+  return x >= 1 ? (REAL)1 : sol;
+}
+static REAL FN(muscle_dynamics)(REAL ctrl, REAL act, const REAL* prm) { /* :205-232 */
+  REAL ctrlclamp = ctrl < 0 ? (REAL)0 : (ctrl > 1 ? (REAL)1 : ctrl), actclamp = act < 0 ? (REAL)0 : (act > 1 ? (REAL)1 : act);
+  REAL tau_act = prm[0] * ((REAL)0.5 + (REAL)1.5 * actclamp), tau_deact = prm[1] / ((REAL)0.5 + (REAL)1.5 * actclamp), width = prm[2];
+  REAL dctrl = ctrlclamp - act;
+  REAL tau_hard = dctrl > 0 ? tau_act : tau_deact;
+  REAL q = dctrl / (width + (width == 0 ? (REAL)(float)mjMINVAL : (REAL)0)); /* math.safe_div */
+  REAL tau_smooth = tau_deact + (tau_act - tau_deact) * FN(muscle_sigmoid)(q + (REAL)0.5);
+  REAL tau = width < (REAL)mjMINVAL ? tau_hard : tau_smooth;
+  return dctrl / FN(clamp_min)(tau, (REAL)mjMINVAL);
+}
+static REAL FN(muscle_gain_length)(REAL len, REAL lmin, REAL lmax) { /* :235-249 */
+  REAL a = (REAL)0.5 * (lmin + 1), b = (REAL)0.5 * (1 + lmax);
+  REAL out0 = (REAL)0.5 * FN(sq)((len - lmin) / FN(clamp_min)(a - lmin, (REAL)mjMINVAL));
+  REAL out1 = 1 - (REAL)0.5 * FN(sq)((1 - len) / FN(clamp_min)(1 - a, (REAL)mjMINVAL));
+  REAL out2 = 1 - (REAL)0.5 * FN(sq)((len - 1) / FN(clamp_min)(b - 1, (REAL)mjMINVAL));
+  REAL out3 = (REAL)0.5 * FN(sq)((lmax - len) / FN(clamp_min)(lmax - b, (REAL)mjMINVAL));
+  REAL o = len <= b ? out2 : out3;
+  o = len <= 1 ? out1 : o;
+  o = len <= a ? out0 : o;
+  return (lmin <= len && len <= lmax) ? o : (REAL)0;
+}
+static REAL FN(muscle_gain)(REAL len, REAL vel, const REAL* lr, REAL acc0, const REAL* prm) { /* :252-278 */
+  REAL force = prm[2], scale = prm[3], lmin = prm[4], lmax = prm[5], vmax = prm[6], fvmax = prm[8];
+  force = force < 0 ? scale / FN(clamp_min)(acc0, (REAL)mjMINVAL) : force;
+  REAL L0 = (lr[1] - lr[0]) / FN(clamp_min)(prm[1] - prm[0], (REAL)mjMINVAL);
+  REAL L = prm[0] + (len - lr[0]) / FN(clamp_min)(L0, (REAL)mjMINVAL);
+  REAL V = vel / FN(clamp_min)(L0 * vmax, (REAL)mjMINVAL);
+  REAL FL = FN(muscle_gain_length)(L, lmin, lmax);
+  REAL y = fvmax - 1;
+  REAL FV = V <= y ? fvmax - FN(sq)(y - V) / FN(clamp_min)(y, (REAL)mjMINVAL) : fvmax;
+  FV = V <= 0 ? FN(sq)(V + 1) : FV;
+  FV = V <= -1 ? (REAL)0 : FV;
+  return -force * FL * FV;
+}
+static REAL FN(muscle_bias)(REAL len, const REAL* lr, REAL acc0, const REAL* prm) { /* :281-296 */
+  REAL force = prm[2], scale = prm[3], lmax = prm[5], fpmax = prm[7];
+  force = force < 0 ? scale / FN(clamp_min)(acc0, (REAL)mjMINVAL) : force;
+  REAL L0 = (lr[1] - lr[0]) / FN(clamp_min)(prm[1] - prm[0], (REAL)mjMINVAL);
+  REAL L = prm[0] + (len - lr[0]) / FN(clamp_min)(L0, (REAL)mjMINVAL);
+  REAL b = (REAL)0.5 * (1 + lmax);
+  REAL out1 = -force * fpmax * (REAL)0.5 * FN(sq)((L - 1) / FN(clamp_min)(b - 1, (REAL)mjMINVAL));
+  REAL out2 = -force * fpmax * ((REAL)0.5 + (L - b) / FN(clamp_min)(b - 1, (REAL)mjMINVAL));
+  REAL o = L <= b ? out1 : out2;
+  return L <= 1 ? (REAL)0 : o;
+}
+
 static void FN(actuation)(const FN(MjoModel) * M, FN(MjoWork) * w) {
   const mjhModelDesc* m = M->d;
   int nv = m->nv, nu = m->nu;
@@ -1678,6 +1735,7 @@ static void FN(actuation)(const FN(MjoModel) * M, FN(MjoWork) * w) {
         int a = m->act_actadr[i];
         REAL act = w->act[a];
         if (dyn == DYN_INTEGRATOR) w->act_dot[a] = ctrl;
+        else if (dyn == DYN_MUSCLE) w->act_dot[a] = FN(muscle_dynamics)(ctrl, act, M->act_dynprm + 3 * i);
         else {
           REAL tau = M->act_dynprm[3 * i];
           tau = tau > (REAL)mjMINVAL ? tau : (REAL)mjMINVAL;
@@ -1686,10 +1744,12 @@ static void FN(actuation)(const FN(MjoModel) * M, FN(MjoWork) * w) {
         ctrl_act = w->act[a + m->act_actnum[i] - 1];
       }
       REAL len = w->actuator_length[i], vel = w->actuator_velocity[i];
-      const REAL* gp = M->act_gainprm + 3 * i;
-      const REAL* bp = M->act_biasprm + 3 * i;
+      const REAL* gp = M->act_gainprm + 9 * i;
+      const REAL* bp = M->act_biasprm + 9 * i;
       REAL gain = (m->act_gaintype[i] == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
       REAL bias = (m->act_biastype[i] == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : 0;
+      if (m->act_gaintype[i] == GAIN_MUSCLE) gain = FN(muscle_gain)(len, vel, M->act_lengthrange + 2 * i, M->act_acc0[i], gp);
+      if (m->act_biastype[i] == BIAS_MUSCLE) bias = FN(muscle_bias)(len, M->act_lengthrange + 2 * i, M->act_acc0[i], bp);
       REAL force = gain * ctrl_act + bias;
       if (m->act_forcelimited[i]) {
         REAL lo = M->act_forcerange[2 * i], hi = M->act_forcerange[2 * i + 1];

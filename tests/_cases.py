@@ -59,6 +59,8 @@ SEEDED_CASES = [
     ("capsules_topk", {}, F64, 64, dict(max_alt=0.0)),                           # max_contact_points: 13 candidates, the 5 closest kept per environment
     ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, {}),
     ("capsules_topk", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 33, dict(tol_sol=1e-5)),  # ... through the register solver (CG stall accuracy)
+    ("muscle_arm", {}, F64, 64, dict(max_alt=0.0)),                               # muscle actuators: activation dynamics, force-length-velocity gain, passive bias
+    ("muscle_arm", {"integrator": 1}, F32, 33, {}),
     ("tendon_friction", {}, F64, 64, dict(max_alt=0.0)),                         # tendon + dof frictionloss rows, Newton
     ("tendon_friction", {"solver": 1, "integrator": 1}, F64, 32, dict(tol_sol=1e-5)),  # ... CG (stall accuracy, see above), RK4
     # CG models served by the register solver (mjh_sol2_kernel: two environments per wavefront): Euler with the eulerdamp re-solve,
@@ -98,6 +100,9 @@ def seeded_batch(xml, overrides, dtype, B):
             q[:, a : a + 3] += torch.tensor(0.01 * rng.randn(B, 3))
             q[:, a + 3 : a + 7] += torch.tensor(0.03 * rng.randn(B, 4))
         d = d.replace(qpos=q, qvel=torch.tensor(0.2 * rng.randn(B, mx.nv)))
+    if xml == "muscle_arm":  # activations and controls across (and beyond) [0, 1], joint angles and speeds across the force-length-velocity curves
+        d = d.replace(qpos=d.qpos + torch.tensor(np.array([0.6, 0.9]) * rng.randn(B, mx.nq)), qvel=torch.tensor(3.0 * rng.randn(B, mx.nv)),
+                      ctrl=torch.tensor(rng.uniform(-0.3, 1.3, (B, mx.nu))), act=torch.tensor(rng.uniform(-0.1, 1.1, (B, mx.na))))
     if xml == "sensor_rig":  # move and spin the rover so every sensor reads something different per environment
         q = d.qpos.clone()
         q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))
