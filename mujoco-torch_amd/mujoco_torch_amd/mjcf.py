@@ -1238,6 +1238,17 @@ class _Compiler:
                 m.actuator_gainprm[i, 0] = kv
                 m.actuator_biastype[i] = BiasType.AFFINE
                 m.actuator_biasprm[i, :3] = [0.0, 0.0, -kv]
+            elif tag == "intvelocity":  # integrated-velocity servo: an integrator activation tracked by a position servo (MuJoCo XML reference)
+                kp = float(a.get("kp", 1.0))
+                kv = float(a.get("kv", 0.0))
+                m.actuator_dyntype[i] = DynType.INTEGRATOR
+                m.actuator_gainprm[i, 0] = kp
+                m.actuator_biastype[i] = BiasType.AFFINE
+                m.actuator_biasprm[i, :3] = [0.0, -kp, -kv]
+            elif tag == "damper":  # force = -kv * velocity * ctrl (affine gain on the velocity), ctrl >= 0
+                kv = float(a.get("kv", 1.0))
+                m.actuator_gaintype[i] = GainType.AFFINE
+                m.actuator_gainprm[i, :3] = [0.0, 0.0, -kv]
             elif tag == "muscle":
                 # <muscle> shortcut (MuJoCo XML reference): dyntype = gaintype = biastype = muscle; dynprm = timeconst (2), tausmooth;
                 # gainprm = biasprm = range (2), force, scale, lmin, lmax, vmax, fpmax, fvmax.  The length range must be given: the

@@ -220,3 +220,27 @@ def test_disable_flags_shrink_the_constraint_sizes():
     off = sizes("ant", DisableBit.CONTACT)
     assert full[3] == 60 and off[3] == 0 and off[4] == off[2]
     assert sizes("pendula", 0)[3] == 0          # the XML disables contacts itself; 4 + 11 limit rows remain
+
+
+def test_actuator_shortcuts_compile_to_general_parameters():
+    """<intvelocity>, <damper> and <muscle> are shortcuts for <general> (MuJoCo XML reference): the MJCF compiler must produce the general
+    actuator's types and parameters, and one oracle step must show their forces (integrator-tracked servo, velocity-proportional damper)."""
+    import pyoracle
+
+    xml = """<mujoco><compiler autolimits="true"/><worldbody><body><joint name="h" type="hinge" axis="0 0 1" range="-90 90" damping="0.1"/>
+    <geom type="capsule" size="0.05" fromto="0 0 0 0.3 0 0" mass="1"/><body pos="0.3 0 0"><joint name="s" type="slide" axis="1 0 0" range="-0.1 0.1"/>
+    <geom type="sphere" size="0.04" mass="0.5"/></body></body></worldbody>
+    <actuator><intvelocity joint="h" kp="20" kv="1" actrange="-1 1"/><damper joint="s" kv="5" ctrlrange="0 1"/>
+    <muscle joint="h" lengthrange="0.5 1.5" force="40"/></actuator></mujoco>"""
+    lite = mt.mjcf.from_xml_string(xml)
+    assert list(lite.actuator_dyntype) == [1, 0, 4] and list(lite.actuator_gaintype) == [0, 1, 2] and list(lite.actuator_biastype) == [1, 0, 2]
+    assert np.allclose(lite.actuator_gainprm[0, :3], [20, 0, 0]) and np.allclose(lite.actuator_biasprm[0, :3], [0, -20, -1])
+    assert np.allclose(lite.actuator_gainprm[1, :3], [0, 0, -5]) and lite.actuator_ctrllimited[1] and lite.actuator_actlimited[0]
+    assert np.allclose(lite.actuator_gainprm[2, :9], [0.75, 1.05, 40, 200, 0.5, 1.6, 1.5, 1.3, 1.2]) and np.allclose(lite.actuator_dynprm[2, :3], [0.01, 0.04, 0])
+    assert lite.na == 2 and np.allclose(lite.actuator_lengthrange[2], [0.5, 1.5])
+    with pytest.raises(NotImplementedError, match="lengthrange"):
+        mt.mjcf.from_xml_string(xml.replace(' lengthrange="0.5 1.5"', ""))
+    mx = mt.device_put(lite)
+    d = mt.make_data(mx).replace(ctrl=torch.tensor([0.5, 0.7, 0.0], dtype=torch.float64), qvel=torch.tensor([0.3, -0.2], dtype=torch.float64))
+    out = pyoracle.run(mx, d, step=True)
+    assert np.allclose(out["actuator_force"][:2], [-0.3, 0.7]) and np.isclose(out["act"][0], 0.5 * float(mx.opt.timestep))
