@@ -199,6 +199,7 @@ extern "C" {
   X(tendon_damping) /* ntendon */                                                                \
   X(tendon_frictionloss) /* ntendon */ X(tendon_solref_fri) /* ntendon*2 */ X(tendon_solimp_fri) /* ntendon*5 */ \
   X(tendon_lengthspring) /* ntendon*2: the spring is slack between the two lengths (passive.py:121-127) */ \
+  X(tendon_armature) /* ntendon: qM += J^T diag(armature) J (smooth.py:500-522) */ \
   X(body_gravcomp)  /* nbody: fraction of the body's weight compensated (passive.py:148-156); all zero = none */ \
   X(body_invweight0_rot) /* nbody (rotational component; weld rows 3..5, constraint.py:193-194) */         \
   X(eq_data)        /* neq*11 (MuJoCo layout: connect anchors; weld anchors, relpose, torquescale; joint polycoef) */ \

@@ -145,6 +145,8 @@ struct DevModel {
   const REAL* act_ent_coef;
   const int* act_ent_rot;
   const REAL* ten_J0;                      // ntendon*nv: the constant Jacobian of the fixed tendons (ten_J[t, dof] = coef, last term wins: smooth.py:492-494)
+  const REAL* ten_JTAJ;                    // nv*(nv+1)/2 packed lower rows: J^T diag(tendon_armature) J, a model constant for fixed tendons (smooth.py:500-522); valid when has_ten_armature
+  int has_ten_armature;
   int con_direct;                          // plain constraint phase of a small model: contact rows written straight to the efc_J leaf, two environments per wavefront
   int con_general;                         // equality / frictionloss / ball- or tendon-limit rows present: constraint phase kernel 7
   int act_simple;                          // every actuator drives a slide / hinge joint

@@ -943,6 +943,10 @@ struct Env {
       S.qMp()[tri_at<true>(i, j, nv)] = s;
     }
     wave_sync();
+    if (M.has_ten_armature) {  // smooth.tendon_armature :500-522: qM += J^T diag(armature) J, a constant for fixed tendons (every entry, not only the tree's)
+      for (int w = l; w < (nv * (nv + 1)) / 2; w += W) S.qMp()[w] = S.qMp()[w] + M.ten_JTAJ[w];
+      wave_sync();
+    }
     if (out.qM) {
       REAL* gM = out.qM + e * nv * nv;
       for (int w = l; w < nv * nv; w += W) { const int sl = M.qm_slot[w]; gM[w] = sl >= 0 ? S.qMp()[sl] : (REAL)0; }

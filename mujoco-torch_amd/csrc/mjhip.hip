@@ -213,6 +213,13 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       slot[(size_t)i * nv + j] = sl;
       slot[(size_t)j * nv + i] = sl;
     }
+    {  // tendon armature couples dofs of different branches: every entry of qM can be non-zero then
+      bool arm = false;
+      for (int t = 0; t < d->ntendon; t++) arm = arm || d->tendon_armature[t] != 0;
+      if (arm)
+        for (int i = 0; i < nv; i++)
+          for (int j = 0; j <= i; j++) { slot[(size_t)i * nv + j] = (i * (i + 1)) / 2 + j; slot[(size_t)j * nv + i] = (i * (i + 1)) / 2 + j; }
+    }
     fix.push_back({(const void**)&M.qm_slot, bb.add(slot.data(), sizeof(int) * slot.size())});
     fix.push_back({(const void**)&M.qm_pair, bb.add(pairs.data(), sizeof(int) * pairs.size())});
   }
@@ -321,6 +328,19 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     for (int t = 0; t < d->ntendon; t++)
       for (int q = d->ten_adr[t]; q < d->ten_adr[t + 1]; q++) tenJ[(size_t)t * nv + d->ten_dof[q]] = (REAL)d->ten_coef[q];
     fix.push_back({(const void**)&M.ten_J0, bb.add(tenJ.data(), sizeof(REAL) * tenJ.size())});
+    {  // tendon armature: J^T diag(armature) J (products and sums in REAL, tendons in index order)
+      std::vector<REAL> jtaj((size_t)(nv * (nv + 1)) / 2 + 1, (REAL)0);
+      M.has_ten_armature = 0;
+      for (int t = 0; t < d->ntendon; t++) if (d->tendon_armature[t] != 0) M.has_ten_armature = 1;
+      if (M.has_ten_armature)
+        for (int i = 0; i < nv; i++)
+          for (int j = 0; j <= i; j++) {
+            REAL sacc = 0;
+            for (int t = 0; t < d->ntendon; t++) sacc += tenJ[(size_t)t * nv + i] * (tenJ[(size_t)t * nv + j] * (REAL)d->tendon_armature[t]);
+            jtaj[(size_t)(i * (i + 1)) / 2 + j] = sacc;
+          }
+      fix.push_back({(const void**)&M.ten_JTAJ, bb.add(jtaj.data(), sizeof(REAL) * jtaj.size())});
+    }
     std::vector<REAL> moment((size_t)d->nu * nv, (REAL)0);
     std::vector<int> a_adr((size_t)d->nu + 1, 0), a_dof, a_rot;
     std::vector<REAL> a_coef;

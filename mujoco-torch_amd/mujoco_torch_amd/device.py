@@ -83,8 +83,6 @@ def _validate(m):
     if int(_get(m, "ntendon", 0)):
         if np.any(np.asarray(_get(m, "wrap_type", lambda: np.ones(0))) != 1):
             raise NotImplementedError("only fixed tendons (joint wraps) are supported; spatial tendons are a 'next' item.")
-        if np.any(np.asarray(_get(m, "tendon_armature", lambda: np.zeros(0))) != 0):
-            raise NotImplementedError("tendon armature is not supported by the native stepper yet.")
     et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))
     if np.any(et > 2):
         raise NotImplementedError("only connect / weld / joint equality constraints are supported")

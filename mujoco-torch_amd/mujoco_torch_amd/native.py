@@ -83,7 +83,7 @@ def _tendon_reals(src, T, dtype):
     return dict(ten_coef=r(T.tendon["coef"], (-1,)), tendon_range=g("tendon_range", (nt, 2)), tendon_margin=g("tendon_margin", (nt,)),
                 tendon_invweight0=g("tendon_invweight0", (nt,)), tendon_solref_lim=g("tendon_solref_lim", (nt, 2)),
                 tendon_solimp_lim=g("tendon_solimp_lim", (nt, 5)), tendon_stiffness=g("tendon_stiffness", (nt,)),
-                tendon_damping=g("tendon_damping", (nt,)), tendon_frictionloss=g("tendon_frictionloss", (nt,)), tendon_solref_fri=g("tendon_solref_fri", (nt, 2)), tendon_solimp_fri=g("tendon_solimp_fri", (nt, 5)), tendon_lengthspring=g("tendon_lengthspring", (nt, 2)))
+                tendon_damping=g("tendon_damping", (nt,)), tendon_frictionloss=g("tendon_frictionloss", (nt,)), tendon_solref_fri=g("tendon_solref_fri", (nt, 2)), tendon_solimp_fri=g("tendon_solimp_fri", (nt, 5)), tendon_lengthspring=g("tendon_lengthspring", (nt, 2)), tendon_armature=g("tendon_armature", (nt,)))
 
 
 def pack_model(m, dtype: torch.dtype):

@@ -90,6 +90,9 @@ CASES = {
     # fixed tendons: lengths, limit rows, springs / dampers, tendon transmissions (smooth.py:470-497, constraint.py:375-405, passive.py:119-144)
     "tendon_fixed_f64": ("tendon_fixed", {}, "float64", 3, 3, "tendon"),
     "tendon_fixed_cg_rk4_f32": ("tendon_fixed", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
+    # tendon armature (smooth.py:500-522): qM gains J^T diag(armature) J, off the kinematic tree's sparsity pattern
+    "tendon_armature_f64": ("tendon_armature", {}, "float64", 3, 3, "tendon"),
+    "tendon_armature_cg_rk4_f32": ("tendon_armature", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
     # tendon frictionloss rows (constraint.py:230-234) next to dof frictionloss, tendon limits and a contact
     "tendon_friction_f64": ("tendon_friction", {}, "float64", 3, 3, "tendon"),
     "tendon_friction_cg_f64": ("tendon_friction", {"solver": 1}, "float64", 2, 2, "tendon"),

@@ -504,6 +504,17 @@ static void FN(crb_factor)(const FN(MjoModel) * M, FN(MjoWork) * w) {
       j = m->dof_parentid[j];
     }
   }
+  if (m->ntendon > 0) { /* smooth.tendon_armature :500-522: qM += J^T diag(armature) J, ahead of factor_m */
+    int any = 0;
+    for (int t = 0; t < m->ntendon; t++) any |= M->tendon_armature[t] != 0;
+    if (any)
+      for (int i = 0; i < nv; i++)
+        for (int j = 0; j < nv; j++) {
+          REAL s = 0;
+          for (int t = 0; t < m->ntendon; t++) s += w->ten_J[t * nv + i] * (w->ten_J[t * nv + j] * M->tendon_armature[t]);
+          w->qM[i * nv + j] = w->qM[i * nv + j] + s;
+        }
+  }
   FN(cholesky)(w->qM, w->qLD, nv);
 }
 

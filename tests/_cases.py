@@ -56,6 +56,7 @@ SEEDED_CASES = [
     ("halfcheetah", {"disableflags": (1 << 5) | (1 << 3)}, F64, 32, dict(max_alt=0.0)),      # ... springs (hence every passive force) and limits off
     ("pendula", {}, F64, 64, dict(max_alt=0.0)),                                # bundled: every joint type, ball limits, gravcomp, mocap, tendons
     ("tendon_fixed", {"solver": 1}, F64, 64, dict(max_alt=0.0)),
+    ("tendon_armature", {}, F64, 64, dict(max_alt=0.0)),                          # tendon armature: qM += J^T diag(armature) J off the tree's sparsity pattern
     ("capsules_topk", {}, F64, 64, dict(max_alt=0.0)),                           # max_contact_points: 13 candidates, the 5 closest kept per environment
     ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, {}),
     ("capsules_topk", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 33, dict(tol_sol=1e-5)),  # ... through the register solver (CG stall accuracy)
