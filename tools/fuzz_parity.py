@@ -31,6 +31,7 @@ CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("tendon_fixed", {}, torch.float64, 1e-6), ("gravcomp_arm", {}, torch.float64, 1e-6), ("gravcomp_arm", {"integrator": 1}, torch.float64, 1e-6), ("ball_free_actuators", {}, torch.float64, 1e-6),
     ("mocap_target", {}, torch.float64, 1e-6), ("pendula", {}, torch.float64, 1e-6), ("pendula", {"integrator": 1, "solver": 1}, torch.float32, 5e-3),
     ("frictionloss_dof", {}, torch.float64, 1e-7), ("ant_frictionloss", {}, torch.float64, 1e-6),
+    ("muscle_arm", {}, torch.float64, 1e-7), ("tendon_armature", {}, torch.float64, 1e-6), ("tendon_friction", {}, torch.float64, 1e-6), ("capsules_topk", {}, torch.float64, 1e-6),
 ]
 TOL_PRE = {torch.float64: 1e-9, torch.float32: 1e-3}  # float32: near-degenerate contact normals amplify eps under these perturbations
 import _util  # noqa: E402
