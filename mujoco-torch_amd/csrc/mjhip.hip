@@ -17,6 +17,19 @@
 #include "mjh_sensor.h"
 #include "mjh_reset.h"
 #include "mjh_io.h"
+#include "mjh_instances.h"
+
+// the kernels are compiled in their own translation units (mjh_inst.hip, one per build group): this file is the host side only
+#define X_(R, P, W) extern template __global__ void mjh_phase_kernel<R, P, W>(KArgs<R>);
+#define S_(R, N, RPL) extern template __global__ void mjh_sol2_kernel<R, N, RPL>(KArgs<R>);
+#define C_(R) extern template __global__ void mjh_convex_kernel<R>(KArgs<R>);
+#define N_(R) extern template __global__ void mjh_sensor_kernel<R>(KArgs<R>);
+MJH_INST_ALL(X_, S_, C_, N_, double)
+MJH_INST_ALL(X_, S_, C_, N_, float)
+#undef X_
+#undef S_
+#undef C_
+#undef N_
 
 static thread_local std::string g_err;
 static unsigned long long* g_stamps = nullptr;  // diagnostic builds only (mjh_debug_set_stamps)
