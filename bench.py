@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument("--workload", default="humanoid", choices=["humanoid", "humanoid32k", "ant", "mesh", "cartpole"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="N > 1 humanoid runs also time BASELINE config 4 (32768 envs/GPU); skip it")
+    ap.add_argument("--no-other-workloads", action="store_true", help="the default humanoid run also times BASELINE configs 3 (ant) and 5 (mesh scene); skip them")
+    ap.add_argument("--no-long-run", action="store_true", help="skip the 1000-step run of the headline workload reported beside `value`")
     return ap.parse_args()
 
 
@@ -158,26 +160,26 @@ def build_inputs(mx, B, dtype, device, seed=42):
 
 
 def cpu_baseline(mx, dtype, B_sample, steps):
-    """Times the CPU oracle (scalar C restatement of the reference step, OpenMP over envs) on host cores."""
+    """Times the CPU oracle (scalar C restatement of the reference step, OpenMP over envs) on host cores: every hardware thread of the
+    box (the figure moves with whatever else the host is running) and ONE thread (load-independent)."""
     import pyoracle
 
     pyoracle.build()
     threads = pyoracle.lib().mjo_max_threads()
-    d = mt.make_data(mx).expand(B_sample).clone()
-    d = d.replace(qvel=torch.tensor(0.01 * np.random.RandomState(42).randn(B_sample, mx.nv)))
-    if dtype != torch.float64:
-        d = d.to(dtype)
-    d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))  # warm
-    t0 = time.perf_counter()
-    done = 0
-    while True:  # a bounded sample: at least `steps` steps and ~12 s of CPU work, at most 40 s
-        d = pyoracle.apply(d, pyoracle.run(mx, d, step=True, nthreads=threads))
-        done += 1
-        dt = time.perf_counter() - t0
-        if (done >= steps and dt >= 12.0) or dt >= 40.0:
-            break
-    return dict(value=B_sample * done / dt, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{B_sample} envs x {done} steps, oracle/mjoracle.c with OpenMP over environments ({dt:.1f} s)")
+
+    def sample(nB, nthreads, min_steps, t_min, t_max):
+        d = mt.make_data(mx).expand(nB).clone()
+        d = d.replace(qvel=torch.tensor(0.01 * np.random.RandomState(42).randn(nB, mx.nv)))
+        if dtype != torch.float64:
+            d = d.to(dtype)
+        return pyoracle.time_steps(mx, d, nthreads, min_steps, t_min, t_max)  # the C step only: packed once, buffers ping-pong
+
+    v, done, dt = sample(B_sample, threads, steps, 10.0, 30.0)
+    n1 = min(B_sample, 256)
+    v1, done1, dt1 = sample(n1, 1, 2, 4.0, 12.0)
+    return dict(value=v, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"{B_sample} envs x {done} steps of one trajectory, oracle/mjoracle.c (mjo_step calls only) with OpenMP over environments ({dt:.1f} s)",
+                single_thread=dict(value=v1, unit="env-steps/s", cores=1, sample=f"{n1} envs x {done1} steps on one thread ({dt1:.1f} s)"))
 
 
 class Loop:
@@ -235,6 +237,102 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 
 
+PROFILE_ROUND = "r03"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
+
+
+def setup_workload(key, B, device, rank):
+    wl = WORKLOADS[key]
+    B = B or wl["batch"]
+    dtype = wl["dtype"]
+    lite = mt.mjcf.from_xml_path(mt.test_data_path(wl["xml"] + ".xml"))
+    for k, v in wl["overrides"].items():
+        setattr(lite.opt, k, v)
+    mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
+    mdev = mx.to(device)
+    # different seeds per rank: independent environments, no collective on the data path
+    loop = Loop(mdev, build_inputs(mx, B, dtype, device, seed=42 + rank))
+    return wl, B, dtype, mx, mdev, loop
+
+
+def spin_up(mdev, loop, n):
+    """Clocks, allocator pools and the library's plan caches reach their steady state on a SCRATCH copy of the inputs (n untimed
+    steps); the measured loop then starts from the original state."""
+    scratch = Loop(mdev, loop.d.clone())
+    scratch.dropin(n)
+    del scratch
+
+
+def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
+    """The `roofline` object of one workload (rank 0): per-kernel HIP-event times of the drop-in loop (outside the timed region), the
+    library's own byte account per kernel, and -- when the committed PMC file was collected on THIS library -- the measured traffic."""
+    nm = native.get_native_model(mdev, device, dtype)
+    kernels = per_kernel_times(lambda: loop.dropin(1), min(steps, 50), device)  # events around every launch
+    fp = lib_fingerprint()
+    tag = f"{key}_b{B}_{'f64' if dtype == torch.float64 else 'f32'}"
+    tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"hbm_traffic_{tag}.json")
+    tj = None
+    if os.path.exists(tfile):  # PMC counters cannot be collected from inside this process: the committed rocprofv3 result (tools/hbm_traffic.sh)
+        with open(tfile) as f:
+            tj = json.load(f)
+    in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
+    alg = in_b + out_b
+    achieved = alg * B / (kernel_ms * 1e-3) / 1e9
+    rname = "double" if dtype == torch.float64 else "float"
+    kio = kernel_algorithmic_bytes(nm)
+    per_kernel = []
+    for k, t in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"]):
+        rd, wr = kio.get(k, (0, 0))
+        gbs = (rd + wr) * B / (t["avg_ms"] * 1e-3) / 1e9
+        per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "id": k, "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
+                           "algorithmic_bytes_per_env": rd + wr, "read_bytes_per_env": rd, "written_bytes_per_env": wr, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
+    dom = per_kernel[0]
+    ktraffic, traffic, tsrc = None, None, None
+    if tj is not None:
+        stale = tj.get("lib_fingerprint") != fp
+        tsrc = {"file": os.path.relpath(tfile, ROOT), "git_commit": tj.get("git_commit"), "lib_fingerprint": tj.get("lib_fingerprint"),
+                "measured_in_this_run": False, "kernels_changed_since": stale}
+        if not stale:
+            traffic = tj.get("hbm_bytes_per_step")
+            best_disp = 0
+            for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
+                pat = "mjh_sol2_kernel<" if dom["id"] == 9 else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
+                if pat not in name:
+                    continue
+                kb = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
+                if dom["id"] == 9:  # the register solver's two row tiers are two kernels under one timing mark: their bytes add up
+                    ktraffic = (ktraffic or 0) + kb * v.get("dispatches_per_step", 0) / max(dom["launches_per_step"], 1e-9)
+                elif v.get("dispatches_per_step", 0) >= best_disp:  # (the packed variant, not the odd-tail launch)
+                    best_disp = v.get("dispatches_per_step", 0)
+                    ktraffic = kb
+    # dominant kernel of the step: the global-memory bytes its code reads + writes per launch / its average launch duration (HIP
+    # events around each launch, on the launch stream); "step" = the same for the whole launch sequence (SURVEY 8(d) per-unit figure)
+    return {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": ktraffic,
+            "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_env"] * B,
+            "traffic_source": tsrc, "per_kernel": per_kernel,
+            "step": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_env_step": alg,
+                     "algorithmic_bytes_per_step": alg * B, "device_ms_per_step": kernel_ms,
+                     "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}}, nm
+
+
+def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, spin=100):
+    """BASELINE configs 3 / 5 timed by the same drop-in loop inside the headline run: a fixed recipe -- `spin`
+    untimed steps on a scratch copy, then from the ORIGINAL state `warmup` untimed and `steps` timed steps -- independent of the headline's
+    --steps / --warmup, so the figure is the same trajectory window whoever launches the bench."""
+    wl, B, dtype, mx, mdev, loop = setup_workload(key, 0, device, rank)
+    spin_up(mdev, loop, spin)
+    loop.dropin(warmup)
+    elapsed, kernel_ms = timed(loop.dropin, steps, device, world, backend)
+    assert torch.isfinite(loop.d.qpos).all(), f"{key}: non-finite state after the timed steps"
+    res = {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world, "dtype": "f64" if dtype == torch.float64 else "f32",
+           "steps": steps, "warmup": warmup, "spin_up_steps_on_a_scratch_state": spin,
+           "value": B * world * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms}
+    if rank == 0:
+        res["roofline"], _ = roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps)
+    del loop
+    torch.cuda.empty_cache()
+    return res
+
+
 def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -257,29 +355,26 @@ def main(args):
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    wl = WORKLOADS[args.workload]
-    B = args.batch or wl["batch"]
-    dtype = wl["dtype"]
-    lite = mt.mjcf.from_xml_path(mt.test_data_path(wl["xml"] + ".xml"))
-    for k, v in wl["overrides"].items():
-        setattr(lite.opt, k, v)
-    mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
-    mdev = mx.to(device)
-    # different seeds per rank: independent environments, no collective on the data path
-    loop = Loop(mdev, build_inputs(mx, B, dtype, device, seed=42 + rank))
+    wl, B, dtype, mx, mdev, loop = setup_workload(args.workload, args.batch, device, rank)
     loop.bufs, loop.cur = [loop.d.clone(), loop.d.clone()], 0   # the out= loop starts from the same state (solver work depends on it)
 
-    # clocks, allocator pools and the library's plan caches reach their steady state on a SCRATCH copy of the inputs (100 untimed steps, ~25 ms);
-    # the measured loop then starts from the original state: W warm-up steps, K timed steps of that trajectory
     SPIN_UP = 100
-    scratch = Loop(mdev, loop.d.clone())
-    scratch.dropin(SPIN_UP)
-    del scratch
+    spin_up(mdev, loop, SPIN_UP)
     loop.dropin(args.warmup)
     elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)
     assert torch.isfinite(loop.d.qpos).all(), "non-finite state after the timed steps"
     loop.pingpong(args.warmup)
     elapsed_pp, kernel_ms_pp = timed(loop.pingpong, args.steps, device, world, backend)  # extension: step(mx, a, out=b)
+
+    # SURVEY 8(d)'s recipe beside the headline figure: 1000 more steps of the same trajectory through the same loop, so that `value` (the
+    # driver's --steps, 20 at round end = 4 ms) is not the only sample of the headline workload
+    long_run = None
+    if not args.no_long_run:
+        nl = 1000
+        el, kl = timed(loop.dropin, nl, device, world, backend)
+        assert torch.isfinite(loop.d.qpos).all(), "non-finite state after the long run"
+        long_run = {"steps": nl, "value": B * world * nl / el, "unit": "env-steps/s", "ms_per_step": 1e3 * el / nl, "device_ms_per_step": kl,
+                    "starts_after": f"{args.warmup} warm-up + {args.steps} timed steps of the same trajectory"}
 
     config4 = None
     if world > 1 and args.workload == "humanoid" and not args.batch and not args.no_config4:
@@ -293,48 +388,18 @@ def main(args):
         del big
         torch.cuda.empty_cache()
 
+    roof = None
     if rank == 0:
-        nm = native.get_native_model(mdev, device, dtype)
-        kernels = per_kernel_times(lambda: loop.dropin(1), min(args.steps, 50), device)  # events around every launch; outside the timed region
-        fp = lib_fingerprint()
-        tag = f"{args.workload}_b{B}_{'f64' if dtype == torch.float64 else 'f32'}"
-        tfile = next((p for p in (os.path.join(ROOT, "profiles", "r02", f"hbm_traffic_{tag}.json"), os.path.join(ROOT, "profiles", f"hbm_traffic_{tag}.json"))
-                      if os.path.exists(p)), None)
-        tj = None
-        if tfile:  # PMC counters cannot be collected from inside this process: the committed rocprofv3 result (tools/hbm_traffic.sh)
-            with open(tfile) as f:
-                tj = json.load(f)
-        in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
-        alg = in_b + out_b
-        achieved = alg * B / (kernel_ms * 1e-3) / 1e9
+        roof, nm = roofline_of(args.workload, B, dtype, mx, mdev, loop, device, kernel_ms, args.steps)
+
+    # BASELINE configs 3 and 5 in the same line (every rank takes part: the barrier-bracketed timing is collective)
+    others = {}
+    if args.workload == "humanoid" and not args.batch and not args.no_other_workloads:
+        for key in ("ant", "mesh"):
+            others[key] = secondary_workload(key, device, world, rank, backend)
+
+    if rank == 0:
         value = B * world * args.steps / elapsed
-        rname = "double" if dtype == torch.float64 else "float"
-        kio = kernel_algorithmic_bytes(nm)
-        per_kernel = []
-        for k, t in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"]):
-            rd, wr = kio.get(k, (0, 0))
-            gbs = (rd + wr) * B / (t["avg_ms"] * 1e-3) / 1e9
-            per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "id": k, "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
-                               "algorithmic_bytes_per_env": rd + wr, "read_bytes_per_env": rd, "written_bytes_per_env": wr, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
-        dom = per_kernel[0]
-        ktraffic, traffic, tsrc = None, None, None
-        if tj is not None:
-            stale = tj.get("lib_fingerprint") != fp
-            tsrc = {"file": os.path.relpath(tfile, ROOT), "git_commit": tj.get("git_commit"), "lib_fingerprint": tj.get("lib_fingerprint"),
-                    "measured_in_this_run": False, "kernels_changed_since": stale}
-            if not stale:
-                traffic = tj.get("hbm_bytes_per_step")
-                best_disp = 0
-                for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
-                    pat = "mjh_sol2_kernel<" if dom["id"] == 9 else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
-                    if pat not in name:
-                        continue
-                    kb = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
-                    if dom["id"] == 9:  # the register solver's two row tiers are two kernels under one timing mark: their bytes add up
-                        ktraffic = (ktraffic or 0) + kb * v.get("dispatches_per_step", 0) / max(dom["launches_per_step"], 1e-9)
-                    elif v.get("dispatches_per_step", 0) >= best_disp:  # (the packed variant, not the odd-tail launch)
-                        best_disp = v.get("dispatches_per_step", 0)
-                        ktraffic = kb
         line = {
             "metric": "env-steps/sec", "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -348,22 +413,19 @@ def main(args):
             # the same loop through the `out=` extension (ping-pong buffers, no allocation): how far the drop-in call is from it
             "out_buffers": {"value": B * world * args.steps / elapsed_pp, "ms_per_step": 1e3 * elapsed_pp / args.steps, "device_ms_per_step": kernel_ms_pp,
                             "call": "mujoco_torch.step(mx, a, out=b)"},
-            # dominant kernel of the step: the global-memory bytes its code reads + writes per launch / its average launch duration (HIP
-            # events around each launch, on the launch stream); "step" = the same for the whole launch sequence (SURVEY 8(d) per-unit figure)
-            "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": ktraffic,
-                         "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_env"] * B,
-                         "traffic_source": tsrc, "per_kernel": per_kernel,
-                         "step": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_env_step": alg,
-                                  "algorithmic_bytes_per_step": alg * B, "device_ms_per_step": kernel_ms,
-                                  "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}},
+            "roofline": roof,
         }
+        if long_run is not None:
+            line["long_run"] = long_run
+        if others:
+            line["other_workloads"] = others
         if config4 is not None:
             line["config4"] = config4
-        pfile = os.path.join(ROOT, "profiles", "r02", "parity.json")
+        pfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "parity.json")
         if os.path.exists(pfile):  # "float64 max rel-err" half of BASELINE's metric: written by tests/test_gpu_parity.py::test_parity_report
             with open(pfile) as f:
                 pj = json.load(f)
-            line["parity"] = {"file": "profiles/r02/parity.json", "measured_in_this_run": False, **{k: pj[k] for k in ("reference", "summary") if k in pj}}
+            line["parity"] = {"file": f"profiles/{PROFILE_ROUND}/parity.json", "measured_in_this_run": False, **{k: pj[k] for k in ("reference", "summary") if k in pj}}
         if not args.no_cpu_baseline and world == 1:
             nB = min(B, 4096)
             line["cpu_baseline"] = cpu_baseline(mx, dtype, nB, 20 if args.workload != "ant" else 4)

@@ -10,7 +10,8 @@
 # the kernel function itself: the build FAILS if any device function was left un-inlined.
 set -e
 HERE="$(cd "$(dirname "$0")" && pwd)"
-OBJ="$HERE/build"
+OBJ="${MJH_BUILD_DIR:-$HERE/build}"           # diagnostic builds (tools/stamps.py) keep their own objects and library name
+OUT="${MJH_BUILD_OUT:-$HERE/../lib/libmjhip.so}"
 mkdir -p "$HERE/../lib" "$OBJ"
 HIPCC=/opt/rocm/bin/hipcc
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -Rpass-analysis=kernel-resource-usage $*"
@@ -34,12 +35,12 @@ export HERE OBJ HIPCC FLAGS SRC_HASH FLAG_HASH MJH_BUILD_ONLY
 
 LIST=""
 # the heavy groups (register solver: 7 8 9, fused kinematics + velocity: 3) start first
-for g in 7 8 9 3 4 5 0 1 2 6; do [ "$g" -lt "$NG" ] && LIST="$LIST $g:d $g:f"; done
+for g in 7 8 10 11 9 3 4 5 0 1 2 6; do [ "$g" -lt "$NG" ] && LIST="$LIST $g:d $g:f"; done
 echo $LIST | tr ' ' '\n' | xargs -P "$JOBS" -I{} bash -c 'IFS=: read g t <<< "{}"; compile_one $g $t'
 $HIPCC $FLAGS -c -o "$OBJ/mjhip.o" "$HERE/mjhip.hip" 2> "$OBJ/mjhip.log" || { cat "$OBJ/mjhip.log" >&2; exit 1; }
 OBJS="$OBJ/mjhip.o"
 for g in $(seq 0 $((NG - 1))); do OBJS="$OBJS $OBJ/inst_${g}d.o $OBJ/inst_${g}f.o"; done
-$HIPCC --offload-arch=gfx950 -fPIC -shared -o "$HERE/../lib/libmjhip.so" $OBJS
+$HIPCC --offload-arch=gfx950 -fPIC -shared -o "$OUT" $OBJS
 
 LOG="$(mktemp)"
 cat "$OBJ"/inst_*.log "$OBJ/mjhip.log" > "$LOG"
@@ -51,5 +52,6 @@ if [ "$NFUNC" != "$NKERN" ]; then
   grep "Function Name:" "$LOG" | grep -vE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" >&2
   exit 1
 fi
-grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" "$LOG" | sed 's/.*remark: *//' | paste - - - - | sed 's/\[-Rpass[^]]*\]//g' | sort > "$HERE/../lib/resource_usage.txt"
+grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" "$LOG" | sed 's/.*remark: *//' | paste - - - - | sed 's/\[-Rpass[^]]*\]//g' | sort > "${OUT%.so}.resource_usage.txt"
+[ "$OUT" = "$HERE/../lib/libmjhip.so" ] && mv "${OUT%.so}.resource_usage.txt" "$HERE/../lib/resource_usage.txt"
 rm -f "$LOG"

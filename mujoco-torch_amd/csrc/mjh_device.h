@@ -90,7 +90,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
   X(s_Jaref, m.nefc, PH_SOL) X(s_force, m.nefc, PH_SOL) X(s_jv, m.nefc, PH_SOL) X(s_quad, 3 * m.nefc, PH_SOL)  \
   X(tmp_nq, m.nq, PH_SOL | PH_SOL2T)                                                                                        \
   X(r_vs, m.nv, PH_SOL2) X(r_vs2, m.nv, PH_SOL2) /* register solver: vectors staged for broadcast reads */     \
-  X(r_src, m.nefc - m.nl, PH_SOL2) X(r_dst, m.nefc - m.nl, PH_SOL2) /* active-contact row tables (ints) */ X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, m.nefc, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
+  X(r_src, MJH_JC_ROWS(m), PH_SOL2) /* compact dense row -> Data row (ints; as many as this tier keeps rows) */ X(r_dst, (m.nefc - m.nl + 1) / 2, PH_SOL2) /* Data row -> compact row, 16-bit entries, 0xffff = inactive */ X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, MJH_JC_ROWS(m) + m.nl, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
 
 struct LdsOff {
 #define X(n, c, p) int n;
@@ -257,6 +257,43 @@ __device__ __forceinline__ T sub_read(T v, int k) {
     return threadIdx.x < 32 ? a : b;
   }
   return __shfl(v, (int)(threadIdx.x & ~(W - 1)) + k, MJH_WAVE);
+}
+// value of lane K (0..15) of each 16-lane DPP row, in every lane of that row: three DPP moves, no LDS-pipe round trip and no SGPR hop.
+// quad_perm [a, a, a, a] leaves lane 4 q + a in all lanes of quad q; row_half_mirror (lane i <- lane 7 - i of its half) copies the quad that
+// holds lane K into its neighbour -- bank_mask enables the destination write per quad, the other quads keep `old` -- and row_mirror (lane i <-
+// lane 15 - i) copies those two into the other half.  The triangular kernels for n <= 16 keep one dof per lane inside ONE row (the first row of the
+// environment's lane group), so this is their broadcast: a v_readlane pair + select per 32-lane half costs five instructions and two SGPR
+// hazards, a bpermute a dependent LDS round trip inside the substitutions' chains.
+template <int K>
+__device__ __forceinline__ int row_bcast_i32(int v) {
+  constexpr int a = K & 3, kq = (K >> 2) & 3;
+  int x = __builtin_amdgcn_update_dpp(0, v, a * 0x55, 0xf, 0xf, false);
+  x = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 1 << (kq ^ 1), false);
+  x = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, (1 << (3 - kq)) | (1 << (3 - (kq ^ 1))), false);
+  return x;
+}
+template <int K> __device__ __forceinline__ int row_bcast_k(int v) { return row_bcast_i32<K>(v); }
+template <int K> __device__ __forceinline__ float row_bcast_k(float v) { return __builtin_bit_cast(float, row_bcast_i32<K>(__builtin_bit_cast(int, v))); }
+template <int K> __device__ __forceinline__ double row_bcast_k(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = row_bcast_i32<K>((int)(u & 0xffffffffull)), hi = row_bcast_i32<K>((int)(u >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// k is a constant after unrolling at every call site: the switch folds to one case
+template <typename T>
+__device__ __forceinline__ T row_bcast(T v, int k) {
+  switch (k & 15) {
+    case 0: return row_bcast_k<0>(v); case 1: return row_bcast_k<1>(v); case 2: return row_bcast_k<2>(v); case 3: return row_bcast_k<3>(v);
+    case 4: return row_bcast_k<4>(v); case 5: return row_bcast_k<5>(v); case 6: return row_bcast_k<6>(v); case 7: return row_bcast_k<7>(v);
+    case 8: return row_bcast_k<8>(v); case 9: return row_bcast_k<9>(v); case 10: return row_bcast_k<10>(v); case 11: return row_bcast_k<11>(v);
+    case 12: return row_bcast_k<12>(v); case 13: return row_bcast_k<13>(v); case 14: return row_bcast_k<14>(v); default: return row_bcast_k<15>(v);
+  }
+}
+// element k of an n-vector kept one element per lane (n <= NMAX) in the lanes of this environment's group
+template <int W, int NMAX, typename T>
+__device__ __forceinline__ T dof_read(T v, int k) {
+  if constexpr (W < MJH_WAVE && NMAX <= 16) return row_bcast(v, k);
+  else return sub_read<W>(v, k);
 }
 // sum over the lanes of this environment's group, every lane of the group ends with the same bits.  W = 32: the DPP steps leave
 // each 16-lane row's sum in all its lanes; rows 0 + 1 serve the first environment, rows 2 + 3 the second.

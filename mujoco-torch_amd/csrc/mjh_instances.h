@@ -3,7 +3,7 @@
 // Every kernel is one fully inlined function of several thousand lines; compiled in one translation unit the library took four minutes.
 // Each group below is compiled by its own hipcc process (mjh_inst.hip with -DMJH_INST_GROUP=g -DMJH_INST_REAL=double|float, build.sh runs
 // them in parallel); mjhip.hip sees the same list as `extern template` declarations, so it holds the host side only.
-// X(REAL, PHASE, W) for mjh_phase_kernel, S(REAL, NMAX, RPL) for mjh_sol2_kernel, C(REAL) / N(REAL) for the convex and sensor kernels.
+// X(REAL, PHASE, W) for mjh_phase_kernel, S(REAL, NMAX, RPL, W) for mjh_sol2_kernel, C(REAL) / N(REAL) for the convex and sensor kernels.
 #pragma once
 
 #define MJH_INST_G0(X, S, C, N, R) X(R, 0, 64) X(R, 0, 32) X(R, 0, 16)
@@ -13,11 +13,13 @@
 #define MJH_INST_G4(X, S, C, N, R) X(R, 5, 64) X(R, 5, 32) X(R, 5, 16)
 #define MJH_INST_G5(X, S, C, N, R) X(R, 4, 64) X(R, 6, 64) X(R, 7, 64)
 #define MJH_INST_G6(X, S, C, N, R) X(R, 8, 64) X(R, 8, 32) C(R) N(R)
-#define MJH_INST_G7(X, S, C, N, R) S(R, 8, 1) S(R, 8, 2) S(R, 8, 4) S(R, 8, 8)
-#define MJH_INST_G8(X, S, C, N, R) S(R, 16, 1) S(R, 16, 2) S(R, 16, 4) S(R, 16, 8)
-#define MJH_INST_G9(X, S, C, N, R) S(R, 28, 1) S(R, 28, 2)
-#define MJH_INST_NGROUPS 10
+#define MJH_INST_G7(X, S, C, N, R) S(R, 8, 1, 32) S(R, 8, 2, 32) S(R, 8, 4, 32) S(R, 8, 8, 32)
+#define MJH_INST_G8(X, S, C, N, R) S(R, 16, 1, 32) S(R, 16, 2, 32) S(R, 16, 4, 32) S(R, 16, 8, 32)
+#define MJH_INST_G9(X, S, C, N, R) S(R, 28, 1, 32) S(R, 28, 2, 32)
+#define MJH_INST_G10(X, S, C, N, R) S(R, 8, 2, 16) S(R, 8, 5, 16) S(R, 12, 2, 16) S(R, 12, 5, 16)  /* four environments per wavefront (nv <= 16) */
+#define MJH_INST_G11(X, S, C, N, R) S(R, 16, 2, 16) S(R, 16, 5, 16)
+#define MJH_INST_NGROUPS 12
 
 #define MJH_INST_ALL(X, S, C, N, R)                                                                                              \
   MJH_INST_G0(X, S, C, N, R) MJH_INST_G1(X, S, C, N, R) MJH_INST_G2(X, S, C, N, R) MJH_INST_G3(X, S, C, N, R) MJH_INST_G4(X, S, C, N, R) \
-  MJH_INST_G5(X, S, C, N, R) MJH_INST_G6(X, S, C, N, R) MJH_INST_G7(X, S, C, N, R) MJH_INST_G8(X, S, C, N, R) MJH_INST_G9(X, S, C, N, R)
+  MJH_INST_G5(X, S, C, N, R) MJH_INST_G6(X, S, C, N, R) MJH_INST_G7(X, S, C, N, R) MJH_INST_G8(X, S, C, N, R) MJH_INST_G9(X, S, C, N, R) MJH_INST_G10(X, S, C, N, R) MJH_INST_G11(X, S, C, N, R)

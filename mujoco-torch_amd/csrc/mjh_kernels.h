@@ -133,6 +133,8 @@ struct KArgs {
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
+  int it_cap, ls_cap;   // > 0: the register solver leaves an environment to the fallback launch (LDS solver, one environment per wavefront) once its solve has run it_cap Newton iterations or ls_cap line-search iterations: the long solves of a batch are few, and inside a shared wavefront every one of them holds three other environments' lanes
+  int fallback_only;    // LDS solver launch: serve only the environments the register solver flagged (mjh_bail_mark in out.qacc)
   int row_lo, row_hi;   // register solver tiers: this launch serves the environments with row_lo < (dense rows of their active contacts) <= row_hi
   unsigned long long* stamps;  // diagnostic builds (-DMJH_STAMPS): [B, 128] s_memtime stamps, else unused
 };
@@ -400,13 +402,13 @@ __device__ __forceinline__ REAL tri_solve(const TriReg<REAL, NMAX>& T, REAL bi, 
   // no k < n guards: lanes >= n carry s = 0 and inv = 0, rows / columns >= n are zero, so those steps change nothing
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
-    const REAL yk = sub_read<W>(s * T.inv, k);
+    const REAL yk = dof_read<W, NMAX>(s * T.inv, k);
     if (i == k) s = yk;
     else if (i > k) s = s - T.row[k] * yk;
   }
 #pragma unroll
   for (int k = NMAX - 1; k >= 0; k--) {
-    const REAL xk = sub_read<W>(s * T.inv, k);
+    const REAL xk = dof_read<W, NMAX>(s * T.inv, k);
     if (i == k) s = xk;
     else if (i < k) s = s - T.col[k] * xk;
   }
@@ -427,13 +429,13 @@ __device__ __forceinline__ REAL tri_solve(const TriPack<REAL, NMAX>& T, REAL bi,
   REAL s = (i < n) ? bi : (REAL)0;
 #pragma unroll
   for (int k = 0; k < NMAX; k++) {
-    const REAL yk = sub_read<W>(s * T.inv, k);
+    const REAL yk = dof_read<W, NMAX>(s * T.inv, k);
     if (i == k) s = yk;
     else if (i > k) s = s - T.t[k] * yk;
   }
 #pragma unroll
   for (int k = NMAX - 1; k >= 0; k--) {
-    const REAL xk = sub_read<W>(s * T.inv, k);
+    const REAL xk = dof_read<W, NMAX>(s * T.inv, k);
     if (i == k) s = xk;
     else if (i < k) s = s - T.t[k] * xk;
   }
@@ -453,13 +455,13 @@ __device__ __forceinline__ void chol_factor_pack(const REAL* A, TriPack<REAL, NM
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
     if (j < n) {
-      const REAL sj = sub_read<W>(T.t[j], j);
+      const REAL sj = dof_read<W, NMAX>(T.t[j], j);
       const REAL dj = r_sqrt<REAL>(sj > (REAL)1e-12 ? sj : (REAL)1e-12);
       const REAL lij = (i == j) ? dj : ((i > j && valid) ? T.t[j] / dj : (REAL)0);
       if (i >= j) T.t[j] = lij;
 #pragma unroll
       for (int k = j + 1; k < NMAX; k++) {
-        const REAL lkj = sub_read<W>(lij, k);  // L[k][j]: lane j keeps it (its column), lanes below update their rows
+        const REAL lkj = dof_read<W, NMAX>(lij, k);  // L[k][j]: lane j keeps it (its column), lanes below update their rows
         T.t[k] = (i == j) ? lkj : ((i > j) ? T.t[k] - lij * lkj : T.t[k]);
       }
     }
@@ -498,7 +500,7 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
     if (j < n) {
-      REAL s = sub_read<W>(row[j], j);                 // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
+      REAL s = dof_read<W, NMAX>(row[j], j);           // A[j][j] - sum_k L[j][k]^2, accumulated by the updates below
       if (big) s = s + (REAL)1e-10;                  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
       REAL d, lij;
       if (big && sizeof(REAL) == 8) {
@@ -518,7 +520,7 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
       row[j] = lij;
 #pragma unroll
       for (int k = j + 1; k < NMAX; k++) {             // no k < n guard: lanes / columns >= n carry exact zeros, the update is a no-op there
-        const REAL lkj = sub_read<W>(lij, k);          // L[k][j]
+        const REAL lkj = dof_read<W, NMAX>(lij, k);    // L[k][j]
         row[k] = row[k] - lij * lkj;                   // only k <= i is ever read back
       }
     }
@@ -572,6 +574,14 @@ __device__ __forceinline__ REAL dot_seq(const REAL* a, int sa, const REAL* b, in
   for (; k < n; k++) s += a[k * sa] * b[k * sb];
   return s;
 }
+
+// "left to the fallback launch": a quiet NaN with a payload, written to the first element of the environment's qacc row by the register
+// solver and tested (bit pattern) by the LDS solver's fallback launch.  It lives in the call's own output storage, so concurrent calls on
+// other streams / other Data never see each other's marks; a solve that legitimately ends in NaN never produces this payload.
+__device__ __forceinline__ float mjh_bail_mark(float) { return __builtin_bit_cast(float, 0x7fc5eed5u); }
+__device__ __forceinline__ double mjh_bail_mark(double) { return __builtin_bit_cast(double, 0x7ff80005eed5eed5ull); }
+__device__ __forceinline__ bool mjh_is_bail_mark(float x) { return __builtin_bit_cast(unsigned, x) == 0x7fc5eed5u; }
+__device__ __forceinline__ bool mjh_is_bail_mark(double x) { return __builtin_bit_cast(unsigned long long, x) == 0x7ff80005eed5eed5ull; }
 
 // =====================================================================================================================
 // FRIC: the general constraint / solver instantiations (equality, frictionloss, dense limit rows; also max_contact_points);
@@ -2834,6 +2844,10 @@ struct Env {
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
     STAMP0();
+    if (KA.fallback_only) {  // second launch behind the iteration-capped register solver: only the environments it flagged (wave-uniform: one environment per wavefront)
+      const REAL q0 = __hip_atomic_load(out.qacc + e * nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!mjh_is_bail_mark(q0)) return;
+    }
     load_factor_and_accelerate((KA.stages & 0x40) != 0);
     if (!(KA.stages & 0x40)) return;  // forward() with a stage prefix that ends at _acceleration
     STAMP(53);
@@ -2943,7 +2957,7 @@ struct Env {
 
   template <int NMAX, int RPL>
   __device__ __forceinline__ void run_sol2() {
-    static_assert(W == 32, "two environments per wavefront");
+    static_assert(W == 32 || W == 16, "two or four environments per wavefront");
     constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na, nefc = M.nefc, nl = M.nl, nd = nefc - nl;
@@ -2989,24 +3003,28 @@ struct Env {
       for (int k = 0; k < (NEWT ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[k * nv + l] : (REAL)0;
     }
     STAMP(80);
-    REAL qp0 = 0, qp1 = 0, qv = 0, ac = 0, ad = 0, warm = 0;
+    constexpr int NQS = 64 / W;  // qpos slots per lane (nq <= 64)
+    REAL qp[NQS], qv = 0, ac = 0, ad = 0, warm = 0;
+#pragma unroll
+    for (int j = 0; j < NQS; j++) qp[j] = 0;
     REAL Dl = 0, arl = 0, Jl = 0, Dd[RPL], ard[RPL];
     int ldof = 0, limrow = -1;
     int nda = 0;  // dense rows of the ACTIVE contacts of this environment (the rows of inactive contacts are exact zeros throughout, see Env::nrow_)
 #pragma unroll
     for (int j = 0; j < RPL; j++) { Dd[j] = 0; ard[j] = 0; }
     int* rsrc = reinterpret_cast<int*>(S.r_src());  // compact dense row -> Data row
-    int* rdst = reinterpret_cast<int*>(S.r_dst());  // Data row - nl -> compact dense row, -1 = inactive
+    unsigned short* rdst = reinterpret_cast<unsigned short*>(S.r_dst());  // Data row - nl -> compact dense row, 0xffff = inactive
+    const int ndc = nd < KA.row_hi ? nd : KA.row_hi;  // dense rows this tier's arena keeps (r_src, r_fs and efc_Jc are carved for them)
     if (solving) {
       const REAL* gq = KA.cur.qpos + e * nq;
-      qp0 = l < nq ? gq[l] : (REAL)0;
-      qp1 = l + 32 < nq ? gq[l + 32] : (REAL)0;
+#pragma unroll
+      for (int j = 0; j < NQS; j++) qp[j] = l + W * j < nq ? gq[l + W * j] : (REAL)0;
       if (dof) qv = (from_in ? in.qvel : KA.cur.qvel)[e * nv + l];
       if (from_in && KA.do_step) qv = checked(qv, (REAL)0);  // _check_state
       if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; ac = ga ? ga[e * na + l] : (REAL)0; ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
       // the state only feeds the integrator tail: parked in the arena (its own slots, not under the constraint rows)
-      if (l < nq) S.qpos()[l] = qp0;
-      if (l + 32 < nq) S.qpos()[l + 32] = qp1;
+#pragma unroll
+      for (int j = 0; j < NQS; j++) if (l + W * j < nq) S.qpos()[l + W * j] = qp[j];
       if (dof) S.qvel()[l] = qv;
       if (l < na) { S.act()[l] = ac; S.act_dot()[l] = ad; }
       if (nefc > 0) {
@@ -3040,8 +3058,8 @@ struct Env {
               tot = sub_read<W>(x, W - 1);
             }
             for (int k = 0; k < rows; k++) {
-              rdst[start + k] = act ? excl + k : -1;
-              if (act) rsrc[excl + k] = nl + start + k;
+              rdst[start + k] = act ? (unsigned short)(excl + k) : (unsigned short)0xffff;
+              if (act && excl + k < ndc) rsrc[excl + k] = nl + start + k;  // (an environment with more rows than this tier keeps leaves below)
             }
             nda += tot;
           }
@@ -3052,14 +3070,17 @@ struct Env {
     // two -- and none of the eight-slot loops) and serves the environments whose active contacts fit it; a second launch of the full-width
     // instantiation picks up the rest (the ant keeps 4 - 8 of its 60 contacts active: almost none).  Each environment is integrated by exactly one.
     STAMP(82);
-    if (!(nda > KA.row_lo && nda <= KA.row_hi)) return;
+    if (!(nda > KA.row_lo && nda <= KA.row_hi)) {
+      if (KA.it_cap > 0 && nda > KA.row_hi && l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);  // capped models have no wider register tier: the fallback launch takes the environment
+      return;
+    }
     if (solving) {
       if (nefc > 0) {
         const REAL* gJ = out.efc_J + e * nefc * nv;
         wave_sync();
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-          const int r = l + 32 * j;
+          const int r = l + W * j;
           if (r < nda) { const int x = rsrc[r]; Dd[j] = out.efc_D[e * nefc + x]; ard[j] = out.efc_aref[e * nefc + x]; }
         }
         STAMP(83);
@@ -3094,8 +3115,10 @@ struct Env {
         REAL s1 = 0, s2 = 0;
         if (NEWT) {
 #pragma unroll
-          for (int k = 0; k < (NEWT ? NMAX : 1); k++)
-            if (k < nv) { s1 += mrow[k] * a[k]; if (two) s2 += mrow[k] * b[k]; }
+          for (int k = 0; k < (NEWT ? NMAX : 1); k++) {  // (no `k < nv` branch around the reads: columns past nv read a clamped address and meet mrow = 0)
+            const int kc = k < nv ? k : 0;
+            s1 += mrow[k] * a[kc]; s2 += mrow[k] * b[kc];  // callers with one vector pass it twice: the second read is the same address
+          }
         } else if (dof) {
           int k = 0;
           for (; k + 9 <= nv; k += 9) {
@@ -3120,7 +3143,7 @@ struct Env {
       auto mul_J2 = [&](const REAL* a, const REAL* b, REAL (&o1)[RPL], REAL (&o2)[RPL], bool two) {
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-          const int r = l + 32 * j;
+          const int r = l + W * j;
           REAL s1 = 0, s2 = 0;
           if (r < nda) {
             const REAL* row = Jc + r * nv;
@@ -3147,7 +3170,7 @@ struct Env {
         }
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
-          const REAL act = (REAL)((l + 32 * j < nda) && jad[j] < 0);
+          const REAL act = (REAL)((l + W * j < nda) && jad[j] < 0);
           frd[j] = Dd[j] * -jad[j] * act;
           part += Dd[j] * jad[j] * jad[j] * act;
         }
@@ -3159,12 +3182,12 @@ struct Env {
       // qfrc_constraint = J^T efc_force (rows in index order: the single-column rows first), from the forces in frl / frd
       auto constraint_qfrc = [&]() -> REAL {
 #pragma unroll
-        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = frd[j];
-        if (lim) fs[nd + l] = Jl * frl;
+        for (int j = 0; j < RPL; j++) if (l + W * j < nda) fs[l + W * j] = frd[j];
+        if (lim) fs[ndc + l] = Jl * frl;
         wave_sync();
         REAL s = 0;
         if (dof) {
-          if (limrow >= 0) s += fs[nd + limrow];
+          if (limrow >= 0) s += fs[ndc + limrow];
           int r = 0;
           for (; r + 8 <= nda; r += 8) {
             REAL jj[8], ff[8];
@@ -3216,8 +3239,8 @@ struct Env {
         TriPack<REAL, NMAX> H;
         // weights of the rows in the quadratic set, staged for broadcast reads (fs is rewritten by the next constraint_qfrc)
 #pragma unroll
-        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = jad[j] < 0 ? Dd[j] : (REAL)0;
-        if (lim) fs[nd + l] = jal < 0 ? (Jl * Dl * (REAL)1) * Jl : (REAL)0;
+        for (int j = 0; j < RPL; j++) if (l + W * j < nda) fs[l + W * j] = jad[j] < 0 ? Dd[j] : (REAL)0;
+        if (lim) fs[ndc + l] = jal < 0 ? (Jl * Dl * (REAL)1) * Jl : (REAL)0;
         wave_sync();
 #pragma unroll
         for (int k = 0; k < NMAX; k++) H.t[k] = (NEWT && k <= l) ? mrow[NEWT ? k : 0] : (REAL)0;
@@ -3226,26 +3249,33 @@ struct Env {
         for (int k = 0; k < NMAX; k++) acc[k] = 0;
         if (dof && limrow >= 0) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
 #pragma unroll
-          for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[nd + limrow];
+          for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[ndc + limrow];
         }
         // The 32 lanes of the environment split into G = 32 / NMAX groups of NMAX: lane (g, i) sums row i of J^T diag(w) J over the rows
         // r = g, g + G, ... (a counted loop whose LDS reads pipeline; a row outside the quadratic set has weight 0 and adds (J * 0) * J = +-0),
         // then the groups' partial sums are added across lanes.  One lane per dof walking every row was a quarter of the lanes doing
         // four times the trips.
         {
-          constexpr int G = NEWT ? 32 / NMAX : 1;
-          const int hi = NEWT ? (l & (NMAX - 1)) : l, hg = NEWT ? l / NMAX : 0;
+          constexpr int G = NEWT ? W / NMAX : 1;
+          static_assert(G == 1 || (NMAX & (NMAX - 1)) == 0, "several lane groups need a power-of-two NMAX");
+          const int hg = NEWT ? l / NMAX : 0, hi = NEWT ? l - hg * NMAX : l;  // (lanes past the last group run the loop on rows nobody reads)
           const REAL* jr = Jc + hg * nv;
 #pragma unroll 2
           for (int r = hg; r < nda; r += G, jr += G * nv) {
+            // no `k < nv` branches around the reads: a scalar branch per column made every LDS read its own round trip (the compiler waits at each
+            // block boundary) -- 14 dependent trips per row on the mesh scene.  Columns past nv read a clamped address; their sums are never read back
+            // (only k <= l < nv is), and lanes past nv multiply by ji = 0.
             const REAL ji = (hi < nv ? jr[hi] : (REAL)0) * fs[r] * (REAL)1;
+            REAL jk[NMAX];
 #pragma unroll
-            for (int k = 0; k < NMAX; k++) if (k < nv) acc[k] += ji * jr[k];  // only k <= l is read back
+            for (int k = 0; k < NMAX; k++) jk[k] = jr[k < nv ? k : 0];
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) acc[k] += ji * jk[k];  // only k <= l is read back
           }
 #pragma unroll
-          for (int o = NMAX; o < 32; o <<= 1) {
+          for (int o = NMAX; o < NMAX * G; o <<= 1) {
 #pragma unroll
-            for (int k = 0; k < NMAX; k++) acc[k] += __shfl_xor(acc[k], o, 32);
+            for (int k = 0; k < NMAX; k++) acc[k] += __shfl_xor(acc[k], o, W);
           }
         }
 #pragma unroll
@@ -3256,13 +3286,13 @@ struct Env {
 #pragma unroll
         for (int j = 0; j < NMAX; j++) {
           if (j < nv) {
-            const REAL sj = sub_read<W>(H.t[j], j);
+            const REAL sj = dof_read<W, NMAX>(H.t[j], j);
             const REAL dj = r_sqrt<REAL>(sj > (REAL)1e-12 ? sj : (REAL)1e-12);
             const REAL lij = (l == j) ? dj : ((l > j && dof) ? H.t[j] / dj : (REAL)0);
             if (l >= j) H.t[j] = lij;
 #pragma unroll
             for (int k = j + 1; k < NMAX; k++) {
-              const REAL lkj = sub_read<W>(lij, k);
+              const REAL lkj = dof_read<W, NMAX>(lij, k);
               H.t[k] = (l == j) ? lkj : ((l > j) ? H.t[k] - lij * lkj : H.t[k]);
             }
           }
@@ -3282,7 +3312,9 @@ struct Env {
       REAL Mgrad = precondition(grad);
       REAL search = -Mgrad;
       REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step: only read when another iteration follows
-      int it = 0, niter = 0;
+      int it = 0, niter = 0, ls_total = 0;
+      bool bail = false;
+      const int it_cap = KA.it_cap, ls_cap = KA.ls_cap;
       for (;;) {
         if (M.iterations == 1) { if (it >= 1) break; }
         else if (fixed) { if (it >= M.iterations) break; }
@@ -3295,6 +3327,7 @@ struct Env {
           done |= gradient < (REAL)M.tolerance;
           if (done) break;
         }
+        if (it_cap > 0 && (it >= it_cap || ls_total >= ls_cap)) { bail = true; break; }  // another iteration is due: the fallback launch redoes this solve from its inputs
         const bool need_grad = !(it + 1 >= M.iterations);
         // ---- _linesearch :378-497 -----------------------------------------------------------------------------------------------------------------
         {
@@ -3327,7 +3360,7 @@ struct Env {
 #pragma unroll
             for (int j = 0; j < RPL; j++) {
               const REAL x = jad[j] + alpha * jvd[j];
-              const REAL act = (REAL)((l + 32 * j < nda) && x < 0);
+              const REAL act = (REAL)((l + W * j < nda) && x < 0);
               q0 += qd0[j] * act; q1 += qd1[j] * act; q2 += qd2[j] * act;
             }
             q0 = sub_sum<W>(q0); q1 = sub_sum<W>(q1); q2 = sub_sum<W>(q2);
@@ -3367,7 +3400,10 @@ struct Env {
             const bool s6 = ls_swap(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
             swap = s1 | s2 | s3 | s4 | s5 | s6;
             ls_iter++;
+            if (it_cap > 0 && ls_total + ls_iter >= ls_cap) { bail = true; break; }
           }
+          ls_total += ls_iter;
+          if (bail) break;
           const REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
           const REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
           qacc = qacc + improved * search * alpha;
@@ -3397,9 +3433,13 @@ struct Env {
         }
         niter++; it++;
       }
+      if (bail) {  // nothing of this environment's solve is kept: the mark hands it to the fallback launch, which writes every output of the phase
+        if (l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);
+        return;
+      }
       if (newton) {  // the Hessian weights overwrote the staged forces: stage the final ones for the row-order store below
 #pragma unroll
-        for (int j = 0; j < RPL; j++) if (l + 32 * j < nda) fs[l + 32 * j] = frd[j];
+        for (int j = 0; j < RPL; j++) if (l + W * j < nda) fs[l + W * j] = frd[j];
         wave_sync();
       }
       if (dof) {
@@ -3409,7 +3449,7 @@ struct Env {
       }
       if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
         if (lim) out.efc_force[e * nefc + l] = frl;
-        for (int r = l; r < nd; r += W) { const int q = rdst[r]; out.efc_force[e * nefc + nl + r] = q >= 0 ? fs[q] : (REAL)0; }
+        for (int r = l; r < nd; r += W) { const int q = rdst[r]; out.efc_force[e * nefc + nl + r] = q != 0xffff ? fs[q] : (REAL)0; }
       }
     } else {
       if (dof && out.qacc) out.qacc[e * nv + l] = qacc;
@@ -3437,6 +3477,9 @@ struct Env {
 #ifndef MJH_SOL2_T1_WAVES
 #define MJH_SOL2_T1_WAVES 4  /* float32 register solver, NMAX = 8, one row slot per lane (the ant's first tier): 128 VGPRs + 80 B of scratch at four waves per SIMD, 94 us; 164 VGPRs at three: 100.7 us */
 #endif
+#ifndef MJH_SOL2_W16_WAVES
+#define MJH_SOL2_W16_WAVES 4  /* ... the same tier at four environments per wavefront */
+#endif
 #ifndef MJH_SOL32_WAVES
 #define MJH_SOL32_WAVES 3  /* float32 LDS solver: 168 VGPRs + ~96 B of scratch; measured on the mesh scene: 2 waves (173 VGPRs, no scratch) 374 us, 3 waves 338 us, 4 waves (128 + 156 B) 362 us */
 #endif
@@ -3452,16 +3495,17 @@ struct Env {
 // step (197 / 181 / 185 -> 168 VGPRs = 3 waves, 132 -> 128 = 4 waves) and spill only 5-24 dwords to get under it; with
 // 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
 // The register solver's kernel: two environments per wavefront; an odd last environment leaves the second half of its wave idle.
-template <typename REAL, int NMAX, int RPL>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL == 1) ? MJH_SOL2_T1_WAVES : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+template <typename REAL, int NMAX, int RPL, int W>
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL * W == 32) ? (W == 16 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
-  const int sub = (int)(threadIdx.x >> 5);
+  constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
+  const int sub = (int)(threadIdx.x / W);
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
-  for (int64_t blk = blockIdx.x; blk * 2 < K.env_count; blk += gridDim.x) {
-    const int64_t idx = blk * 2 + sub;
+  for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {
+    const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {
-      Env<REAL, 32, false> E(lds, K.env_begin + idx, K.flags);
+      Env<REAL, W, false> E(lds, K.env_begin + idx, K.flags);
       E.template run_sol2<NMAX, RPL>();
     }
     wave_sync();

@@ -21,7 +21,7 @@
 
 // the kernels are compiled in their own translation units (mjh_inst.hip, one per build group): this file is the host side only
 #define X_(R, P, W) extern template __global__ void mjh_phase_kernel<R, P, W>(KArgs<R>);
-#define S_(R, N, RPL) extern template __global__ void mjh_sol2_kernel<R, N, RPL>(KArgs<R>);
+#define S_(R, N, RPL, W) extern template __global__ void mjh_sol2_kernel<R, N, RPL, W>(KArgs<R>);
 #define C_(R) extern template __global__ void mjh_convex_kernel<R>(KArgs<R>);
 #define N_(R) extern template __global__ void mjh_sensor_kernel<R>(KArgs<R>);
 MJH_INST_ALL(X_, S_, C_, N_, double)
@@ -64,6 +64,9 @@ struct mjhModel {
   LdsOff off_kv;
   int lds_kv = 0;
   int sol2_tiers = 0;                      // 1: a first launch with ONE row slot per lane serves the environments whose active contacts fit 32 dense rows
+  int sol2_w16_rpl = 0;                    // > 0: that first launch runs FOUR environments per wavefront (16 lanes each, nv <= 16) with this many row slots per lane
+  int sol2_w16_nmax = 0;                   // ... instantiated for 8, 12 or 16 dofs
+  int sol2_it_cap = 0, sol2_ls_cap = 0;    // > 0: that launch leaves long solves (Newton iterations / line-search iterations beyond the caps) to a fallback launch of the LDS solver
   LdsOff off_tier;                         // ... from an arena of its own (32 rows of efc_J instead of all of them)
   int lds_tier = 0;
   int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
@@ -459,13 +462,42 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     // when the solves are short -- measured on MI355X: ant (nv 8, 1 - 3 iterations) solver phase 229 -> 175 us, mesh scene (nv 12, up to
     // 100 iterations x 50 line-search steps, very uneven across environments) 548 -> 691 us.  MJH_SOL2_NEWTON_NV moves the cut.
     static const int newton_nv = [] { const char* e = getenv("MJH_SOL2_NEWTON_NV"); return e ? atoi(e) : 8; }();
-    const bool solver_ok = d->solver == SOL_CG || (d->solver == SOL_NEWTON && nmax <= 16 && d->nv <= newton_nv);
+    // (... with FOUR environments per wavefront -- the first tier of models whose nv, na and single-column rows fit 16 lanes, see below -- the shared
+    // nv-sized work outweighs the wait: the mesh scene's solver phase 338 -> see profiles/r03/notes.md)
+    static const bool w16_off = [] { const char* e = getenv("MJH_SOL2_W16"); return e && e[0] == '0'; }();
+    const bool w16 = !w16_off && nmax <= 16 && d->nv <= 16 && d->na <= 16 && d->nl <= 16;
+    const bool solver_ok = d->solver == SOL_CG || (d->solver == SOL_NEWTON && nmax <= 16 && (d->nv <= newton_nv || w16));
     if (!off && solver_ok && !general && d->nv <= 28 && nd <= 32 * (nmax <= 16 ? 8 : 2) && d->nl <= 32 && d->na <= 32 && d->nq <= 64 && 2 * out->lds_bytes[5] <= 64 * 1024) {
       out->sol2_nmax = nmax;
       out->sol2_rpl = rpl;
       // measured on MI355X (profiles/r02/notes.md): ant solver phase 124 -> 114 us (the narrow tier runs three waves per SIMD).  MJH_SOL2_TIERS=0 keeps the single full-width launch.
       static const bool tiers_off = [] { const char* e = getenv("MJH_SOL2_TIERS"); return e && e[0] == '0'; }();
-      if (rpl > 1 && !tiers_off) {
+      // Small models (nv, na and the single-column rows fit 16 lanes): the first tier packs FOUR environments per wavefront.  The solver's nv-sized
+      // work (substitutions, Cholesky of the Newton Hessian, M products) costs a wave the same whatever it carries, so its cost per environment
+      // halves, and a CU keeps twice the environments in flight.  Row slots of that tier: 2 per lane (32 rows) for contacts of up to 4 rows,
+      // 5 (80 rows) for wider ones (condim 6 pyramidal: 10 rows per contact).  MJH_SOL2_W16=0 keeps two per wavefront; MJH_SOL2_W16_RPL picks the slots.
+      static const int w16_rpl_env = [] { const char* e = getenv("MJH_SOL2_W16_RPL"); return e ? atoi(e) : 0; }();
+      const int w16_rpl = (w16_rpl_env == 2 || w16_rpl_env == 5) ? w16_rpl_env : ((M.con_rows > 0 && M.con_rows <= 4) || nd <= 32 ? 2 : 5);
+      if (w16) {
+        DevModel<REAL> Mc = M;
+        Mc.sol2_row_cap = 16 * w16_rpl;
+        out->lds_tier = lds_carve(Mc, PH_SOL2, out->off_tier) * (int)sizeof(REAL);
+        if (4 * out->lds_tier <= 64 * 1024) {
+          out->sol2_tiers = 1; out->sol2_w16_rpl = w16_rpl;
+          out->sol2_w16_nmax = d->nv <= 8 ? 8 : (d->nv <= 12 ? 12 : 16);
+          // Opt-in (MJH_SOL2_ITCAP / MJH_SOL2_LSCAP > 0): long Newton solves leave the packed tier once they pass the caps and are redone by the LDS
+          // solver, which gives ONE environment all 64 lanes.  Measured on the mesh scene (B = 8192, profiles/r03/notes.md): solver
+          // phase 257 us without caps, 323 / 346 / 377 / 407 us with caps of 2/6, 3/8, 4/12, 5/20 iterations / line-search iterations -- redoing a long
+          // solve from its inputs at one environment per wavefront costs more than the three lane groups it frees, so the default is no caps.
+          static const int it_env = [] { const char* e = getenv("MJH_SOL2_ITCAP"); return e ? atoi(e) : -1; }();
+          static const int ls_env = [] { const char* e = getenv("MJH_SOL2_LSCAP"); return e ? atoi(e) : -1; }();
+          if (it_env >= 0) out->sol2_it_cap = it_env;
+          if (ls_env >= 0) out->sol2_ls_cap = ls_env;
+          if (out->sol2_it_cap <= 0 || out->sol2_ls_cap <= 0) out->sol2_it_cap = out->sol2_ls_cap = 0;
+          if (d->solver != SOL_NEWTON || (d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0)) out->sol2_it_cap = out->sol2_ls_cap = 0;  // the fallback is kernel 4
+        }
+      }
+      if (!out->sol2_tiers && rpl > 1 && !tiers_off) {
         DevModel<REAL> Mc = M;
         Mc.sol2_row_cap = 32;
         out->lds_tier = lds_carve(Mc, PH_SOL2, out->off_tier) * (int)sizeof(REAL);
@@ -546,9 +578,14 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   if (out->pack2[3]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[3]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_convex_kernel<REAL>), hipFuncAttributeMaxDynamicSharedMemorySize, out->cvx_lds_bytes));
   if (out->sol2_nmax) {
-#define SET_SOL2(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[5]));
+#define SET_SOL2(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[5]));
     SET_SOL2(8, 1) SET_SOL2(8, 2) SET_SOL2(8, 4) SET_SOL2(8, 8) SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(16, 4) SET_SOL2(16, 8) SET_SOL2(28, 1) SET_SOL2(28, 2)
 #undef SET_SOL2
+    if (out->sol2_w16_rpl) {
+#define SET_SOL2W(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_tier));
+      SET_SOL2W(8, 2) SET_SOL2W(8, 5) SET_SOL2W(12, 2) SET_SOL2W(12, 5) SET_SOL2W(16, 2) SET_SOL2W(16, 5)
+#undef SET_SOL2W
+    }
   }
   return 0;
 }
@@ -589,33 +626,63 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   return launch_range<REAL, P, MJH_WAVE>(m, a, 0, a.B, stream);
 }
 
-// the solver phase through the register solver: two environments per wavefront
+// the solver phase through the register solver: two (or, first tier of a small model, four) environments per wavefront
 template <typename REAL>
 int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.env_begin = 0; a.env_count = a.B;
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-#define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
-  if (m->sol2_tiers) {  // first tier: one row slot per lane, its own (smaller) arena
+#define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 32>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
+#define GOW(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a)
+  const int nd = a.M.nefc - a.M.nf - a.M.nl;
+  bool second = true;
+  if (m->sol2_tiers) {  // first tier: fewer row slots per lane, its own (smaller) arena
     a.off = m->off_tier;
     a.lds_reals = m->lds_tier / (int)sizeof(REAL);
-    a.row_lo = -1; a.row_hi = 32;
-    const size_t lds = (size_t)(2 * m->lds_tier);
-    if (m->sol2_nmax == 8) GO(8, 1); else if (m->sol2_nmax == 16) GO(16, 1); else GO(28, 1);
+    if (m->sol2_w16_rpl) {
+      const int64_t blocks4 = (a.B + 3) / 4;
+      const int64_t grid4 = blocks4 < (int64_t)1 << 20 ? blocks4 : (int64_t)1 << 20;
+      a.row_lo = -1; a.row_hi = 16 * m->sol2_w16_rpl;
+      const size_t lds = (size_t)(4 * m->lds_tier);
+      const bool capped = m->sol2_it_cap > 0 && !(a.flags & MJH_FLAG_FIXED_ITERATIONS) && a.cur.qacc;
+      a.it_cap = capped ? m->sol2_it_cap : 0; a.ls_cap = capped ? m->sol2_ls_cap : 0;
+      if (m->sol2_w16_nmax == 8) { if (m->sol2_w16_rpl == 2) GOW(8, 2); else GOW(8, 5); }
+      else if (m->sol2_w16_nmax == 12) { if (m->sol2_w16_rpl == 2) GOW(12, 2); else GOW(12, 5); }
+      else { if (m->sol2_w16_rpl == 2) GOW(16, 2); else GOW(16, 5); }
+      a.it_cap = a.ls_cap = 0;
+      if (capped) {  // the LDS solver takes what the packed tier left: more rows than it keeps, or a solve past the caps
+        HIP_TRY(hipGetLastError());
+        a.fallback_only = 1;
+        const int rc = launch_phase<REAL, 4>(m, a, stream);
+        a.fallback_only = 0;
+        if (rc) return rc;
+        g_timing.n -= (g_timing.on && g_timing.n > 0) ? 1 : 0;  // (launch_phase marked kernel 4: both launches belong under the solver phase's one mark below)
+        second = false;
+      } else {
+        second = nd > a.row_hi;  // every environment fits the first tier otherwise
+      }
+    } else {
+      a.row_lo = -1; a.row_hi = 32;
+      const size_t lds = (size_t)(2 * m->lds_tier);
+      if (m->sol2_nmax == 8) GO(8, 1); else if (m->sol2_nmax == 16) GO(16, 1); else GO(28, 1);
+    }
     HIP_TRY(hipGetLastError());
-    a.row_lo = 32;
+    a.row_lo = a.row_hi;
   } else {
     a.row_lo = -1;
   }
-  a.row_hi = 0x7fffffff;
-  a.off = m->off[5];
-  a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
-  const size_t lds = (size_t)(2 * m->lds_bytes[5]);
-  if (m->sol2_nmax == 8) { if (m->sol2_rpl == 1) GO(8, 1); else if (m->sol2_rpl == 2) GO(8, 2); else if (m->sol2_rpl == 4) GO(8, 4); else GO(8, 8); }
-  else if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
-  else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
+  if (second) {
+    a.row_hi = 0x7fffffff;
+    a.off = m->off[5];
+    a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
+    const size_t lds = (size_t)(2 * m->lds_bytes[5]);
+    if (m->sol2_nmax == 8) { if (m->sol2_rpl == 1) GO(8, 1); else if (m->sol2_rpl == 2) GO(8, 2); else if (m->sol2_rpl == 4) GO(8, 4); else GO(8, 8); }
+    else if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
+    else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
+    HIP_TRY(hipGetLastError());
+  }
 #undef GO
-  HIP_TRY(hipGetLastError());
+#undef GOW
   timing_mark(stream, 9);  // both tiers under one mark: the solver phase
   return 0;
 }

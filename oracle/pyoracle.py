@@ -110,6 +110,37 @@ def _call(step, desc, pin, pout, B, dt, stages, flags, nthreads, knife, knife_po
     return rc
 
 
+def time_steps(m, d, nthreads, min_steps, t_min, t_max):
+    """bench.py's cpu_baseline leg: (env-steps/s, steps, seconds) of the oracle's C step alone on a state that is carried from step to step --
+    model and Data are packed once, the two buffer sets ping-pong, and only the `mjo_step` calls sit between the clock reads (going through
+    run() / apply() every step spends most of the time copying ~50 KB per environment through numpy and torch)."""
+    import time
+
+    dtype = d.qpos.dtype
+    desc, keep = native.pack_model(m, dtype)
+    a = data_to_numpy(d)
+    b = {n: np.array(x, copy=True) for n, x in a.items()}
+    batch = tuple(d.qpos.shape[:-1])
+    B = int(np.prod(batch)) if batch else 1
+    pa, pb = _ptrs(a), _ptrs(b)
+    dt = 0 if dtype == torch.float64 else 1
+    lib().mjo_set_contact_hint(None, None, None, None)
+    lib().mjo_set_stage_tie_flip(0, None)
+    if _call(True, desc, pa, pb, B, dt, native.STAGE_ALL, 0, nthreads, None, -1) != 0:  # warm (pages, thread pool)
+        raise RuntimeError("oracle failed")
+    pa, pb = pb, pa
+    done, t0 = 0, time.perf_counter()
+    while True:
+        if _call(True, desc, pa, pb, B, dt, native.STAGE_ALL, 0, nthreads, None, -1) != 0:
+            raise RuntimeError("oracle failed")
+        pa, pb = pb, pa
+        done += 1
+        el = time.perf_counter() - t0
+        if (done >= min_steps and el >= t_min) or el >= t_max:
+            break
+    return B * done / el, done, el
+
+
 def apply(d, out):
     """Returns a new Data with the oracle's output leaves (torch, CPU)."""
     top, con = {}, {}

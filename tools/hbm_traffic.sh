@@ -6,7 +6,7 @@ w=$1
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_${w}_$c
-  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python3 /root/repo/bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python3 /root/repo/bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --no-other-workloads --no-long-run > /tmp/pmc_${w}_$c.log 2>&1
 done
 mkdir -p /root/repo/gpurun_out
 python3 - "$w" <<'PY'

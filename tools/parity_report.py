@@ -1,6 +1,6 @@
 """GPU box: the "float64 max rel-err" half of BASELINE.json's metric as numbers -- per-leaf error of the HIP step against the CPU
 oracle on the BASELINE configs (2: humanoid f64 Euler+CG, 3: ant f32 RK4+Newton elliptic, 5: mesh scene f32 Newton; config 4 is
-config 2's model) in the bench's input recipe, three consecutive steps.  Writes gpurun_out/parity.json (copied to profiles/r02/).
+config 2's model) in the bench's input recipe, three consecutive steps.  Writes gpurun_out/parity.json (copied to profiles/<round>/).
 
 Errors are max-norm per leaf: |got - want|max / max(|want|max, floor) (tests/_util.rel_err), NOT element-wise.  Solver-dependent
 leaves are reported twice: against the oracle's natural run and against the closest admissible branch per environment.

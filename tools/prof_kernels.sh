@@ -3,7 +3,7 @@
 w=$1; steps=${2:-50}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$w
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 /root/repo/bench.py --workload $w --steps $steps --warmup 5 --no-cpu-baseline > /tmp/prof_$w.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w -- python3 /root/repo/bench.py --workload $w --steps $steps --warmup 5 --no-cpu-baseline --no-other-workloads --no-long-run > /tmp/prof_$w.log 2>&1
 f=$(find /tmp/prof_$w -name "*kernel_stats.csv" | head -1)
 mkdir -p /root/repo/gpurun_out
 cp $f /root/repo/gpurun_out/${w}_kernel_stats.csv

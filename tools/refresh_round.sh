@@ -1,8 +1,9 @@
 #!/bin/bash
-# GPU box: regenerates every measured artefact of the round under gpurun_out/r02/ (copy to profiles/r02/ afterwards):
+# GPU box: regenerates every measured artefact of a round under gpurun_out/<round>/ (copy to profiles/<round>/ afterwards):
 # rocprofv3 kernel stats, PMC traffic (stamped with the library fingerprint bench.py checks), parity report, counter calibration,
-# and the bench lines of the three BASELINE workloads.  Usage: MJH_GIT_COMMIT=<sha> bash tools/refresh_r02.sh
-O=gpurun_out/r02
+# and the bench lines of the three BASELINE workloads.  Usage: MJH_GIT_COMMIT=<sha> bash tools/refresh_round.sh r03
+R=${1:-r03}
+O=gpurun_out/$R
 mkdir -p $O
 bash tools/fetch_calib.sh 2>&1 | grep -E "FETCH_SIZE|WRITE_SIZE" > $O/fetch_calibration.txt
 for w in humanoid ant mesh; do
@@ -13,24 +14,28 @@ done
 python tools/parity_report.py > $O/parity_report.log 2>&1
 cp gpurun_out/parity.json $O/parity.json
 # traffic + parity files must be where bench.py looks for them before the bench lines are taken
-mkdir -p profiles/r02
-python - <<'PY'
-import json, shutil
+mkdir -p profiles/$R
+python - $R <<'PY'
+import json, shutil, sys
+R = sys.argv[1]
 names = {"humanoid": "humanoid_b4096_f64", "ant": "ant_b16384_f32", "mesh": "mesh_b8192_f32"}
 for w, tag in names.items():
-    shutil.copy(f"gpurun_out/hbm_traffic_{w}.json", f"profiles/r02/hbm_traffic_{tag}.json")
-    shutil.copy(f"gpurun_out/hbm_traffic_{w}.json", f"gpurun_out/r02/hbm_traffic_{tag}.json")
-shutil.copy("gpurun_out/parity.json", "profiles/r02/parity.json")
+    shutil.copy(f"gpurun_out/hbm_traffic_{w}.json", f"profiles/{R}/hbm_traffic_{tag}.json")
+    shutil.copy(f"gpurun_out/hbm_traffic_{w}.json", f"gpurun_out/{R}/hbm_traffic_{tag}.json")
+shutil.copy("gpurun_out/parity.json", f"profiles/{R}/parity.json")
 PY
-for w in humanoid ant mesh; do
+python bench.py --steps 200 --warmup 20 > $O/bench_humanoid.json 2> $O/bench_humanoid.err   # carries ant + mesh as other_workloads
+python bench.py --steps 20 --warmup 5 > $O/bench_humanoid_driver_flags.json 2> /dev/null            # the driver's round-end flags
+for w in ant mesh; do
   python bench.py --workload $w --steps 200 --warmup 20 > $O/bench_$w.json 2> $O/bench_$w.err
 done
 python bench.py --workload humanoid32k --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_humanoid32k.json 2>/dev/null
 MJH_BENCH_SHARE_GPU=1 MJH_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_humanoid_2ranks_one_gpu.json 2>/dev/null
-python - <<'PY'
-import json
+python - $R <<'PY'
+import json, sys
+R = sys.argv[1]
 for w in ("humanoid", "ant", "mesh", "humanoid32k"):
-    j = json.load(open(f"gpurun_out/r02/bench_{w}.json"))
+    j = json.load(open(f"gpurun_out/{R}/bench_{w}.json"))
     r = j["roofline"]
     print(f"{w:12s} {j['value'] / 1e6:7.3f} M env-steps/s  {j['ms_per_step']:.4f} ms/step  out= {j['out_buffers']['value'] / 1e6:7.3f} M  dominant {r['kernel'][:44]} {r['kernel_avg_us']:.1f} us frac {r['frac']:.3f} traffic {r['traffic']}  step frac {r['step']['frac']:.3f} step traffic {r['step']['traffic']}")
 PY

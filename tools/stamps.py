@@ -12,8 +12,8 @@ import numpy as np, torch
 lib = os.path.join(R, "mujoco-torch_amd", "lib", "libmjhip_stamps.so")
 src = [os.path.join(R, "mujoco-torch_amd", "csrc", f) for f in os.listdir(os.path.join(R, "mujoco-torch_amd", "csrc")) if f.endswith((".h", ".hip"))]
 if not os.path.exists(lib) or (os.environ.get("MJH_STAMPS_NOBUILD") != "1" and os.path.getmtime(lib) < max(os.path.getmtime(f) for f in src)):  # build it in the container: it travels with the snapshot
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17", "-ffp-contract=off", "-DMJH_STAMPS",
-                    "-o", lib, os.path.join(R, "mujoco-torch_amd", "csrc", "mjhip.hip")], check=True)
+    csrc = os.path.join(R, "mujoco-torch_amd", "csrc")
+    subprocess.run([os.path.join(csrc, "build.sh"), "-DMJH_STAMPS"], check=True, env=dict(os.environ, MJH_BUILD_DIR=os.path.join(csrc, "build", "stamps"), MJH_BUILD_OUT=lib))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 from mujoco_torch_amd import native
