@@ -518,10 +518,38 @@ __device__ __forceinline__ void chol_factor_reg(const REAL* A, REAL* L, int n) {
         lij = (i == j) ? d : ((i < n) ? row[j] / d : (REAL)0);  // lanes i < j hold zeros: harmless; lanes >= n stay zero
       }
       row[j] = lij;
+      if constexpr (NMAX > 16) {
+        // The trailing update needs column j of the factor -- lane k's lij -- in EVERY lane.  Broadcast lane by lane that is a v_readlane (two for a
+        // double) per value, half of the instructions of the whole factorisation at n = 27; instead the column goes through LDS once: each lane
+        // writes its entry, and every lane reads the column back with uniform addresses (LDS broadcast reads, two doubles / four floats per
+        // instruction).  Two alternating buffers at the head of L (dead until the factor is stored below): one barrier per column.  The products and
+        // differences are the same expressions in the same order.
+        REAL* col = L + (j & 1) * NMAX;
+        if (i < NMAX) col[i] = lij;  // (no barrier: one wavefront's LDS operations complete in order, and the compiler keeps the store ahead of the reads of the same buffer)
+        constexpr int CH = 8;  // column entries per batch of reads (adjacent ones merge into two-element LDS reads): 16 VGPRs of a double factorisation
 #pragma unroll
-      for (int k = j + 1; k < NMAX; k++) {             // no k < n guard: lanes / columns >= n carry exact zeros, the update is a no-op there
-        const REAL lkj = dof_read<W, NMAX>(lij, k);    // L[k][j]
-        row[k] = row[k] - lij * lkj;                   // only k <= i is ever read back
+        for (int k0 = 0; k0 < NMAX; k0 += CH) {
+          if (k0 + CH - 1 > j) {
+            REAL c[CH];
+#pragma unroll
+            for (int t = 0; t < CH; t++) c[t] = (k0 + t > j && k0 + t < NMAX) ? col[k0 + t] : (REAL)0;
+#pragma unroll
+            for (int t = 0; t < CH; t++) {
+              if (k0 + t > j && k0 + t < NMAX) {
+                row[k0 + t] = row[k0 + t] - lij * c[t];
+                // the update is only consumed at step k: left alone the scheduler sinks it there and keeps every column read so far in registers
+                // (a left-looking factorisation holding n^2 / 2 values: 256 VGPRs, 256 AGPRs and 500 bytes of scratch).  Pin the value here.
+                asm volatile("" : "+v"(row[k0 + t]));
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = j + 1; k < NMAX; k++) {           // no k < n guard: lanes / columns >= n carry exact zeros, the update is a no-op there
+          const REAL lkj = dof_read<W, NMAX>(lij, k);  // L[k][j]
+          row[k] = row[k] - lij * lkj;                 // only k <= i is ever read back
+        }
       }
     }
   }
@@ -3513,7 +3541,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : 1))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
