@@ -41,12 +41,24 @@ class UnbatchedTensor:
     def __len__(self):
         return len(self.data)
 
+    def __eq__(self, other):  # value equality: pytree contexts of a step's input and output compare equal (tree_map over both works)
+        if not isinstance(other, UnbatchedTensor):
+            return NotImplemented
+        a, b = self.data, other.data
+        if a is b:
+            return True
+        if a is None or b is None or a.shape != b.shape or a.dtype != b.dtype:
+            return False
+        return bool(torch.equal(a.detach().cpu(), b.detach().cpu()))
+
+    __hash__ = None
+
     def __repr__(self):
         return f"UnbatchedTensor({self.data!r})"
 
 
 # host-side attributes that belong to ONE container instance and are never inherited by containers derived from it
-_PRIVATE = ("_fields", "_bs", "_ver", "_child_keys", "_lazy", "_ptab", "_native_cache")
+_PRIVATE = ("_fields", "_bs", "_ver", "_child_keys", "_lazy", "_ptab", "_native_cache", "_order", "_op_key")
 
 
 def _carve(spec):
@@ -88,6 +100,23 @@ def _register_pytree(cls):
     from torch.utils import _pytree
 
     def flatten(obj):
+        if torch.compiler.is_compiling():  # Dynamo traces this (torch.vmap flattens its arguments inside the compiled function): no __dict__ access
+            keys, children, rest = [], [], {}
+            f = obj._fields_traced()
+            pinned = obj._child_keys
+            for k in f:
+                v = f[k]
+                if (k in pinned) if pinned is not None else isinstance(v, (torch.Tensor, MjTensorClass)):
+                    keys.append(k)
+                    children.append(v)
+                else:
+                    rest[k] = v
+            probe = None
+            for i in range(len(children)):
+                if probe is None and isinstance(children[i], torch.Tensor):
+                    probe = i
+            event = children[probe].dim() - len(obj._bs) if probe is not None else 0
+            return children, (tuple(keys), rest, probe, event, tuple(f), {}, tuple(obj._bs))
         keys, children, rest = [], [], {}
         pinned = obj.__dict__.get("_child_keys")  # set by unflatten: placeholder leaves (pytree's own spec arithmetic) keep the structure
         for k, v in obj._all().items():
@@ -105,6 +134,14 @@ def _register_pytree(cls):
         keys, rest, probe, event, order, extra, bs = ctx
         vals = dict(rest)
         vals.update(zip(keys, children))
+        if torch.compiler.is_compiling():
+            if probe is not None and isinstance(children[probe], torch.Tensor):
+                t = children[probe]
+                bs = tuple(t.shape[: t.dim() - event]) if t.dim() >= event else ()
+            new = cls(batch_size=bs, **{k: vals[k] for k in order})
+            if not all(isinstance(c, (torch.Tensor, MjTensorClass)) for c in children):
+                new._child_keys = frozenset(keys)  # placeholder leaves (pytree's own spec arithmetic) keep the structure
+            return new
         new = cls.__new__(cls)
         object.__setattr__(new, "_fields", {k: vals[k] for k in order})
         if probe is not None and isinstance(children[probe], torch.Tensor):
@@ -115,6 +152,7 @@ def _register_pytree(cls):
             object.__setattr__(new, k, v)
         if not all(isinstance(c, (torch.Tensor, MjTensorClass)) for c in children):
             object.__setattr__(new, "_child_keys", frozenset(keys))
+        new._post_init()
         return new
 
     _pytree.register_pytree_node(cls, flatten, unflatten)
@@ -122,6 +160,15 @@ def _register_pytree(cls):
 
 class MjTensorClass(metaclass=_Meta):
     """Attribute container over a plain dict of leaves plus a leading ``batch_size``."""
+
+    # defaults of the per-instance host attributes (_PRIVATE): code that is traced by Dynamo reads them as plain attributes -- it cannot go
+    # through ``__dict__`` -- and finds these when an instance has none of its own
+    _lazy = None
+    _order = None
+    _child_keys = None
+
+    def _post_init(self):
+        """Hook run on every freshly built instance (constructor, derived containers, pytree unflatten)."""
 
     def __init__(self, *args, batch_size=None, **kwargs):
         names = type(self)._field_names
@@ -135,19 +182,23 @@ class MjTensorClass(metaclass=_Meta):
                 d[k] = type(self)._field_defaults.get(k)
         object.__setattr__(self, "_fields", d)
         object.__setattr__(self, "_bs", tuple(batch_size) if batch_size is not None else ())
+        self._post_init()
 
     # ---- attribute access ---------------------------------------------------------------
     def __getattr__(self, name):
-        d = object.__getattribute__(self, "__dict__")
-        try:
-            return d["_fields"][name]
-        except KeyError:
-            lz = d.get("_lazy")
-            if lz and name in lz:  # a leaf of a step's output slab, carved on first access (forward.py)
-                t = _carve(lz.pop(name))
-                d["_fields"][name] = t
-                return t
-            raise AttributeError(f"{type(self).__name__} has no field {name!r}") from None
+        if name == "_fields":  # (only reached on a half-built instance: no recursion through the lookups below)
+            raise AttributeError(name)
+        f = self._fields
+        if name in f:
+            return f[name]
+        lz = self._lazy
+        if lz and name in lz:  # a leaf of a step's output slab, carved on first access (forward.py)
+            if torch.compiler.is_compiling():
+                return _carve(lz[name])  # traced: a view of the slab in the graph, the container is left as it is
+            t = _carve(lz.pop(name))
+            f[name] = t
+            return t
+        raise AttributeError(f"{type(self).__name__} has no field {name!r}")
 
     def __setattr__(self, name, value):
         if name in type(self)._field_names:
@@ -201,7 +252,31 @@ class MjTensorClass(metaclass=_Meta):
         for k, v in self.__dict__.items():
             if k not in _PRIVATE:
                 object.__setattr__(new, k, v)
+        new._post_init()
         return new
+
+    def _fields_traced(self):
+        """Every field with the lazily carved leaves as views, in declaration order, WITHOUT touching the container (Dynamo-traceable)."""
+        f, lz = self._fields, self._lazy
+        if not lz:
+            return f
+        names = self._order or type(self)._field_names
+        out = {}
+        for k in names:
+            if k in f:
+                out[k] = f[k]
+            elif k in lz:
+                out[k] = _carve(lz[k])
+        for k in f:
+            if k not in out:
+                out[k] = f[k]
+        return out
+
+    def _replace_traced(self, kwargs):
+        """``replace`` for code traced by Dynamo: plain dict / constructor operations only (Data and Contact carry no extra host attributes)."""
+        f = dict(self._fields_traced())
+        f.update(kwargs)
+        return type(self)(batch_size=self._bs, **f)
 
     def map_tensors(self, fn):
         """Applies ``fn`` to every tensor leaf, recursing into nested containers; other values are kept."""
@@ -225,9 +300,13 @@ class MjTensorClass(metaclass=_Meta):
         lz = self.__dict__.get("_lazy")
         if lz:
             object.__setattr__(new, "_lazy", dict(lz))  # same slab regions, carved independently
+            if "_order" in self.__dict__:  # the field order the lazy leaves re-enter in belongs with them (and with nothing else: _PRIVATE)
+                object.__setattr__(new, "_order", self.__dict__["_order"])
         return new
 
     def replace(self, **kwargs: Any):
+        if torch.compiler.is_compiling():
+            return self._replace_traced(kwargs)
         new = self.clone(recurse=False)
         lz = new.__dict__.get("_lazy")
         if lz:

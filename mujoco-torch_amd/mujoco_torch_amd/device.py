@@ -16,6 +16,9 @@ from __future__ import annotations
 
 import itertools
 
+import collections
+import weakref
+
 import numpy as np
 import torch
 
@@ -181,7 +184,8 @@ class StaticTables:
     """
 
     def __init__(self):
-        self.native = {}
+        self.native = weakref.WeakValueDictionary()  # value digest -> device blob, alive while some Model (its _native_cache) or `native_recent` holds it
+        self.native_recent = collections.OrderedDict()  # strong references to the few most recently used blobs (native._NATIVE_LRU)
         self.uid = next(_cache_id_counter)  # never reused (unlike id()): keys the host-side plan / pointer caches
 
 

@@ -10,8 +10,9 @@ B = 1 case.
 
 Host side of one call (what keeps ``d = step(mx, d)`` device-bound at B = 4096):
 
-* the written leaves of a call are ONE allocation (``torch.empty`` of the summed, 256-byte aligned sizes) -- fresh storage per
-  call, as the reference's ``update_`` of new tensors -- carved by a plan cached per (model, batch shape, dtype, stages); the
+* the written leaves of a call are TWO allocations (``torch.empty`` of the summed, 256-byte aligned sizes: the bulk, and a small one
+  for the state leaves callers keep across steps -- ``_SMALL_LEAVES`` -- so that a logged ``d.qpos`` does not pin ~50 KB per
+  environment) -- fresh storage per call, as the reference's ``update_`` of new tensors -- carved by a plan cached per (model, batch shape, dtype, stages); the
   returned ``Data`` materialises a leaf's tensor view only when somebody reads it (``container._carve``);
 * every ``Data`` carries a table of the raw device pointers of its leaves (``_PtrTab``) that follows it through ``replace`` /
   ``update_`` / attribute assignment: only leaves that changed are looked at (and validated) again, and the result of a step
@@ -54,6 +55,10 @@ _KEY = {n: native.DATA_PATH[n][-1] for n in _ALL_NAMES}          # field key ins
 _IN_CONTACT = [len(native.DATA_PATH[n]) == 2 for n in _ALL_NAMES]
 _CONTACT_IDX = frozenset(i for i in range(_NLEAF) if _IN_CONTACT[i])
 _ALIGN = 256
+# Leaves a rollout typically keeps per step (logging, replay buffers).  They get a small allocation of their own: every leaf of a
+# step's output is a view of the allocation it was carved from, so a kept `d.qpos` pins that whole allocation -- a few KB per
+# environment-row here, not the ~50 KB per environment of the full output (198 MB per kept humanoid step at B = 4096).
+_SMALL_LEAVES = frozenset("qpos qvel act time qacc qacc_warmstart sensordata".split())
 
 
 def _written_names(m: Model, step: bool):
@@ -177,7 +182,7 @@ def _table(d: Data, sig, counts, B: int, dtype, device, dest: bool = False) -> _
 class _Plan:
     """Where the leaves one call writes live inside its output slab (cached per model / batch shape / dtype / stages)."""
 
-    __slots__ = ("names", "widx", "wmask", "off", "total", "top", "con", "top_names", "con_names", "empties")
+    __slots__ = ("names", "widx", "wmask", "off", "total", "top", "con", "top_names", "con_names", "empties", "total_small", "widx_small", "widx_bulk")
 
 
 _PLANS = {}
@@ -201,7 +206,8 @@ def _plan(m: Model, d: Data, names, batch, dtype, device, plan_key) -> _Plan:
     p.wmask = np.zeros(_NLEAF, dtype=bool)
     p.off = np.zeros(_NLEAF, dtype=np.uint64)
     p.top, p.con, p.empties = [], [], {}
-    off = 0
+    off, off_small = 0, 0
+    small = np.zeros(_NLEAF, dtype=bool)
     con = d._fields["contact"]
     for n in names:
         i = _IDX[n]
@@ -213,12 +219,23 @@ def _plan(m: Model, d: Data, names, batch, dtype, device, plan_key) -> _Plan:
             p.empties[n] = torch.empty(shape, dtype=want, device=device)
             continue
         nbytes = nel * torch.empty((), dtype=want).element_size()
-        (p.con if _IN_CONTACT[i] else p.top).append((_KEY[n], off, nbytes, want, shape))
+        is_small = n in _SMALL_LEAVES
+        here = off_small if is_small else off
+        # spec: (which allocation: 0 bulk / 1 small, byte offset, byte length, dtype, shape)
+        (p.con if _IN_CONTACT[i] else p.top).append((_KEY[n], here, nbytes, want, shape, 1 if is_small else 0))
         p.wmask[i] = True
-        p.off[i] = off
-        off += (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        p.off[i] = here
+        small[i] = is_small
+        step_bytes = (nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        if is_small:
+            off_small += step_bytes
+        else:
+            off += step_bytes
     p.total = off
+    p.total_small = off_small
     p.widx = np.nonzero(p.wmask)[0]
+    p.widx_small = np.nonzero(p.wmask & small)[0]
+    p.widx_bulk = np.nonzero(p.wmask & ~small)[0]
     p.top_names = [s[0] for s in p.top] + [_KEY[n] for n in p.empties if not _IN_CONTACT[_IDX[n]]]
     p.con_names = [s[0] for s in p.con] + [_KEY[n] for n in p.empties if _IN_CONTACT[_IDX[n]]]
     if len(_PLANS) > 256:
@@ -264,41 +281,30 @@ def _stream_and_guard(device):
     return stream, None
 
 
-def _under_vmap(m, d, fixed_iterations, step, stages):
-    """``torch.vmap(lambda d: step(mx, d))(dx)`` -- the reference's batching idiom (README, benchmarks/_helpers.py:44-60).
-
-    Inside vmap every mapped leaf is a functorch BatchedTensor.  The native step is batched already, so the leaves are
-    unwrapped (mapped dimension moved to the front, unmapped leaves broadcast), stepped as ONE native batch and the result is
-    wrapped back at the same vmap level: the idiom costs one launch sequence, not a per-sample loop."""
-    F = torch._C._functorch
-    level = F.maybe_get_level(d.qpos)
-    raw = F.get_unwrapped(d.qpos)
-    if F.is_batchedtensor(raw):
-        raise NotImplementedError("nested torch.vmap over step is not supported: pass a Data with two leading batch dims instead")
-    B = raw.shape[F.maybe_get_bdim(d.qpos)]
-
-    def unwrap(t):
-        if F.is_batchedtensor(t) and F.maybe_get_level(t) == level:
-            return F.get_unwrapped(t).movedim(F.maybe_get_bdim(t), 0)
-        return t.unsqueeze(0).expand(B, *t.shape)
-
-    plain = d.map_tensors(unwrap)
-    object.__setattr__(plain, "_bs", (B, *plain._bs))
-    if isinstance(plain.contact, type(d.contact)):
-        object.__setattr__(plain.contact, "_bs", (B, *plain.contact._bs))
-    res = _run(m, plain, fixed_iterations, step, None, stages)
-    wrapped = res.map_tensors(lambda t: F._add_batch_dim(t, 0, level))
-    object.__setattr__(wrapped, "_bs", tuple(d._bs))
-    object.__setattr__(wrapped.contact, "_bs", tuple(d.contact._bs))
-    return wrapped
+def _plain(t) -> bool:
+    """False for tensors without storage of their own: functorch batched tensors (``torch.vmap``), fake / functional tensors."""
+    try:
+        t.data_ptr()
+        return True
+    except RuntimeError:
+        return False
 
 
 def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None = None, stages: int = native.STAGE_ALL) -> Data:
-    qpos = d.qpos
-    if torch._C._functorch.is_batchedtensor(qpos):
+    """Traced by Dynamo (``torch.compile``, also ``fullgraph=True``) or called under ``torch.vmap`` -- the reference's batching idiom
+    (README, benchmarks/_helpers.py:44-60, bench_compile.py:39-43): the call goes through ``torch.ops.mujoco_torch_amd.step_leaves``
+    (compile_op.py), whose vmap rule turns the mapped call into ONE native batch.  Plain tensors take the direct path below."""
+    if torch.compiler.is_compiling() or not _plain(d.qpos):
         if out is not None:
-            raise ValueError("step(..., out=) cannot be used under torch.vmap")
-        return _under_vmap(m, d, fixed_iterations, step, stages)
+            raise ValueError("step(..., out=) cannot be used under torch.compile / torch.vmap")
+        from . import compile_op
+
+        return compile_op.run_through_op(m, d, fixed_iterations, step, stages)
+    return _run_native(m, d, fixed_iterations, step, out, stages)
+
+
+def _run_native(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None = None, stages: int = native.STAGE_ALL) -> Data:
+    qpos = d.qpos
     _require_device(qpos.device)
     dtype = qpos.dtype
     if dtype not in (torch.float64, torch.float32):
@@ -321,8 +327,10 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
     out_arr = np.frombuffer(out_struct, dtype=np.uint64)
     if out is None:
         slab = torch.empty(plan.total, dtype=torch.uint8, device=device)
+        slabs = (slab, torch.empty(plan.total_small, dtype=torch.uint8, device=device))  # the commonly kept state leaves live apart (_SMALL_LEAVES)
         out_arr[:] = plan.off
-        out_arr[plan.widx] += np.uint64(slab.data_ptr())
+        out_arr[plan.widx_bulk] += np.uint64(slab.data_ptr())
+        out_arr[plan.widx_small] += np.uint64(slabs[1].data_ptr())
     else:
         if out is d:
             raise ValueError("step(..., out=d) with out being the input itself is not supported: use a second buffer (ping-pong)")
@@ -362,7 +370,7 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
         lz = {}
         object.__setattr__(res, "_lazy", lz)
     for sp in plan.top:
-        lz[sp[0]] = (slab, sp[1], sp[2], sp[3], sp[4])
+        lz[sp[0]] = (slabs[sp[5]], sp[1], sp[2], sp[3], sp[4])
     con = f["contact"]
     if plan.con or any(_IN_CONTACT[_IDX[n]] for n in plan.empties):
         con = con.clone(recurse=False)
@@ -376,7 +384,7 @@ def _run(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data | None
             clz = {}
             object.__setattr__(con, "_lazy", clz)
         for sp in plan.con:
-            clz[sp[0]] = (slab, sp[1], sp[2], sp[3], sp[4])
+            clz[sp[0]] = (slabs[sp[5]], sp[1], sp[2], sp[3], sp[4])
         f["contact"] = con
     for n, t in plan.empties.items():
         (con._fields if _IN_CONTACT[_IDX[n]] else f)[_KEY[n]] = t

@@ -1294,6 +1294,10 @@ class _Compiler:
                 limarr[i] = (has and self.autolimits) if lim == "auto" else _bool(lim)
             if "lengthrange" in a:
                 m.actuator_lengthrange[i] = _floats(a["lengthrange"])
+            elif m.actuator_gaintype[i] == GainType.MUSCLE or m.actuator_biastype[i] == BiasType.MUSCLE:
+                # (the <muscle> shortcut raised above; this is <general gaintype="muscle"> / biastype="muscle"): MuJoCo would compute the range by
+                # simulation (mj_setLengthRange); with (0, 0) the muscle's L0 is 0, clamped to mjMINVAL, and the forces are silently wrong
+                raise NotImplementedError(f"actuator {a.get('name', i)!r}: muscle gain / bias needs an explicit lengthrange (automatic length-range computation is not supported)")
             if m.actuator_dyntype[i] != DynType.NONE:
                 m.actuator_actadr[i] = na
                 m.actuator_actnum[i] = 1

@@ -16,6 +16,8 @@ import re
 import numpy as np
 import torch
 
+from .container import UnbatchedTensor
+
 from .io import model_float_leaves
 from .device import static_contact_fields
 
@@ -320,16 +322,25 @@ def _structure_key(opt):
 
 def _stamp(m):
     """Cheap per-call check that nothing pack_model reads has changed since the blob was cached ON THIS CONTAINER: container
-    versions (update_ / attribute assignment) and the in-place version counters of the tensor leaves."""
+    versions (update_ / attribute assignment) and the in-place version counters of every tensor leaf pack_model reads -- Model,
+    opt and stat (``stat.meaninertia`` is packed), plain or wrapped in an ``UnbatchedTensor``.  The opt / stat containers are
+    compared by identity through references held in the cache entry (an ``id()`` can be reused after garbage collection)."""
     opt, stat = m.opt, m.stat
     v = 0
-    for t in m._fields.values():
-        if isinstance(t, torch.Tensor):
-            v += t._version
-    for t in opt._fields.values():
-        if isinstance(t, torch.Tensor):
-            v += t._version
-    return (m.__dict__.get("_ver", 0), id(opt), opt.__dict__.get("_ver", 0), id(stat), stat.__dict__.get("_ver", 0), v)
+    for c in (m, opt, stat):
+        for t in c._fields.values():
+            if isinstance(t, UnbatchedTensor):
+                t = t.data
+            if isinstance(t, torch.Tensor):
+                v += t._version
+    return (m.__dict__.get("_ver", 0), opt, opt.__dict__.get("_ver", 0), stat, stat.__dict__.get("_ver", 0), v)
+
+
+def _same_stamp(a, b):
+    return a[0] == b[0] and a[1] is b[1] and a[2] == b[2] and a[3] is b[3] and a[4] == b[4] and a[5] == b[5]
+
+
+_NATIVE_LRU = 4  # blobs the shared tables keep alive on their own (most recently used); every Model also holds the one it stepped
 
 
 def _desc_digest(desc, keep):
@@ -353,7 +364,7 @@ def get_native_model(m, device: torch.device, dtype: torch.dtype) -> NativeModel
     local = m.__dict__.get("_native_cache")
     if local is not None:
         hit = local.get(key)
-        if hit is not None and hit[0] == stamp:
+        if hit is not None and _same_stamp(hit[0], stamp):
             return hit[1]
     T = m.tables
     built = getattr(T, "structure_key", None)
@@ -367,7 +378,18 @@ def get_native_model(m, device: torch.device, dtype: torch.dtype) -> NativeModel
     nm = T.native.get(shared_key)
     if nm is None:
         nm = NativeModel(desc, keep, torch.device(device.type, key[0]) if key[0] >= 0 else device, dtype)
+        # RK4 workspaces are sized by the model's STRUCTURE (leaf counts), not its values: one pool per tables object and (device, dtype), so
+        # per-episode domain randomisation (mx.replace(body_mass=...)) re-uses the same scratch instead of growing a pool per blob
+        nm._work = T.__dict__.setdefault("_workspaces", {}).setdefault((key, nm.work_bytes), {})
         T.native[shared_key] = nm
+    # T.native holds blobs weakly: one lives as long as a Model that stepped it (its _native_cache) does, so `mx.replace(body_mass=...)` per
+    # episode frees the previous episode's blob with its Model instead of leaking device memory.  The few most recently used ones are also
+    # held strongly, so alternating between a handful of value sets through fresh `replace` results does not rebuild every time.
+    recent = T.native_recent
+    recent.pop(shared_key, None)
+    recent[shared_key] = nm
+    while len(recent) > _NATIVE_LRU:
+        recent.popitem(last=False)
     if local is None:
         local = {}
         object.__setattr__(m, "_native_cache", local)

@@ -9,6 +9,9 @@ tensordict-free ``MjTensorClass`` of ``container.py``.
 from __future__ import annotations
 
 import numpy as np
+import itertools
+import weakref
+
 import torch
 
 from ._enums import (  # noqa: F401  (re-exported: the reference exposes them from types)
@@ -99,6 +102,10 @@ MODEL_FIELDS = (
 )
 
 
+_MODEL_KEYS = itertools.count(1)
+_MODELS_BY_KEY = weakref.WeakValueDictionary()
+
+
 class Model(MjTensorClass):
     """Static model.  Leaves named in ``MODEL_FIELDS`` plus derived host tables (``device.py``)."""
 
@@ -138,6 +145,12 @@ class Model(MjTensorClass):
     def tables(self):
         """Host-side static tables (contact order, static contact params, native descriptors)."""
         return self.__dict__["_tables"]
+
+    def _post_init(self):
+        # every Model gets a process-unique integer: `torch.ops.mujoco_torch_amd.step_leaves` (compile_op.py) takes it as a plain int argument
+        # and finds the Model again through a weak registry -- a custom op cannot take a container
+        object.__setattr__(self, "_op_key", next(_MODEL_KEYS))
+        _MODELS_BY_KEY[self._op_key] = self
 
 
 # attach the by-name leaves as annotations so they are real fields

@@ -280,13 +280,30 @@ def test_vmap_idiom_is_one_native_batch():
     got = torch.vmap(lambda x: mt.step(mdev, x.replace(ctrl=ctrl)))(dg)
     want = mt.step(mdev, dg.replace(ctrl=ctrl.expand(B, -1).clone()))
     assert torch.equal(got.qvel, want.qvel)
-    with pytest.raises(NotImplementedError):
-        torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))
-    # the reference's published mode, benchmarks/bench_compile.py:39-43: compile(vmap(step)) -- Dynamo finds nothing to fuse and hands
-    # the call to the same native batch
-    compiled = torch.compile(torch.vmap(lambda x: mt.step(mdev, x)))
+    two = torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))   # nested maps: one native batch of 2 x 4
+    assert tuple(two.qpos.shape) == (2, 4, mx.nq) and torch.equal(two.qpos.reshape(8, -1), mt.step(mdev, dg[:8].clone()).qpos)
+
+
+def test_fullgraph_compile_of_vmap_step_is_the_native_batch():
+    """The reference's published mode verbatim -- `torch.compile(torch.vmap(lambda d: step(mx, d)), fullgraph=True)`
+    (benchmarks/bench_compile.py:39-43) -- traces without a graph break: `step` reaches Dynamo as ONE opaque operator
+    (`mujoco_torch_amd::step_leaves`, compile_op.py) whose vmap rule is the native batch.  Bit-equal to the direct call, every leaf,
+    and the returned container feeds the next compiled call."""
+    mx = load_model("humanoid", {"solver": 1})
+    B = 32
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(3).randn(B, mx.nv)))
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    want = mt.step(mdev, dg)
+    compiled = torch.compile(torch.vmap(lambda x: mt.step(mdev, x)), fullgraph=True)
     got = compiled(dg)
-    assert torch.equal(got.qpos, mt.step(mdev, dg).qpos) and torch.equal(compiled(got).qvel, mt.step(mdev, mt.step(mdev, dg)).qvel)
+    for n in REAL_LEAVES + INT_LEAVES:
+        assert torch.equal(leaf(got, n), leaf(want, n)), n
+    assert tuple(got.batch_size) == (B,) and int(got.ncon) == int(want.ncon)
+    assert torch.equal(compiled(got).qvel, mt.step(mdev, want).qvel)
+    plain = torch.compile(lambda x: mt.step(mdev, x), fullgraph=True)(dg)    # without vmap: the batched Data straight through the operator
+    assert torch.equal(plain.qpos, want.qpos) and torch.equal(plain.efc_force, want.efc_force)
+    fwd = torch.compile(torch.vmap(lambda x: mt.forward(mdev, x)), fullgraph=True)(dg)
+    assert torch.equal(fwd.qacc, mt.forward(mdev, dg).qacc)
 
 
 @pytest.mark.parametrize("scale,batch,nsteps", [(2.0, 64, 500), (50.0, 16, 200)])

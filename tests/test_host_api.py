@@ -64,6 +64,12 @@ def test_unsupported_features_raise_not_implemented():
     lite.geom_condim[3] = 2
     with pytest.raises(NotImplementedError):
         mt.device_put(lite)
+    # a <general> actuator with muscle gain / bias and no lengthrange: MuJoCo would compute the range; (0, 0) would give silently wrong forces
+    xml = """<mujoco><worldbody><body><joint name="j" type="hinge"/><geom size="0.1"/></body></worldbody>
+             <actuator><general joint="j" gaintype="muscle" biastype="muscle" dyntype="muscle"/></actuator></mujoco>"""
+    with pytest.raises(NotImplementedError, match="lengthrange"):
+        mt.mjcf.from_xml_string(xml)
+    assert mt.mjcf.from_xml_string(xml.replace('dyntype="muscle"', 'dyntype="muscle" lengthrange="0.1 0.4"')).actuator_lengthrange[0, 1] == 0.4
 
 
 def mx_path(name):

@@ -248,7 +248,77 @@ def test_compile_and_vmap_wrappers_run_the_native_step(sim):
     mx = load_model("hopper")
     d = seeded(mx, 4)
     want = mt.step(mx, d)
-    for wrap in (torch.vmap(lambda x: mt.step(mx, x)), torch.compile(torch.vmap(lambda x: mt.step(mx, x))), torch.compile(lambda x: mt.step(mx, x))):
+    for wrap in (torch.vmap(lambda x: mt.step(mx, x)), torch.compile(torch.vmap(lambda x: mt.step(mx, x)), fullgraph=True),
+                 torch.compile(lambda x: mt.step(mx, x), fullgraph=True)):
         got = wrap(d)
         assert tuple(got.batch_size) == (4,) and torch.equal(got.qpos, want.qpos) and torch.equal(got.contact.dist, want.contact.dist)
+        assert_same(got, pyoracle.run(mx, d, step=True))
+        assert list(k for k, _ in got.items()) == list(k for k, _ in d.items())
         assert torch.equal(wrap(got).qpos, mt.step(mx, want).qpos)
+    two = torch.vmap(torch.vmap(lambda x: mt.step(mx, x)))(torch.stack([d[:2], d[2:]]))  # nested maps are one 2 x 2 native batch
+    assert torch.equal(two.qpos.reshape(4, -1), want.qpos)
+    ctrl = torch.full((mx.nu,), 0.25, dtype=torch.float64)                                # a closed-over, unmapped leaf is broadcast
+    got = torch.vmap(lambda x: mt.step(mx, x.replace(ctrl=ctrl)))(d)
+    assert torch.equal(got.qvel, mt.step(mx, d.replace(ctrl=ctrl.expand(4, -1).clone())).qvel)
+
+
+def test_kept_state_leaves_do_not_pin_the_whole_step_output(sim):
+    """every leaf of a step's output is a view of an allocation shared with other leaves; the leaves a rollout keeps
+    (qpos, qvel, act, time, qacc, qacc_warmstart, sensordata) come from a small allocation of their own, so a logged `d.qpos` holds a
+    few hundred bytes per environment, not the ~50 KB per environment of the full output."""
+    mx = load_model("humanoid", {"solver": 1})
+    B = 8
+    got = mt.step(mx, seeded(mx, B))
+    small = got.qpos.untyped_storage().nbytes()
+    bulk = got.efc_J.untyped_storage().nbytes()
+    assert got.qpos.untyped_storage().data_ptr() == got.qvel.untyped_storage().data_ptr() != got.xpos.untyped_storage().data_ptr()
+    assert small <= B * 8 * (mx.nq + 4 * mx.nv + 64 * 7) and bulk > 20 * small
+    for n in ("qpos", "qvel", "qacc", "qacc_warmstart", "time"):
+        assert getattr(got, n).untyped_storage().nbytes() == small
+
+
+def test_blobs_of_replaced_models_are_released_with_their_models(sim):
+    """`mx.replace(body_mass=...)` per episode must not grow the shared blob table without bound: blobs are held weakly by
+    the table (strongly by the Models that stepped them and by a four-entry most-recently-used list)."""
+    import gc
+
+    mx = load_model("hopper")
+    d = seeded(mx, 2)
+    mt.step(mx, d)
+    T = mx.tables
+    for k in range(12):
+        mt.step(mx.replace(body_mass=mx.body_mass * (1.0 + 0.01 * (k + 1))), d)
+    gc.collect()
+    assert len(T.native_recent) <= 4 and len(T.native) <= 5   # the most recent four + the original (alive through mx itself)
+    built = sim.built
+    mt.step(mx, d)                                             # ... which still steps without a rebuild
+    assert sim.built == built
+
+
+def test_in_place_edits_of_stat_are_seen(sim):
+    """`stat.meaninertia` is packed into the blob; an in-place edit has to rebuild it."""
+    mx = load_model("hopper")
+    d = seeded(mx, 2)
+    mt.step(mx, d)
+    built = sim.built
+    mx.stat.update_(meaninertia=torch.tensor(float(mx.stat.meaninertia) * 3.0, dtype=torch.float64))   # the reference keeps it as a tensor leaf
+    got = mt.step(mx, d)
+    assert sim.built == built + 1
+    assert_same(got, pyoracle.run(mx, d, step=True))
+    mx.stat.meaninertia.mul_(0.5)                                                                        # ... edited in place
+    got = mt.step(mx, d)
+    assert sim.built == built + 2
+    assert_same(got, pyoracle.run(mx, d, step=True))
+
+
+def test_step_output_has_the_treespec_of_its_input(sim):
+    """`_order` / ncon / nefc made the pytree context of a step's output differ from its input's."""
+    from torch.utils import _pytree
+
+    mx = load_model("hopper")
+    d = seeded(mx, 2)
+    got = mt.step(mx, d)
+    s0, s1 = _pytree.tree_structure(d), _pytree.tree_structure(got)
+    assert s0 == s1
+    summed = _pytree.tree_map(lambda a, b: a + b, d, got)
+    assert torch.equal(summed.qpos, d.qpos + got.qpos)
