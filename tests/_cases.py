@@ -24,11 +24,11 @@ SEEDED_CASES = [
     ("humanoid", {"solver": 1}, F64, 256, dict(max_alt=0.40)),
     ("humanoid", {}, F64, 64, dict(max_alt=0.65)),
     ("humanoid", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 64, dict(max_alt=0.0)),   # converged: branches re-converge
-    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 128, {}),          # BASELINE config 3
+    ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 128, dict(tol_sol=5e-6)),  # BASELINE config 3 (measured 3.9e-7)
     ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F64, 64, dict(max_alt=0.0)),
     ("ant", {}, F64, 64, dict(max_alt=0.0)),
     ("cartpole", {}, F64, 64, dict(max_alt=0.0)),
-    ("mesh_contact", {}, F32, 256, {}),                                         # BASELINE config 5 (box + mesh, condim 6, Newton, float32)
+    ("mesh_contact", {}, F32, 256, dict(tol_sol=5e-4)),                         # BASELINE config 5 (box + mesh, condim 6, Newton, float32; measured 5.8e-5)
     ("mesh_contact", {}, F64, 64, dict(max_alt=0.0)),
     # CG on a piecewise-quadratic cost does not reach 1e-8: it ends where a line search stops improving the cost (improvement <
     # tolerance, solver.py:501-508) with the scaled gradient still ~1e-6, and two correct implementations end at points that far
@@ -47,7 +47,8 @@ SEEDED_CASES = [
     ("halfcheetah", {}, F64, 64, dict(max_alt=0.0)),
     ("hopper", {}, F64, 64, dict(max_alt=0.0)),
     ("equality_loops", {}, F64, 64, dict(max_alt=0.0)),                         # equality rows: closed loop, weld, joint couplings
-    ("equality_loops", {"integrator": 1, "solver": 1}, F64, 32, dict(tol_sol=1e-3)),  # RK4 + CG stalling in each of four solves on stiff always-active rows (cond 2.5e2; measured 6e-5 .. 1.1e-4 depending on the summation order of the build; Newton one line up: 2e-13)
+    # (equality_loops with RK4 + CG -- four stalling solves on stiff always-active rows per step -- is covered by the PROPERTY it has, not by
+    # a loose bound: tests/test_gpu_parity.py::test_stalling_cg_stays_inside_the_oracles_own_band)
     ("equality", {}, F64, 32, dict(max_alt=0.0)),                               # bundled: site-form constraints carried inactive
     ("ant", {"disableflags": 1 << 4}, F64, 32, dict(max_alt=0.0)),              # disable flags (test/constraint_test.py:148-200): contacts off
     ("humanoid", {"disableflags": 1}, F64, 32, dict(max_alt=0.0)),              # ... every constraint off (nefc = 0)
@@ -118,7 +119,7 @@ def seeded_batch(xml, overrides, dtype, B):
 # the differential campaign of round 1 (tools/fuzz_parity.py): big perturbations, every input leaf randomised
 FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("humanoid", {"solver": 1}, F64, 1e-8), ("humanoid", {}, F64, 1e-8), ("humanoid", {"iterations": 20, "ls_iterations": 20}, F32, 5e-3),
-    ("ant", {}, F64, 1e-7), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 5e-3), ("ant", {"solver": 1, "cone": 1}, F64, 1e-5),
+    ("ant", {}, F64, 1e-8), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 5e-3), ("ant", {"solver": 1, "cone": 1}, F64, 1e-5),
     ("halfcheetah", {}, F64, 1e-8), ("hopper", {}, F64, 1e-8), ("walker2d", {"integrator": 1}, F64, 1e-8),
     ("swimmer", {"viscosity": 0.05}, F64, 1e-8), ("cartpole", {}, F64, 1e-8), ("satellite_small", {}, F64, 1e-8),
     ("sensor_rig", {}, F64, 1e-8), ("mesh_contact", {}, F64, 1e-8), ("mesh_contact", {"integrator": 1}, F64, 1e-8), ("convex_primitives", {}, F64, 1e-8),
@@ -126,7 +127,15 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("tendon_fixed", {}, F64, 1e-8), ("gravcomp_arm", {}, F64, 1e-8), ("gravcomp_arm", {"integrator": 1}, F64, 1e-8), ("ball_free_actuators", {}, F64, 1e-8),
     ("mocap_target", {}, F64, 1e-8), ("pendula", {}, F64, 1e-8), ("pendula", {"integrator": 1, "solver": 1}, F32, 5e-3),
     ("frictionloss_dof", {}, F64, 1e-8), ("ant_frictionloss", {}, F64, 1e-8),
+    ("muscle_arm", {}, F64, 1e-8), ("tendon_armature", {}, F64, 1e-8), ("tendon_friction", {}, F64, 1e-8), ("capsules_topk", {}, F64, 1e-8),
 ]
+# float32 cases of the campaign: near-degenerate contact normals amplify eps under these perturbations (pre-solver 1e-3); qfrc_constraint /
+# efc_force of the ant cancel forces of ~1e5, the dynamics leaves carry the comparison there
+FUZZ_TOL_PRE = {F64: 1e-9, F32: 1e-3}
+# convex_primitives under the campaign's perturbations runs Newton into its 10-iteration cap on ~0.6 % of the environments: the reference's own
+# admissible outcomes are 2e-6 .. 0.76 apart there (tests/test_oracle_golden.py::test_iteration_capped_newton_states_are_implementation_defined,
+# test_pinned_campaign_outliers): those environments are held to the oracle's own spread instead (band), the rest to 1e-8
+FUZZ_BAND = {"convex_primitives": 4.0}
 
 
 def fuzz_batch(xml, overrides, dtype, B):

@@ -80,6 +80,21 @@ def leaf(d, name):
 SOLVER_FLOOR = 1e-3  # solver outputs (accelerations, forces) are O(1..1e3); below 1e-3 they are solver-tolerance noise
 
 
+def solver_floor(name, want_env):
+    """Scale floor of one solver leaf of ONE environment.  qfrc_constraint = J^T efc_force is a sum of force terms that can cancel
+    (the ant's four always-penetrating leg pairs carry 3.5e5 each and cancel to 1e-11 of rounding residue): its error is read on the
+    scale of the forces it is made of, not on the scale of what is left of them."""
+    if name == "qfrc_constraint":
+        f = np.asarray(want_env["efc_force"], dtype=np.float64)
+        return max(SOLVER_FLOOR, float(np.abs(f).max()) if f.size else 0.0)
+    return SOLVER_FLOOR
+
+
+def solver_err(got_env, want_env, names=None):
+    """Worst per-leaf error of the solver-dependent leaves of one environment (got_env / want_env: {leaf: array of that environment})."""
+    return max(rel_err(got_env[n], want_env[n], solver_floor(n, want_env)) for n in (names or SOLVER_LEAVES))
+
+
 def rel_err(got, want, floor=1e-6):
     if np.asarray(want).dtype == np.float32:
         floor = max(floor, 1e-3)  # float32 leaves that are all cancellation residue (|x| ~ 1e-8 from O(1) terms) carry no relative information
@@ -178,11 +193,16 @@ def compare_with_oracle(model, d_cpu, got, step=True, **kw):
     batched = d_cpu.qpos.ndim > 1
     B = d_cpu.qpos.shape[0] if batched else 1
     err_nat, err_best, which = np.zeros(B), np.zeros(B), np.zeros(B, dtype=np.int32)
+    need = set(SOLVER_LEAVES) | {"efc_force"}
+    env_of = (lambda a, e: {n: a[n][e] for n in need}) if batched else (lambda a, e: {n: a[n] for n in need})
+    leaf_nat = {n: 0.0 for n in SOLVER_LEAVES}
     for e in range(B):
-        pick = (lambda a, n: a[n][e]) if batched else (lambda a, n: a[n])
-        errs = [max(rel_err(pick(got, n), pick(a, n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for a in alts]
+        ge = env_of(got, e)
+        errs = [solver_err(ge, env_of(a, e)) for a in alts]
         err_nat[e], err_best[e], which[e] = errs[0], min(errs), int(np.argmin(errs))
-    leaf_nat = {n: rel_err(got[n], nat[n], SOLVER_FLOOR) for n in SOLVER_LEAVES}
+        ne = env_of(nat, e)
+        for n in SOLVER_LEAVES:
+            leaf_nat[n] = max(leaf_nat[n], rel_err(ge[n], ne[n], solver_floor(n, ne)))
     return dict(pre=pre, pre_worst=max(pre.values()) if pre else 0.0, ints_ok=ints_ok, err_nat=err_nat, err_best=err_best, which=which,
                 n_alts=len(alts), tie_pairs=tie_pairs, leaf_nat=leaf_nat, alts=alts, knife=knife)
 
@@ -210,8 +230,9 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
     if band is not None:
         batched = d_cpu.qpos.ndim > 1
         for e in np.nonzero(c["err_best"] > tol_solver)[0]:
-            pick = (lambda a, n: a[n][e]) if batched else (lambda a, n: a[n])
-            spread = max(max(rel_err(pick(a, n), pick(c["alts"][0], n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for a in c["alts"])
+            need = set(SOLVER_LEAVES) | {"efc_force"}
+            env_of = (lambda a: {n: a[n][e] for n in need}) if batched else (lambda a: {n: a[n] for n in need})
+            spread = max(solver_err(env_of(a), env_of(c["alts"][0])) for a in c["alts"])
             assert c["knife"][e] >= 2 and c["err_best"][e] <= band * spread, f"{what} env {e}: error {c['err_best'][e]:.2e} outside {band} x the oracle's own spread {spread:.2e} (knife {c['knife'][e]})"
             c["err_best"][e] = 0.0
             c["err_nat"][e] = np.inf  # counted as off the natural branch
@@ -233,6 +254,26 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
         tied = int((c["tie_pairs"] > 0).sum())
         assert tied / B <= max_tie_frac, f"{what}: {tied}/{B} envs needed a non-natural narrow-phase tie outcome (bound {max_tie_frac})"
     return need_alt / B, float(c["err_best"].max())
+
+
+def solve_cost(model, out):
+    """The objective the constraint solver minimises (solver.py:320-357), evaluated per environment at ``out["qacc"]`` from the leaves of
+    the same forward pass: 1/2 (a - a_smooth)^T M (a - a_smooth) + sum over active rows of 1/2 D (J a - aref)^2, equality rows always
+    active, the others where J a - aref < 0.  Models without frictionloss rows only.  ``out``: {leaf: array [B, ...]}."""
+    ne, nf, nl, ncon, nefc = model.constraint_sizes_py
+    assert nf == 0, "frictionloss rows have a piecewise cost of their own"
+    a = np.asarray(out["qacc"], dtype=np.float64)
+    B, nv = a.shape
+    M = np.asarray(out["qM"], dtype=np.float64).reshape(B, nv, nv)
+    da = a - np.asarray(out["qacc_smooth"], dtype=np.float64)
+    cost = 0.5 * np.einsum("bi,bij,bj->b", da, M, da)
+    if nefc:
+        J = np.asarray(out["efc_J"], dtype=np.float64).reshape(B, nefc, nv)
+        r = np.einsum("brj,bj->br", J, a) - np.asarray(out["efc_aref"], dtype=np.float64)
+        act = r < 0
+        act[:, :ne] = True
+        cost = cost + 0.5 * (np.asarray(out["efc_D"], dtype=np.float64) * r * r * act).sum(1)
+    return cost
 
 
 def load_outlier(name, extra_overrides=None):
@@ -260,5 +301,5 @@ def policy_spread(model, d, **kw):
     spread = 0.0
     for pol in range(MAX_KNIFE_POLICIES):
         o = pyoracle.run(model, d, knife_policy=pol, **kw)
-        spread = max(spread, max(rel_err(o[n], nat[n], SOLVER_FLOOR) for n in SOLVER_LEAVES))
+        spread = max(spread, solver_err(o, nat))
     return spread, int(knife[0])

@@ -11,11 +11,17 @@ import torch
 
 import mujoco_torch_amd as mt
 import pyoracle
-from _cases import SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, seeded_batch
-from _util import (OUTLIER_CASES, compare_with_oracle, load_outlier, policy_spread, CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+from _cases import FUZZ_BAND, FUZZ_CASES, FUZZ_TOL_PRE, SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, fuzz_batch, seeded_batch
+from _util import (solve_cost, solver_err, OUTLIER_CASES, compare_with_oracle, load_outlier, policy_spread, CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
 
 pytestmark = pytest.mark.gpu
+
+
+# goldens whose HIP step may legitimately land on another admissible branch than the one the reference's rounding took: the one-iteration
+# humanoid recordings (line search cut on its knife edge) and CG stalling on the stiff equality rows.  Every other golden is a
+# converged solve: the HIP step must reproduce the recorded numbers directly, without the oracle's help.
+VIA_ORACLE_ALLOWED = {"humanoid_cg_f64", "humanoid_cg_f64_perturbed", "humanoid_cg_fixed_f64", "humanoid_newton_f64", "humanoid_cg_f32", "equality_loops_cg_f64"}
 
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
@@ -26,7 +32,7 @@ def test_step_matches_reference_golden(case, oracle_lib):
     mdev = g.model.to("cuda")
     d = g.input_data()  # all envs batched
     tol_pre, tol_sol = TOL_PRE[g.dtype], max(TOL_SOL[g.dtype], CASE_TOL_SOL.get(case, 0.0))
-    via_oracle = 0
+    via_oracle, detail = 0, []
     for s in range(g.nsteps):
         out = gpu_out_to_numpy(mt.step(mdev, d.to("cuda"), fixed_iterations=g.fixed_iterations))
         want = lambda n: np.stack([g.expected(e, s, n) for e in range(g.nenv)])
@@ -34,14 +40,17 @@ def test_step_matches_reference_golden(case, oracle_lib):
         assert_ints_equal(lambda n: out[n], want, what=what)
         for e in range(g.nenv):
             err_pre = max(rel_err(out[n][e], g.expected(e, s, n)) for n in PRE_SOLVER)
-            err_gold = max(rel_err(out[n][e], g.expected(e, s, n), SOLVER_FLOOR) for n in SOLVER_LEAVES)
+            err_gold = solver_err({n: out[n][e] for n in SOLVER_LEAVES}, {n: g.expected(e, s, n) for n in SOLVER_LEAVES})
             if err_pre > tol_pre or err_gold > tol_sol:
                 # not the branch the reference's rounding took: it must still be an admissible outcome of the same
                 # algorithm (line-search noise candidates, narrow-phase index ties), which the oracle verifies
                 via_oracle += 1
+                if err_pre <= tol_pre:  # same problem data as the recording (no narrow-phase tie upstream), another solver end point
+                    detail.append((s, e, float(f"{err_pre:.2e}"), float(f"{err_gold:.2e}")))
                 check_against_oracle(g.model, d[e], {n: out[n][e] for n in out}, tol_pre, tol_sol, what=f"{what} env{e}", fixed_iterations=g.fixed_iterations)
         d = pyoracle.apply(d, {n: want(n) for n in REAL_LEAVES + INT_LEAVES})
     print(f"{case}: {via_oracle}/{g.nsteps * g.nenv} env-steps verified through an admissible oracle branch instead of the golden one")
+    assert not detail or case in VIA_ORACLE_ALLOWED, f"{case}: a converged solve left the recorded branch on (step, env, pre-solver err, solver err) {detail}"
 
 
 @pytest.mark.parametrize("case", SEEDED_CASES, ids=case_id)
@@ -59,6 +68,46 @@ def test_step_matches_oracle_on_seeded_batch(case, oracle_lib):
         frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4,
                                            max_alt_frac=bounds.get("max_alt", 1.0), max_tie_frac=bounds.get("max_tie", 1.0), band=bounds.get("band"))
         print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural line-search branch, worst solver rel err {worst:.2e}")
+        dg = og
+
+
+@pytest.mark.parametrize("case", FUZZ_CASES, ids=lambda c: f"{c[0]}-{'-'.join(f'{k}{v}' for k, v in c[1].items()) or 'default'}-{str(c[2])[6:]}")
+def test_differential_campaign(case, oracle_lib):
+    """The differential campaign inside the suite: every input leaf randomised -- joint angles, un-normalised quaternions,
+    velocities, controls, applied forces, warm starts, mocap poses, equality switches -- with far larger perturbations than the seeded
+    cases; 128 environments x 2 steps per (model, options, dtype), each step checked leaf by leaf against the oracle at the bounds of
+    tests/_cases.py (float64: 1e-8 on the accepted branch unless the case states a measured reason)."""
+    xml, overrides, dtype, tol_sol = case
+    mx, d = fuzz_batch(xml, overrides, dtype, 128)
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    for s in range(2):
+        og = mt.step(mdev, dg)
+        frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), FUZZ_TOL_PRE[dtype], tol_sol, what=f"{xml} step{s}", nthreads=4, band=FUZZ_BAND.get(xml))
+        print(f"{xml} {overrides} step {s}: {frac:.1%} envs on a non-natural branch, worst solver rel err {worst:.2e}")
+        dg = og
+
+
+def test_stalling_cg_stays_inside_the_oracles_own_band(oracle_lib):
+    """RK4 + CG on the closed loops of equality_loops: CG on a piecewise-quadratic cost ends where a line search stops improving the cost
+    (solver.py:501-508) with the scaled gradient still ~1e-6, four times per step, and two correct implementations end 6e-5 .. 1e-4 apart in
+    qacc along the cost's flat directions (Newton on the same scene agrees to 2e-13, tests/_cases.py).  What they DO share is tested instead of
+    a loose bound on the end point: everything upstream of the solver at 1e-9, integer leaves exactly, the OBJECTIVE at the two
+    end points to 1e-8 of its scale (both are minimisers to second order in their gradients), and the state within the stall accuracy."""
+    mx, d = seeded_batch("equality_loops", {"integrator": 1, "solver": 1}, torch.float64, 32)
+    mdev, dg = mx.to("cuda"), d.to("cuda")
+    for s in range(3):
+        og = mt.step(mdev, dg)
+        out = gpu_out_to_numpy(og)
+        nat = pyoracle.run(mx, dg.cpu(), step=True, nthreads=4)
+        assert_leaves_close(lambda n: out[n], lambda n: nat[n], 1e-9, names=PRE_SOLVER, what=f"equality_loops rk4 cg step{s}")
+        assert_ints_equal(lambda n: out[n], lambda n: nat[n], what=f"step{s}")
+        c_nat = solve_cost(mx, nat)
+        c_hip = solve_cost(mx, dict(nat, qacc=out["qacc"]))   # the HIP end point in the oracle's problem data (equal to 1e-9 above)
+        scale = np.maximum(np.abs(c_nat), 1e-3)
+        assert (np.abs(c_hip - c_nat) <= 1e-8 * scale).all(), f"step{s}: objective at the HIP end point differs: {np.abs(c_hip - c_nat).max():.2e} (scale {scale.max():.2e})"
+        e_state = max(rel_err(out[n], nat[n], SOLVER_FLOOR) for n in ("qpos", "qvel"))
+        assert e_state <= 1e-4, f"step{s}: state {e_state:.2e} beyond the stall accuracy of four CG solves"
+        print(f"step {s}: objective gap {np.abs(c_hip - c_nat).max() / scale.max():.1e}, qacc gap {rel_err(out['qacc'], nat['qacc'], SOLVER_FLOOR):.1e}, state gap {e_state:.1e}")
         dg = og
 
 

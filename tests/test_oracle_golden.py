@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import pyoracle
-from _util import (OUTLIER_CASES, load_outlier, policy_spread, CASE_TOL_SOL, HINT_LEAVES, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
+from _util import (solver_err, OUTLIER_CASES, load_outlier, policy_spread, CASE_TOL_SOL, HINT_LEAVES, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, oracle_alternatives, rel_err)
 
 # float64: the oracle follows the reference's operation order, differences are summation order in
@@ -33,7 +33,8 @@ def test_oracle_matches_reference_golden(case, oracle_lib):
             alts = oracle_alternatives(g.model, d, hint={n: want(n) for n in HINT_LEAVES}, fixed_iterations=g.fixed_iterations)
             assert_leaves_close(lambda n: alts[0][n], want, tol, names=PRE_SOLVER, what=what)
             assert_ints_equal(lambda n: alts[0][n], want, what=what)
-            errs = [max(rel_err(o[n], want(n), SOLVER_FLOOR) for n in SOLVER_LEAVES) for o in alts]
+            gold = {n: want(n) for n in SOLVER_LEAVES}
+            errs = [solver_err(o, gold) for o in alts]
             assert min(errs) <= CASE_TOL_SOL.get(case, tol), f"{what}: solver outputs match no admissible branch, errors {errs}"
             natural += errs[0] <= tol
             total += 1

@@ -20,7 +20,7 @@ import torch  # noqa: E402
 
 import mujoco_torch_amd as mt  # noqa: E402
 from _cases import seeded_batch  # noqa: E402
-from _util import INT_LEAVES, PRE_SOLVER, SOLVER_FLOOR, SOLVER_LEAVES, compare_with_oracle, gpu_out_to_numpy, rel_err  # noqa: E402
+from _util import INT_LEAVES, PRE_SOLVER, SOLVER_LEAVES, compare_with_oracle, gpu_out_to_numpy, rel_err, solver_floor  # noqa: E402
 
 CONFIGS = {
     "config2_humanoid_f64_euler_cg": ("humanoid", {"solver": 1}, torch.float64, 1024),
@@ -30,7 +30,7 @@ CONFIGS = {
     "config2_twin_f64_of_config5": ("mesh_contact", {}, torch.float64, 256),
 }
 out = {"reference": "CPU oracle (oracle/mjoracle.c), pinned bit-for-bit-reproducibly by goldens recorded from the reference's own Python step; MJX parity unpinned (no jax / mujoco offline)",
-       "metric": "max-norm relative error per leaf, |got - want|max / max(|want|max, floor); floor 1e-6 (1e-3 for solver leaves and float32)",
+       "metric": "max-norm relative error per leaf, |got - want|max / max(|want|max, floor); floor 1e-6 (1e-3 for solver leaves and float32; qfrc_constraint on the scale of the environment's largest |efc_force|)",
        "git_commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or os.environ.get("MJH_GIT_COMMIT"),
        "configs": {}, "summary": {}}
 for name, (xml, ov, dt, B) in CONFIGS.items():
@@ -43,7 +43,7 @@ for name, (xml, ov, dt, B) in CONFIGS.items():
         c = compare_with_oracle(mx, dg.cpu(), got, nthreads=32)
         best = {}
         for n in SOLVER_LEAVES:  # per leaf on each environment's accepted branch
-            best[n] = max(rel_err(got[n][e], c["alts"][int(c["which"][e])][n][e], SOLVER_FLOOR) for e in range(B))
+            best[n] = max(rel_err(got[n][e], c["alts"][int(c["which"][e])][n][e], solver_floor(n, {"efc_force": c["alts"][int(c["which"][e])]["efc_force"][e]})) for e in range(B))
         steps.append({"pre_solver_leaves": {n: c["pre"][n] for n in PRE_SOLVER}, "integer_leaves_bit_exact": bool(c["ints_ok"]),
                       "solver_leaves_vs_natural_oracle_run": c["leaf_nat"], "solver_leaves_on_accepted_branch": best,
                       "envs_on_non_natural_branch": float((c["err_nat"] > (1e-8 if dt == torch.float64 else 2e-3)).mean()),
