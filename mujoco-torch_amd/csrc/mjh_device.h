@@ -12,7 +12,7 @@
 #include "../../include/mjhip.h"
 
 #define MJH_WAVE 64
-#define MJH_MAX_DEPTH 32
+#define MJH_MAX_DEPTH 128
 
 // ---- constants (reference reads them from the mujoco package) ---------------------------------
 #define mjMINVAL 1e-15
@@ -122,8 +122,9 @@ struct DevModel {
   const int* body_depth;       // nbody: number of non-world ancestors-or-self
   const int* body_chain;       // nbody*max_depth: chain[b][k] = k-th body on the path world -> b (k=0: child of world)
   const int* body_subtree_end; // nbody: one past the last body of b's subtree (bodies are in DFS order)
-  const unsigned long long* body_dofmask;  // nbody: dofs whose body is an ancestor-or-self of b
-  const unsigned long long* dof_ancmask;   // nv: dofs that are ancestor-or-self of dof d
+  const unsigned long long* body_dofmask;  // nbody * mask_words: dofs whose body is an ancestor-or-self of b (bit d & 63 of word d >> 6)
+  int mask_words;                          // 64-bit words per dof mask: 1 up to 64 dofs
+  int big;                                 // nv > 64: the kernels with multi-word mask reads serve the model (5, 7; kinematics + velocity not fused)
   const int* chain_dof;        // nbody*max_depth: dofadr | dofnum << 16 of the k-th body on the path world -> b
   const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none
   int max_jnt;

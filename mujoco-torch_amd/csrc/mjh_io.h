@@ -19,7 +19,7 @@ inline int mjh_kernel_io(const DevModel<REAL>& m, int kernel, int do_step, int64
   const int64_t ndense = nefc - nsingle;           // dense rows (equality, ball / tendon limits, contacts)
   const int64_t tri = nv * (nv + 1) / 2;
   const bool general_con = m.con_general != 0, general_sol = (m.nf > 0 || m.nft > 0 || m.ne > 0 || m.nlb > 0 || m.nlt > 0);
-  const bool opt_vel = (m.has_fluid || m.has_gravcomp || m.ntendon > 0);
+  const bool opt_vel = (m.has_fluid || m.has_gravcomp || m.ntendon > 0 || m.big);
   int64_t rd = 0, wr = 0;
   const bool scratch = do_step == 2;  // RK4 stage 1..3
   switch (kernel) {

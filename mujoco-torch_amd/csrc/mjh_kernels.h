@@ -293,12 +293,21 @@ __device__ __forceinline__ void chol_factor_lds(const REAL* A, REAL* L, int n) {
     REAL s = L[j * n + j];
     if (big) s = s + (REAL)1e-10;  // torch.linalg.cholesky(A + 1e-10 I), math.py:108-113
     const REAL d = big ? r_sqrt<REAL>(s) : r_sqrt<REAL>(s > (REAL)1e-12 ? s : (REAL)1e-12);
+    if (n > W) {  // more rows than lanes (models beyond 64 dofs): each lane scales the column entries of ITS rows in place -- only the pivot is shared
+      wave_sync();  // everyone has read the pivot before its owner overwrites it
+      for (int r = i; r < n; r += W) {
+        if (r > j) L[r * n + j] = L[r * n + j] / d;
+        else if (r == j) L[j * n + j] = d;
+      }
+      wave_sync();
+    } else {
     REAL lij = 0;
     if (i > j && i < n) { lij = L[i * n + j] / d; }
     wave_sync();  // everyone has read column j before it is overwritten
     if (i > j && i < n) L[i * n + j] = lij;
     if (i == j) L[j * n + j] = d;
     wave_sync();
+    }
     {  // trailing update L[r][c] -= L[r][j] * L[c][j] for j < c <= r < n, spread over all lanes (2D index)
       const int m = n - j - 1;
       const float inv_m = 1.0f / (float)(m > 0 ? m : 1);
@@ -331,8 +340,36 @@ __device__ __forceinline__ void chol_inv_diag(const REAL* L, REAL* inv, int n) {
 // running right-hand side; the value solved at step k is broadcast.  Per element the operation order equals
 // the reference's row loops (k ascending forward, descending backward); the divisions by L[k][k] are
 // multiplications by the precomputed reciprocal (<= 1 ulp per step off the reference's quotient).
+// ... with more rows than lanes (models beyond 64 dofs; a capacity path, not a tuned one): the running right-hand side lives in x (LDS), every
+// lane updates the rows it owns, two barriers per step.  Per element the same operations in the same order as below.
+template <int W, bool PACKED, typename REAL>
+__device__ __forceinline__ void chol_solve_lds_big(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
+  const int i = sub_lane<W>();
+  for (int r = i; r < n; r += W) x[r] = b[r];
+  wave_sync();
+  for (int k = 0; k < n; k++) {
+    const REAL yk = x[k] * inv[k];
+    wave_sync();
+    for (int r = i; r < n; r += W) {
+      if (r == k) x[r] = yk;
+      else if (r > k) x[r] = x[r] - L[tri_at<PACKED>(r, k, n)] * yk;
+    }
+    wave_sync();
+  }
+  for (int k = n - 1; k >= 0; k--) {
+    const REAL xk = x[k] * inv[k];
+    wave_sync();
+    for (int r = i; r < n; r += W) {
+      if (r == k) x[r] = xk;
+      else if (r < k) x[r] = x[r] - L[tri_at<PACKED>(k, r, n)] * xk;
+    }
+    wave_sync();
+  }
+}
+
 template <int W, bool PACKED, typename REAL>
 __device__ __forceinline__ void chol_solve_lds(const REAL* L, const REAL* inv, const REAL* b, REAL* x, int n) {
+  if (n > W) { chol_solve_lds_big<W, PACKED>(L, inv, b, x, n); return; }
   const int i = sub_lane<W>();
   REAL s = (i < n) ? b[i] : (REAL)0;
   const REAL myinv = (i < n) ? inv[i] : (REAL)0;
@@ -1202,8 +1239,10 @@ struct Env {
 
   // ---- constraint rows (constraint.py:600-768) ---------------------------------------------------------------------------------------------------
   // support.jac :138-153 restricted to one dof: jacp / jacr of `point` on `body`, masked to ancestor dofs
+  // BIG: the instantiation may serve models with more than 64 dofs (masks of several words); the headline instantiations keep the one-word read
+  template <bool BIG = false>
   __device__ __forceinline__ void jac_dof(const REAL* point, int body, int dof, REAL* jp, REAL* jr) const {
-    const REAL on = (REAL)((M.body_dofmask[body] >> dof) & 1ull);
+    const REAL on = BIG ? (REAL)((M.body_dofmask[body * M.mask_words + (dof >> 6)] >> (dof & 63)) & 1ull) : (REAL)((M.body_dofmask[body] >> dof) & 1ull);
     const REAL* rc = S.subtree_com() + 3 * M.body_rootid[body];
     const REAL off[3] = {point[0] - rc[0], point[1] - rc[1], point[2] - rc[2]};
     const REAL* cd = S.cdof() + 6 * dof;
@@ -1325,8 +1364,8 @@ struct Env {
         cpos[i] = pos1[i] - pos2[i];
       }
       REAL jp1[3], jr1[3], jp2[3], jr2[3];
-      jac_dof(pos1, id1, d, jp1, jr1);
-      jac_dof(pos2, id2, d, jp2, jr2);
+      jac_dof<FRIC>(pos1, id1, d, jp1, jr1);
+      jac_dof<FRIC>(pos2, id2, d, jp2, jr2);
 #pragma unroll
       for (int i = 0; i < 3; i++) S.efc_J()[(row + i) * nv + d] = (jp1[i] - jp2[i]) * active;
       const REAL iwt = M.body_invweight0[id1] + M.body_invweight0[id2];
@@ -1515,8 +1554,8 @@ struct Env {
         continue;
       }
       REAL jp1[3], jr1[3], jp2[3], jr2[3];
-      jac_dof(cpos, b2, d, jp2, jr2);
-      jac_dof(cpos, b1, d, jp1, jr1);
+      jac_dof<FRIC>(cpos, b2, d, jp2, jr2);
+      jac_dof<FRIC>(cpos, b1, d, jp1, jr1);
       const REAL dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]};
       const REAL dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
       REAL diff[6];
@@ -1816,7 +1855,7 @@ struct Env {
             const REAL mg = M.body_mass[b] * M.body_gravcomp[b];
             const REAL f[3] = {-M.gravity[0] * mg, -M.gravity[1] * mg, -M.gravity[2] * mg};
             REAL jp[3], jr[3];
-            jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+            jac_dof<FLUID>(S.xipos() + 3 * b, b, d, jp, jr);
             acc += dot3(jp, f);
           }
           S.qfrc_gravcomp()[d] = acc;
@@ -1882,7 +1921,7 @@ struct Env {
           REAL acc = 0;
           for (int b = 0; b < nb; b++) {
             REAL jp[3], jr[3];
-            jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+            jac_dof<FLUID>(S.xipos() + 3 * b, b, d, jp, jr);
             acc += dot3(jp, S.cfrc() + 6 * b) + dot3(jr, S.cfrc() + 6 * b + 3);
           }
           S.qfrc_passive()[d] = S.qfrc_passive()[d] + acc;
@@ -2080,7 +2119,7 @@ struct Env {
         for (int b = 0; b < M.nbody; b++) {
           const REAL* f = in.xfrc_applied + (e * M.nbody + b) * 6;
           REAL jp[3], jr[3];
-          jac_dof(S.xipos() + 3 * b, b, d, jp, jr);
+          jac_dof<FLUID>(S.xipos() + 3 * b, b, d, jp, jr);
           const REAL ff[3] = {f[0], f[1], f[2]}, tt[3] = {f[3], f[4], f[5]};
           acc += dot3(jp, ff) + dot3(jr, tt);
         }
@@ -2255,24 +2294,24 @@ struct Env {
         return;
       }
     }
-    {  // rows in index order
+    for (int c = l; c < nv; c += W) {  // rows in index order; one dof per lane (a second pass only beyond 64 dofs)
       REAL s = 0;
-      if (nl > 0 && l < nv) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch column l
+      if (nl > 0) {  // the single-column rows come first; at most two of them (frictionloss, limit) touch column c
         const int nslot = nf_() > 0 ? 2 : 1;  // without frictionloss rows the second slot of every dof is empty
         for (int q = 0; q < nslot; q++) {
-          const int lr = dof_limrow_lds()[2 * l + q];
+          const int lr = dof_limrow_lds()[2 * c + q];
           if (lr >= 0) { const REAL f = S.s_force()[lr]; if (f != 0) s += S.efc_Jl()[lr] * f; }
         }
       }
       // a counted loop over the compacted rows: the loads of consecutive rows pipeline (the force is one broadcast read), where
       // picking the non-zero forces out of a ballot made every row a dependent round trip; rows with a zero force add +-0
-      if (l < nv) {
-        const REAL* jc = S.efc_Jc() + l;
+      {
+        const REAL* jc = S.efc_Jc() + c;
         const REAL* fr = S.s_force();
 #pragma unroll 8
         for (int r = nl; r < nefc; r++) s += jc[(r - nl) * nv] * fr[r];
       }
-      if (l < nv) S.s_qfrc()[l] = s;
+      S.s_qfrc()[c] = s;
     }
     wave_sync();
   }

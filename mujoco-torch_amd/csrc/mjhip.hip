@@ -181,7 +181,12 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef X
   // ---- derived topology tables ----
   const int nb = d->nbody, nv = d->nv;
-  if (nb > 64 || nv > 64) return fail(-22, "this build keeps ancestor sets in 64-bit masks: nbody and nv must be <= 64");
+  if (nv > 256) return fail(-22, "nv must be <= 256 (inertia-matrix pair table packs two 8-bit dof indices)");
+  const int NW = nv > 64 ? (nv + 63) / 64 : 1;  // 64-bit words per dof mask
+  M.mask_words = NW;
+  M.big = nv > 64 ? 1 : 0;
+  if (M.big) M.con_general = 1;  // the general constraint kernel (7) reads multi-word masks; so does the optional-physics velocity kernel (5)
+  if (M.big) M.con_direct = 0;
   std::vector<int> depth(nb, 0), sub_end(nb, 0);
   int max_depth = 1;
   for (int b = 1; b < nb; b++) {
@@ -205,15 +210,16 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       while (a > b) a = d->body_parentid[a];
       if (a != b) return fail(-22, "bodies are not in depth-first order");
     }
-  std::vector<unsigned long long> body_dofmask(nb, 0ull), dof_ancmask(nv, 0ull);
+  std::vector<unsigned long long> body_dofmask((size_t)nb * NW, 0ull), dof_ancmask((size_t)nv * NW, 0ull);
+  auto anc = [&](int i, int j) { return (dof_ancmask[(size_t)i * NW + (j >> 6)] >> (j & 63)) & 1ull; };
   for (int dd = 0; dd < nv; dd++) {
     int a = dd;
-    while (a >= 0) { dof_ancmask[dd] |= 1ull << a; a = d->dof_parentid[a]; }
+    while (a >= 0) { dof_ancmask[(size_t)dd * NW + (a >> 6)] |= 1ull << (a & 63); a = d->dof_parentid[a]; }
   }
   for (int b = 0; b < nb; b++) {
     int a = b;
     while (a > 0) {
-      for (int dd = 0; dd < nv; dd++) if (d->dof_bodyid[dd] == a) body_dofmask[b] |= 1ull << dd;
+      for (int dd = 0; dd < nv; dd++) if (d->dof_bodyid[dd] == a) body_dofmask[(size_t)b * NW + (dd >> 6)] |= 1ull << (dd & 63);
       a = d->body_parentid[a];
     }
   }
@@ -221,7 +227,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     std::vector<int> pairs;
     for (int i = 0; i < nv; i++)
       for (int j = 0; j <= i; j++)
-        if ((dof_ancmask[i] >> j) & 1ull) pairs.push_back((i << 8) | j);
+        if (anc(i, j)) pairs.push_back((i << 8) | j);
     M.nqmpair = (int)pairs.size();
     std::vector<int> slot((size_t)nv * nv, -1);
     for (int pk : pairs) {
@@ -292,7 +298,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     for (int c = 0; c < d->ncon; c++) {
       const int b1 = d->geom_bodyid[d->con_geom1[c]], b2 = d->geom_bodyid[d->con_geom2[c]];
       cbody[4 * c] = b1; cbody[4 * c + 1] = b2; cbody[4 * c + 2] = d->body_rootid[b1]; cbody[4 * c + 3] = d->body_rootid[b2];
-      cmask[2 * c] = body_dofmask[b1]; cmask[2 * c + 1] = body_dofmask[b2];
+      cmask[2 * c] = body_dofmask[(size_t)b1 * NW]; cmask[2 * c + 1] = body_dofmask[(size_t)b2 * NW];  // (first word: the table serves the small-model kernel only)
     }
     fix.push_back({(const void**)&M.con_body, bb.add(cbody.data(), sizeof(int) * cbody.size())});
     fix.push_back({(const void**)&M.con_dmask, bb.add(cmask.data(), sizeof(unsigned long long) * cmask.size())});
@@ -317,8 +323,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.body_depth, bb.add(depth.data(), sizeof(int) * nb)});
   fix.push_back({(const void**)&M.body_chain, bb.add(chain.data(), sizeof(int) * chain.size())});
   fix.push_back({(const void**)&M.body_subtree_end, bb.add(sub_end.data(), sizeof(int) * nb)});
-  fix.push_back({(const void**)&M.body_dofmask, bb.add(body_dofmask.data(), sizeof(unsigned long long) * nb)});
-  fix.push_back({(const void**)&M.dof_ancmask, bb.add(dof_ancmask.data(), sizeof(unsigned long long) * nv)});
+  fix.push_back({(const void**)&M.body_dofmask, bb.add(body_dofmask.data(), sizeof(unsigned long long) * body_dofmask.size())});
   fix.push_back({(const void**)&M.efc_row_con, bb.add(row_con.data(), sizeof(int) * row_con.size())});
   {
     const int nrf = d->nsensor > 0 ? d->sns_rfadr[d->nsensor] : 0;
@@ -450,6 +455,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 
   for (int p = 0; p < MJH_NARENA; p++) {
     out->lds_bytes[p] = lds_carve(M, 1 << p, out->off[p]) * (int)sizeof(REAL);
+    if (p == 4 && out->lds_bytes[p] > 160 * 1024 && M.sol_qm_lds) {  // a large model: qM stays in global memory (L2) for the solver's products
+      M.sol_qm_lds = 0;
+      out->lds_bytes[p] = lds_carve(M, 1 << p, out->off[p]) * (int)sizeof(REAL);
+    }
     if (p < MJH_NPHASE && out->lds_bytes[p] > 160 * 1024) return fail(-12, "model does not fit the 160 KiB LDS of one CU");
   }
   {  // register solver: CG, slide / hinge limit rows + contact rows only, one dof per lane of a 32-lane half
@@ -539,7 +548,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   {  // fused kinematics + velocity kernel (plain velocity phase only).  Measured on MI355X: profiles/r02/notes.md.  MJH_FUSE_KV=0 keeps two launches.
     static const bool fuse_off = [] { const char* e = getenv("MJH_FUSE_KV"); return e && e[0] == '0'; }();
     out->lds_kv = lds_carve(M, PH_KINVEL, out->off_kv) * (int)sizeof(REAL);
-    out->fuse_kv = (!fuse_off && !(M.has_fluid || M.has_gravcomp || M.ntendon > 0) && out->lds_kv <= 160 * 1024) ? 1 : 0;
+    out->fuse_kv = (!fuse_off && !(M.has_fluid || M.has_gravcomp || M.ntendon > 0 || M.big) && out->lds_kv <= 160 * 1024) ? 1 : 0;
     if (out->fuse_kv) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kv));
       if (2 * out->lds_kv <= 64 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_kv));
@@ -704,7 +713,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
-  if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
+  if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
     hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);

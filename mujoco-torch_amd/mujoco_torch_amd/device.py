@@ -69,7 +69,7 @@ def _validate(m):
             "sparse inertia (jacobian=sparse, or auto with nv >= 60) is not carried: the reference's own sparse factor_m loses "
             "eliminations (scatter with repeated indices, smooth.py:325-326) and its solve_m is 13-27 % off the dense solve on the "
             "bundled models (oracle/probe_reference_sparse.py, profiles/r02/reference_sparse_probe.txt), so there is no result to be "
-            "identical to.  Use jacobian=dense (nv <= 64 in this build).")
+            "identical to.  Set <option jacobian=\"dense\"/> (opt.jacobian = DENSE): the dense path serves models up to 256 dofs.")
     if any(int(d) not in SUPPORTED_CONDIM for d in np.asarray(m.geom_condim)) or any(
         int(d) not in SUPPORTED_CONDIM for d in np.asarray(m.pair_dim)
     ):

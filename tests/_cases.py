@@ -61,6 +61,8 @@ SEEDED_CASES = [
     ("capsules_topk", {}, F64, 64, dict(max_alt=0.0)),                           # max_contact_points: 13 candidates, the 5 closest kept per environment
     ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, {}),
     ("capsules_topk", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 33, dict(tol_sol=1e-5)),  # ... through the register solver (CG stall accuracy)
+    ("centipede", {}, F64, 24, dict(max_alt=0.0)),                                # 72 dofs / 74 bodies (jacobian=dense): multi-word dof masks, more dofs than lanes in the LDS solver
+    ("centipede", {"integrator": 1}, F32, 17, {}),
     ("muscle_arm", {}, F64, 64, dict(max_alt=0.0)),                               # muscle actuators: activation dynamics, force-length-velocity gain, passive bias
     ("muscle_arm", {"integrator": 1}, F32, 33, {}),
     ("tendon_friction", {}, F64, 64, dict(max_alt=0.0)),                         # tendon + dof frictionloss rows, Newton
@@ -105,6 +107,8 @@ def seeded_batch(xml, overrides, dtype, B):
     if xml == "muscle_arm":  # activations and controls across (and beyond) [0, 1], joint angles and speeds across the force-length-velocity curves
         d = d.replace(qpos=d.qpos + torch.tensor(np.array([0.6, 0.9]) * rng.randn(B, mx.nq)), qvel=torch.tensor(3.0 * rng.randn(B, mx.nv)),
                       ctrl=torch.tensor(rng.uniform(-0.3, 1.3, (B, mx.nu))), act=torch.tensor(rng.uniform(-0.1, 1.1, (B, mx.na))))
+    if xml == "centipede":  # bend the legs so that tips reach the floor and limited joints pass their ranges
+        d = d.replace(qpos=d.qpos + torch.tensor(0.5 * rng.randn(B, mx.nq)), qvel=torch.tensor(0.5 * rng.randn(B, mx.nv)))
     if xml == "sensor_rig":  # move and spin the rover so every sensor reads something different per environment
         q = d.qpos.clone()
         q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))

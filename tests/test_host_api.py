@@ -64,6 +64,12 @@ def test_unsupported_features_raise_not_implemented():
     lite.geom_condim[3] = 2
     with pytest.raises(NotImplementedError):
         mt.device_put(lite)
+    # nv >= 60 with the default jacobian=auto is the reference's sparse inertia path (defective: oracle/probe_reference_sparse.py); dense runs
+    big = mt.mjcf.from_xml_path(mx_path("centipede"))
+    assert mt.device_put(big).nv == 72
+    big.opt.jacobian = 2  # AUTO
+    with pytest.raises(NotImplementedError, match="sparse inertia"):
+        mt.device_put(big)
     # a <general> actuator with muscle gain / bias and no lengthrange: MuJoCo would compute the range; (0, 0) would give silently wrong forces
     xml = """<mujoco><worldbody><body><joint name="j" type="hinge"/><geom size="0.1"/></body></worldbody>
              <actuator><general joint="j" gaintype="muscle" biastype="muscle" dyntype="muscle"/></actuator></mujoco>"""
