@@ -84,8 +84,14 @@ def _validate(m):
             if int(v) not in [int(x) for x in ok]:
                 raise NotImplementedError(f"{enum(int(v)).name} {name} not implemented.")
     if int(_get(m, "ntendon", 0)):
-        if np.any(np.asarray(_get(m, "wrap_type", lambda: np.ones(0))) != 1):
-            raise NotImplementedError("only fixed tendons (joint wraps) are supported; spatial tendons are a 'next' item.")
+        # Spatial tendons (site / geom / pulley wraps) are carried the way the reference carries them: smooth.tendon (:470-497) evaluates the
+        # tendons whose FIRST wrap is a joint wrap (device.py:850) and leaves length 0 and a zero Jacobian row for every other one.  A tendon
+        # that mixes joint and other wraps is not a valid MuJoCo tendon (and breaks the reference's segment arithmetic, device.py:853-870).
+        wt = np.asarray(_get(m, "wrap_type", lambda: np.ones(0)))
+        for t in range(int(m.ntendon)):
+            a, n = int(m.tendon_adr[t]), int(m.tendon_num[t])
+            if n and len({int(x) == 1 for x in wt[a : a + n]}) > 1:
+                raise NotImplementedError("a tendon mixing joint wraps with site / geom / pulley wraps is not supported")
     et = np.asarray(_get(m, "eq_type", lambda: np.zeros(0, dtype=np.int32)))
     if np.any(et > 2):
         raise NotImplementedError("only connect / weld / joint equality constraints are supported")
@@ -289,6 +295,9 @@ def _tendon_tables(m, flags) -> dict:
     out = dict(adr=[0], dof=[], qpos=[], coef=[], lim=[])
     for t in range(nt):
         a, n = int(m.tendon_adr[t]), int(m.tendon_num[t])
+        if n and int(np.asarray(m.wrap_type)[a]) != 1:  # a spatial tendon: the reference leaves ten_length = 0 and ten_J = 0 for it (smooth.py:470-497)
+            out["adr"].append(len(out["dof"]))
+            continue
         for w in range(a, a + n):
             j = int(m.wrap_objid[w])
             out["dof"].append(int(m.jnt_dofadr[j])); out["qpos"].append(int(m.jnt_qposadr[j])); out["coef"].append(float(m.wrap_prm[w]))

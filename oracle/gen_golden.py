@@ -90,6 +90,10 @@ CASES = {
     # fixed tendons: lengths, limit rows, springs / dampers, tendon transmissions (smooth.py:470-497, constraint.py:375-405, passive.py:119-144)
     "tendon_fixed_f64": ("tendon_fixed", {}, "float64", 3, 3, "tendon"),
     "tendon_fixed_cg_rk4_f32": ("tendon_fixed", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
+    # spatial tendons in the reference's own (degenerate) form: a tendon whose first wrap is not a joint wrap keeps length 0 and a zero
+    # Jacobian row (smooth.py:470-497, device.py:850).  The fixed-tendon model with t1 (limited, spring, damper) and t4 (spring) retyped to
+    # site wraps: their limit row, passive force and constants stay in the model, their kinematics read zero.
+    "tendon_spatial_degenerate_f64": ("tendon_fixed", {"model.wrap_type": [3, 3, 1, 1, 1, 1, 1, 3]}, "float64", 3, 3, "tendon"),
     # tendon armature (smooth.py:500-522): qM gains J^T diag(armature) J, off the kinematic tree's sparsity pattern
     "tendon_armature_f64": ("tendon_armature", {}, "float64", 3, 3, "tendon"),
     "tendon_armature_cg_rk4_f32": ("tendon_armature", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),
@@ -237,6 +241,9 @@ def main(only=None):
         dtype = getattr(torch, dtype_s)
         lite = mjcf.from_xml_path(os.path.join(REPO, "mujoco-torch_amd", "mujoco_torch_amd", "test_data", xml + ".xml"))
         for k, v in overrides.items():
+            if k.startswith("model."):  # an edit of the compiled model itself (tests/_util.load_model applies the same)
+                setattr(lite, k[6:], np.array(v, dtype=np.asarray(getattr(lite, k[6:])).dtype) if isinstance(v, list) else v)
+                continue
             setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
         has_convex = any(int(t) in (6, 7) for t in lite.geom_type) and not (int(lite.opt.disableflags) & (1 << 4))  # convex tables matter only with contacts on
         # float32 + rangefinder raises inside the reference (float64 ray tables, ray.py:317): record those cases sensor-less

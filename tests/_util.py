@@ -41,6 +41,10 @@ def strip_sensors(lite):
 def load_model(xml, overrides=None, dtype=torch.float64, keep_sensors=True):
     lite = mt.mjcf.from_xml_path(mt.test_data_path(xml + ".xml"))
     for k, v in (overrides or {}).items():
+        if k.startswith("model."):  # an edit of the compiled model itself (integer arrays keep their dtype): {"model.wrap_type": [...]}
+            cur = getattr(lite, k[6:])
+            setattr(lite, k[6:], np.array(v, dtype=np.asarray(cur).dtype) if isinstance(v, list) else v)
+            continue
         setattr(lite.opt, k, np.array(v, dtype=np.float64) if isinstance(v, list) else v)
     if not keep_sensors:
         strip_sensors(lite)

@@ -70,6 +70,15 @@ def test_unsupported_features_raise_not_implemented():
     big.opt.jacobian = 2  # AUTO
     with pytest.raises(NotImplementedError, match="sparse inertia"):
         mt.device_put(big)
+    # spatial tendons: device_put carries them as the reference does (zero length, zero Jacobian row; golden tendon_spatial_degenerate_f64),
+    # a tendon mixing joint and site wraps is rejected
+    lite = mt.mjcf.from_xml_path(mx_path("tendon_fixed"))
+    lite.wrap_type = np.array([3, 3, 1, 1, 1, 1, 1, 3], dtype=np.int32)
+    T = mt.device_put(lite).tables.tendon
+    assert list(T["adr"]) == [0, 0, 2, 5, 5]
+    lite.wrap_type = np.array([3, 1, 1, 1, 1, 1, 1, 1], dtype=np.int32)
+    with pytest.raises(NotImplementedError, match="mixing"):
+        mt.device_put(lite)
     # a <general> actuator with muscle gain / bias and no lengthrange: MuJoCo would compute the range; (0, 0) would give silently wrong forces
     xml = """<mujoco><worldbody><body><joint name="j" type="hinge"/><geom size="0.1"/></body></worldbody>
              <actuator><general joint="j" gaintype="muscle" biastype="muscle" dyntype="muscle"/></actuator></mujoco>"""
