@@ -180,46 +180,50 @@ class MujocoTorchEnv(EnvBase):
 
     # ---- TorchRL interface --------------------------------------------------------------------------------------------
 
+    def _flags(self, value: bool = False):
+        """A (*batch, 1) bool tensor: TorchRL's layout for done / terminated / truncated."""
+        return torch.full((*self.batch_size, 1), value, dtype=torch.bool, device=self.device)
+
+    def _start_episodes(self):
+        """Every environment from scratch: fresh batch, step counters at zero."""
+        self._dx = self._make_batch(self.num_envs)
+        self._step_count = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
+
+    def _upload_ctrl(self, ctrl):
+        """The controls of this step into the resident Data.  Written in place when the leaf has the right layout, so the device pointers
+        the native step cached for the ping-pong buffers stay valid; a differently shaped / typed control replaces the leaf."""
+        leaf = self._dx.ctrl
+        if (leaf.shape, leaf.dtype, leaf.device) == (ctrl.shape, ctrl.dtype, ctrl.device):
+            leaf.copy_(ctrl)
+        else:
+            self._dx.update_(ctrl=ctrl)
+
     def _reset(self, tensordict=None, **kwargs):
-        mask = None
-        if tensordict is not None and "_reset" in tensordict.keys():
-            mask = tensordict["_reset"].squeeze(-1)
-        if mask is None or not hasattr(self, "_dx"):
-            self._dx = self._make_batch(self.num_envs)
-            self._step_count = torch.zeros(self.num_envs, dtype=torch.long, device=self.device)
-        elif not self.auto_reset:  # with auto_reset the step already did it
-            self._reset_masked(mask)
-        return TensorDict(
-            {
-                **self._build_obs(),
-                "done": torch.zeros(*self.batch_size, 1, dtype=torch.bool, device=self.device),
-                "terminated": torch.zeros(*self.batch_size, 1, dtype=torch.bool, device=self.device),
-            },
-            batch_size=self.batch_size,
-            device=self.device,
-        )
+        # TorchRL hands a partial reset as tensordict["_reset"]; anything else (first call, reset() without a mask) restarts all
+        partial = tensordict["_reset"].squeeze(-1) if (tensordict is not None and "_reset" in tensordict.keys()) else None
+        if partial is None or not hasattr(self, "_dx"):
+            self._start_episodes()
+        elif not self.auto_reset:
+            self._reset_masked(partial)  # (with auto_reset on, _step has already replaced the finished environments)
+        out = dict(self._build_obs())
+        out["done"] = self._flags()
+        out["terminated"] = self._flags()
+        return TensorDict(out, batch_size=self.batch_size, device=self.device)
 
     def _step(self, tensordict):
         action = tensordict["action"].to(self.dtype)
-        ctrl = self._prepare_ctrl(action)
-        qpos_before = self._dx.qpos.clone()
-
-        old = self._dx.ctrl
-        if old.shape == ctrl.shape and old.dtype == ctrl.dtype and old.device == ctrl.device:
-            old.copy_(ctrl)  # same storage: the native pointer tables of the buffers stay valid
-        else:
-            self._dx.update_(ctrl=ctrl)
+        self._upload_ctrl(self._prepare_ctrl(action))
+        before = self._dx.qpos.clone()          # rewards are functions of the displacement over the frame-skipped step
         self._dx = self._physics_step(self._dx)
         self._step_count += 1
 
-        reward = self._compute_reward(qpos_before, action)
-        terminated = self._compute_terminated()
-        truncated = (self._step_count >= self.max_episode_steps).unsqueeze(-1)
-        done = terminated | truncated
-        obs = self._build_obs()  # from the terminal state, before any reset
+        out = {"reward": self._compute_reward(before, action)}
+        out["terminated"] = self._compute_terminated()
+        out["done"] = out["terminated"] | (self._step_count >= self.max_episode_steps).unsqueeze(-1)
+        out.update(self._build_obs())           # the observation of the state that earned the reward: taken BEFORE any reset below
         if self.auto_reset:
-            self._reset_masked(done.squeeze(-1))
-        return TensorDict({**obs, "reward": reward, "done": done, "terminated": terminated}, batch_size=self.batch_size, device=self.device)
+            self._reset_masked(out["done"].squeeze(-1))  # one masked native launch; no host sync on done.any()
+        return TensorDict(out, batch_size=self.batch_size, device=self.device)
 
     def _set_seed(self, seed):
         torch.manual_seed(seed)

@@ -48,7 +48,7 @@ def _host_env(auto_reset):
     env._physics_step = lambda d: d
     env._ctrl_dtype = env._sim_dtype = torch.float64
     env._dx0 = FakeBatch(torch.zeros(1, 2, dtype=torch.float64), torch.zeros(1, 2, dtype=torch.float64), torch.zeros(1, 1, dtype=torch.float64))
-    for name in ("_reset_state", "_make_batch", "_reset", "_step", "_prepare_ctrl"):
+    for name in ("_reset_state", "_make_batch", "_reset", "_step", "_prepare_ctrl", "_flags", "_start_episodes", "_upload_ctrl"):
         setattr(env, name, MethodType(getattr(MujocoTorchEnv, name), env))
 
     def reset_masked(mask):  # host stand-in for the native launch: the reference's own route (zoo/base.py:289-293)
