@@ -3375,10 +3375,14 @@ struct Env {
         STAMP(75);
         return hx;
       };
+      // The preconditioned gradient (M^-1 grad, or the Newton direction: Hessian build + factorisation + substitution) is only ever consumed by the
+      // NEXT line search: cond (:501-508) looks at the plain gradient and the cost.  The reference computes it inside _update_gradient at the
+      // end of every iteration (and once in _Context.create); here it is computed at the head of an iteration, after cond has decided that
+      // there is one -- one Hessian factorisation less per solve (the mesh scene builds 3.4 per solve otherwise), same numbers in every output.
       REAL grad = dof ? (Ma - f) - qfrc : (REAL)0;
-      REAL Mgrad = precondition(grad);
-      REAL search = -Mgrad;
-      REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step: only read when another iteration follows
+      REAL Mgrad = 0, search = 0;
+      bool first_dir = true;
+      REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step
       int it = 0, niter = 0, ls_total = 0;
       bool bail = false;
       const int it_cap = KA.it_cap, ls_cap = KA.ls_cap;
@@ -3396,6 +3400,20 @@ struct Env {
         }
         if (it_cap > 0 && (it >= it_cap || ls_total >= ls_cap)) { bail = true; break; }  // another iteration is due: the fallback launch redoes this solve from its inputs
         const bool need_grad = !(it + 1 >= M.iterations);
+        {  // search direction of this iteration: -H^-1 grad (Newton), -M^-1 grad at the start, Polak-Ribiere afterwards (CG, :519-523)
+          const REAL Mg = precondition(grad);
+          if (first_dir || newton) {
+            search = -Mg;
+          } else {
+            const REAL pgrad = dof ? pg[l] : (REAL)0, pMgrad = dof ? pg[nv + l] : (REAL)0;  // written by this lane
+            const REAL num = sub_sum<W>(grad * (Mg - pMgrad)), den = sub_sum<W>(pgrad * pMgrad);
+            REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
+            beta = beta > 0 ? beta : (REAL)0;
+            search = -Mg + beta * search;
+          }
+          Mgrad = Mg;
+          first_dir = false;
+        }
         // ---- _linesearch :378-497 -----------------------------------------------------------------------------------------------------------------
         {
           if (dof) vs[l] = search;
@@ -3485,19 +3503,7 @@ struct Env {
         cost = constraint_cost(jal, jad, Ma, qacc, gauss);
         qfrc = constraint_qfrc();
         STAMP(78);
-        if (need_grad) {  // _update_gradient :359-376 and the next direction: Newton -H^-1 grad, CG Polak-Ribiere :519-523
-          grad = dof ? (Ma - f) - qfrc : (REAL)0;
-          Mgrad = precondition(grad);
-          if (newton) {
-            search = -Mgrad;
-          } else {
-            const REAL pgrad = dof ? pg[l] : (REAL)0, pMgrad = dof ? pg[nv + l] : (REAL)0;  // written by this lane
-            const REAL num = sub_sum<W>(grad * (Mgrad - pMgrad)), den = sub_sum<W>(pgrad * pMgrad);
-            REAL beta = num / (den > (REAL)mjMINVAL ? den : (REAL)mjMINVAL);
-            beta = beta > 0 ? beta : (REAL)0;
-            search = -Mgrad + beta * search;
-          }
-        }
+        if (need_grad) grad = dof ? (Ma - f) - qfrc : (REAL)0;  // _update_gradient :359-376, the part cond reads (its preconditioned half: next loop head)
         niter++; it++;
       }
       if (bail) {  // nothing of this environment's solve is kept: the mark hands it to the fallback launch, which writes every output of the phase
