@@ -1460,6 +1460,7 @@ struct Env {
       S.efc_invweight()[r] = M.dof_invweight0[da];
     }
     const bool elliptic = M.cone == CONE_ELLIPTIC;
+    int nact_contacts = 0;  // small models: active contacts of this environment (compact list in S.i_con_act())
     if constexpr (!FRIC && DIRECT) {
       // Small models (rows straight to the leaf).  (A) one lane per contact: which contacts are active, as a compact list and as a per-row flag; (B) the rows of the
       // inactive contacts are zeroed by a straight loop over the block (no table reads); (C) one lane per (ACTIVE contact, dof) forms the
@@ -1487,6 +1488,7 @@ struct Env {
         for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
         nact += tot;
       }
+      nact_contacts = nact;
       wave_sync();
       REAL* const Jdst = out.efc_J + (e * nefc + nl) * nv;  // row 0 = first contact row
       // RK4 stages 1..3 write a private workspace Data whose only reader is this stage's solver phase, and that gathers the rows of the ACTIVE
@@ -1579,7 +1581,17 @@ struct Env {
     wave_sync();
     STAMP(25);
     const int ns = ne + nfa + nlb + nl + nlt;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
-    for (int r = l; r < nefc; r += W) {  // :683-693
+    // RK4 stages 1..3 of a small model (their Data is a private workspace, see above): only the limit rows and the rows of the ACTIVE contacts are
+    // visited -- one pass of the lanes for the ant (8 + 3 x (4 .. 8) rows) where the walk over all 188 rows took six dependent passes
+    const bool compact_rows = !FRIC && DIRECT && KA.rk_stage > 0 && M.con_rows > 0;
+    const int nvisit = compact_rows ? ns + nact_contacts * M.con_rows : nefc;
+    for (int idx = l; idx < nvisit; idx += W) {  // :683-693
+      int r = idx;
+      if (compact_rows && idx >= ns) {
+        int a, k;
+        split_index(idx - ns, M.con_rows, 1.0f / (float)M.con_rows, a, k);
+        r = M.con_efc_address[reinterpret_cast<const int*>(S.i_con_act())[a]] + k;
+      }
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
       bool con_row_active = false;
