@@ -840,6 +840,7 @@ struct Env {
       if (out.geom_xmat) for (int i = 0; i < 9; i++) out.geom_xmat[(e * M.ngeom + g) * 9 + i] = mat[i];
     }
     {
+      if (out.site_xpos || out.site_xmat)  // (RK4 stages 1..3 keep no site frames: nothing reads them there)
       for (int s = l; s < M.nsite; s += W) {
         const int b = M.site_bodyid[s];
         REAL p[3], mat[9];
@@ -3565,6 +3566,9 @@ struct Env {
 #ifndef MJH_SOL2_W16_WAVES
 #define MJH_SOL2_W16_WAVES 4  /* ... the same tier at four environments per wavefront */
 #endif
+#ifndef MJH_CON32D_WAVES
+#define MJH_CON32D_WAVES 4  /* float32 small-model constraint phase */
+#endif
 #ifndef MJH_SOL32_WAVES
 #define MJH_SOL32_WAVES 3  /* float32 LDS solver: 168 VGPRs + ~96 B of scratch; measured on the mesh scene: 2 waves (173 VGPRs, no scratch) 374 us, 3 waves 338 us, 4 waves (128 + 156 B) 362 us */
 #endif
@@ -3598,7 +3602,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
