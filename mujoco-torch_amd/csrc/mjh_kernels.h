@@ -134,6 +134,8 @@ struct KArgs {
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
   int it_cap, ls_cap;   // > 0: the register solver leaves an environment to the fallback launch (LDS solver, one environment per wavefront) once its solve has run it_cap Newton iterations or ls_cap line-search iterations: the long solves of a batch are few, and inside a shared wavefront every one of them holds three other environments' lanes
+  int mark_leftover;    // register solver, first tier with a second one behind it: an environment with more active rows than this tier keeps gets mjh_bail_mark in out.qacc
+  int scan_marks;       // register solver, second tier: waves scan 64 environments' marks each and serve the marked ones (instead of one wave per environment pair counting rows)
   int fallback_only;    // LDS solver launch: serve only the environments the register solver flagged (mjh_bail_mark in out.qacc)
   int row_lo, row_hi;   // register solver tiers: this launch serves the environments with row_lo < (dense rows of their active contacts) <= row_hi
   unsigned long long* stamps;  // diagnostic builds (-DMJH_STAMPS): [B, 128] s_memtime stamps, else unused
@@ -3046,7 +3048,7 @@ struct Env {
     const bool from_in = !KA.state_from_cur;
     const bool newton = NEWT && M.solver == SOL_NEWTON;
     STAMP0();
-    if (KA.row_lo >= 0) {
+    if (KA.row_lo >= 0 && !KA.scan_marks) {
       // Second (full-width) tier: almost every environment was served by the first launch.  Count the rows of the active contacts before
       // anything else is requested and leave -- the full prologue (factor rows, state, limit rows) cost the ant 21 us per launch for nothing.
       int rows_active = 0;
@@ -3151,7 +3153,7 @@ struct Env {
     // instantiation picks up the rest (the ant keeps 4 - 8 of its 60 contacts active: almost none).  Each environment is integrated by exactly one.
     STAMP(82);
     if (!(nda > KA.row_lo && nda <= KA.row_hi)) {
-      if (KA.it_cap > 0 && nda > KA.row_hi && l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);  // capped models have no wider register tier: the fallback launch takes the environment
+      if ((KA.it_cap > 0 || KA.mark_leftover) && nda > KA.row_hi && l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);  // the next launch (wider tier / LDS-solver fallback) finds the environment by this mark
       return;
     }
     if (solving) {
@@ -3591,6 +3593,32 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
   const int sub = (int)(threadIdx.x / W);
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
+  if (K.scan_marks) {
+    // Second tier behind a first one that marked what it left (mjh_bail_mark in out.qacc): each wave reads the marks of 64 environments with
+    // one load and serves the marked ones NSUB at a time.  A launch of one wave per environment pair, each counting its active rows only to
+    // leave, cost the ant 11.5 us per RK4 stage for a tier that serves (almost) nobody.
+    for (int64_t base = (int64_t)blockIdx.x * MJH_WAVE; base < K.env_count; base += (int64_t)gridDim.x * MJH_WAVE) {
+      const int64_t mine = base + threadIdx.x;
+      bool marked = false;
+      if (mine < K.env_count) marked = mjh_is_bail_mark(__hip_atomic_load(K.cur.qacc + (K.env_begin + mine) * K.M.nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      unsigned long long todo = __ballot(marked);
+      while (todo) {
+        int pick = -1;
+#pragma unroll
+        for (int q = 0; q < NSUB; q++) {
+          int nxt = -1;
+          if (todo) { nxt = __ffsll((long long)todo) - 1; todo &= todo - 1; }
+          if (q == sub) pick = nxt;
+        }
+        if (pick >= 0) {
+          Env<REAL, W, false> E(lds, K.env_begin + base + pick, K.flags);
+          E.template run_sol2<NMAX, RPL>();
+        }
+        wave_sync();
+      }
+    }
+    return;
+  }
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {

@@ -645,6 +645,8 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 #define GOW(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a)
   const int nd = a.M.nefc - a.M.nf - a.M.nl;
   bool second = true;
+  const bool marks = m->sol2_tiers && a.cur.qacc != nullptr;  // the first tier marks what it leaves, the second scans the marks (needs the qacc leaf)
+  a.mark_leftover = marks ? 1 : 0;
   if (m->sol2_tiers) {  // first tier: fewer row slots per lane, its own (smaller) arena
     a.off = m->off_tier;
     a.lds_reals = m->lds_tier / (int)sizeof(REAL);
@@ -680,15 +682,20 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   } else {
     a.row_lo = -1;
   }
+  a.mark_leftover = 0;
   if (second) {
     a.row_hi = 0x7fffffff;
     a.off = m->off[5];
     a.lds_reals = m->lds_bytes[5] / (int)sizeof(REAL);
+    a.scan_marks = marks ? 1 : 0;
+    const int64_t sblocks = (a.B + MJH_WAVE - 1) / MJH_WAVE;
+    const int64_t grid = marks ? (sblocks < 4096 ? sblocks : 4096) : (blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20);
     const size_t lds = (size_t)(2 * m->lds_bytes[5]);
     if (m->sol2_nmax == 8) { if (m->sol2_rpl == 1) GO(8, 1); else if (m->sol2_rpl == 2) GO(8, 2); else if (m->sol2_rpl == 4) GO(8, 4); else GO(8, 8); }
     else if (m->sol2_nmax == 16) { if (m->sol2_rpl == 1) GO(16, 1); else if (m->sol2_rpl == 2) GO(16, 2); else if (m->sol2_rpl == 4) GO(16, 4); else GO(16, 8); }
     else { if (m->sol2_rpl == 1) GO(28, 1); else GO(28, 2); }
     HIP_TRY(hipGetLastError());
+    a.scan_marks = 0;
   }
 #undef GO
 #undef GOW
