@@ -366,13 +366,18 @@ struct CvxPair {
   }
 
   // ---- convex_convex :805-856 with _sat_hull_hull :464-601 ------------------------------------------------------------------------
-  __device__ __forceinline__ void convex_convex(const REAL* pos1, const REAL* mat1, CvxView<REAL> c1, const REAL* pos2, const REAL* mat2, CvxView<REAL> c2) {
+  __device__ __forceinline__ void convex_convex(const REAL* pos1_in, const REAL* mat1_in, CvxView<REAL> c1, const REAL* pos2_in, const REAL* mat2_in, CvxView<REAL> c2) {
     CSTAMP(99);
     const int K = c1.nfv > c2.nfv ? c1.nfv : c2.nfv;
     const bool swapped = c1.nvert > c2.nvert;
+    // the two frames are swapped by VALUE (selects on registers): swapping the pointers made the compiler keep the caller's four arrays in
+    // scratch memory (112 bytes per lane) for every later read
+    REAL pos1[3], pos2[3], mat1[9], mat2[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pos1[i] = swapped ? pos2_in[i] : pos1_in[i]; pos2[i] = swapped ? pos1_in[i] : pos2_in[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) { mat1[i] = swapped ? mat2_in[i] : mat1_in[i]; mat2[i] = swapped ? mat1_in[i] : mat2_in[i]; }
     if (swapped) {
-      const REAL* t = pos1; pos1 = pos2; pos2 = t;
-      t = mat1; mat1 = mat2; mat2 = t;
       const CvxView<REAL> c = c1; c1 = c2; c2 = c;
     }
     const int V1 = c1.nvert, V2 = c2.nvert, F1 = c1.nface, F2 = c2.nface, E1 = c1.nedge, E2 = c2.nedge;
@@ -585,7 +590,10 @@ struct CvxPair {
 
 // grid: B * ncvxpair workgroups of one wave (grid-stride beyond 2^20)
 template <typename REAL>
-__global__ __launch_bounds__(MJH_WAVE) void mjh_convex_kernel(KArgs<REAL> args) {
+#ifndef MJH_CVX32_WAVES
+#define MJH_CVX32_WAVES 4  /* float32 convex narrow phase: waves per SIMD the register allocation must fit -- mesh scene, B = 8192: 3 waves (161 VGPRs) 114.7 us, 4 waves (128 VGPRs + 52 B scratch) 103.5 us, 5 waves: see profiles/r03/notes.md */
+#endif
+__global__ __launch_bounds__(MJH_WAVE, sizeof(REAL) == 4 ? MJH_CVX32_WAVES : 1) void mjh_convex_kernel(KArgs<REAL> args) {
   extern __shared__ unsigned char cvx_smem[];
   REAL* lds = reinterpret_cast<REAL*>(cvx_smem);
   const int npc = M.ncvxpair;
