@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 12
+#define MJH_ABI_VERSION 13
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -349,14 +349,17 @@ typedef struct mjhModel mjhModel; /* opaque: device-resident constant blob + lau
 int mjh_model_create(const mjhModelDesc* desc, int dtype, mjhModel** out);
 void mjh_model_destroy(mjhModel* m);
 
-/* forward dynamics for B environments (forward.py:373-401), optionally only a prefix of stages. */
-int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int stages, int flags,
+/* forward dynamics for B environments (forward.py:373-401), optionally only a prefix of stages.
+ * `work`: as for mjh_step; a forward pass needs it only for models whose max_contact_points selection runs over box / mesh candidates
+ * (the convex narrow phase hands its candidate contacts to the constraint phase there), NULL otherwise. */
+int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int stages, int flags,
                 void* hip_stream);
 
 /* one simulation step for B environments (forward.py:463-496): _check_state, forward, Euler/RK4.
  * `work`: caller-owned device scratch of mjh_model_work_bytes(m) * B bytes (contents undefined, may be
  * NULL when that is 0).  RK4 keeps its stage Data (stages 1..3 of forward.py:356-367) and the running
- * sums there; Euler needs none. */
+ * sums there; max_contact_points over box / mesh pairs keeps the candidate contacts of the convex narrow phase there
+ * (collision_driver.py:822-840: every candidate is computed, the closest are kept); other Euler models need none. */
 int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* hip_stream);
 int64_t mjh_model_work_bytes(const mjhModel* m);
 

@@ -177,14 +177,18 @@ struct CvxPair {
   // writes contact q of the pair (world frame) to its slot
   __device__ __forceinline__ void emit(int q, REAL dist, const REAL* pos, const REAL* normal_w) const {
     const int c = M.pair_dst[p * MJH_MAX_PAIR_CONTACTS + q];
-    const int64_t nc = M.ncon;
+    const bool cand = M.topk != 0;  // max_contact_points: `c` is a CANDIDATE index, the arrays are the workspace's (the constraint phase selects)
+    const int64_t nc = cand ? M.ncand : M.ncon, B = KA.B;
+    REAL* const gd = cand ? KA.cand : out.contact_dist;
+    REAL* const gp = cand ? KA.cand + B * nc : out.contact_pos;
+    REAL* const gf = cand ? KA.cand + 4 * B * nc : out.contact_frame;
     REAL frame[9];
     make_frame(normal_w, frame);
-    out.contact_dist[e * nc + c] = dist;
+    gd[e * nc + c] = dist;
 #pragma unroll
-    for (int i = 0; i < 3; i++) out.contact_pos[(e * nc + c) * 3 + i] = pos[i];
+    for (int i = 0; i < 3; i++) gp[(e * nc + c) * 3 + i] = pos[i];
 #pragma unroll
-    for (int i = 0; i < 9; i++) out.contact_frame[(e * nc + c) * 9 + i] = frame[i];
+    for (int i = 0; i < 9; i++) gf[(e * nc + c) * 9 + i] = frame[i];
   }
 
   // ---- plane_convex :604-623 ------------------------------------------------------------------------------------------

@@ -132,6 +132,7 @@ struct KArgs {
   int do_step;
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
+  REAL* cand;           // max_contact_points over convex pairs: candidate contacts of the convex narrow phase, [B, ncand] dist | [B, ncand, 3] pos | [B, ncand, 9] frame (workspace)
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
   int it_cap, ls_cap;   // > 0: the register solver leaves an environment to the fallback launch (LDS solver, one environment per wavefront) once its solve has run it_cap Newton iterations or ls_cap line-search iterations: the long solves of a batch are few, and inside a shared wavefront every one of them holds three other environments' lanes
   int mark_leftover;    // register solver, first tier with a second one behind it: an environment with more active rows than this tier keeps gets mjh_bail_mark in out.qacc
@@ -1112,9 +1113,16 @@ struct Env {
       multi_load<W, 2, 3>(dst, src, cnt, e);
     }
     if (M.ncvxpair > 0) {  // box / mesh pairs were narrow-phased by mjh_convex_kernel (mjh_convex.h) into their contact slots
-      row_load<W>(S.con_dist(), out.contact_dist, M.ncon, e);
-      row_load<W>(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
-      row_load<W>(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
+      if (FRIC && M.topk) {  // ... or, with max_contact_points, into the candidate arrays of the workspace (selection below)
+        const int64_t B = KA.B, nc = M.ncand;
+        row_load<W>(S.con_dist(), KA.cand, (int)nc, e);
+        row_load<W>(S.con_pos(), KA.cand + B * nc, 3 * (int)nc, e);
+        row_load<W>(S.con_frame(), KA.cand + 4 * B * nc, 9 * (int)nc, e);
+      } else {
+        row_load<W>(S.con_dist(), out.contact_dist, M.ncon, e);
+        row_load<W>(S.con_pos(), out.contact_pos, 3 * M.ncon, e);
+        row_load<W>(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
+      }
     }
     wave_sync();
     for (int p = l; p < M.npair; p += W) {

@@ -85,7 +85,8 @@ struct mjhModel {
   mutable hipEvent_t split_done[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_fork = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
-  int64_t work_reals;                      // per-environment REALs of RK4 workspace (0 for Euler)
+  int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
+  int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the END of an environment-major workspace: the first B * cand_reals reals)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
   DevModel<float> m32;
@@ -526,6 +527,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
+  out->cand_reals = (d->topk && M.ncvxpair > 0) ? 13 * (int64_t)d->ncand : 0;  // candidate contacts of the convex narrow phase (dist, pos, frame)
+  out->work_reals += out->cand_reals;
 
   void* dev = nullptr;
   HIP_TRY(hipMalloc(&dev, bb.host.size() + 16));
@@ -756,13 +759,18 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
   if (M.ncvxpair > 0 && (a.stages & 0x7c) && !(fin.contact_dist && fin.contact_pos && fin.contact_frame && fin.geom_xpos && fin.geom_xmat))
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
+  REAL* w = (REAL*)work;
+  if (m->cand_reals > 0 && (a.stages & 0x7c)) {  // max_contact_points over box / mesh pairs: the candidates live at the head of the workspace
+    if (!work) return fail(-22, "max_contact_points with box / mesh pairs needs a workspace of mjh_model_work_bytes(m) * B bytes");
+    a.cand = w;
+    w += m->cand_reals * B;
+  }
   if (!do_step || M.integrator == INT_EULER) return forward_pass<REAL>(m, a, s);
 
   // ---- RK4 (forward.py:331-370): stage 0 computes the returned Data; stages 1..3 run in the workspace Data ----
   if (!work) return fail(-22, "RK4 needs a workspace of mjh_model_work_bytes(m) * B bytes");
   DevData<REAL> scr;
   memset(&scr, 0, sizeof(scr));
-  REAL* w = (REAL*)work;
   {
     REAL** slots = reinterpret_cast<REAL**>(&scr);
     const char* names[] = {
@@ -939,10 +947,10 @@ void mjh_model_destroy(mjhModel* m) {
   delete m;
 }
 
-int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, int64_t B, int stages, int flags, void* stream) {
+int mjh_forward(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int stages, int flags, void* stream) {
   if (!m || !in || !out) return fail(-22, "null argument");
-  return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, nullptr, B, flags, 0, stages, stream)
-                             : run<float>(m, m->m32, in, out, nullptr, B, flags, 0, stages, stream);
+  return m->dtype == MJH_F64 ? run<double>(m, m->m64, in, out, work, B, flags, 0, stages, stream)
+                             : run<float>(m, m->m32, in, out, work, B, flags, 0, stages, stream);
 }
 
 int mjh_step(const mjhModel* m, const mjhData* in, mjhData* out, void* work, int64_t B, int flags, void* stream) {

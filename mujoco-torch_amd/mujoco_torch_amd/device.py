@@ -229,10 +229,10 @@ def _build_tables(m, dtype) -> StaticTables:
     T.topk = bool(ncon > 0 and cap > -1 and len(dims_unsorted) > cap)
     if T.topk:
         if len(set(dims_unsorted)) != 1:
-            raise NotImplementedError("max_contact_points with mixed condims is not supported (the reference sizes its row groups from the "
-                                      "smallest condims, collision_driver.py:618-644, whatever the selected contacts' condims are)")
-        if any(p[0] >= 5 for p in pairs):
-            raise NotImplementedError("max_contact_points with box / mesh pairs is not supported by the native stepper")
+            raise NotImplementedError("max_contact_points with mixed condims is not supported: the reference sizes its row groups from the "
+                                      "smallest condims (collision_driver.py:618-644) whatever the selected contacts' condims are, so a kept "
+                                      "condim-3 contact is given a frictionless row and contact.efc_address disagrees with the rows "
+                                      "(oracle/probe_reference_topk_mixed.py, profiles/r03/reference_topk_mixed_probe.txt)")
         order = ct.contact_order([dims_unsorted[0]] * ncon)  # final slot s holds the order[s]-th closest contact
         T.topk_slot = np.empty(ncon, dtype=np.int32)
         T.topk_slot[order] = np.arange(ncon)

@@ -345,12 +345,13 @@ def _run_native(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data
     flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
     stream, prev = _stream_and_guard(device)
     try:
+        work = nm.workspace(B, stream)  # RK4 stages; candidate contacts of max_contact_points over box / mesh pairs; None for most Euler models
         if step:
-            work = nm.workspace(B, stream)
             rc = nm.lib.mjh_step(nm.handle, ctypes.byref(tab.struct), ctypes.byref(out_struct),
                                  ctypes.c_void_p(work.data_ptr() if work is not None else None), B, flags, ctypes.c_void_p(stream))
         else:
-            rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(tab.struct), ctypes.byref(out_struct), B, stages, flags, ctypes.c_void_p(stream))
+            rc = nm.lib.mjh_forward(nm.handle, ctypes.byref(tab.struct), ctypes.byref(out_struct),
+                                    ctypes.c_void_p(work.data_ptr() if work is not None else None), B, stages, flags, ctypes.c_void_p(stream))
     finally:
         if prev is not None:
             torch.cuda.set_device(prev)

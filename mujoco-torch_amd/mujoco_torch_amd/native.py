@@ -177,7 +177,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 12
+    desc.abi_version = 13
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))
@@ -222,7 +222,7 @@ def load_library(path: str | None = None):
     lib.mjh_model_create.restype = ctypes.c_int
     lib.mjh_model_destroy.argtypes = [ctypes.c_void_p]
     lib.mjh_model_destroy.restype = None
-    lib.mjh_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    lib.mjh_forward.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     lib.mjh_forward.restype = ctypes.c_int
     lib.mjh_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(DataPtrs), ctypes.POINTER(DataPtrs), ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     lib.mjh_step.restype = ctypes.c_int

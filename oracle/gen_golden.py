@@ -110,6 +110,9 @@ CASES = {
     "muscle_arm_rk4_f32": ("muscle_arm", {"integrator": 1}, "float32", 3, 3, "muscle"),
     "capsules_topk_f64": ("capsules_topk", {}, "float64", 4, 3, "topk"),
     "capsules_topk_ell_rk4_f32": ("capsules_topk", {"integrator": 1, "cone": 1}, "float32", 3, 2, "topk"),
+    # ... with box / mesh candidates: 22 candidate contacts of boxes, a capsule and a sphere, the 6 closest kept
+    "boxes_topk_f64": ("boxes_topk", {}, "float64", 4, 3, "topk"),
+    "boxes_topk_ell_rk4_f64": ("boxes_topk", {"integrator": 1, "cone": 1}, "float64", 3, 2, "topk"),
     # the last bundled model: every joint type stacked, ball limits, gravity compensation, mocap bodies, fixed tendons, motors on
     # ball / free joints, camera modes (contacts disabled in the XML)
     "pendula_f64": ("pendula", {}, "float64", 3, 3, "pendula"),

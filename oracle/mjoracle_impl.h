@@ -1101,7 +1101,7 @@ static void FN(collision)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* collisio
     REAL dist[MJH_MAX_PAIR_CONTACTS], pos[MJH_MAX_PAIR_CONTACTS][3], frame[MJH_MAX_PAIR_CONTACTS][9];
     int k = m->pair_ncon[p];
     const int* dst = m->pair_dst + p * MJH_MAX_PAIR_CONTACTS;
-    if (w->hint_dist && m->pair_fn[p] >= MJH_FN_PLANE_CONVEX) {
+    if (w->hint_dist && !m->topk && m->pair_fn[p] >= MJH_FN_PLANE_CONVEX) {  /* (hints are in contact-slot order: with max_contact_points the slots are per environment) */
       /* enumerate the pair's tie events; keep the outcome closest to the hint (the natural one on equality) */
       REAL bd[MJH_MAX_PAIR_CONTACTS], bp[MJH_MAX_PAIR_CONTACTS][3], bf[MJH_MAX_PAIR_CONTACTS][9], best_err = 0;
       int runs = 0, natural = 1;
@@ -1129,7 +1129,7 @@ static void FN(collision)(const FN(MjoModel) * M, FN(MjoWork) * w) { /* collisio
       if (!natural) w->tie_pairs++;
       memcpy(dist, bd, sizeof(bd)); memcpy(pos, bp, sizeof(bp)); memcpy(frame, bf, sizeof(bf));
     } else {
-      w->prim_hint_n = (w->hint_dist && w->hint_frame) ? w->hint_frame + 9 * dst[0] : NULL; /* sphere / capsule pairs: one contact, normal = first frame row */
+      w->prim_hint_n = (w->hint_dist && w->hint_frame && !m->topk) ? w->hint_frame + 9 * dst[0] : NULL; /* sphere / capsule pairs: one contact, normal = first frame row */
       w->prim_adopted = 0;
       if (w->stage_mode && m->pair_fn[p] >= MJH_FN_PLANE_CONVEX) w->tie_on = 2;
       FN(pair_contacts)(M, w, p, dist, pos, frame);

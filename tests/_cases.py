@@ -60,6 +60,8 @@ SEEDED_CASES = [
     ("tendon_armature", {}, F64, 64, dict(max_alt=0.0)),                          # tendon armature: qM += J^T diag(armature) J off the tree's sparsity pattern
     ("capsules_topk", {}, F64, 64, dict(max_alt=0.0)),                           # max_contact_points: 13 candidates, the 5 closest kept per environment
     ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, {}),
+    ("boxes_topk", {}, F64, 48, dict(max_alt=0.0)),                               # ... over box candidates: the convex narrow phase hands 22 candidates to the selection through the workspace
+    ("boxes_topk", {"integrator": 1, "cone": 1}, F32, 33, {}),
     ("capsules_topk", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 33, dict(tol_sol=1e-5)),  # ... through the register solver (CG stall accuracy)
     ("centipede", {}, F64, 24, dict(max_alt=0.0)),                                # 72 dofs / 74 bodies (jacobian=dense): multi-word dof masks, more dofs than lanes in the LDS solver
     ("centipede", {"integrator": 1}, F32, 17, {}),
@@ -132,6 +134,7 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("mocap_target", {}, F64, 1e-8), ("pendula", {}, F64, 1e-8), ("pendula", {"integrator": 1, "solver": 1}, F32, 5e-3),
     ("frictionloss_dof", {}, F64, 1e-8), ("ant_frictionloss", {}, F64, 1e-8),
     ("muscle_arm", {}, F64, 1e-8), ("tendon_armature", {}, F64, 1e-8), ("tendon_friction", {}, F64, 1e-8), ("capsules_topk", {}, F64, 1e-8),
+    ("centipede", {}, F64, 1e-8),
 ]
 # float32 cases of the campaign: near-degenerate contact normals amplify eps under these perturbations (pre-solver 1e-3); qfrc_constraint /
 # efc_force of the ant cancel forces of ~1e5, the dynamics leaves carry the comparison there

@@ -47,7 +47,7 @@ class _Lib:
         self.calls += 1
         return pyoracle.lib().mjo_step(ctypes.byref(self.o.desc), pin, pout, B, self.o.dt, flags, 1, None, -1)
 
-    def mjh_forward(self, handle, pin, pout, B, stages, flags, stream):
+    def mjh_forward(self, handle, pin, pout, work, B, stages, flags, stream):
         self.calls += 1
         return pyoracle.lib().mjo_forward(ctypes.byref(self.o.desc), pin, pout, B, self.o.dt, stages, flags, 1, None, -1)
 
