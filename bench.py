@@ -314,18 +314,30 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
                      "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}}, nm
 
 
-def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, spin=100):
+def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, spin=100, repeats=2):
     """BASELINE configs 3 / 5 timed by the same drop-in loop inside the headline run: a fixed recipe -- `spin`
     untimed steps on a scratch copy, then from the ORIGINAL state `warmup` untimed and `steps` timed steps -- independent of the headline's
-    --steps / --warmup, so the figure is the same trajectory window whoever launches the bench."""
-    wl, B, dtype, mx, mdev, loop = setup_workload(key, 0, device, rank)
-    spin_up(mdev, loop, spin)
-    loop.dropin(warmup)
-    elapsed, kernel_ms = timed(loop.dropin, steps, device, world, backend)
-    assert torch.isfinite(loop.d.qpos).all(), f"{key}: non-finite state after the timed steps"
+    --steps / --warmup, so the figure is the same trajectory window whoever launches the bench.  The recipe runs `repeats` times from
+    scratch (same seeds, same trajectory): device clocks on this pool move the same window by up to 8 % between repetitions
+    (profiles/r03/notes.md); `value` is the fastest repetition, `repeats` lists every one."""
+    runs, best = [], None
+    for _ in range(repeats):
+        torch.cuda.empty_cache()  # the previous workload's cached blocks go back to the driver: this one allocates like a process of its own
+        wl, B, dtype, mx, mdev, loop = setup_workload(key, 0, device, rank)
+        spin_up(mdev, loop, spin)
+        loop.dropin(warmup)
+        elapsed, kernel_ms = timed(loop.dropin, steps, device, world, backend)
+        assert torch.isfinite(loop.d.qpos).all(), f"{key}: non-finite state after the timed steps"
+        runs.append({"value": B * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms})
+        if best is None or elapsed < best[0]:
+            best = (elapsed, kernel_ms, loop, mx, mdev)
+        else:
+            del loop
+    elapsed, kernel_ms, loop, mx, mdev = best
     res = {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world, "dtype": "f64" if dtype == torch.float64 else "f32",
            "steps": steps, "warmup": warmup, "spin_up_steps_on_a_scratch_state": spin,
-           "value": B * world * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms}
+           "value": B * world * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms,
+           "repeats": runs}
     if rank == 0:
         res["roofline"], _ = roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps)
     del loop
