@@ -370,7 +370,7 @@ def main(args):
     wl, B, dtype, mx, mdev, loop = setup_workload(args.workload, args.batch, device, rank)
     loop.bufs, loop.cur = [loop.d.clone(), loop.d.clone()], 0   # the out= loop starts from the same state (solver work depends on it)
 
-    SPIN_UP = 100
+    SPIN_UP = int(os.environ.get("BENCH_SPIN_UP", "100"))
     spin_up(mdev, loop, SPIN_UP)
     loop.dropin(args.warmup)
     elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)

@@ -3601,7 +3601,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
   const int sub = (int)(threadIdx.x / W);
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
-  if (K.scan_marks) {
+  if constexpr (RPL > 1 && W == 32) if (K.scan_marks) {  // (only the full-width instantiations ever run as a second tier: the others carry none of this)
     // Second tier behind a first one that marked what it left (mjh_bail_mark in out.qacc): each wave reads the marks of 64 environments with
     // one load and serves the marked ones NSUB at a time.  A launch of one wave per environment pair, each counting its active rows only to
     // leave, cost the ant 11.5 us per RK4 stage for a tier that serves (almost) nobody.
