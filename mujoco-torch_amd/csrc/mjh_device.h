@@ -13,6 +13,7 @@
 
 #define MJH_WAVE 64
 #define MJH_MAX_DEPTH 128
+#define MJH_CHAIN_PRE 3  /* joints of a body whose descriptors the tree sweeps keep in registers (the rest are read from the table inside the sweep) */
 
 // ---- constants (reference reads them from the mujoco package) ---------------------------------
 #define mjMINVAL 1e-15
@@ -173,7 +174,17 @@ struct DevModel {
 __device__ __forceinline__ int lane_id() { return threadIdx.x; }
 
 // LDS visibility point for a single-wave workgroup (s_waitcnt + barrier; the barrier is free for 1 wave).
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// A workgroup is one wavefront: what a "barrier" has to order is the LDS traffic of its lanes.  __syncthreads() carries a workgroup-scope
+// fence over GLOBAL memory too, i.e. s_waitcnt vmcnt(0): every barrier behind a burst of leaf stores stalled the wave until L2 had taken all of
+// them (the stores of one phase are 60 - 80 MB per launch, issued by all waves at the same moment) -- 10 of the fused kinematics + velocity
+// kernel's 75 us on the humanoid.  The fences below are restricted to the LDS address space; the stores drain behind the arithmetic that follows.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// ... and the full barrier, for the one place where a wave reads back through L2 what it has just stored (the small-model constraint phase)
+__device__ __forceinline__ void wave_sync_global() { __syncthreads(); }
 
 template <typename T>
 __device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, src_lane, MJH_WAVE); }

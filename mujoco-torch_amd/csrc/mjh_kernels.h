@@ -152,6 +152,9 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define KA (kargs<REAL>())
 // In-kernel stamps (diagnostic build only, never in the shipped library): lane 0 records the shader clock at
 // section boundaries into a buffer of its own; tools/stamps.py turns them into a per-section cycle profile.
+#ifndef MJH_ABLATE
+#define MJH_ABLATE 0
+#endif
 #ifdef MJH_STAMPS
 // each STAMP adds the shader-clock time since the previous STAMP of this environment's phase to its slot: sections inside loops
 // accumulate over the iterations
@@ -170,13 +173,23 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define STAMP0() do {} while (0)
 #endif
 
+// the value is only known from here on, as far as the optimiser can tell (an environment index is wave-uniform for a whole-wave environment)
+template <int W>
+__device__ __forceinline__ void late_bind(int64_t& v) {
+  if constexpr (W == MJH_WAVE) asm volatile("" : "+s"(v));
+  else asm volatile("" : "+v"(v));
+}
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
 // Four independent transfers are issued per trip so one HBM/L2 (or LDS) round trip covers 256 elements.
 template <int W, typename REAL>
 __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t env) {
   if (!g) return;
+  // (the row's address is formed HERE: left to the optimiser, the address arithmetic of every leaf store of a phase is hoisted to the kernel's head,
+  // spilled, and reloaded in front of the store -- and a scratch reload queues behind the stores already in flight: vmcnt is in order on gfx9)
+  late_bind<W>(env);
   REAL* dst = g + env * n;
   int i = sub_lane<W>();
+  asm volatile("" : "+v"(i));
   for (; i + 3 * W < n; i += 4 * W) {
     const REAL a = l[i], b = l[i + W], c = l[i + 2 * W], d = l[i + 3 * W];
     dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = c; dst[i + 3 * W] = d;
@@ -187,8 +200,10 @@ __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t
 template <int W, typename REAL>
 __device__ __forceinline__ void row_copy_const(REAL* g, const REAL* c, int n, int64_t env) {
   if (!g) return;
+  late_bind<W>(env);
   REAL* dst = g + env * n;
   int i = sub_lane<W>();
+  asm volatile("" : "+v"(i));
   for (; i + 7 * W < n; i += 8 * W) {
     REAL t[8];
 #pragma unroll
@@ -741,6 +756,7 @@ struct Env {
       for (int i = 0; i < 4; i++) S.jquat()[4 * j + i] = q[i];
     }
     wave_sync();
+if (MJH_ABLATE != 3) {
     for (int b = l; b < M.nbody; b += W) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
@@ -824,6 +840,7 @@ struct Env {
       quat_to_mat(quat, S.xmat() + 9 * b);
       local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, S.ximat() + 9 * b);
     }
+}  // MJH_ABLATE 3
     wave_sync();
     STAMP(2);
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
@@ -835,6 +852,7 @@ struct Env {
         for (int i = 0; i < 4; i++) S.qpos()[o + i] = S.jquat()[4 * j + i];
       }
     }
+if (MJH_ABLATE != 4) {
     for (int g = l; g < M.ngeom; g += W) {
       const int b = M.geom_bodyid[g];
       REAL p[3], mat[9];
@@ -889,12 +907,15 @@ struct Env {
         }
       }
     }
+}  // MJH_ABLATE 4
     wave_sync();
     STAMP(3);
+if (MJH_ABLATE != 10) {
     put(out.qpos, S.qpos(), M.nq);
     put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
     put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
     put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+}  // MJH_ABLATE 10
     STAMP(4);
   }
 
@@ -905,6 +926,7 @@ struct Env {
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
     // the per-body terms first (one global read of the mass per term, staged where cinert will be written later), so the
     // subtree loops below run on LDS only
+if (MJH_ABLATE != 5) {
     REAL* term = S.cinert();
     for (int w = l; w < nb * 4; w += W) {
       const int b = w >> 2, k = w & 3;
@@ -975,9 +997,12 @@ struct Env {
         for (int k = 0; k < 3; k++) { S.cdof()[6 * d + k] = 0; S.cdof()[6 * d + 3 + k] = S.xaxis()[3 * j + k]; }
       }
     }
+}  // MJH_ABLATE 5
     wave_sync();
     STAMP(6);
+if (MJH_ABLATE != 10) {
     put(out.subtree_com, S.subtree_com(), 3 * nb); put(out.cinert, S.cinert(), 10 * nb); put(out.cdof, S.cdof(), 6 * M.nv);
+}  // MJH_ABLATE 10
     STAMP(7);
   }
 
@@ -1589,7 +1614,8 @@ struct Env {
         for (int r = 0; r < dim; r++) Jdst[(row0 + r) * nv + d] = diff[r];
       }
     }
-    wave_sync();
+    if constexpr (!FRIC && DIRECT) wave_sync_global();  // the aref loop below reads the rows back through L2: the stores must have landed
+    else wave_sync();
     STAMP(25);
     const int ns = ne + nfa + nlb + nl + nlt;  // efc_pos / efc_pos_norm / efc_invweight only hold the equality / frictionloss / limit rows
     // RK4 stages 1..3 of a small model (their Data is a private workspace, see above): only the limit rows and the rows of the ACTIVE contacts are
@@ -1712,6 +1738,30 @@ struct Env {
     if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (r >= ne && r < ne + nf) ? M.dof_frictionloss[M.fric_dof[r - ne]] : ((r >= ne + nf && r < ne + nfa) ? M.tendon_frictionloss[M.fric_tendon[r - ne - nf]] : (REAL)0);
   }
 
+  // sum over the dofs [d, d + width) of the products cdof * qvel staged in cdof_dot, in dof order (width 1 or 3)
+  __device__ __forceinline__ void dof_sum(int d, int width, REAL* s) {
+    const REAL* p = S.cdof_dot() + 6 * d;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      REAL a = p[k];
+      if (width == 3) a = (a + p[6 + k]) + p[12 + k];
+      s[k] = a;
+    }
+  }
+  // v += the contribution of one joint (pk = (type + 1) | dofadr << 8); a free joint adds its translational sum, then its rotational one
+  __device__ __forceinline__ void cvel_add_joint(int pk, REAL* v) {
+    const int t = (pk & 0xff) - 1, d = pk >> 8;
+    REAL s[6];
+    dof_sum(d, t == JNT_HINGE || t == JNT_SLIDE ? 1 : 3, s);
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = v[k] + s[k];
+    if (t == JNT_FREE) {
+      dof_sum(d + 3, 3, s);
+#pragma unroll
+      for (int k = 0; k < 6; k++) v[k] = v[k] + s[k];
+    }
+  }
+
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
   template <bool FLUID, bool FUSED = false>
   __device__ __forceinline__ void velocity() {
@@ -1747,6 +1797,7 @@ struct Env {
       row_store<W>(out.ten_J, M.ten_J0, nt * nv, e);
       wave_sync();
     }
+if (MJH_ABLATE != 8) {
     row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
     if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
       for (int i = l; i < nu; i += W) {
@@ -1789,51 +1840,78 @@ struct Env {
       S.act_length()[i] = len;
       S.act_velocity()[i] = vel;
     }
+}  // MJH_ABLATE 8
     STAMP(32);
-    // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
-    for (int b = l; b < nb; b += W) {
-      REAL cvel[6] = {0, 0, 0, 0, 0, 0};
-      const int depth = M.body_depth[b], md = M.max_depth, mj = M.max_jnt;
-      for (int kk = 0; kk < md; kk++) {  // uniform trip counts; the joint list of every level comes from one flat table
-        if (kk >= depth) continue;      // (its addresses depend on (b, level) only, so the loads run ahead of the arithmetic)
-        const bool own = (kk == depth - 1);
-        for (int jj = 0; jj < mj; jj++) {
-          const int pk = M.chain_jnt[(b * md + kk) * mj + jj];
-          if (pk == 0) continue;
-          const int t = (pk & 0xff) - 1, d = pk >> 8;
-          if (t == JNT_FREE) {
-            REAL s[6];
+    // com_vel (smooth.py:385-424): cvel[b] = cvel[parent] + the sums of b's own joints, in joint order -- the reference's scan over the tree,
+    // level by level.  What does not depend on the parent is taken off the serial part: the products cdof * qvel are formed by one lane per
+    // entry first (staged in cdof_dot, which nobody has written yet), and cdof_dot = cvel-before-the-joint x cdof is formed for all bodies at once
+    // after the sweep (a lane rebuilds its body's partial sums from the parent's cvel: the same additions in the same order).  The sweep itself
+    // is six additions per joint and one LDS round trip per level (it used to walk every lane down its whole ancestor chain: depth x joints
+    // dependent table reads and multiply-adds per lane).
+if (MJH_ABLATE != 1) {
+    for (int w = l; w < 6 * nv; w += W) S.cdof_dot()[w] = S.cdof()[w] * S.qvel()[w / 6];
+    if (l < 6) S.cvel()[l] = 0;  // the world body
+    wave_sync();
+    {
+      const int md = M.max_depth, mj = M.max_jnt;
+      for (int b0 = 0; b0 < nb; b0 += W) {  // parents precede their children: a chunk of W bodies only needs earlier chunks and its own lower levels
+        const int b = b0 + l;
+        const bool has = b < nb;
+        const int depth = has ? M.body_depth[b] : 0, par = has ? M.body_parentid[b] : 0;
+        const int* own = M.chain_jnt + ((size_t)(has ? b : 0) * md + (depth > 0 ? depth - 1 : 0)) * mj;
+        int pkj[MJH_CHAIN_PRE];
 #pragma unroll
-            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * d + k] * S.qvel()[d] + S.cdof()[6 * (d + 1) + k] * S.qvel()[d + 1]) + S.cdof()[6 * (d + 2) + k] * S.qvel()[d + 2];
+        for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) pkj[jj] = (depth > 0 && jj < mj) ? own[jj] : 0;
+        for (int kk = 0; kk < md; kk++) {
+          if (depth == kk + 1) {
+            REAL v[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
-            if (own) {
-              for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof_dot()[6 * (d + r) + k] = 0;
-              for (int r = 3; r < 6; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
-            }
+            for (int k = 0; k < 6; k++) v[k] = S.cvel()[6 * par + k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * (d + 3) + k] * S.qvel()[d + 3] + S.cdof()[6 * (d + 4) + k] * S.qvel()[d + 4]) + S.cdof()[6 * (d + 5) + k] * S.qvel()[d + 5];
+            for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) if (pkj[jj]) cvel_add_joint(pkj[jj], v);
+            for (int jj = MJH_CHAIN_PRE; jj < mj; jj++) { const int pk = own[jj]; if (pk) cvel_add_joint(pk, v); }
 #pragma unroll
-            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
-          } else {
-            const int width = (t == JNT_BALL) ? 3 : 1;
-            if (own) for (int r = 0; r < width; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
-            REAL s[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-              s[k] = S.cdof()[6 * d + k] * S.qvel()[d];
-              for (int r = 1; r < width; r++) s[k] = s[k] + S.cdof()[6 * (d + r) + k] * S.qvel()[d + r];
-            }
-#pragma unroll
-            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+            for (int k = 0; k < 6; k++) S.cvel()[6 * b + k] = v[k];
           }
+          wave_sync();
         }
-      }
+        if (depth > 0) {  // cdof_dot of the body's own dofs (each lane touches its own body's slots only: the staged products are read before they are overwritten)
+          REAL v[6];
 #pragma unroll
-      for (int k = 0; k < 6; k++) S.cvel()[6 * b + k] = cvel[k];
+          for (int k = 0; k < 6; k++) v[k] = S.cvel()[6 * par + k];
+          auto own_joint = [&](int pk) {
+            if (pk == 0) return;
+            const int t = (pk & 0xff) - 1, d = pk >> 8;
+            if (t == JNT_FREE) {
+              REAL tr[6], rot[6];
+              dof_sum(d, 3, tr);
+              dof_sum(d + 3, 3, rot);  // read before its slots are overwritten
+#pragma unroll
+              for (int k = 0; k < 6; k++) v[k] = v[k] + tr[k];
+              for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof_dot()[6 * (d + r) + k] = 0;
+              for (int r = 3; r < 6; r++) motion_cross(v, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+#pragma unroll
+              for (int k = 0; k < 6; k++) v[k] = v[k] + rot[k];
+            } else {
+              const int width = (t == JNT_BALL) ? 3 : 1;
+              REAL sj[6];
+              dof_sum(d, width, sj);
+              for (int r = 0; r < width; r++) motion_cross(v, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+#pragma unroll
+              for (int k = 0; k < 6; k++) v[k] = v[k] + sj[k];
+            }
+          };
+#pragma unroll
+          for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) own_joint(pkj[jj]);
+          for (int jj = MJH_CHAIN_PRE; jj < mj; jj++) own_joint(own[jj]);
+        }
+        wave_sync();
+      }
     }
+}  // MJH_ABLATE 1
     STAMP(33);
     // passive forces
+if (MJH_ABLATE != 7) {
     if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = 0;
       if (FLUID && M.has_gravcomp) for (int d = l; d < nv; d += W) { S.qfrc_gravcomp()[d] = 0; if (out.qfrc_gravcomp) out.qfrc_gravcomp[e * nv + d] = 0; }  // passive.py:178-183
@@ -1952,37 +2030,57 @@ struct Env {
         wave_sync();
       }
     }
+}  // MJH_ABLATE 7
     wave_sync();
     STAMP(35);
-    // rne: cacc along the ancestor chain (needs cdof_dot of ancestors: written above, visible after the sync)
-    for (int b = l; b < nb; b += W) {
-      REAL cacc[6];
+    // rne (smooth.py:427-467): cacc[b] = cacc[parent] + sum over b's dofs of cdof_dot * qvel -- the same level sweep: the sums are formed for all
+    // bodies at once, the sweep is one addition per component and level, the local forces follow for all bodies at once
+if (MJH_ABLATE != 2) {
+    {
       const bool nograv = M.disableflags & DSBL_GRAVITY;
-#pragma unroll
-      for (int k = 0; k < 3; k++) { cacc[k] = 0; cacc[3 + k] = nograv ? (REAL)0 : -M.gravity[k]; }
-      const int depth = M.body_depth[b], md = M.max_depth;
-      for (int kk = 0; kk < md; kk++) {
-        if (kk >= depth) continue;
-        const int pk = M.chain_dof[b * md + kk];
-        const int d0 = pk & 0xffff, nd = pk >> 16;
+      if (l < 6) S.cacc()[l] = (l < 3 || nograv) ? (REAL)0 : -M.gravity[l - 3];  // the world body
+      const int md = M.max_depth;
+      for (int b0 = 0; b0 < nb; b0 += W) {
+        const int b = b0 + l;
+        const bool has = b < nb;
+        const int depth = has ? M.body_depth[b] : 0, par = has ? M.body_parentid[b] : 0;
+        const int d0 = has ? M.body_dofadr[b] : 0, nd = (has && depth > 0) ? M.body_dofnum[b] : 0;
+        REAL vm[6] = {0, 0, 0, 0, 0, 0};
         if (nd > 0) {
 #pragma unroll
           for (int k = 0; k < 6; k++) {
             REAL s = S.cdof_dot()[6 * d0 + k] * S.qvel()[d0];
             for (int r = 1; r < nd; r++) s = s + S.cdof_dot()[6 * (d0 + r) + k] * S.qvel()[d0 + r];
-            cacc[k] = cacc[k] + s;
+            vm[k] = s;
           }
         }
-      }
-      REAL f1[6], f2[6], f3[6];
-      inert_mul(S.cinert() + 10 * b, cacc, f1);
-      inert_mul(S.cinert() + 10 * b, S.cvel() + 6 * b, f2);
-      motion_cross_force(S.cvel() + 6 * b, f2, f3);
+        wave_sync();  // (first chunk: the world body's row; later chunks: nothing pending)
+        for (int kk = 0; kk < md; kk++) {
+          if (depth == kk + 1) {
 #pragma unroll
-      for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc (cacc itself is not a Data output)
+            for (int k = 0; k < 6; k++) {
+              const REAL c = S.cacc()[6 * par + k];
+              S.cacc()[6 * b + k] = nd > 0 ? c + vm[k] : c;
+            }
+          }
+          wave_sync();
+        }
+      }
+      for (int b = l; b < nb; b += W) {
+        REAL cacc[6], f1[6], f2[6], f3[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) cacc[k] = S.cacc()[6 * b + k];
+        inert_mul(S.cinert() + 10 * b, cacc, f1);
+        inert_mul(S.cinert() + 10 * b, S.cvel() + 6 * b, f2);
+        motion_cross_force(S.cvel() + 6 * b, f2, f3);
+#pragma unroll
+        for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc, over the body's own cacc (cacc itself is not a Data output)
+      }
     }
+}  // MJH_ABLATE 2
     wave_sync();
     STAMP(36);
+if (MJH_ABLATE != 9) {
     for (int w = l; w < nb * 6; w += W) {  // subtree sums of the body forces
       const int b = w / 6, k = w - 6 * b;
       const int end = M.body_subtree_end[b];
@@ -1999,11 +2097,14 @@ struct Env {
       for (int k = 0; k < 6; k++) s += S.cdof()[6 * d + k] * cf[k];
       S.qfrc_bias()[d] = s;
     }
+}  // MJH_ABLATE 9
     wave_sync();
     STAMP(38);
+if (MJH_ABLATE != 11) {
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
     put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
     put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
+}  // MJH_ABLATE 11
     STAMP(39);
   }
 
@@ -2926,7 +3027,7 @@ struct Env {
   __device__ __forceinline__ void run_vel() {
     STAMP0();
     velocity<FLUID, FUSED>();
-    if (KA.stages & 0x60) actuation<FLUID>();
+    if (MJH_ABLATE != 6) if (KA.stages & 0x60) actuation<FLUID>();
   }
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(MJH_WAVE) void mjh_sensor_kernel(KArgs<REAL> args) 
   const int nsd = M.nsensordata, nrf = M.nrfq;
   for (int64_t e = blockIdx.x; e < KA.B; e += gridDim.x) {
     for (int q = lane_id(); q < nrf; q += MJH_WAVE) rf_x[q] = rf_task<REAL>(e, q);
-    __syncthreads();
+    wave_sync();
     for (int k = lane_id(); k < nsd; k += MJH_WAVE) {
       const int s = M.slot_sensor[k];
       REAL v;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(MJH_WAVE) void mjh_sensor_kernel(KArgs<REAL> args) 
       }
       out.sensordata[e * nsd + k] = v;
     }
-    __syncthreads();  // the next environment of this workgroup reuses rf_x
+    wave_sync();  // the next environment of this workgroup reuses rf_x
   }
 }
 
