@@ -701,6 +701,9 @@ struct Env {
   }
   LdsView<REAL> S;
   int64_t e;      // environment index
+  // from here on the environment index is news to the optimiser: the address arithmetic of a store section (e * leaf width, one 64-bit value per leaf) is
+  // formed where the stores are instead of at the kernel's head, where it sat in registers -- or in scratch -- across the whole phase
+  __device__ __forceinline__ void rebind() { late_bind<W>(e); }
   int flags;
 #ifdef MJH_STAMPS
   unsigned long long stamp_prev = 0;
@@ -1726,8 +1729,21 @@ if (MJH_ABLATE != 10) {
     STAMP(26);
     if (FRIC) put(out.efc_J, S.efc_J(), nefc * nv);
     else if (out.efc_J) {
+      rebind();
       REAL* gJ = out.efc_J + e * nefc * nv;
-      for (int w = l; w < nl * nv; w += W) {  // single-column rows: zeros and the one entry, written once, coalesced
+      if (nl <= W) {
+        // single-column rows: zeros and the one entry, written once, coalesced.  Lane r holds the column of row r; an element looks its row's column up
+        // across the lanes (LDS crossbar) -- a table read per element queued behind the stores already in flight (vmcnt is in order) and made every
+        // pass of this loop wait for the previous pass's stores to land
+        const int mycol = l < nl ? M.lim_dof[M.nf + l] : -1;
+        for (int w = l; w - l < nl * nv; w += W) {
+          int r, d;
+          split_index(w < nl * nv ? w : 0, nv, M.inv_nv, r, d);
+          const int col = __shfl(mycol, (int)(lane_id() & ~(W - 1)) + r, MJH_WAVE);
+          if (w < nl * nv) gJ[w] = (d == col) ? S.efc_jl()[r] : (REAL)0;
+        }
+      } else
+      for (int w = l; w < nl * nv; w += W) {
         int r, d;
         split_index(w, nv, M.inv_nv, r, d);
         gJ[w] = (d == M.jnt_dofadr[M.lim_jnt[r]]) ? S.efc_jl()[r] : (REAL)0;
@@ -3058,6 +3074,7 @@ if (MJH_ABLATE != 11) {
     const int l = lane();
     const int nq = M.nq, nv = M.nv, na = M.na;
     if (!KA.do_step) return;
+    rebind();
     const REAL dt = M.timestep;
     const REAL time0 = in.time ? in.time[e] : (REAL)0;
     const int rk = KA.rk_stage;
@@ -3634,6 +3651,7 @@ if (MJH_ABLATE != 11) {
         if (l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);
         return;
       }
+      rebind();
       if (newton) {  // the Hessian weights overwrote the staged forces: stage the final ones for the row-order store below
 #pragma unroll
         for (int j = 0; j < RPL; j++) if (l + W * j < nda) fs[l + W * j] = frd[j];
