@@ -217,6 +217,35 @@ __device__ __forceinline__ void row_copy_const(REAL* g, const REAL* c, int n, in
   }
   for (; i < n; i += W) dst[i] = c[i];
 }
+// K model constants into K leaves: the first T * W elements of every array are read before the first store (longer arrays finish with row_copy_const)
+template <int W, int K, int T, typename REAL>
+__device__ __forceinline__ void multi_copy_const(REAL* const (&dst)[K], const REAL* const (&src)[K], const int (&n)[K], int64_t env) {
+  late_bind<W>(env);
+  int l = sub_lane<W>();
+  asm volatile("" : "+v"(l));
+  REAL v[K][T];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int i = l + t * W; v[k][t] = (dst[k] && i < n[k]) ? src[k][i] : (REAL)0; }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++) { const int i = l + t * W; if (dst[k] && i < n[k]) dst[k][env * n[k] + i] = v[k][t]; }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++)
+    if (dst[k] && n[k] > T * W) {
+      REAL* d = dst[k] + env * n[k];
+      int i = l + T * W;
+      for (; i + 3 * W < n[k]; i += 4 * W) {
+        const REAL a = src[k][i], b = src[k][i + W], c = src[k][i + 2 * W], e2 = src[k][i + 3 * W];
+        d[i] = a; d[i + W] = b; d[i + 2 * W] = c; d[i + 3 * W] = e2;
+      }
+      for (; i < n[k]; i += W) d[i] = src[k][i];
+    }
+}
 template <int W, typename REAL>
 __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
   if (!g) { for (int i = sub_lane<W>(); i < n; i += W) l[i] = 0; return; }
@@ -846,6 +875,14 @@ if (MJH_ABLATE != 3) {
 }  // MJH_ABLATE 3
     wave_sync();
     STAMP(2);
+    // the frames go out now, ahead of the geom / site / camera loops: a phase's leaf stores are bursts of tens of MB issued by every wave at the same
+    // moment, and the first table read behind one waits until L2 has taken it (vmcnt is in order) -- several smaller bursts with arithmetic between them drain
+    // in the background where one large one does not
+if (MJH_ABLATE != 10) {
+    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
+    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
+    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+}  // MJH_ABLATE 10
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -915,9 +952,6 @@ if (MJH_ABLATE != 4) {
     STAMP(3);
 if (MJH_ABLATE != 10) {
     put(out.qpos, S.qpos(), M.nq);
-    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
-    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
-    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
 }  // MJH_ABLATE 10
     STAMP(4);
   }
@@ -1258,17 +1292,21 @@ if (MJH_ABLATE != 10) {
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
-      row_store<W>(out.contact_includemargin, M.con_includemargin, nc, e);
-      row_store<W>(out.contact_friction, M.con_friction, 5 * nc, e);
-      row_store<W>(out.contact_solref, M.con_solref, 2 * nc, e);
-      row_store<W>(out.contact_solreffriction, M.con_solreffriction, 2 * nc, e);
-      row_store<W>(out.contact_solimp, M.con_solimp, 5 * nc, e);
+      // (all the reads first, then the stores: a read between two stores waits for the first store to land -- vmcnt is in order -- and the optimiser
+      // may not move it up past a store it cannot prove distinct)
+      {
+        REAL* const dst[5] = {out.contact_includemargin, out.contact_friction, out.contact_solref, out.contact_solreffriction, out.contact_solimp};
+        const REAL* const src[5] = {M.con_includemargin, M.con_friction, M.con_solref, M.con_solreffriction, M.con_solimp};
+        const int cnt[5] = {nc, 5 * nc, 2 * nc, 2 * nc, 5 * nc};
+        multi_copy_const<W, 5, 1>(dst, src, cnt, e);
+      }
       for (int c = l; c < nc; c += W) {
-        if (out.contact_dim) out.contact_dim[e * nc + c] = M.con_dim[c];
-        if (out.contact_geom1) out.contact_geom1[e * nc + c] = M.con_geom1[c];
-        if (out.contact_geom2) out.contact_geom2[e * nc + c] = M.con_geom2[c];
-        if (out.contact_geom) { out.contact_geom[(e * nc + c) * 2] = M.con_geom1[c]; out.contact_geom[(e * nc + c) * 2 + 1] = M.con_geom2[c]; }
-        if (out.contact_efc_address) out.contact_efc_address[e * nc + c] = M.con_efc_address[c];
+        const int dim = M.con_dim[c], g1 = M.con_geom1[c], g2 = M.con_geom2[c], adr = M.con_efc_address[c];
+        if (out.contact_dim) out.contact_dim[e * nc + c] = dim;
+        if (out.contact_geom1) out.contact_geom1[e * nc + c] = g1;
+        if (out.contact_geom2) out.contact_geom2[e * nc + c] = g2;
+        if (out.contact_geom) { out.contact_geom[(e * nc + c) * 2] = g1; out.contact_geom[(e * nc + c) * 2 + 1] = g2; }
+        if (out.contact_efc_address) out.contact_efc_address[e * nc + c] = adr;
       }
     }
   }
@@ -1814,7 +1852,7 @@ if (MJH_ABLATE != 10) {
       wave_sync();
     }
 if (MJH_ABLATE != 8) {
-    row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591)
+    if (!M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591); all of it for act_simple models: velocity_stores()
     if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
       for (int i = l; i < nu; i += W) {
         const REAL gear = M.act_gear[6 * i];
@@ -2116,12 +2154,18 @@ if (MJH_ABLATE != 9) {
 }  // MJH_ABLATE 9
     wave_sync();
     STAMP(38);
+    STAMP(39);
+  }
+  // the leaves of the velocity stage go out at the very end of the phase, behind _actuation: nothing waits for a store that has no read behind it
+  // (in front of _actuation, its first table read waited for all of them to land)
+  __device__ __forceinline__ void velocity_stores() {
+    const int nv = M.nv, nb = M.nbody, nu = M.nu;
 if (MJH_ABLATE != 11) {
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
     put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
     put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
+    if (M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant moment matrix (smooth.py:535-591): 4.5 KB per humanoid
 }  // MJH_ABLATE 11
-    STAMP(39);
   }
 
   // ---- muscle actuators (support.py:197-296) ---------------------------------------------------------------------------------------------
@@ -3044,6 +3088,7 @@ if (MJH_ABLATE != 11) {
     STAMP0();
     velocity<FLUID, FUSED>();
     if (MJH_ABLATE != 6) if (KA.stages & 0x60) actuation<FLUID>();
+    velocity_stores();
   }
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.
