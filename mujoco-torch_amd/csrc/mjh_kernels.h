@@ -152,9 +152,6 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define KA (kargs<REAL>())
 // In-kernel stamps (diagnostic build only, never in the shipped library): lane 0 records the shader clock at
 // section boundaries into a buffer of its own; tools/stamps.py turns them into a per-section cycle profile.
-#ifndef MJH_ABLATE
-#define MJH_ABLATE 0
-#endif
 #ifdef MJH_STAMPS
 // each STAMP adds the shader-clock time since the previous STAMP of this environment's phase to its slot: sections inside loops
 // accumulate over the iterations
@@ -788,7 +785,6 @@ struct Env {
       for (int i = 0; i < 4; i++) S.jquat()[4 * j + i] = q[i];
     }
     wave_sync();
-if (MJH_ABLATE != 3) {
     for (int b = l; b < M.nbody; b += W) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
@@ -872,17 +868,14 @@ if (MJH_ABLATE != 3) {
       quat_to_mat(quat, S.xmat() + 9 * b);
       local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, S.ximat() + 9 * b);
     }
-}  // MJH_ABLATE 3
     wave_sync();
     STAMP(2);
     // the frames go out now, ahead of the geom / site / camera loops: a phase's leaf stores are bursts of tens of MB issued by every wave at the same
     // moment, and the first table read behind one waits until L2 has taken it (vmcnt is in order) -- several smaller bursts with arithmetic between them drain
     // in the background where one large one does not
-if (MJH_ABLATE != 10) {
     put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
     put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
     put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
-}  // MJH_ABLATE 10
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -892,7 +885,6 @@ if (MJH_ABLATE != 10) {
         for (int i = 0; i < 4; i++) S.qpos()[o + i] = S.jquat()[4 * j + i];
       }
     }
-if (MJH_ABLATE != 4) {
     for (int g = l; g < M.ngeom; g += W) {
       const int b = M.geom_bodyid[g];
       REAL p[3], mat[9];
@@ -947,12 +939,9 @@ if (MJH_ABLATE != 4) {
         }
       }
     }
-}  // MJH_ABLATE 4
     wave_sync();
     STAMP(3);
-if (MJH_ABLATE != 10) {
     put(out.qpos, S.qpos(), M.nq);
-}  // MJH_ABLATE 10
     STAMP(4);
   }
 
@@ -963,7 +952,6 @@ if (MJH_ABLATE != 10) {
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
     // the per-body terms first (one global read of the mass per term, staged where cinert will be written later), so the
     // subtree loops below run on LDS only
-if (MJH_ABLATE != 5) {
     REAL* term = S.cinert();
     for (int w = l; w < nb * 4; w += W) {
       const int b = w >> 2, k = w & 3;
@@ -1034,12 +1022,9 @@ if (MJH_ABLATE != 5) {
         for (int k = 0; k < 3; k++) { S.cdof()[6 * d + k] = 0; S.cdof()[6 * d + 3 + k] = S.xaxis()[3 * j + k]; }
       }
     }
-}  // MJH_ABLATE 5
     wave_sync();
     STAMP(6);
-if (MJH_ABLATE != 10) {
     put(out.subtree_com, S.subtree_com(), 3 * nb); put(out.cinert, S.cinert(), 10 * nb); put(out.cdof, S.cdof(), 6 * M.nv);
-}  // MJH_ABLATE 10
     STAMP(7);
   }
 
@@ -1851,7 +1836,6 @@ if (MJH_ABLATE != 10) {
       row_store<W>(out.ten_J, M.ten_J0, nt * nv, e);
       wave_sync();
     }
-if (MJH_ABLATE != 8) {
     if (!M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant part of the moment matrix (smooth.py:535-591); all of it for act_simple models: velocity_stores()
     if (M.act_simple) {  // every transmission is a slide / hinge joint: one constant non-zero per moment row
       for (int i = l; i < nu; i += W) {
@@ -1894,15 +1878,57 @@ if (MJH_ABLATE != 8) {
       S.act_length()[i] = len;
       S.act_velocity()[i] = vel;
     }
-}  // MJH_ABLATE 8
     STAMP(32);
+    if constexpr (W <= 16) {  // small models (four environments per wavefront): shallow trees, where the plain walk down the ancestor chain is shorter than the sweep's passes
+    // com_vel: lane b accumulates cvel along its ancestor chain, in the reference's per-body order
+    for (int b = l; b < nb; b += W) {
+      REAL cvel[6] = {0, 0, 0, 0, 0, 0};
+      const int depth = M.body_depth[b], md = M.max_depth, mj = M.max_jnt;
+      for (int kk = 0; kk < md; kk++) {  // uniform trip counts; the joint list of every level comes from one flat table
+        if (kk >= depth) continue;      // (its addresses depend on (b, level) only, so the loads run ahead of the arithmetic)
+        const bool own = (kk == depth - 1);
+        for (int jj = 0; jj < mj; jj++) {
+          const int pk = M.chain_jnt[(b * md + kk) * mj + jj];
+          if (pk == 0) continue;
+          const int t = (pk & 0xff) - 1, d = pk >> 8;
+          if (t == JNT_FREE) {
+            REAL s[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * d + k] * S.qvel()[d] + S.cdof()[6 * (d + 1) + k] * S.qvel()[d + 1]) + S.cdof()[6 * (d + 2) + k] * S.qvel()[d + 2];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+            if (own) {
+              for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof_dot()[6 * (d + r) + k] = 0;
+              for (int r = 3; r < 6; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[k] = (S.cdof()[6 * (d + 3) + k] * S.qvel()[d + 3] + S.cdof()[6 * (d + 4) + k] * S.qvel()[d + 4]) + S.cdof()[6 * (d + 5) + k] * S.qvel()[d + 5];
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+          } else {
+            const int width = (t == JNT_BALL) ? 3 : 1;
+            if (own) for (int r = 0; r < width; r++) motion_cross(cvel, S.cdof() + 6 * (d + r), S.cdof_dot() + 6 * (d + r));
+            REAL s[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+              s[k] = S.cdof()[6 * d + k] * S.qvel()[d];
+              for (int r = 1; r < width; r++) s[k] = s[k] + S.cdof()[6 * (d + r) + k] * S.qvel()[d + r];
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) cvel[k] = cvel[k] + s[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) S.cvel()[6 * b + k] = cvel[k];
+    }
+    } else {
     // com_vel (smooth.py:385-424): cvel[b] = cvel[parent] + the sums of b's own joints, in joint order -- the reference's scan over the tree,
     // level by level.  What does not depend on the parent is taken off the serial part: the products cdof * qvel are formed by one lane per
     // entry first (staged in cdof_dot, which nobody has written yet), and cdof_dot = cvel-before-the-joint x cdof is formed for all bodies at once
     // after the sweep (a lane rebuilds its body's partial sums from the parent's cvel: the same additions in the same order).  The sweep itself
     // is six additions per joint and one LDS round trip per level (it used to walk every lane down its whole ancestor chain: depth x joints
     // dependent table reads and multiply-adds per lane).
-if (MJH_ABLATE != 1) {
     for (int w = l; w < 6 * nv; w += W) S.cdof_dot()[w] = S.cdof()[w] * S.qvel()[w / 6];
     if (l < 6) S.cvel()[l] = 0;  // the world body
     wave_sync();
@@ -1962,10 +1988,9 @@ if (MJH_ABLATE != 1) {
         wave_sync();
       }
     }
-}  // MJH_ABLATE 1
+    }
     STAMP(33);
     // passive forces
-if (MJH_ABLATE != 7) {
     if (M.disableflags & (DSBL_SPRING | DSBL_DAMPER)) {
       for (int d = l; d < nv; d += W) S.qfrc_passive()[d] = 0;
       if (FLUID && M.has_gravcomp) for (int d = l; d < nv; d += W) { S.qfrc_gravcomp()[d] = 0; if (out.qfrc_gravcomp) out.qfrc_gravcomp[e * nv + d] = 0; }  // passive.py:178-183
@@ -2084,12 +2109,39 @@ if (MJH_ABLATE != 7) {
         wave_sync();
       }
     }
-}  // MJH_ABLATE 7
     wave_sync();
     STAMP(35);
+    if constexpr (W <= 16) {
+    // rne: cacc along the ancestor chain (needs cdof_dot of ancestors: written above, visible after the sync)
+    for (int b = l; b < nb; b += W) {
+      REAL cacc[6];
+      const bool nograv = M.disableflags & DSBL_GRAVITY;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { cacc[k] = 0; cacc[3 + k] = nograv ? (REAL)0 : -M.gravity[k]; }
+      const int depth = M.body_depth[b], md = M.max_depth;
+      for (int kk = 0; kk < md; kk++) {
+        if (kk >= depth) continue;
+        const int pk = M.chain_dof[b * md + kk];
+        const int d0 = pk & 0xffff, nd = pk >> 16;
+        if (nd > 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) {
+            REAL s = S.cdof_dot()[6 * d0 + k] * S.qvel()[d0];
+            for (int r = 1; r < nd; r++) s = s + S.cdof_dot()[6 * (d0 + r) + k] * S.qvel()[d0 + r];
+            cacc[k] = cacc[k] + s;
+          }
+        }
+      }
+      REAL f1[6], f2[6], f3[6];
+      inert_mul(S.cinert() + 10 * b, cacc, f1);
+      inert_mul(S.cinert() + 10 * b, S.cvel() + 6 * b, f2);
+      motion_cross_force(S.cvel() + 6 * b, f2, f3);
+#pragma unroll
+      for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc (cacc itself is not a Data output)
+    }
+    } else {
     // rne (smooth.py:427-467): cacc[b] = cacc[parent] + sum over b's dofs of cdof_dot * qvel -- the same level sweep: the sums are formed for all
     // bodies at once, the sweep is one addition per component and level, the local forces follow for all bodies at once
-if (MJH_ABLATE != 2) {
     {
       const bool nograv = M.disableflags & DSBL_GRAVITY;
       if (l < 6) S.cacc()[l] = (l < 3 || nograv) ? (REAL)0 : -M.gravity[l - 3];  // the world body
@@ -2131,10 +2183,9 @@ if (MJH_ABLATE != 2) {
         for (int k = 0; k < 6; k++) S.cacc()[6 * b + k] = f1[k] + f3[k];  // local cfrc, over the body's own cacc (cacc itself is not a Data output)
       }
     }
-}  // MJH_ABLATE 2
+    }
     wave_sync();
     STAMP(36);
-if (MJH_ABLATE != 9) {
     for (int w = l; w < nb * 6; w += W) {  // subtree sums of the body forces
       const int b = w / 6, k = w - 6 * b;
       const int end = M.body_subtree_end[b];
@@ -2151,7 +2202,6 @@ if (MJH_ABLATE != 9) {
       for (int k = 0; k < 6; k++) s += S.cdof()[6 * d + k] * cf[k];
       S.qfrc_bias()[d] = s;
     }
-}  // MJH_ABLATE 9
     wave_sync();
     STAMP(38);
     STAMP(39);
@@ -2160,12 +2210,10 @@ if (MJH_ABLATE != 9) {
   // (in front of _actuation, its first table read waited for all of them to land)
   __device__ __forceinline__ void velocity_stores() {
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
-if (MJH_ABLATE != 11) {
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
     put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
     put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
     if (M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant moment matrix (smooth.py:535-591): 4.5 KB per humanoid
-}  // MJH_ABLATE 11
   }
 
   // ---- muscle actuators (support.py:197-296) ---------------------------------------------------------------------------------------------
@@ -3087,7 +3135,7 @@ if (MJH_ABLATE != 11) {
   __device__ __forceinline__ void run_vel() {
     STAMP0();
     velocity<FLUID, FUSED>();
-    if (MJH_ABLATE != 6) if (KA.stages & 0x60) actuation<FLUID>();
+    if (KA.stages & 0x60) actuation<FLUID>();
     velocity_stores();
   }
 

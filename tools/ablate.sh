@@ -5,8 +5,8 @@ groups="$1"; shift
 one() {
   n=$1
   rm -rf $C/build_ab$n; cp -r $C/build $C/build_ab$n
-  (cd $C && MJH_BUILD_JOBS=2 MJH_BUILD_DIR=$C/build_ab$n MJH_BUILD_OUT=$R/mujoco-torch_amd/lib/libmjhip_ab$n.so MJH_BUILD_ONLY="$groups" ./build.sh -DMJH_ABLATE=$n > /dev/null 2>&1) && echo "built ab$n" || echo "FAILED ab$n"
+  (cd $C && MJH_BUILD_JOBS=2 MJH_BUILD_DIR=$C/build_ab$n MJH_BUILD_OUT=$R/mujoco-torch_amd/lib/libmjhip_ab$n.so MJH_BUILD_ONLY="$groups" ./build.sh -D${ABL_MACRO:-MJH_ABLATE}=$n > /dev/null 2>&1) && echo "built ab$n" || echo "FAILED ab$n"
   rm -rf $C/build_ab$n
 }
-export -f one; export R C groups
+export -f one; export R C groups ABL_MACRO
 printf "%s\n" "$@" | xargs -P 4 -I{} bash -c 'one {}'
