@@ -698,6 +698,9 @@ __device__ __forceinline__ bool mjh_is_bail_mark(double x) { return __builtin_bi
 template <typename REAL, int W = 64, bool FRIC = false, bool DIRECT = false>
 struct Env {
   __device__ __forceinline__ static int lane() { return sub_lane<W>(); }
+  // the lane index of a stage function: opaque to the optimiser, so the address arithmetic that hangs off it is formed inside the stage -- hoisted to the
+  // kernel's head (every stage is inlined into one function) the addresses of ALL stages are live, or spilled, across the whole kernel
+  __device__ __forceinline__ static int lane_here() { int l = sub_lane<W>(); asm volatile("" : "+v"(l)); __builtin_assume(l >= 0 && l < W); return l; }
   // dof-frictionloss rows of the SOLVER phase: its frictionloss-free instantiation (kernel 4) carries none of their code,
   // models that have such rows run kernel 6
   __device__ __forceinline__ static int nf_() { return FRIC ? M.nf : 0; }
@@ -765,7 +768,7 @@ struct Env {
 
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
   __device__ __forceinline__ void kinematics(bool with_cams) {
-    const int l = lane();
+    const int l = lane_here();
     // joint-local rotations first, one lane per joint: the trigonometry and the quaternion normalisations leave the
     // serial ancestor walk below (same expressions, smooth.py:85-120)
     for (int j = l; j < M.njnt; j += W) {
@@ -947,7 +950,7 @@ struct Env {
 
   // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
   __device__ __forceinline__ void com_pos() {
-    const int l = lane();
+    const int l = lane_here();
     const int nb = M.nbody;
     // subtree mass / mass-weighted position: bodies are in DFS order, a subtree is a contiguous id range
     // the per-body terms first (one global read of the mass per term, staged where cinert will be written later), so the
@@ -1030,7 +1033,7 @@ struct Env {
 
   // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
   __device__ __forceinline__ void crb_factor() {
-    const int l = lane();
+    const int l = lane_here();
     const int nb = M.nbody, nv = M.nv;
     STAMP0();
     {
@@ -1143,7 +1146,7 @@ struct Env {
 
   bool con_inputs_loaded_ = false;  // collision() already fetched what make_constraint() reads (plain instantiation)
   __device__ __forceinline__ void collision() {
-    const int l = lane();
+    const int l = lane_here();
     if (!FRIC && (KA.stages & 0x78) && M.nefc > 0) {
       // plain instantiation with the rows to follow: qvel, subtree_com and cdof ride in the same round trip as the geom frames -- loaded at the
       // head of make_constraint() they were a second, fully exposed trip behind the narrow phase (16 k of the phase's 77 k cycles on the humanoid)
@@ -1358,7 +1361,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void make_constraint() {
-    const int l = lane();
+    const int l = lane_here();
     // FRIC = false: the plain instantiation (slide / hinge limits and contacts only); equality, frictionloss, ball- and tendon-limit
     // rows compile away and cost the headline kernel no registers
     const int nv = M.nv, nefc = M.nefc, nl = M.nl, nf = FRIC ? M.nf : 0, nft = FRIC ? M.nft : 0, nfa = nf + nft, ne = FRIC ? M.ne : 0, nlb = FRIC ? M.nlb : 0, nlt = FRIC ? M.nlt : 0;
@@ -1804,7 +1807,7 @@ struct Env {
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
   template <bool FLUID, bool FUSED = false>
   __device__ __forceinline__ void velocity() {
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     if (!FUSED) load_qpos(false);
     load_qvel(); load_act();
@@ -2275,7 +2278,7 @@ struct Env {
   // ---- _actuation + _acceleration (forward.py:102-228, support.xfrc_accumulate :184-194) --------------------------------------------------
   template <bool FLUID>
   __device__ __forceinline__ void actuation() {
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nu = M.nu;
     const bool off = (nu == 0) || (M.disableflags & DSBL_ACTUATION);
     if (off) {
@@ -2429,7 +2432,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void update_constraint(Ctx& c) {  // :320-357
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nefc = nrow_;
     REAL part = 0, fneg = 0, fpos = 0;
     const int nf = nf_();
@@ -2484,7 +2487,7 @@ struct Env {
   // second half of _update_constraint: qfrc_constraint = J^T efc_force.  Only needed once a context is iterated on or
   // returned -- the cost-only contexts of the warm-start choice (:526-531) never read it.
   __device__ __forceinline__ void constraint_qfrc() {
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nefc = nrow_;
     const int nl = nf_() + M.nl;
     if constexpr (W == 64 && sizeof(REAL) == 8) {
@@ -2549,7 +2552,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void update_gradient() {  // :359-376
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nefc = nrow_;
     for (int d = l; d < nv; d += W) S.s_grad()[d] = (S.s_Ma()[d] - S.qfrc_smooth()[d]) - S.s_qfrc()[d];
     wave_sync();
@@ -2746,7 +2749,7 @@ struct Env {
   }
 
   __device__ __forceinline__ void linesearch(Ctx& c) {  // :378-497
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nefc = nrow_;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     REAL ss = 0;
@@ -2966,7 +2969,7 @@ struct Env {
   //              context is still in place and only the gradient is added.
   //   P_ITER   : cond :501-508, then body :509-524 (line search, constraint update, gradient, new direction)
   __device__ __forceinline__ void solve() {
-    const int l = lane();
+    const int l = lane_here();
     const int nv = M.nv, nefc = M.nefc;
     const REAL scale = (REAL)(M.meaninertia * (double)(nv > 1 ? nv : 1));
     const bool fixed = flags & MJH_FLAG_FIXED_ITERATIONS;
@@ -3103,7 +3106,7 @@ struct Env {
   // _advance :255-310 into the RETURNED Data (KArgs::out): qvel += qacc dt, qpos integrated with qvel_for_pos
   // (the new qvel when null), act, time.
   __device__ __forceinline__ void advance(const REAL* qpos0, const REAL* qvel0, const REAL* act0, REAL time0, const REAL* act_dot, const REAL* qacc, const REAL* qvel_for_pos) {
-    const int l = lane();
+    const int l = lane_here();
     const REAL dt = M.timestep;
     const StatePtrs<REAL>& fin = KA.fin;
     advance_act(act0, act_dot, fin.act);
@@ -3141,7 +3144,7 @@ struct Env {
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.
   __device__ __forceinline__ void run_sol() {
-    const int l = lane();
+    const int l = lane_here();
     const int nq = M.nq, nv = M.nv, na = M.na;
     STAMP0();
     if (KA.fallback_only) {  // second launch behind the iteration-capped register solver: only the environments it flagged (wave-uniform: one environment per wavefront)
@@ -3164,7 +3167,7 @@ struct Env {
   // the integrator on the solved accelerations: _euler :313-328, or one stage of _rungekutta4 :331-370.  Reads S.qacc / qpos / qvel /
   // act / act_dot / qfrc_smooth / qfrc_constraint from the arena (both solver kernels leave them there).
   __device__ __forceinline__ void integrate_tail() {
-    const int l = lane();
+    const int l = lane_here();
     const int nq = M.nq, nv = M.nv, na = M.na;
     if (!KA.do_step) return;
     rebind();
@@ -3260,7 +3263,7 @@ struct Env {
   __device__ __forceinline__ void run_sol2() {
     static_assert(W == 32 || W == 16, "two or four environments per wavefront");
     constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
-    const int l = lane();
+    const int l = lane_here();
     const int nq = M.nq, nv = M.nv, na = M.na, nefc = M.nefc, nl = M.nl, nd = nefc - nl;
     const bool dof = l < nv, lim = l < nl;
     const bool solving = (KA.stages & 0x40) != 0;
