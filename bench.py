@@ -111,7 +111,8 @@ KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kern
                6: "mjh_phase_kernel<{r}, 6, 64> (solve / integrate, general rows)", 7: "mjh_phase_kernel<{r}, 7, 64> (collision / constraint, general rows)",
                8: "mjh_phase_kernel<{r}, 8, W> (collision / constraint, rows straight to the leaf)",
                9: "mjh_sol2_kernel<{r}, NMAX, RPL> (solve / integrate: register solver, two environments per wavefront)", 10: "mjh_convex_kernel<{r}>", 11: "mjh_sensor_kernel<{r}>",
-               12: "mjh_phase_kernel<{r}, 12, W> (kinematics + velocity in one launch)"}
+               12: "mjh_phase_kernel<{r}, 12, W> (kinematics + velocity in one launch)",
+               13: "mjh_phase_kernel<{r}, 13, W> (kinematics + crb / factor + velocity in one launch)"}
 
 
 def kernel_algorithmic_bytes(nm):
@@ -120,7 +121,7 @@ def kernel_algorithmic_bytes(nm):
     import ctypes
 
     out = {}
-    for k in range(13):
+    for k in range(14):
         rw = (ctypes.c_int64 * 2)()
         if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
             out[k] = (int(rw[0]), int(rw[1]))

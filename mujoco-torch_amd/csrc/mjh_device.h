@@ -47,6 +47,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
 #define PH_SOL2T 64  /* ... and the arrays of the integrator tail, carved over it once the constraint rows are dead           */
 #define PH_SOL2P 128 /* ... after the state the tail integrates, which is parked for the whole phase                           */
 #define PH_KINVEL 256 /* arena of the fused kinematics + velocity kernel (12): the arrays both phases use, then the kinematics-only and the velocity-only arrays OVER each other */
+#define PH_KCV 512  /* arena of the fused kinematics + crb + velocity kernel (13): what kinematics and velocity share, then the kinematics-only, the crb-only and the velocity-only arrays OVER each other */
 #define MJH_NPHASE 5
 #define MJH_NARENA 6  /* arenas carved per model: the five phases + the register solver */
 #define MJH_LDS_ARRAYS(X, m)                                                                                   \

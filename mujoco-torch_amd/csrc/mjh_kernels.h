@@ -74,6 +74,24 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
 #undef X
     off = ka > va ? ka : va;
   }
+  if (phase_bit == PH_KCV) {
+    // kinematics -> crb / factor -> velocity in one kernel: the crb stage runs between the two others on the arrays they share (cinert, cdof); its own
+    // arrays, the kinematics-only frames (stored by then) and the velocity-only quantities (not yet written) start from one common offset.  The factor is
+    // written from registers over the crb stage's own arrays (n <= 32), past the shared part
+    int s0 = 0;
+#define X(n, c, p) if (((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = s0; s0 += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    int ka = s0, ca = s0, va = s0;
+#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = va; va += (((c) + 1) & ~1); } else if (((p) & PH_CRB) && !((p) & (PH_KIN | PH_VEL))) { o.n = ca; ca += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    const int nn = ((m.nv * m.nv + 1) & ~1);
+    if (m.nv <= 32) { o.qLD = s0; if (ca < s0 + nn) ca = s0 + nn; }
+    else { o.qLD = ca; ca += nn; }
+    off = ka > va ? ka : va;
+    if (ca > off) off = ca;
+  }
   if (phase_bit == PH_CRB) {
     // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
     // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
@@ -1032,11 +1050,12 @@ struct Env {
   }
 
   // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
+  template <bool FUSED = false>
   __device__ __forceinline__ void crb_factor() {
     const int l = lane_here();
     const int nb = M.nbody, nv = M.nv;
     STAMP0();
-    {
+    if (!FUSED) {  // (fused behind the kinematics: cinert and cdof are still in the arena)
       REAL* const dst[2] = {S.cinert(), S.cdof()};
       const REAL* const src[2] = {out.cinert, out.cdof};
       const int cnt[2] = {10 * nb, 6 * nv};
@@ -3128,7 +3147,7 @@ struct Env {
     kinematics(KA.rk_stage <= 0);
     com_pos();
   }
-  __device__ __forceinline__ void run_crb() { crb_factor(); }
+  __device__ __forceinline__ void run_crb() { crb_factor<false>(); }
   __device__ __forceinline__ void run_con() {
     STAMP0();
     if (M.ncon > 0) collision();
@@ -3800,6 +3819,9 @@ struct Env {
 #ifndef MJH_KV32_WAVES
 #define MJH_KV32_WAVES 2  /* float32 fused kinematics + velocity kernel, packed: 256 VGPRs and no scratch; at 3 waves (168 VGPRs + ~300 B of scratch, twice the instructions) the ant ran it in 99.6 us instead of 86.3 */
 #endif
+#ifndef MJH_KCV32_WAVES
+#define MJH_KCV32_WAVES 2  /* float32 fused kinematics + crb + velocity kernel, packed: 173 VGPRs; at three waves per SIMD (168 + 20 B of scratch) the ant ran it in 99.7 us instead of 95.7, at four (128 + 112 B) in 104.5 */
+#endif
 #ifndef MJH_CON64_WAVES
 #define MJH_CON64_WAVES 4  /* float64 plain constraint phase: 128 VGPRs + ~108 B of scratch buys the fourth wave per SIMD (16 environments per CU) */
 #endif
@@ -3853,7 +3875,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && PHASE == 12) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 13 && W < 64) ? MJH_KCV32_WAVES : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && (PHASE == 12 || PHASE == 13)) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
@@ -3866,6 +3888,7 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ?
     else if (PHASE == 2 || PHASE == 7 || PHASE == 8) E.run_con();  // 8: plain constraint phase of small models, contact rows straight to the leaf  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
+    else if (PHASE == 13) { E.run_kin(); wave_sync(); E.template crb_factor<true>(); wave_sync(); E.template run_vel<false, true>(); }  // ... and the crb / factor stage between them (small models: the three stages of one RK4 stage are one launch)
     else if (PHASE == 12) { E.run_kin(); wave_sync(); E.template run_vel<false, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
     wave_sync();

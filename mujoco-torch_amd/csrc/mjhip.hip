@@ -63,6 +63,10 @@ struct mjhModel {
   int fuse_kv = 0;                         // kinematics + velocity phases run as ONE kernel (12) from an arena of their own
   LdsOff off_kv;
   int lds_kv = 0;
+  int fuse_kcv = 0;                        // ... and the crb / factor stage between them: ONE kernel (13) for the three (models whose crb stage packs like the other two)
+  LdsOff off_kcv;
+  int lds_kcv = 0;
+  int64_t kcv_max_envs = 0;                // ... while the batch is ONE round of that kernel's waves (it needs more registers than either of its parts: two waves per SIMD)
   int sol2_tiers = 0;                      // 1: a first launch with ONE row slot per lane serves the environments whose active contacts fit 32 dense rows
   int sol2_w16_rpl = 0;                    // > 0: that first launch runs FOUR environments per wavefront (16 lanes each, nv <= 16) with this many row slots per lane
   int sol2_w16_nmax = 0;                   // ... instantiated for 8, 12 or 16 dofs
@@ -584,6 +588,23 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     SET_PACK4(0, 0) SET_PACK4(1, 1) SET_PACK4(3, 3) SET_PACK4(5, 3)
 #undef SET_PACK4
   }
+  {  // kinematics + crb / factor + velocity as ONE kernel (13): when the crb stage packs environments per wavefront the way the other two do (float32 models with
+     // nv <= 16; MJH_CRB_PACK for the rest).  Saves the crb kernel's loads of cinert / cdof, its launch and the wait between the launches.  MJH_FUSE_CRB=0: off.
+    static const bool off = [] { const char* e = getenv("MJH_FUSE_CRB"); return e && e[0] == '0'; }();
+    out->lds_kcv = lds_carve(M, PH_KCV, out->off_kcv) * (int)sizeof(REAL);
+    const bool same_pack = out->pack2[1] == (out->pack2[0] && out->pack2[3] && 2 * out->lds_kv <= 64 * 1024) && out->pack4[1] == (out->pack4[0] && out->pack4[3] && 4 * out->lds_kv <= 64 * 1024);
+    out->fuse_kcv = (!off && out->fuse_kv && same_pack && out->pack2[1] && out->lds_kcv <= 160 * 1024 && 2 * out->lds_kcv <= 64 * 1024 && (!out->pack4[1] || 4 * out->lds_kcv <= 64 * 1024)) ? 1 : 0;
+    if (out->fuse_kcv) {
+      // measured (MI355X, profiles/r03/notes.md): mesh scene, B = 8192 = one round of 2048 four-environment waves at two per SIMD: 45.3 us against 33.7 + 20.4 in two launches;
+      // ant, B = 16384 = two rounds: 95.7 us against 76.4 + 20.9 -- the separate kernels fit four waves per SIMD.  Larger batches keep the separate launches.
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      out->kcv_max_envs = (int64_t)cus * 4 /* SIMDs */ * 2 /* waves per SIMD */ * (out->pack4[1] ? 4 : 2);
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kcv));
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_kcv));
+      if (out->pack4[1]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_kcv));
+    }
+  }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 7, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
@@ -607,8 +628,8 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
   constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : ((P == 7 || P == 8) ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
-  const int arena_bytes = P == 12 ? m->lds_kv : m->lds_bytes[P == 12 ? 0 : A];
-  a.off = P == 12 ? m->off_kv : m->off[P == 12 ? 0 : A];
+  const int arena_bytes = P == 13 ? m->lds_kcv : (P == 12 ? m->lds_kv : m->lds_bytes[(P == 12 || P == 13) ? 0 : A]);
+  a.off = P == 13 ? m->off_kcv : (P == 12 ? m->off_kv : m->off[(P == 12 || P == 13) ? 0 : A]);
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = arena_bytes / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
@@ -620,10 +641,10 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8 || P == 12);
-  constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : (P == 12 ? 0 : P)));  // index into the per-phase packing flags
-  const bool can2 = !PACKABLE ? false : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]);
-  const bool can4 = !PACKABLE ? false : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && m->pack4[PI]));
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8 || P == 12 || P == 13);
+  constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : ((P == 12 || P == 13) ? 0 : P)));  // index into the per-phase packing flags
+  const bool can2 = !PACKABLE ? false : (P == 13 ? (bool)m->pack2[1] : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]));  // (13: fuse_kcv holds only when the crb stage packs like the other two)
+  const bool can4 = !PACKABLE ? false : (P == 13 ? (bool)m->pack4[1] : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && m->pack4[PI])));
   if (PACKABLE && can2 && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
     int64_t done = 0;
     int rc = 0;
@@ -712,7 +733,8 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
   const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
-  if ((st & 0x7f) && (rc = fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream))) return rc;
+  const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
+  if ((st & 0x7f) && (rc = fused_kcv ? launch_phase<REAL, 13>(m, a, stream) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
     const int64_t items = a.B * a.M.ncvxpair;
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
@@ -720,7 +742,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     timing_mark(stream, 10);
   }
-  if ((st & 0x7e) && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
+  if ((st & 0x7e) && !fused_kcv && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
   if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
@@ -1032,6 +1054,7 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   if (!m || !read_write_bytes) return fail(-22, "null argument");
   if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
+  if (kernel == 13 && !m->fuse_kcv) return -2;  // (a model with kernel 13 reports both accounts: which one a step launches depends on the batch)
   if ((kernel == 12) != (m->fuse_kv != 0) && (kernel == 12 || kernel == 0 || kernel == 3)) return -2;  // kinematics + velocity: ONE kernel (12) or two (0, 3)
   const bool f64 = m->dtype == MJH_F64;
   const bool rk4 = (f64 ? m->m64.integrator : m->m32.integrator) == INT_RK4;
@@ -1045,12 +1068,12 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     return rc;
   };
   int64_t a[2] = {0, 0};
-  if (kernel == 12) {  // the two accounts minus what stays in the arena between the phases: qpos, cdof, cinert, subtree_com, xipos are not read back
-    int64_t k0[2] = {0, 0}, k3[2] = {0, 0};
-    if (io_of(0, k0) != 0 || io_of(3, k3) != 0) return -2;
+  if (kernel == 12 || kernel == 13) {  // the accounts of the fused stages minus what stays in the arena between them: qpos, cdof, cinert, subtree_com, xipos are not read back (13: nor cinert, cdof by the crb stage)
+    int64_t k0[2] = {0, 0}, k3[2] = {0, 0}, k1[2] = {0, 0};
+    if (io_of(0, k0) != 0 || io_of(3, k3) != 0 || (kernel == 13 && io_of(1, k1) != 0)) return -2;
     const int64_t R = f64 ? 8 : 4, nq = f64 ? m->m64.nq : m->m32.nq, nv = f64 ? m->m64.nv : m->m32.nv, nb = f64 ? m->m64.nbody : m->m32.nbody;
-    read_write_bytes[0] = k0[0] + k3[0] - (nq + 6 * nv + 10 * nb + 3 * nb + 3 * nb) * R;
-    read_write_bytes[1] = k0[1] + k3[1];
+    read_write_bytes[0] = k0[0] + k3[0] - (nq + 6 * nv + 10 * nb + 3 * nb + 3 * nb) * R + (kernel == 13 ? k1[0] - (10 * nb + 6 * nv) * R : 0);
+    read_write_bytes[1] = k0[1] + k3[1] + (kernel == 13 ? k1[1] : 0);
     return 0;
   }
   const int k = kernel == 9 ? 4 : kernel;  // the register solver moves the same leaves as the plain LDS solver
