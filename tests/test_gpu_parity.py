@@ -589,6 +589,29 @@ def test_config4_batch_properties():
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("xml, ov, B", [("ant", {"integrator": 1, "solver": 2, "cone": 1}, 16384), ("mesh_contact", {}, 8200)])
+def test_config3_and_5_batches_run_the_separate_launches(xml, ov, B):
+    """Small float32 models step through ONE kinematics + crb + velocity kernel while the batch is a single round of its waves (every seeded parity test
+    of these models) and through separate launches beyond that (BASELINE configs 3 and 5 at their full sizes are at / past the limit).  Both routes are
+    the same arithmetic: environments tiled to the full batch are bit-identical to their 64-environment twins after two steps."""
+    mx = load_model(xml, ov, torch.float32)
+    U = 64
+    rng = np.random.RandomState(3)
+    base = mt.make_data(mx).expand(U).clone().replace(qvel=torch.tensor(0.01 * rng.randn(U, mx.nv))).to(torch.float32)
+    idx = torch.arange(B) % U
+    mdev = mx.to("cuda")
+    small = mt.step(mdev, mt.step(mdev, base.to("cuda")))
+    big = mt.step(mdev, mt.step(mdev, base[idx].clone().to("cuda")))
+    idx = idx.to("cuda")
+    for n in ("qpos", "qvel", "qacc", "efc_force", "efc_J", "efc_aref", "contact_frame", "contact_dist", "qM", "qLD", "cvel", "qfrc_bias", "actuator_moment", "sensordata"):
+        a, b = leaf(big, n), leaf(small, n)
+        assert torch.equal(a, b[idx]), f"{n}: tiled environments differ"
+        if a.is_floating_point():
+            assert torch.isfinite(a).all(), n
+    del big
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", OUTLIER_CASES)
 def test_pinned_campaign_outliers(name, oracle_lib):
     """The environments of the round-1 differential campaign that matched no oracle branch (profiles/r01/fuzz_parity.txt), pinned:
