@@ -142,6 +142,8 @@ struct DevModel {
   const int* dof_act_adr;                  // nv+1: CSR of the actuators driving each dof, in actuator order
   const int* dof_act_id;
   const REAL* dof_act_coef;                // per entry of dof_act_id: the constant moment coefficient (a gear component)
+  const int* dof_frc_lim;                  // nv: jnt_actfrclimited of the dof's joint (one read instead of a chain dof -> joint -> flag -> range)
+  const REAL* dof_frc_range;               // 2*nv: jnt_actfrcrange of the dof's joint
   const int* dof_act_rot;                  // per entry: -1, or the component of the actuator's rotated gear axis that is the coefficient
   const int* act_ent_adr;                  // nu+1: CSR of the non-zeros of each actuator's moment row
   const int* act_ent_dof;

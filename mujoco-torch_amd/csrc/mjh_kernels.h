@@ -2304,14 +2304,18 @@ struct Env {
       for (int i = l; i < M.na; i += W) S.act_dot()[i] = 0;
     } else {
       for (int i = l; i < nu; i += W) {
+        // every table entry of the actuator is requested up front, unconditionally: behind a flag each one was a round trip of its own (flag, branch, value)
         REAL ctrl = in.ctrl ? in.ctrl[e * nu + i] : (REAL)0;
-        if (!(M.disableflags & DSBL_CLAMPCTRL) && M.act_ctrllimited[i]) {
-          const REAL lo = M.act_ctrlrange[2 * i], hi = M.act_ctrlrange[2 * i + 1];
-          ctrl = ctrl > lo ? ctrl : lo;
-          ctrl = ctrl < hi ? ctrl : hi;
+        const int ctrllim = M.act_ctrllimited[i], dyn = M.act_dyntype[i], gt = M.act_gaintype[i], bt = M.act_biastype[i], frclim = M.act_forcelimited[i];
+        const REAL clo = M.act_ctrlrange[2 * i], chi = M.act_ctrlrange[2 * i + 1], flo = M.act_forcerange[2 * i], fhi = M.act_forcerange[2 * i + 1];
+        const REAL* gp = M.act_gainprm + 9 * i;
+        const REAL* bp = M.act_biasprm + 9 * i;
+        const REAL gp0 = gp[0], gp1 = gp[1], gp2 = gp[2], bp0 = bp[0], bp1 = bp[1], bp2 = bp[2];
+        if (!(M.disableflags & DSBL_CLAMPCTRL) && ctrllim) {
+          ctrl = ctrl > clo ? ctrl : clo;
+          ctrl = ctrl < chi ? ctrl : chi;
         }
         REAL ctrl_act = ctrl;
-        const int dyn = M.act_dyntype[i];
         if (dyn != DYN_NONE) {
           const int a = M.act_actadr[i];
           const REAL act = S.act()[a];
@@ -2325,18 +2329,12 @@ struct Env {
           ctrl_act = S.act()[a + M.act_actnum[i] - 1];
         }
         const REAL len = S.act_length()[i], vel = S.act_velocity()[i];
-        const REAL* gp = M.act_gainprm + 9 * i;
-        const REAL* bp = M.act_biasprm + 9 * i;
-        const int gt = M.act_gaintype[i], bt = M.act_biastype[i];
-        REAL gain = (gt == GAIN_FIXED) ? gp[0] : gp[0] + gp[1] * len + gp[2] * vel;
-        REAL bias = (bt == BIAS_AFFINE) ? bp[0] + bp[1] * len + bp[2] * vel : (REAL)0;
+        REAL gain = (gt == GAIN_FIXED) ? gp0 : gp0 + gp1 * len + gp2 * vel;
+        REAL bias = (bt == BIAS_AFFINE) ? bp0 + bp1 * len + bp2 * vel : (REAL)0;
         if (gt == GAIN_MUSCLE) gain = muscle_gain(len, vel, M.act_lengthrange + 2 * i, M.act_acc0[i], gp);
         if (bt == BIAS_MUSCLE) bias = muscle_bias(len, M.act_lengthrange + 2 * i, M.act_acc0[i], bp);
         REAL force = gain * ctrl_act + bias;
-        if (M.act_forcelimited[i]) {
-          const REAL lo = M.act_forcerange[2 * i], hi = M.act_forcerange[2 * i + 1];
-          force = force < lo ? lo : (force > hi ? hi : force);
-        }
+        if (frclim) force = force < flo ? flo : (force > fhi ? fhi : force);
         S.act_force()[i] = force;
       }
     }
@@ -2352,19 +2350,20 @@ struct Env {
     }
     for (int d = l; d < nv; d += W) {
       REAL s = 0;
+      // (the dof's table entries and the applied force in one round trip: they used to hang off each other -- dof -> joint -> flag -> range, entry -> actuator -> gear)
+      const int q0 = M.dof_act_adr[d], q1 = M.dof_act_adr[d + 1], flim = M.dof_frc_lim[d];
+      const REAL flo = M.dof_frc_range[2 * d], fhi = M.dof_frc_range[2 * d + 1];
+      const REAL qapp = in.qfrc_applied ? in.qfrc_applied[e * nv + d] : (REAL)0;
       if (!off) {
         // moment^T force: only the actuators on this dof have a non-zero moment entry (actuator order kept)
-        for (int q = M.dof_act_adr[d]; q < M.dof_act_adr[d + 1]; q++) {
+        for (int q = q0; q < q1; q++) {
           const int i = M.dof_act_id[q];
-          const REAL coef = M.act_simple ? M.act_gear[6 * i] : ((M.act_has_rot && M.dof_act_rot[q] >= 0) ? S.act_rot()[3 * i + M.dof_act_rot[q]] : M.dof_act_coef[q]);
+          const REAL cq = M.dof_act_coef[q];  // (a simple transmission's gear is the entry's constant coefficient)
+          const REAL coef = M.act_simple ? cq : ((M.act_has_rot && M.dof_act_rot[q] >= 0) ? S.act_rot()[3 * i + M.dof_act_rot[q]] : cq);
           s += coef * S.act_force()[i];
         }
-        const int j = M.dof_jntid[d];
-        if (FLUID && M.has_gravcomp) s = s + S.qfrc_gravcomp()[d] * (REAL)M.jnt_actgravcomp[j];  // forward.py:206-207 (the leaf is zero while gravity is disabled)
-        if (M.jnt_actfrclimited[j]) {
-          const REAL lo = M.jnt_actfrcrange[2 * j], hi = M.jnt_actfrcrange[2 * j + 1];
-          s = s < lo ? lo : (s > hi ? hi : s);
-        }
+        if (FLUID && M.has_gravcomp) s = s + S.qfrc_gravcomp()[d] * (REAL)M.jnt_actgravcomp[M.dof_jntid[d]];  // forward.py:206-207 (the leaf is zero while gravity is disabled)
+        if (flim) s = s < flo ? flo : (s > fhi ? fhi : s);
       }
       S.qfrc_actuator()[d] = s;
       // xfrc_accumulate: sum over bodies of jacp^T f + jacr^T tau at the body's inertial origin
@@ -2378,7 +2377,7 @@ struct Env {
           acc += dot3(jp, ff) + dot3(jr, tt);
         }
       }
-      const REAL applied = (in.qfrc_applied ? in.qfrc_applied[e * nv + d] : (REAL)0) + acc;
+      const REAL applied = qapp + acc;
       S.qfrc_smooth()[d] = ((S.qfrc_passive()[d] - S.qfrc_bias()[d]) + s) + applied;
     }
     wave_sync();
@@ -3817,7 +3816,7 @@ struct Env {
 #define MJH_SOL32_WAVES 3  /* float32 LDS solver: 168 VGPRs + ~96 B of scratch; measured on the mesh scene: 2 waves (173 VGPRs, no scratch) 374 us, 3 waves 338 us, 4 waves (128 + 156 B) 362 us */
 #endif
 #ifndef MJH_KV32_WAVES
-#define MJH_KV32_WAVES 2  /* float32 fused kinematics + velocity kernel, packed: 256 VGPRs and no scratch; at 3 waves (168 VGPRs + ~300 B of scratch, twice the instructions) the ant ran it in 99.6 us instead of 86.3 */
+#define MJH_KV32_WAVES 2  /* float32 fused kinematics + velocity kernel, packed: a lower bound -- the kernel needs ~122 VGPRs since the stage functions stopped sharing hoisted address arithmetic (round 2: 256) and runs four waves per SIMD: the ant's B = 16384 is one round.  Requesting the caller's cold ctrl / applied-force rows at the kernel's head instead of at their use: 129 VGPRs, humanoid -0.7 us, ant +2.4 us: not kept */
 #endif
 #ifndef MJH_KCV32_WAVES
 #define MJH_KCV32_WAVES 2  /* float32 fused kinematics + crb + velocity kernel, packed: 173 VGPRs; at three waves per SIMD (168 + 20 B of scratch) the ant ran it in 99.7 us instead of 95.7, at four (128 + 112 B) in 104.5 */

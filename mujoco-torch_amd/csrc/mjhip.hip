@@ -416,6 +416,17 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     fix.push_back({(const void**)&M.act_ent_dof, bb.add(a_dof.data(), sizeof(int) * a_dof.size())});
     fix.push_back({(const void**)&M.act_ent_coef, bb.add(a_coef.data(), sizeof(REAL) * a_coef.size())});
     fix.push_back({(const void**)&M.act_ent_rot, bb.add(a_rot.data(), sizeof(int) * a_rot.size())});
+    {
+      std::vector<int> flim((size_t)nv + 1, 0);
+      std::vector<REAL> frange((size_t)2 * nv + 2, (REAL)0);
+      for (int dd = 0; dd < nv; dd++) {
+        const int j = d->dof_jntid[dd];
+        flim[dd] = d->jnt_actfrclimited[j];
+        frange[2 * dd] = (REAL)d->jnt_actfrcrange[2 * j]; frange[2 * dd + 1] = (REAL)d->jnt_actfrcrange[2 * j + 1];
+      }
+      fix.push_back({(const void**)&M.dof_frc_lim, bb.add(flim.data(), sizeof(int) * flim.size())});
+      fix.push_back({(const void**)&M.dof_frc_range, bb.add(frange.data(), sizeof(REAL) * frange.size())});
+    }
     M.inv_nv = nv > 0 ? 1.0f / (float)nv : 0.0f;
   }
   // single-column rows: dof-frictionloss rows (J = e_dof) first, then slide/hinge limit rows (J = +-e_dof or 0)
