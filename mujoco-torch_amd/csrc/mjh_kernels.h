@@ -549,8 +549,11 @@ template <int W, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_factor_pack(const REAL* A, TriPack<REAL, NMAX>& T, int n) {
   const int i = sub_lane<W>();
   const bool valid = i < n;
+  {  // row i of A is contiguous: one base address, every lane reads a valid one (the guard selects afterwards -- a guarded read is an exec-masked round trip of its own)
+    const REAL* row = A + (valid ? (i * (i + 1)) / 2 : 0);
 #pragma unroll
-  for (int k = 0; k < NMAX; k++) T.t[k] = (k < n && valid && k <= i) ? A[(i * (i + 1)) / 2 + k] : (REAL)0;
+    for (int k = 0; k < NMAX; k++) { const bool c = k < n && valid && k <= i; const REAL a = row[c ? k : 0]; T.t[k] = c ? a : (REAL)0; }
+  }
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
     if (j < n) {
