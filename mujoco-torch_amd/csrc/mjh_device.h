@@ -197,14 +197,15 @@ __device__ __forceinline__ T wave_bcast(T v, int src_lane) { return __shfl(v, sr
 // added uniformly, so every lane ends with the same bits.  EXEC must be all ones (callers are wave-uniform).
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));  // (folds into v_add_f32_dpp)
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
   unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   int lo = (int)(u & 0xffffffffull), hi = (int)(u >> 32);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  // every lane has a source under the controls used here: no `old` value to set up (update_dpp(0, ...) cost a v_mov of zero per half and step)
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
   return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ float read_lane(float v, int lane) {
@@ -310,6 +311,22 @@ __device__ __forceinline__ T dof_read(T v, int k) {
   if constexpr (W < MJH_WAVE && NMAX <= 16) return row_bcast(v, k);
   else return sub_read<W>(v, k);
 }
+// x[even row] + x[odd row] of each pair of 16-lane rows, in all 32 lanes of the pair: v_permlane16_swap (gfx950) exchanges the odd rows of one register with the even rows
+// of the other -- fed two copies of x it leaves [r0, r0, r2, r2] and [r1, r1, r3, r3]; one add.  (Was: four v_readlane per dword, scalar adds, a select.)
+__device__ __forceinline__ float row_pair_sum(float x) {
+  const int u = __builtin_bit_cast(int, x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ double row_pair_sum(double x) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+  const int lo = (int)(u & 0xffffffffull), hi = (int)(u >> 32);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double a = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[0] << 32) | (unsigned)rl[0]);
+  const double b = __builtin_bit_cast(double, ((unsigned long long)(unsigned)rh[1] << 32) | (unsigned)rl[1]);
+  return a + b;
+}
 // sum over the lanes of this environment's group, every lane of the group ends with the same bits.  W = 32: the DPP steps leave
 // each 16-lane row's sum in all its lanes; rows 0 + 1 serve the first environment, rows 2 + 3 the second.
 template <int W, typename T>
@@ -320,8 +337,7 @@ __device__ __forceinline__ T sub_sum(T v) {
   v += dpp_move<0x4E>(v);
   v += dpp_move<0x141>(v);
   v += dpp_move<0x140>(v);
-  const T a = read_lane(v, 0) + read_lane(v, 16), b = read_lane(v, 32) + read_lane(v, 48);
-  return threadIdx.x < 32 ? a : b;
+  return row_pair_sum(v);  // row 0 + row 1 in the first environment's lanes, row 2 + row 3 in the second's
 }
 
 // ---- small-vector math, reference math.py ------------------------------------------------------------------
