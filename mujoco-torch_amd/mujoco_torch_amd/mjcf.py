@@ -1388,10 +1388,14 @@ class _Compiler:
             if node.tag == "connect":
                 m.eq_data[i, 0:3] = _floats(a["anchor"])
             else:
-                if "relpose" in a and np.any(_floats(a["relpose"])[3:] != 0):
-                    raise NotImplementedError("weld with an explicit relpose is outside this build's MJCF subset")
                 m.eq_data[i, 0:3] = _floats(a["anchor"]) if "anchor" in a else np.zeros(3)
                 m.eq_data[i, 10] = float(a.get("torquescale", 1.0))
+                if "relpose" in a and np.any(_floats(a["relpose"])[3:] != 0):
+                    # an explicit pose of body2 in the frame of body1 (position, quaternion): stored as given -- the quaternion normalised -- and left alone by
+                    # the reference-pose pass below (MuJoCo's set0 skips welds whose quaternion is set); all-zero quaternion = "use qpos0", the default
+                    rp = _floats(a["relpose"])
+                    m.eq_data[i, 3:6] = rp[:3]
+                    m.eq_data[i, 6:10] = rp[3:7] / np.linalg.norm(rp[3:7])
 
     def _build_tendons(self, m):
         """<tendon><fixed>: linear combinations of scalar joint positions (MuJoCo wrap objects of type JOINT)."""
@@ -1679,6 +1683,8 @@ def _equality_set0(m):
         if int(m.eq_type[i]) == 0:  # connect: data[0:3] is in body1, data[3:6] the same point in body2
             glob = xpos[b1] + xmat[b1] @ m.eq_data[i, 0:3]
             m.eq_data[i, 3:6] = xmat[b2].T @ (glob - xpos[b2])
+        elif np.any(m.eq_data[i, 6:10] != 0):  # weld with an explicit relpose: nothing to derive
+            continue
         else:  # weld: data[0:3] is in body2, data[3:6] the same point in body1; relpose = body2 in the frame of body1
             glob = xpos[b2] + xmat[b2] @ m.eq_data[i, 0:3]
             m.eq_data[i, 3:6] = xmat[b1].T @ (glob - xpos[b1])

@@ -265,3 +265,22 @@ def test_actuator_shortcuts_compile_to_general_parameters():
     d = mt.make_data(mx).replace(ctrl=torch.tensor([0.5, 0.7, 0.0], dtype=torch.float64), qvel=torch.tensor([0.3, -0.2], dtype=torch.float64))
     out = pyoracle.run(mx, d, step=True)
     assert np.allclose(out["actuator_force"][:2], [-0.3, 0.7]) and np.isclose(out["act"][0], 0.5 * float(mx.opt.timestep))
+
+
+def test_weld_with_an_explicit_relpose_is_stored_as_given():
+    """`<weld relpose="x y z qw qx qy qz">`: the pose of body2 in the frame of body1, kept verbatim (quaternion normalised) instead of being derived from qpos0
+    (MuJoCo's set0 skips welds whose quaternion is set); an all-zero quaternion is the default and means "derive".  Writing the derived pose back as an explicit
+    one reproduces the same eq_data."""
+    xml = """<mujoco><worldbody>
+      <body name="a" pos="0 0 1"><freejoint/><geom size=".1"/></body>
+      <body name="b" pos="0.3 0 1.2" quat="0.9 0.1 0 0.2"><freejoint/><geom size=".1"/></body></worldbody>
+      <equality><weld body1="a" body2="b" anchor="0 0 .05" {rp}/></equality></mujoco>"""
+    derived = mt.mjcf.from_xml_string(xml.format(rp=""))
+    pose = derived.eq_data[0, 3:10]
+    assert np.isclose(np.linalg.norm(pose[3:]), 1.0)
+    explicit = mt.mjcf.from_xml_string(xml.format(rp='relpose="' + " ".join(repr(float(x)) for x in pose) + '"'))
+    assert np.allclose(explicit.eq_data, derived.eq_data, atol=1e-15)
+    scaled = mt.mjcf.from_xml_string(xml.format(rp='relpose="0.1 0.2 0.3 2 0 0 0"'))
+    assert np.allclose(scaled.eq_data[0, 3:10], [0.1, 0.2, 0.3, 1, 0, 0, 0]) and np.allclose(scaled.eq_data[0, 0:3], [0, 0, 0.05])
+    zero = mt.mjcf.from_xml_string(xml.format(rp='relpose="9 9 9 0 0 0 0"'))  # all-zero quaternion: ignored
+    assert np.allclose(zero.eq_data, derived.eq_data)
