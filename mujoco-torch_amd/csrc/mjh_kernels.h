@@ -1304,19 +1304,39 @@ struct Env {
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
       // (all the reads first, then the stores: a read between two stores waits for the first store to land -- vmcnt is in order -- and the optimiser
       // may not move it up past a store it cannot prove distinct)
+      // in three groups, each with all of its reads in flight before its first store (the ant has 60 contacts: 900 constants per environment, ten passes of 32 lanes
+      // for the wide leaves -- copied pass by pass, every pass's reads waited for the previous pass's stores: 64 us of the ant's stage-0 launch)
       {
-        REAL* const dst[5] = {out.contact_includemargin, out.contact_friction, out.contact_solref, out.contact_solreffriction, out.contact_solimp};
-        const REAL* const src[5] = {M.con_includemargin, M.con_friction, M.con_solref, M.con_solreffriction, M.con_solimp};
-        const int cnt[5] = {nc, 5 * nc, 2 * nc, 2 * nc, 5 * nc};
-        multi_copy_const<W, 5, 1>(dst, src, cnt, e);
+        REAL* const dst[3] = {out.contact_includemargin, out.contact_solref, out.contact_solreffriction};
+        const REAL* const src[3] = {M.con_includemargin, M.con_solref, M.con_solreffriction};
+        const int cnt[3] = {nc, 2 * nc, 2 * nc};
+        multi_copy_const<W, 3, 4>(dst, src, cnt, e);
       }
-      for (int c = l; c < nc; c += W) {
-        const int dim = M.con_dim[c], g1 = M.con_geom1[c], g2 = M.con_geom2[c], adr = M.con_efc_address[c];
-        if (out.contact_dim) out.contact_dim[e * nc + c] = dim;
-        if (out.contact_geom1) out.contact_geom1[e * nc + c] = g1;
-        if (out.contact_geom2) out.contact_geom2[e * nc + c] = g2;
-        if (out.contact_geom) { out.contact_geom[(e * nc + c) * 2] = g1; out.contact_geom[(e * nc + c) * 2 + 1] = g2; }
-        if (out.contact_efc_address) out.contact_efc_address[e * nc + c] = adr;
+      {
+        REAL* const dst[1] = {out.contact_friction};
+        const REAL* const src[1] = {M.con_friction};
+        const int cnt[1] = {5 * nc};
+        multi_copy_const<W, 1, 10>(dst, src, cnt, e);
+      }
+      {
+        REAL* const dst[1] = {out.contact_solimp};
+        const REAL* const src[1] = {M.con_solimp};
+        const int cnt[1] = {5 * nc};
+        multi_copy_const<W, 1, 10>(dst, src, cnt, e);
+      }
+      for (int c0 = l; c0 < nc; c0 += 2 * W) {  // two passes of the lanes per trip: their reads first
+        const int c1 = c0 + W;
+        const bool h1 = c1 < nc;
+        const int dim0 = M.con_dim[c0], g10 = M.con_geom1[c0], g20 = M.con_geom2[c0], adr0 = M.con_efc_address[c0];
+        const int dim1 = h1 ? M.con_dim[c1] : 0, g11 = h1 ? M.con_geom1[c1] : 0, g21 = h1 ? M.con_geom2[c1] : 0, adr1 = h1 ? M.con_efc_address[c1] : 0;
+        if (out.contact_dim) { out.contact_dim[e * nc + c0] = dim0; if (h1) out.contact_dim[e * nc + c1] = dim1; }
+        if (out.contact_geom1) { out.contact_geom1[e * nc + c0] = g10; if (h1) out.contact_geom1[e * nc + c1] = g11; }
+        if (out.contact_geom2) { out.contact_geom2[e * nc + c0] = g20; if (h1) out.contact_geom2[e * nc + c1] = g21; }
+        if (out.contact_geom) {
+          out.contact_geom[(e * nc + c0) * 2] = g10; out.contact_geom[(e * nc + c0) * 2 + 1] = g20;
+          if (h1) { out.contact_geom[(e * nc + c1) * 2] = g11; out.contact_geom[(e * nc + c1) * 2 + 1] = g21; }
+        }
+        if (out.contact_efc_address) { out.contact_efc_address[e * nc + c0] = adr0; if (h1) out.contact_efc_address[e * nc + c1] = adr1; }
       }
     }
   }
@@ -1581,11 +1601,26 @@ struct Env {
       // RK4 stages 1..3 write a private workspace Data whose only reader is this stage's solver phase, and that gathers the rows of the ACTIVE
       // contacts only (load_solver_inputs / run_sol2): the zero rows, and further down D / aref of the inactive rows, are not written there
       const bool scratch_stage = KA.rk_stage > 0;
-      if (!scratch_stage)
-      for (int w = l; w < nd * nv; w += W) {
-        int q, d;
-        split_index(w, nv, M.inv_nv, q, d);
-        if (!row_act[q]) Jdst[w] = 0;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+      if (!scratch_stage) {
+        constexpr int VW = 16 / (int)sizeof(REAL);  // elements per 16-byte store
+        typedef REAL zvec __attribute__((ext_vector_type(VW)));
+        if (nv % VW == 0 && (reinterpret_cast<uintptr_t>(Jdst) & 15) == 0) {
+          // rows are whole 16-byte groups: a quarter (float) / half (double) of the passes of the element-wise loop below (the ant: 45 -> 12)
+          const int gpr = nv / VW;  // groups per row
+          zvec z;
+#pragma unroll
+          for (int i = 0; i < VW; i++) z[i] = 0;
+          for (int w = l; w < nd * gpr; w += W) {
+            int q, g;
+            split_index(w, gpr, 1.0f / (float)gpr, q, g);
+            if (!row_act[q]) reinterpret_cast<zvec*>(Jdst)[w] = z;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+          }
+        } else
+        for (int w = l; w < nd * nv; w += W) {
+          int q, d;
+          split_index(w, nv, M.inv_nv, q, d);
+          if (!row_act[q]) Jdst[w] = 0;
+        }
       }
       for (int w = l; w < nact * nv; w += W) {
         int a, d;
@@ -1673,6 +1708,12 @@ struct Env {
     // visited -- one pass of the lanes for the ant (8 + 3 x (4 .. 8) rows) where the walk over all 188 rows took six dependent passes
     const bool compact_rows = !FRIC && DIRECT && KA.rk_stage > 0 && M.con_rows > 0;
     const int nvisit = compact_rows ? ns + nact_contacts * M.con_rows : nefc;
+    // Small models, several passes of the lanes over the rows (the ant: 188 rows, six passes): aref and D are staged in LDS over the contact positions / frames (dead by
+    // now) and stored in one go behind the loop.  Stored inside it, every pass's table reads and row read-backs waited for the previous pass's stores to land (vmcnt is in order):
+    // 20 of the ant's 83 us per launch.
+    REAL* const ad_stage = S.con_pos();
+    const bool stage_ad = !FRIC && DIRECT && !compact_rows && nvisit > W && 2 * nefc <= (int)((S.con_frame() + 9 * M.ncand) - S.con_pos()) && out.efc_aref && out.efc_D;
+    if (stage_ad) wave_sync();  // (the row loops above read the frames)
     for (int idx = l; idx < nvisit; idx += W) {  // :683-693
       int r = idx;
       if (compact_rows && idx >= ns) {
@@ -1771,8 +1812,15 @@ struct Env {
         for (; k < nv; k++) s += __hip_atomic_load(jr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * S.qvel()[k];
         jv = s;
       }
-      if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
-      if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
+      if (stage_ad) { ad_stage[r] = -b * jv - k * imp * pos; ad_stage[nefc + r] = 1 / rr; }
+      else {
+        if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
+        if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
+      }
+    }
+    if (stage_ad) {
+      wave_sync();
+      put(out.efc_aref, ad_stage, nefc); put(out.efc_D, ad_stage + nefc, nefc);
     }
     STAMP(26);
     if (FRIC) put(out.efc_J, S.efc_J(), nefc * nv);
