@@ -219,6 +219,13 @@ __device__ __forceinline__ void row_copy_const(REAL* g, const REAL* c, int n, in
   REAL* dst = g + env * n;
   int i = sub_lane<W>();
   asm volatile("" : "+v"(i));
+  for (; i + 15 * W < n; i += 16 * W) {  // (sixteen reads, then sixteen stores: a read behind a store waits for the store to land)
+    REAL t[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) t[q] = c[i + q * W];
+#pragma unroll
+    for (int q = 0; q < 16; q++) dst[i + q * W] = t[q];
+  }
   for (; i + 7 * W < n; i += 8 * W) {
     REAL t[8];
 #pragma unroll
@@ -1100,7 +1107,14 @@ struct Env {
     }
     if (out.qM) {
       REAL* gM = out.qM + e * nv * nv;
-      for (int w = l; w < nv * nv; w += W) { const int sl = M.qm_slot[w]; gM[w] = sl >= 0 ? S.qMp()[sl] : (REAL)0; }
+      // (entry (i, j) is slot (max, min) of the packed copy, whose structurally zero entries hold the +0 they were initialised with: no table read per
+      // pass -- behind the previous pass's stores each one waited for them to land, twelve times for the humanoid)
+      for (int w = l; w < nv * nv; w += W) {
+        int i, j;
+        split_index(w, nv, M.inv_nv, i, j);
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        gM[w] = S.qMp()[(hi * (hi + 1)) / 2 + lo];
+      }
     }
     STAMP(14);
     put(out.crb, S.crb(), 10 * nb);
