@@ -126,6 +126,7 @@ struct DevModel {
   const int* body_subtree_end; // nbody: one past the last body of b's subtree (bodies are in DFS order)
   const unsigned long long* body_dofmask;  // nbody * mask_words: dofs whose body is an ancestor-or-self of b (bit d & 63 of word d >> 6)
   int mask_words;                          // 64-bit words per dof mask: 1 up to 64 dofs
+  int kv_defer;                            // fused kinematics + velocity kernel: the kinematics stage's leaves are stored by the velocity stage, in front of its LDS-only sweeps (the arena keeps them intact until then)
   int big;                                 // nv > 64: the kernels with multi-word mask reads serve the model (5, 7; kinematics + velocity not fused)
   const int* chain_dof;        // nbody*max_depth: dofadr | dofnum << 16 of the k-th body on the path world -> b
   const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none

@@ -14,6 +14,7 @@
 // Data-parallel axes: bodies / joints / dofs / geoms / contact pairs / constraint rows -> lanes;
 // tree recursions -> each lane walks its own ancestor chain; dot products -> per-lane partials + wave all-reduce.
 #pragma once
+#include <cstring>
 #include "mjh_device.h"
 
 // view of the arena: offsets (in REALs) come with the launch (kernarg, scalar loads); the view only carries the
@@ -29,7 +30,7 @@ struct LdsView {
 
 // carve the arena of one phase on the host; returns the number of REALs used.
 template <typename MM>
-inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
+inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = nullptr) {
   int off = 0;
 #define X(n, c, p) o.n = off; if ((p) & phase_bit) off += (((c) + 1) & ~1);
   MJH_LDS_ARRAYS(X, m)
@@ -68,8 +69,16 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o) {
 #define X(n, c, p) if (((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = s0; s0 += (((c) + 1) & ~1); }
     MJH_LDS_ARRAYS(X, m)
 #undef X
+    // Within the overlaid part: the kinematics stage's scratch arrays (never stored) lead its side, the arrays the velocity stage writes FIRST (its inputs and the
+    // transmission's outputs) lead the other -- so the frame leaves stay intact in LDS until the velocity stage stores them in front of its first sweep (velocity(), kv_defer)
     int ka = s0, va = s0;
-#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = va; va += (((c) + 1) & ~1); }
+    auto early_k = [](const char* n) { return !strcmp(n, "jquat") || !strcmp(n, "sub_mass") || !strcmp(n, "sub_pos"); };
+    auto early_v = [](const char* n) { return !strcmp(n, "qvel") || !strcmp(n, "act") || !strcmp(n, "act_length") || !strcmp(n, "act_velocity") || !strcmp(n, "act_rot"); };
+#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL) && early_k(#n)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL) && early_v(#n)) { o.n = va; va += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    if (kv_defer_ok) *kv_defer_ok = (va <= ka) ? 1 : 0;
+#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL) && !early_k(#n)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL) && !early_v(#n)) { o.n = va; va += (((c) + 1) & ~1); }
     MJH_LDS_ARRAYS(X, m)
 #undef X
     off = ka > va ? ka : va;
@@ -794,7 +803,16 @@ struct Env {
     row_load<W>(S.act(), src, M.na, e);
   }
 
+  __device__ __forceinline__ void frame_stores() {
+    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
+    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
+    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+  }
+  __device__ __forceinline__ void com_stores() {
+    put(out.subtree_com, S.subtree_com(), 3 * M.nbody); put(out.cinert, S.cinert(), 10 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv);
+  }
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
+  template <bool DEFER = false>
   __device__ __forceinline__ void kinematics(bool with_cams) {
     const int l = lane_here();
     // joint-local rotations first, one lane per joint: the trigonometry and the quaternion normalisations leave the
@@ -904,9 +922,7 @@ struct Env {
     // the frames go out now, ahead of the geom / site / camera loops: a phase's leaf stores are bursts of tens of MB issued by every wave at the same
     // moment, and the first table read behind one waits until L2 has taken it (vmcnt is in order) -- several smaller bursts with arithmetic between them drain
     // in the background where one large one does not
-    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
-    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
-    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+    if (!(DEFER && W > 16 && M.kv_defer)) frame_stores();  // (fused with the velocity stage: they go out in front of its LDS-only sweep, see velocity())
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -977,6 +993,7 @@ struct Env {
   }
 
   // ---- com_pos (smooth.py:210-288) --------------------------------------------------------------------------------------------------------------
+  template <bool DEFER = false>
   __device__ __forceinline__ void com_pos() {
     const int l = lane_here();
     const int nb = M.nbody;
@@ -1055,7 +1072,7 @@ struct Env {
     }
     wave_sync();
     STAMP(6);
-    put(out.subtree_com, S.subtree_com(), 3 * nb); put(out.cinert, S.cinert(), 10 * nb); put(out.cdof, S.cdof(), 6 * M.nv);
+    if (!(DEFER && W > 16 && M.kv_defer)) com_stores();
     STAMP(7);
   }
 
@@ -1889,7 +1906,7 @@ struct Env {
   }
 
   // ---- transmission + _velocity (smooth.py:535-591, forward.py:87-99, smooth.com_vel :385-424, passive.py:80-200, smooth.rne :427-467) ----------
-  template <bool FLUID, bool FUSED = false>
+  template <bool FLUID, bool FUSED = false, bool DEFER = false>
   __device__ __forceinline__ void velocity() {
     const int l = lane_here();
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
@@ -2016,19 +2033,29 @@ struct Env {
     // after the sweep (a lane rebuilds its body's partial sums from the parent's cvel: the same additions in the same order).  The sweep itself
     // is six additions per joint and one LDS round trip per level (it used to walk every lane down its whole ancestor chain: depth x joints
     // dependent table reads and multiply-adds per lane).
-    for (int w = l; w < 6 * nv; w += W) S.cdof_dot()[w] = S.cdof()[w] * S.qvel()[w / 6];
-    if (l < 6) S.cvel()[l] = 0;  // the world body
-    wave_sync();
     {
       const int md = M.max_depth, mj = M.max_jnt;
+      // the descriptors of the first chunk of bodies are the sweep's only table reads: requested first, because ...
+      const int depth0 = l < nb ? M.body_depth[l] : 0, par0 = l < nb ? M.body_parentid[l] : 0;
+      const int* const own0 = M.chain_jnt + ((size_t)(l < nb ? l : 0) * md + (depth0 > 0 ? depth0 - 1 : 0)) * mj;
+      int pkj0[MJH_CHAIN_PRE];
+#pragma unroll
+      for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) pkj0[jj] = (depth0 > 0 && jj < mj) ? own0[jj] : 0;
+      // ... the frame leaves of the kinematics stage go out HERE (fused kernel): everything from here to the end of the sweep works on LDS and registers, so the burst (21 MB
+      // for the humanoid batch) drains behind ~8 us of arithmetic.  Stored at the end of the kinematics stage, the next table read -- any vector load, vmcnt is in order -- waited for all of it.
+      // (The arrays the velocity stage has written so far -- qvel, act, actuator length / velocity -- overlay the kinematics stage's scratch arrays, not the frames: lds_carve.)
+      if (DEFER && M.kv_defer) frame_stores();
+      for (int w = l; w < 6 * nv; w += W) S.cdof_dot()[w] = S.cdof()[w] * S.qvel()[w / 6];
+      if (l < 6) S.cvel()[l] = 0;  // the world body
+      wave_sync();
       for (int b0 = 0; b0 < nb; b0 += W) {  // parents precede their children: a chunk of W bodies only needs earlier chunks and its own lower levels
         const int b = b0 + l;
         const bool has = b < nb;
-        const int depth = has ? M.body_depth[b] : 0, par = has ? M.body_parentid[b] : 0;
-        const int* own = M.chain_jnt + ((size_t)(has ? b : 0) * md + (depth > 0 ? depth - 1 : 0)) * mj;
+        const int depth = b0 == 0 ? depth0 : (has ? M.body_depth[b] : 0), par = b0 == 0 ? par0 : (has ? M.body_parentid[b] : 0);
+        const int* own = b0 == 0 ? own0 : M.chain_jnt + ((size_t)(has ? b : 0) * md + (depth > 0 ? depth - 1 : 0)) * mj;
         int pkj[MJH_CHAIN_PRE];
 #pragma unroll
-        for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) pkj[jj] = (depth > 0 && jj < mj) ? own[jj] : 0;
+        for (int jj = 0; jj < MJH_CHAIN_PRE; jj++) pkj[jj] = b0 == 0 ? pkj0[jj] : ((depth > 0 && jj < mj) ? own[jj] : 0);
         for (int kk = 0; kk < md; kk++) {
           if (depth == kk + 1) {
             REAL v[6];
@@ -2233,11 +2260,17 @@ struct Env {
       const bool nograv = M.disableflags & DSBL_GRAVITY;
       if (l < 6) S.cacc()[l] = (l < 3 || nograv) ? (REAL)0 : -M.gravity[l - 3];  // the world body
       const int md = M.max_depth;
+      const int depth0 = l < nb ? M.body_depth[l] : 0, par0 = l < nb ? M.body_parentid[l] : 0;
+      const int d00 = l < nb ? M.body_dofadr[l] : 0, nd0 = (l < nb && depth0 > 0) ? M.body_dofnum[l] : 0;
+      if (DEFER && M.kv_defer) {  // (same reasoning as in front of the com_vel sweep: the rest of the kinematics stage's leaves and the two velocity leaves that are final by now)
+        com_stores();
+        put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
+      }
       for (int b0 = 0; b0 < nb; b0 += W) {
         const int b = b0 + l;
         const bool has = b < nb;
-        const int depth = has ? M.body_depth[b] : 0, par = has ? M.body_parentid[b] : 0;
-        const int d0 = has ? M.body_dofadr[b] : 0, nd = (has && depth > 0) ? M.body_dofnum[b] : 0;
+        const int depth = b0 == 0 ? depth0 : (has ? M.body_depth[b] : 0), par = b0 == 0 ? par0 : (has ? M.body_parentid[b] : 0);
+        const int d0 = b0 == 0 ? d00 : (has ? M.body_dofadr[b] : 0), nd = b0 == 0 ? nd0 : ((has && depth > 0) ? M.body_dofnum[b] : 0);
         REAL vm[6] = {0, 0, 0, 0, 0, 0};
         if (nd > 0) {
 #pragma unroll
@@ -2295,10 +2328,11 @@ struct Env {
   }
   // the leaves of the velocity stage go out at the very end of the phase, behind _actuation: nothing waits for a store that has no read behind it
   // (in front of _actuation, its first table read waited for all of them to land)
+  template <bool DEFER = false>
   __device__ __forceinline__ void velocity_stores() {
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
-    put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
+    if (!(DEFER && W > 16 && M.kv_defer)) { put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv); }  // (else: in front of the rne sweep)
     put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
     if (M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant moment matrix (smooth.py:535-591): 4.5 KB per humanoid
   }
@@ -3203,13 +3237,14 @@ struct Env {
   }
 
   // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
+  template <bool DEFER = false>
   __device__ __forceinline__ void run_kin() {
     STAMP0();
     load_qpos(true);
     wave_sync();
     STAMP(1);
-    kinematics(KA.rk_stage <= 0);
-    com_pos();
+    kinematics<DEFER>(KA.rk_stage <= 0);
+    com_pos<DEFER>();
   }
   __device__ __forceinline__ void run_crb() { crb_factor<false>(); }
   __device__ __forceinline__ void run_con() {
@@ -3217,12 +3252,12 @@ struct Env {
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
-  template <bool FLUID, bool FUSED = false>
+  template <bool FLUID, bool FUSED = false, bool DEFER = false>
   __device__ __forceinline__ void run_vel() {
     STAMP0();
-    velocity<FLUID, FUSED>();
+    velocity<FLUID, FUSED, DEFER>();
     if (KA.stages & 0x60) actuation<FLUID>();
-    velocity_stores();
+    velocity_stores<DEFER>();
   }
 
   // solve, then (when stepping) the integrator: _euler :313-328, or one stage of _rungekutta4 :331-370.
@@ -3947,13 +3982,13 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ?
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
     Env<REAL, W, PHASE == 6 || PHASE == 7, PHASE == 8> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
-    if (PHASE == 0) E.run_kin();
+    if (PHASE == 0) E.template run_kin<false>();
     else if (PHASE == 1) E.run_crb();
     else if (PHASE == 2 || PHASE == 7 || PHASE == 8) E.run_con();  // 8: plain constraint phase of small models, contact rows straight to the leaf  // 7: constraint phase of models with equality / frictionloss / ball- or tendon-limit rows
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
-    else if (PHASE == 13) { E.run_kin(); wave_sync(); E.template crb_factor<true>(); wave_sync(); E.template run_vel<false, true>(); }  // ... and the crb / factor stage between them (small models: the three stages of one RK4 stage are one launch)
-    else if (PHASE == 12) { E.run_kin(); wave_sync(); E.template run_vel<false, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
+    else if (PHASE == 13) { E.template run_kin<false>(); wave_sync(); E.template crb_factor<true>(); wave_sync(); E.template run_vel<false, true>(); }  // ... and the crb / factor stage between them (small models: the three stages of one RK4 stage are one launch)
+    else if (PHASE == 12) { E.template run_kin<true>(); wave_sync(); E.template run_vel<false, true, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
     wave_sync();
   }

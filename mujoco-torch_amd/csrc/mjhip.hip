@@ -565,7 +565,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   SET_PACK(0) SET_PACK(3)
   {  // fused kinematics + velocity kernel (plain velocity phase only).  Measured on MI355X: profiles/r02/notes.md.  MJH_FUSE_KV=0 keeps two launches.
     static const bool fuse_off = [] { const char* e = getenv("MJH_FUSE_KV"); return e && e[0] == '0'; }();
-    out->lds_kv = lds_carve(M, PH_KINVEL, out->off_kv) * (int)sizeof(REAL);
+    int defer_ok = 0;
+    out->lds_kv = lds_carve(M, PH_KINVEL, out->off_kv, &defer_ok) * (int)sizeof(REAL);
+    static const bool defer_off = [] { const char* e = getenv("MJH_KV_DEFER"); return e && e[0] == '0'; }();
+    M.kv_defer = (defer_ok && !defer_off) ? 1 : 0;
     out->fuse_kv = (!fuse_off && !(M.has_fluid || M.has_gravcomp || M.ntendon > 0 || M.big) && out->lds_kv <= 160 * 1024) ? 1 : 0;
     if (out->fuse_kv) {
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 12, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kv));
