@@ -328,11 +328,22 @@ def _stamp(m):
     opt, stat = m.opt, m.stat
     v = 0
     for c in (m, opt, stat):
-        for t in c._fields.values():
-            if isinstance(t, UnbatchedTensor):
-                t = t.data
-            if isinstance(t, torch.Tensor):
-                v += t._version
+        # the tensor leaves of a container only change with its version (attribute assignment / update_): the list is kept per container and version, so a
+        # step pays one `_version` read per tensor instead of walking ~450 fields through isinstance (45 of the host's 110 us per call)
+        d = c.__dict__
+        ver = d.get("_ver", 0)
+        ts = d.get("_stamp_ts")
+        if ts is None or ts[0] != ver:
+            lst = []
+            for t in c._fields.values():
+                if isinstance(t, UnbatchedTensor):
+                    t = t.data
+                if isinstance(t, torch.Tensor):
+                    lst.append(t)
+            ts = (ver, lst)
+            object.__setattr__(c, "_stamp_ts", ts)
+        for t in ts[1]:
+            v += t._version
     return (m.__dict__.get("_ver", 0), opt, opt.__dict__.get("_ver", 0), stat, stat.__dict__.get("_ver", 0), v)
 
 
