@@ -5,6 +5,7 @@
 R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
+uptime > $O/host_load.txt  # the boxes' hosts are shared: a loaded host starves the calling thread of the drop-in loop (profiles/r03/notes.md)
 bash tools/fetch_calib.sh 2>&1 | grep -E "FETCH_SIZE|WRITE_SIZE" > $O/fetch_calibration.txt
 for w in humanoid ant mesh; do
   bash tools/prof_kernels.sh $w 100 > $O/kernel_stats_$w.txt 2>&1
