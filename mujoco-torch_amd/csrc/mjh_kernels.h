@@ -280,8 +280,10 @@ __device__ __forceinline__ void multi_copy_const(REAL* const (&dst)[K], const RE
 template <int W, typename REAL>
 __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t env) {
   if (!g) { for (int i = sub_lane<W>(); i < n; i += W) l[i] = 0; return; }
+  late_bind<W>(env);  // (as for the stores: addresses formed here, not hoisted to the kernel's head and spilled)
   const REAL* src = g + env * n;
   int i = sub_lane<W>();
+  asm volatile("" : "+v"(i));
   for (; i + 3 * W < n; i += 4 * W) {
     const REAL a = src[i], b = src[i + W], c = src[i + 2 * W], d = src[i + 3 * W];
     l[i] = a; l[i + W] = b; l[i + 2 * W] = c; l[i + 3 * W] = d;
@@ -294,7 +296,9 @@ __device__ __forceinline__ void row_load(REAL* l, const REAL* g, int n, int64_t 
 // phase.  The first T * W elements of each of the K arrays are requested up front (predicated), then stored; longer tails loop.
 template <int W, int K, int T, typename REAL>
 __device__ __forceinline__ void multi_load(REAL* const (&dst)[K], const REAL* const (&src)[K], const int (&n)[K], int64_t env) {
-  const int l = sub_lane<W>();
+  late_bind<W>(env);
+  int l = sub_lane<W>();
+  asm volatile("" : "+v"(l));
   REAL v[K][T];
 #pragma unroll
   for (int k = 0; k < K; k++) {
