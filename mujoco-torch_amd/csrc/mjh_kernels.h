@@ -569,10 +569,13 @@ template <int W, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_factor_pack(const REAL* A, TriPack<REAL, NMAX>& T, int n) {
   const int i = sub_lane<W>();
   const bool valid = i < n;
-  {  // row i of A is contiguous: one base address, every lane reads a valid one (the guard selects afterwards -- a guarded read is an exec-masked round trip of its own)
+  if constexpr (sizeof(REAL) == 4) {  // row i of A is contiguous: one base address, every lane reads a valid one (the guard selects afterwards -- a guarded read is an exec-masked round trip of its own)
     const REAL* row = A + (valid ? (i * (i + 1)) / 2 : 0);
 #pragma unroll
     for (int k = 0; k < NMAX; k++) { const bool c = k < n && valid && k <= i; const REAL a = row[c ? k : 0]; T.t[k] = c ? a : (REAL)0; }
+  } else {  // (double: the extra values in flight cost the LDS solver's float64 instantiation its second wave per SIMD, 213 -> 256 VGPRs)
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) T.t[k] = (k < n && valid && k <= i) ? A[(i * (i + 1)) / 2 + k] : (REAL)0;
   }
 #pragma unroll
   for (int j = 0; j < NMAX; j++) {
