@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage: tools/ablate.sh "<groups>" n1 n2 ...   builds lib/libmjhip_ab<n>.so with -DMJH_ABLATE=<n> (only the listed groups recompiled)
+# The kernels carry no MJH_ABLATE guards: wrap the sections to be priced in `if (MJH_ABLATE != n) { ... }` for the experiment (profiles/r03/notes.md has the
+# results of two such series), run tools/ablate_run.sh on the GPU box, and take the guards out again.  ABL_MACRO=<name> uses another macro (A/B of two code variants).
 R=/root/repo; C=$R/mujoco-torch_amd/csrc
 groups="$1"; shift
 one() {
