@@ -3384,7 +3384,7 @@ struct Env {
     return tri_solve<W, REAL, NMAX>(T, bi, M.nv);
   }
 
-  template <int NMAX, int RPL>
+  template <int NMAX, int RPL, bool NEWTON_ONLY = false>
   __device__ __forceinline__ void run_sol2() {
     static_assert(W == 32 || W == 16, "two or four environments per wavefront");
     constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
@@ -3393,7 +3393,7 @@ struct Env {
     const bool dof = l < nv, lim = l < nl;
     const bool solving = (KA.stages & 0x40) != 0;
     const bool from_in = !KA.state_from_cur;
-    const bool newton = NEWT && M.solver == SOL_NEWTON;
+    const bool newton = NEWTON_ONLY ? NEWT : (NEWT && M.solver == SOL_NEWTON);  // (NEWTON_ONLY: a constant -- the CG state, the factor of M past the first solve and the Polak-Ribiere pair, is compiled out)
     STAMP0();
     if (KA.row_lo >= 0 && !KA.scan_marks) {
       // Second (full-width) tier: almost every environment was served by the first launch.  Count the rows of the active contacts before
@@ -3937,8 +3937,12 @@ struct Env {
 // step (197 / 181 / 185 -> 168 VGPRs = 3 waves, 132 -> 128 = 4 waves) and spill only 5-24 dwords to get under it; with
 // 32-64 environments per CU (ant B = 16384, mesh B = 8192) the extra wave in flight is worth +13 % / +12 % end to end.
 // The register solver's kernel: two environments per wavefront; an odd last environment leaves the second half of its wave idle.
-template <typename REAL, int NMAX, int RPL, int W>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL * W == 32) ? (W == 16 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+// WT: lanes per environment (32 or 16); WT = 17 is the four-per-wavefront kernel of NEWTON models (16 lanes, Newton-only code: 128 VGPRs + 116 B of scratch instead of + 160 B
+// for the ant's first tier, 227 instead of 243 VGPRs for the mesh scene's; ant 53.6 -> 52.2 us per launch, mesh scene 223.7 -> 219.1 us)
+template <typename REAL, int NMAX, int RPL, int WT>
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+  constexpr int W = WT == 17 ? 16 : WT;
+  constexpr bool NEWTON_ONLY = WT == 17;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
@@ -3963,7 +3967,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
         }
         if (pick >= 0) {
           Env<REAL, W, false> E(lds, K.env_begin + base + pick, K.flags);
-          E.template run_sol2<NMAX, RPL>();
+          E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
         }
         wave_sync();
       }
@@ -3974,7 +3978,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {
       Env<REAL, W, false> E(lds, K.env_begin + idx, K.flags);
-      E.template run_sol2<NMAX, RPL>();
+      E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }
     wave_sync();
   }

@@ -629,7 +629,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     SET_SOL2(8, 1) SET_SOL2(8, 2) SET_SOL2(8, 4) SET_SOL2(8, 8) SET_SOL2(16, 1) SET_SOL2(16, 2) SET_SOL2(16, 4) SET_SOL2(16, 8) SET_SOL2(28, 1) SET_SOL2(28, 2)
 #undef SET_SOL2
     if (out->sol2_w16_rpl) {
-#define SET_SOL2W(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_tier));
+#define SET_SOL2W(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_tier)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 17>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_tier));
       SET_SOL2W(8, 2) SET_SOL2W(8, 5) SET_SOL2W(12, 2) SET_SOL2W(12, 5) SET_SOL2W(16, 2) SET_SOL2W(16, 5)
 #undef SET_SOL2W
     }
@@ -680,7 +680,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
 #define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 32>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
-#define GOW(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a)
+#define GOW(N, R) do { if (a.M.solver == SOL_NEWTON) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 17>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a); else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a); } while (0)  /* 17: the Newton-only code of the four-per-wavefront tier */
   const int nd = a.M.nefc - a.M.nf - a.M.nl;
   bool second = true;
   const bool marks = m->sol2_tiers && a.cur.qacc != nullptr;  // the first tier marks what it leaves, the second scans the marks (needs the qacc leaf)
