@@ -315,7 +315,7 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
                      "kernels": "every launch of one step (torch events on the launch stream over the timed region)"}}, nm
 
 
-def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, spin=100, repeats=2):
+def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, spin=100, repeats=3):
     """BASELINE configs 3 / 5 timed by the same drop-in loop inside the headline run: a fixed recipe -- `spin`
     untimed steps on a scratch copy, then from the ORIGINAL state `warmup` untimed and `steps` timed steps -- independent of the headline's
     --steps / --warmup, so the figure is the same trajectory window whoever launches the bench.  The recipe runs `repeats` times from

@@ -606,11 +606,12 @@ __device__ __forceinline__ void chol_factor_solve_n(const REAL* A, const REAL* b
   if (i < n) x[i] = xi;
   wave_sync();
 }
-template <int W, typename REAL>
+template <int W, typename REAL, int NLO = 0, int NHI = 16>
 __device__ __forceinline__ void chol_factor_solve(const REAL* A, const REAL* b, REAL* x, int n) {
-  if (n <= 8) chol_factor_solve_n<W, REAL, 8>(A, b, x, n);
-  else if (n <= 12) chol_factor_solve_n<W, REAL, 12>(A, b, x, n);
-  else chol_factor_solve_n<W, REAL, 16>(A, b, x, n);
+  // NLO <= n <= NHI is known to the caller at compile time (an instantiation of the register solver serves one range of nv): the variants outside it are not compiled
+  if (NLO <= 8 && (NHI <= 8 || n <= 8)) { if constexpr (NLO <= 8) chol_factor_solve_n<W, REAL, 8>(A, b, x, n); }
+  else if (NLO <= 12 && NHI > 8 && (NHI <= 12 || n <= 12)) { if constexpr (NLO <= 12 && NHI > 8) chol_factor_solve_n<W, REAL, 12>(A, b, x, n); }
+  else { if constexpr (NHI > 12) chol_factor_solve_n<W, REAL, 16>(A, b, x, n); }
 }
 
 // Cholesky of the symmetric matrix A (LDS, n x n) into L (LDS, lower triangle, zeros above)
@@ -3291,6 +3292,8 @@ struct Env {
 
   // the integrator on the solved accelerations: _euler :313-328, or one stage of _rungekutta4 :331-370.  Reads S.qacc / qpos / qvel /
   // act / act_dot / qfrc_smooth / qfrc_constraint from the arena (both solver kernels leave them there).
+  // NLO <= nv <= NHI: what the calling instantiation knows about the model it serves (the register solver: one range of nv per NMAX)
+  template <int NLO = 0, int NHI = (1 << 30)>
   __device__ __forceinline__ void integrate_tail() {
     const int l = lane_here();
     const int nq = M.nq, nv = M.nv, na = M.na;
@@ -3310,13 +3313,15 @@ struct Env {
         }
         for (int d = l; d < nv; d += W) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
-        if (nv <= 16) {
-          chol_factor_solve<W, REAL>(S.H(), S.s_grad(), S.s_Mgrad(), nv);
+        if (NLO <= 16 && (NHI <= 16 || nv <= 16)) {
+          if constexpr (NLO <= 16) chol_factor_solve<W, REAL, NLO, (NHI < 16 ? NHI : 16)>(S.H(), S.s_grad(), S.s_Mgrad(), nv);
         } else {
-          chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
-          chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
-          wave_sync();
-          chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+          if constexpr (NHI > 16) {
+            chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
+            chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
+            wave_sync();
+            chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
+          }
         }
         qacc = S.s_Mgrad();
       }
@@ -3896,7 +3901,7 @@ struct Env {
     wave_sync();
     if (dof) { S.qacc()[l] = qacc; S.qfrc_smooth()[l] = f; S.qfrc_constraint()[l] = qfrc; }
     wave_sync();
-    integrate_tail();
+    integrate_tail<(NMAX == 8 ? 0 : (NMAX <= 16 ? 9 : 17)), NMAX>();  // (this instantiation serves nv in that range: the variants of the implicit-damping solve for other sizes are not compiled in)
   }
 };
 
