@@ -179,6 +179,11 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define KA (kargs<REAL>())
 // In-kernel stamps (diagnostic build only, never in the shipped library): lane 0 records the shader clock at
 // section boundaries into a buffer of its own; tools/stamps.py turns them into a per-section cycle profile.
+#ifdef MJH_SOL2_CAPS
+#define MJH_SOL2_CAPS_ON 1
+#else
+#define MJH_SOL2_CAPS_ON 0
+#endif
 #ifdef MJH_STAMPS
 // each STAMP adds the shader-clock time since the previous STAMP of this environment's phase to its slot: sections inside loops
 // accumulate over the iterations
@@ -3505,7 +3510,7 @@ struct Env {
     // instantiation picks up the rest (the ant keeps 4 - 8 of its 60 contacts active: almost none).  Each environment is integrated by exactly one.
     STAMP(82);
     if (!(nda > KA.row_lo && nda <= KA.row_hi)) {
-      if ((KA.it_cap > 0 || KA.mark_leftover) && nda > KA.row_hi && l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);  // the next launch (wider tier / LDS-solver fallback) finds the environment by this mark
+      if (((MJH_SOL2_CAPS_ON && KA.it_cap > 0) || KA.mark_leftover) && nda > KA.row_hi && l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);  // the next launch (wider tier / LDS-solver fallback) finds the environment by this mark
       return;
     }
     if (solving) {
@@ -3752,7 +3757,8 @@ struct Env {
       REAL* pg = S.r_pg();  // previous gradient / M^-1 gradient of the Polak-Ribiere step
       int it = 0, niter = 0, ls_total = 0;
       bool bail = false;
-      const int it_cap = KA.it_cap, ls_cap = KA.ls_cap;
+      // (iteration caps: measured slower than letting the packed tier finish its solves, profiles/r03/notes.md -- compiled in only with -DMJH_SOL2_CAPS, so the kernels do not carry their bookkeeping)
+      const int it_cap = MJH_SOL2_CAPS_ON ? KA.it_cap : 0, ls_cap = MJH_SOL2_CAPS_ON ? KA.ls_cap : 0;
       for (;;) {
         if (M.iterations == 1) { if (it >= 1) break; }
         else if (fixed) { if (it >= M.iterations) break; }

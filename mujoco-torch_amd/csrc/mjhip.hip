@@ -693,7 +693,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
       const int64_t grid4 = blocks4 < (int64_t)1 << 20 ? blocks4 : (int64_t)1 << 20;
       a.row_lo = -1; a.row_hi = 16 * m->sol2_w16_rpl;
       const size_t lds = (size_t)(4 * m->lds_tier);
-      const bool capped = m->sol2_it_cap > 0 && !(a.flags & MJH_FLAG_FIXED_ITERATIONS) && a.cur.qacc;
+      const bool capped = MJH_SOL2_CAPS_ON && m->sol2_it_cap > 0 && !(a.flags & MJH_FLAG_FIXED_ITERATIONS) && a.cur.qacc;  // (a build with -DMJH_SOL2_CAPS; MJH_SOL2_ITCAP / MJH_SOL2_LSCAP then set the caps)
       a.it_cap = capped ? m->sol2_it_cap : 0; a.ls_cap = capped ? m->sol2_ls_cap : 0;
       if (m->sol2_w16_nmax == 8) { if (m->sol2_w16_rpl == 2) GOW(8, 2); else GOW(8, 5); }
       else if (m->sol2_w16_nmax == 12) { if (m->sol2_w16_rpl == 2) GOW(12, 2); else GOW(12, 5); }
