@@ -192,6 +192,8 @@ class Loop:
 
     def dropin(self, n):
         d, m = self.d, self.mdev
+        self.d = None  # (the loop holds the only reference: a second one kept the first input's storage alive for the whole loop -- one more slab in flight than the
+        #                warm-up ever had, i.e. a driver-level allocation of 1.5 GB (B = 32768) inside the timed region that costs up to 40 ms when the driver is slow to serve it)
         for _ in range(n):
             d = mt.step(m, d)
         self.d = d
@@ -204,6 +206,9 @@ class Loop:
             self.cur = 1 - self.cur
 
 
+LAST_TIMED = {}
+
+
 def timed(fn, steps, device, world, backend):
     """barrier + synchronize on both sides of exactly `steps` steps; wall time (max over ranks) and device time (events)."""
     torch.cuda.synchronize(device)
@@ -211,11 +216,15 @@ def timed(fn, steps, device, world, backend):
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(device)
+    ms0 = torch.cuda.memory_stats(device)
+    a0, r0 = ms0.get("num_device_alloc", 0), ms0.get("reserved_bytes.all.current", 0)
     t0 = time.perf_counter()
     ev0.record()
     fn(steps)
     ev1.record()
     torch.cuda.synchronize(device)
+    ms1 = torch.cuda.memory_stats(device)
+    LAST_TIMED["device_allocs"] = [ms1.get("num_device_alloc", 0) - a0, (ms1.get("reserved_bytes.all.current", 0) - r0) >> 20]  # driver-level allocations inside the region and the MiB they added (0 once the caching allocator is warm)
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -375,6 +384,7 @@ def main(args):
     spin_up(mdev, loop, SPIN_UP)
     loop.dropin(args.warmup)
     elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)
+    allocs_in_region = LAST_TIMED.get("device_allocs")
     assert torch.isfinite(loop.d.qpos).all(), "non-finite state after the timed steps"
     loop.pingpong(args.warmup)
     elapsed_pp, kernel_ms_pp = timed(loop.pingpong, args.steps, device, world, backend)  # extension: step(mx, a, out=b)
@@ -427,6 +437,7 @@ def main(args):
             "out_buffers": {"value": B * world * args.steps / elapsed_pp, "ms_per_step": 1e3 * elapsed_pp / args.steps, "device_ms_per_step": kernel_ms_pp,
                             "call": "mujoco_torch.step(mx, a, out=b)"},
             "roofline": roof,
+            "device_allocations_in_timed_region": allocs_in_region,  # hipMalloc calls of torch's caching allocator between the two synchronizes (each one stalls the host for ~1 ms at these sizes)
         }
         if long_run is not None:
             line["long_run"] = long_run
