@@ -589,6 +589,23 @@ def test_config4_batch_properties():
     torch.cuda.empty_cache()
 
 
+def test_drop_in_loop_asks_the_driver_for_no_memory_once_warm():
+    """`d = step(mx, d)` allocates its outputs afresh every call (two slabs); with the loop variable as the only reference to the Data they come back from torch's
+    caching allocator: a warm loop performs no driver-level allocation (one inside a timed region costs 1 - 40 ms: profiles/r03/notes.md)."""
+    mx = load_model("humanoid", {"solver": 1})
+    mdev = mx.to("cuda")
+    d = mt.make_data(mx).expand(2048).clone().to("cuda")
+    for _ in range(6):
+        d = mt.step(mdev, d)
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_stats()["num_device_alloc"]
+    for _ in range(40):
+        d = mt.step(mdev, d)
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_stats()["num_device_alloc"] == before
+    assert torch.isfinite(d.qpos).all()
+
+
 @pytest.mark.parametrize("xml, ov, B", [("ant", {"integrator": 1, "solver": 2, "cone": 1}, 16384), ("mesh_contact", {}, 8200)])
 def test_config3_and_5_batches_run_the_separate_launches(xml, ov, B):
     """Small float32 models step through ONE kinematics + crb + velocity kernel while the batch is a single round of its waves (every seeded parity test
