@@ -112,7 +112,8 @@ KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kern
                8: "mjh_phase_kernel<{r}, 8, W> (collision / constraint, rows straight to the leaf)",
                9: "mjh_sol2_kernel<{r}, NMAX, RPL> (solve / integrate: register solver, two environments per wavefront)", 10: "mjh_convex_kernel<{r}>", 11: "mjh_sensor_kernel<{r}>",
                12: "mjh_phase_kernel<{r}, 12, W> (kinematics + velocity in one launch)",
-               13: "mjh_phase_kernel<{r}, 13, W> (kinematics + crb / factor + velocity in one launch)"}
+               13: "mjh_phase_kernel<{r}, 13, W> (kinematics + crb / factor + velocity in one launch)",
+               14: "mjh_sol2_kernel<{r}, 28, 1, 33> (collision / constraint + register solver + integrator in one launch)"}
 
 
 def kernel_algorithmic_bytes(nm):
@@ -121,7 +122,7 @@ def kernel_algorithmic_bytes(nm):
     import ctypes
 
     out = {}
-    for k in range(14):
+    for k in range(15):
         rw = (ctypes.c_int64 * 2)()
         if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
             out[k] = (int(rw[0]), int(rw[1]))
@@ -178,9 +179,12 @@ def cpu_baseline(mx, dtype, B_sample, steps):
     v, done, dt = sample(B_sample, threads, steps, 10.0, 30.0)
     n1 = min(B_sample, 256)
     v1, done1, dt1 = sample(n1, 1, 2, 4.0, 12.0)
-    return dict(value=v, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{B_sample} envs x {done} steps of one trajectory, oracle/mjoracle.c (mjo_step calls only) with OpenMP over environments ({dt:.1f} s)",
-                single_thread=dict(value=v1, unit="env-steps/s", cores=1, sample=f"{n1} envs x {done1} steps on one thread ({dt1:.1f} s)"))
+    # the one-thread figure comes first: it is the load-independent one (the all-threads figure swings 126 - 223 k with what else the shared host runs)
+    return dict(single_thread=dict(value=v1, unit="env-steps/s", cores=1, sample=f"{n1} envs x {done1} steps on one thread ({dt1:.1f} s)",
+                                   note="load-independent: quote this one when comparing boxes"),
+                value=v, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"{B_sample} envs x {done} steps of one trajectory, oracle/mjoracle.c (mjo_step calls only) with OpenMP over environments ({dt:.1f} s); "
+                       "moves with the shared host's load")
 
 
 class Loop:
@@ -223,15 +227,19 @@ def timed(fn, steps, device, world, backend):
     fn(steps)
     ev1.record()
     torch.cuda.synchronize(device)
-    ms1 = torch.cuda.memory_stats(device)
-    LAST_TIMED["device_allocs"] = [ms1.get("num_device_alloc", 0) - a0, (ms1.get("reserved_bytes.all.current", 0) - r0) >> 20]  # driver-level allocations inside the region and the MiB they added (0 once the caching allocator is warm)
+    own = time.perf_counter() - t0      # this rank's own K steps (before the barrier: a straggler shows up in the per-rank spread below)
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0  # read BEFORE the allocator statistics are collected (building that dict costs ~0.1 ms: ADVICE r03)
+    ms1 = torch.cuda.memory_stats(device)
+    LAST_TIMED["device_allocs"] = [ms1.get("num_device_alloc", 0) - a0, (ms1.get("reserved_bytes.all.current", 0) - r0) >> 20]  # driver-level allocations inside the region and the MiB they added (0 once the caching allocator is warm)
+    LAST_TIMED["per_rank_ms_per_step"] = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed, own, -own], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        # fastest / slowest rank's own time for the same K steps: `value` is computed from the max-reduced bracket, which hides WHICH rank set it
+        LAST_TIMED["per_rank_ms_per_step"] = {"min": 1e3 * -float(t[2].item()) / steps, "max": 1e3 * float(t[1].item()) / steps}
     return elapsed, ev0.elapsed_time(ev1) / steps
 
 
@@ -247,7 +255,7 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r03"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
+PROFILE_ROUND = "r04"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
 
 
 def setup_workload(key, B, device, rank):
@@ -305,7 +313,7 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
             traffic = tj.get("hbm_bytes_per_step")
             best_disp = 0
             for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
-                pat = "mjh_sol2_kernel<" if dom["id"] == 9 else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
+                pat = "mjh_sol2_kernel<" if dom["id"] in (9, 14) else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
                 if pat not in name:
                     continue
                 kb = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]
@@ -329,7 +337,8 @@ def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, 
     untimed steps on a scratch copy, then from the ORIGINAL state `warmup` untimed and `steps` timed steps -- independent of the headline's
     --steps / --warmup, so the figure is the same trajectory window whoever launches the bench.  The recipe runs `repeats` times from
     scratch (same seeds, same trajectory): device clocks on this pool move the same window by up to 8 % between repetitions
-    (profiles/r03/notes.md); `value` is the fastest repetition, `repeats` lists every one."""
+    (profiles/r03/notes.md); `value` is the MEDIAN repetition (round 3 reported the fastest, which is not how the single-shot headline is
+    measured: ADVICE r03), `repeats` lists every one."""
     runs, best = [], None
     for _ in range(repeats):
         torch.cuda.empty_cache()  # the previous workload's cached blocks go back to the driver: this one allocates like a process of its own
@@ -339,15 +348,17 @@ def secondary_workload(key, device, world, rank, backend, steps=200, warmup=20, 
         elapsed, kernel_ms = timed(loop.dropin, steps, device, world, backend)
         assert torch.isfinite(loop.d.qpos).all(), f"{key}: non-finite state after the timed steps"
         runs.append({"value": B * world * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms})
-        if best is None or elapsed < best[0]:
-            best = (elapsed, kernel_ms, loop, mx, mdev)
-        else:
-            del loop
-    elapsed, kernel_ms, loop, mx, mdev = best
+        if best is not None:
+            del best
+        best = (loop, mx, mdev)  # the per-kernel pass below runs on the last repetition's state (same trajectory window every time)
+        del loop
+    loop, mx, mdev = best
+    med = sorted(runs, key=lambda r: r["ms_per_step"])[len(runs) // 2]
+    elapsed, kernel_ms = med["ms_per_step"] * steps / 1e3, med["device_ms_per_step"]
     res = {"workload": wl["name"], "envs_per_gpu": B, "global_batch": B * world, "dtype": "f64" if dtype == torch.float64 else "f32",
            "steps": steps, "warmup": warmup, "spin_up_steps_on_a_scratch_state": spin,
            "value": B * world * steps / elapsed, "unit": "env-steps/s", "ms_per_step": 1e3 * elapsed / steps, "device_ms_per_step": kernel_ms,
-           "repeats": runs}
+           "value_is": f"median of {repeats} repetitions of the same window", "repeats": runs}
     if rank == 0:
         res["roofline"], _ = roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps)
     del loop
@@ -385,6 +396,7 @@ def main(args):
     loop.dropin(args.warmup)
     elapsed, kernel_ms = timed(loop.dropin, args.steps, device, world, backend)       # THE measurement: d = step(mx, d)
     allocs_in_region = LAST_TIMED.get("device_allocs")
+    per_rank = LAST_TIMED.get("per_rank_ms_per_step")
     assert torch.isfinite(loop.d.qpos).all(), "non-finite state after the timed steps"
     loop.pingpong(args.warmup)
     elapsed_pp, kernel_ms_pp = timed(loop.pingpong, args.steps, device, world, backend)  # extension: step(mx, a, out=b)
@@ -403,10 +415,10 @@ def main(args):
     if world > 1 and args.workload == "humanoid" and not args.batch and not args.no_config4:
         # BASELINE config 4 beside the headline batch: 32768 environments per GPU (262144 on 8 GPUs), same loop
         big = Loop(mdev, build_inputs(mx, 32768, dtype, device, seed=1042 + rank))
-        big.dropin(max(2, args.warmup // 4))
-        n4 = max(5, args.steps // 4)
+        big.dropin(max(3, args.warmup // 4))
+        n4 = max(20, args.steps // 4)  # >= 20 steps (~26 ms) whatever --steps is
         e4, k4 = timed(big.dropin, n4, device, world, backend)
-        config4 = {"workload": WORKLOADS["humanoid32k"]["name"], "envs_per_gpu": 32768, "global_batch": 32768 * world, "steps": n4,
+        config4 = {"per_rank_ms_per_step": LAST_TIMED.get("per_rank_ms_per_step"),"workload": WORKLOADS["humanoid32k"]["name"], "envs_per_gpu": 32768, "global_batch": 32768 * world, "steps": n4,
                    "value": 32768 * world * n4 / e4, "unit": "env-steps/s", "ms_per_step": 1e3 * e4 / n4, "device_ms_per_step": k4}
         del big
         torch.cuda.empty_cache()
@@ -439,6 +451,8 @@ def main(args):
             "roofline": roof,
             "device_allocations_in_timed_region": allocs_in_region,  # hipMalloc calls of torch's caching allocator between the two synchronizes (each one stalls the host for ~1 ms at these sizes)
         }
+        if per_rank is not None:
+            line["per_rank_ms_per_step"] = per_rank  # every rank's own K steps, fastest and slowest (the bracket above is max-reduced)
         if long_run is not None:
             line["long_run"] = long_run
         if others:

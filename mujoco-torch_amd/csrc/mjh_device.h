@@ -48,6 +48,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
 #define PH_SOL2P 128 /* ... after the state the tail integrates, which is parked for the whole phase                           */
 #define PH_KINVEL 256 /* arena of the fused kinematics + velocity kernel (12): the arrays both phases use, then the kinematics-only and the velocity-only arrays OVER each other */
 #define PH_KCV 512  /* arena of the fused kinematics + crb + velocity kernel (13): what kinematics and velocity share, then the kinematics-only, the crb-only and the velocity-only arrays OVER each other */
+#define PH_CS 1024  /* arena of the fused constraint + register-solver kernel (mjh_cs_kernel): the contact rows of efc_J stay where the constraint stage built them */
 #define MJH_NPHASE 5
 #define MJH_NARENA 6  /* arenas carved per model: the five phases + the register solver */
 #define MJH_LDS_ARRAYS(X, m)                                                                                   \
@@ -68,9 +69,13 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
   X(qLDp, m.nv * (m.nv + 1) / 2, PH_SOL) /* lower triangle, packed rows */                                      \
   X(qMs, m.sol_qm_lds ? m.nv * m.nv : 0, PH_SOL) /* only when the solver iterates enough to amortise the copy */ \
   X(qLD_inv, m.nv, PH_SOL)                                                                            \
-  X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL | PH_SOL2T)                 \
-  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL | PH_SOL2T) /* packed lower rows */ \
-  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL | PH_SOL2T)              \
+  X(HL_inv, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv : 0, PH_SOL)                 \
+  X(H, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL) /* packed lower rows */ \
+  X(HL, (m.solver == SOL_NEWTON || !(m.disableflags & DSBL_EULERDAMP)) ? m.nv * m.nv : 0, PH_SOL)              \
+  /* integrator tail of the register solver (implicit joint damping, forward.py:313-328): n <= 16 factorises M + dt D from packed rows in LDS; 16 < n <= 28 factorises in   \
+     registers straight from the qM leaf and only needs a two-column broadcast buffer -- the n x n image HL (729 reals for the humanoid) made this arena 11.8 KB: six   \
+     workgroups per CU where B = 4096 needs eight (profiles/r04/notes.md) */                                                                                          \
+  X(H2, (!(m.disableflags & DSBL_EULERDAMP) && m.nv <= 16) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL2T) X(chol_col, (!(m.disableflags & DSBL_EULERDAMP) && m.nv > 16) ? 64 : 0, PH_SOL2T) \
   X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
   X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
   X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(i_con_act, m.con_direct ? m.ncon : 0, PH_CON) X(i_crow_act, m.con_direct ? m.nefc - m.nl : 0, PH_CON) /* small models: compact list of the active contacts, per-row activity (ints) */ X(efc_D, m.nefc, PH_SOL)                                            \

@@ -101,6 +101,57 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = n
     off = ka > va ? ka : va;
     if (ca > off) off = ca;
   }
+  if (phase_bit == PH_CS) {
+    // Fused constraint + register-solver kernel (plain rows, one dense-row slot per lane, no tiers: the humanoid).  Laid out by hand:
+    //   [qvel | act | act_dot | con_dist | efc_jl]                     live through both stages
+    //   [efc_J == efc_Jc]                                              the contact rows: built by the constraint stage, compacted IN PLACE for the solve (the geom frames of the
+    //                                                                  narrow phase are dead before the rows are built and sit under them, as in PH_CON)
+    //   constraint-only [subtree_com cdof con_pos con_frame | efc_pos efc_invweight]   OVER
+    //   solver-only     [efc_D efc_aref | r_src r_dst r_vs r_vs2 r_pg r_fs qpos]       (efc_D / efc_aref are staged by the aref loop, which no longer reads what lies under them)
+    //   integrator tail (PH_SOL2T) over the rows, as in PH_SOL2.
+    // Returns -1 when the overlays do not work out for the model (the caller keeps the two launches).
+    auto ev = [](int c) { return (c + 1) & ~1; };
+    const int nd = m.nefc - m.nl, ns = m.nl;
+    off = 0;
+    o.qvel = off; off += ev(m.nv);
+    o.act = off; off += ev(m.na);
+    o.act_dot = off; off += ev(m.na);
+    o.con_dist = off; off += ev(m.ncand);
+    o.efc_jl = off; off += ev(m.nl);
+    const int rows0 = off, nj = ev(nd * m.nv), n3 = ev(3 * m.ngeom), n9 = ev(9 * m.ngeom);
+    o.efc_J = o.efc_Jc = rows0;
+    if (n3 + n9 > nj) return -1;
+    o.geom_xpos = rows0; o.geom_xmat = rows0 + n3;
+    off += nj;
+    const int ov = off;
+    int ca = ov;
+    o.subtree_com = ca; ca += ev(3 * m.nbody);
+    o.cdof = ca; ca += ev(6 * m.nv);
+    o.con_pos = ca; ca += ev(3 * m.ncand);
+    o.con_frame = ca; ca += ev(9 * m.ncand);
+    const int aref_reads = ca;  // from here on: what the aref loop still reads
+    o.efc_pos = ca; ca += ev(ns);
+    o.efc_invweight = ca; ca += ev(ns);
+    int sa = ov;
+    o.efc_D = sa; sa += ev(m.nefc);
+    o.efc_aref = sa; sa += ev(m.nefc);
+    if (sa > aref_reads) return -1;
+    o.r_src = sa; sa += ev(nd);
+    o.r_dst = sa; sa += ev((nd + 1) / 2);
+    o.r_vs = sa; sa += ev(m.nv);
+    o.r_vs2 = sa; sa += ev(m.nv);
+    o.r_pg = sa; sa += ev(2 * m.nv);
+    o.r_fs = sa; sa += ev(nd + m.nl);
+    const int qpos_at = sa;
+    o.qpos = sa; sa += ev(m.nq);
+    off = ca > sa ? ca : sa;
+    int ta = rows0;
+#define X(n, c, p) if ((p) & PH_SOL2T) { o.n = ta; ta += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    if (ta > qpos_at && ta > off) off = ta;
+    if (ta > qpos_at) return -1;  // (the tail must leave the parked qpos alone)
+  }
   if (phase_bit == PH_CRB) {
     // the Cholesky factor is produced from registers after every other array of the phase is dead: it is written
     // over them (n <= 32, register factorisation); the in-LDS factorisation of larger models gets its own space
@@ -601,6 +652,48 @@ __device__ __forceinline__ void chol_factor_pack(const REAL* A, TriPack<REAL, NM
   for (int k = 0; k < NMAX; k++) dg = (k == i) ? T.t[k] : dg;
   T.inv = valid ? 1 / dg : (REAL)0;
 }
+// Cholesky, 16 < n <= NMAX <= 32, of the symmetric matrix whose row i (entries k <= i) lane i holds in T.t[k]: the torch.linalg.cholesky(A + 1e-10 I) branch of
+// math.small_cholesky (:108-113), right-looking with every element updated in step order -- per element the operations of chol_factor_lds, bit for bit (plain
+// square root and division).  Column j of the factor reaches every lane through a two-column LDS buffer (`colbuf`, 2 * NMAX reals: uniform-address
+// broadcast reads, as in chol_factor_reg) and lane j keeps it: row AND column of the factor end up in the TriPack without an n x n image.
+template <int W, typename REAL, int NMAX>
+__device__ __forceinline__ void chol_pack_big(TriPack<REAL, NMAX>& T, REAL* colbuf, int n) {
+  static_assert(NMAX > 16 && NMAX <= 32 && NMAX <= W, "one lane per row");
+  const int i = sub_lane<W>();
+  const bool valid = i < n;
+#pragma unroll
+  for (int j = 0; j < NMAX; j++) {
+    if (j < n) {
+      const REAL sj = sub_read<W>(T.t[j], j) + (REAL)1e-10;
+      const REAL dj = r_sqrt<REAL>(sj);
+      const REAL lij = (i == j) ? dj : ((i > j && valid) ? T.t[j] / dj : (REAL)0);
+      if (i >= j) T.t[j] = lij;
+      REAL* col = colbuf + (j & 1) * NMAX;
+      if (i < NMAX) col[i] = lij;  // (no barrier: one wavefront's LDS operations complete in order; the two buffers alternate, so step j + 1's stores do not pass step j's reads)
+      constexpr int CH = 8;
+#pragma unroll
+      for (int k0 = 0; k0 < NMAX; k0 += CH) {
+        if (k0 + CH - 1 > j) {
+          REAL c[CH];
+#pragma unroll
+          for (int t = 0; t < CH; t++) c[t] = (k0 + t > j && k0 + t < NMAX) ? col[k0 + t] : (REAL)0;
+#pragma unroll
+          for (int t = 0; t < CH; t++) {
+            if (k0 + t > j && k0 + t < NMAX) {
+              T.t[k0 + t] = (i == j) ? c[t] : ((i > j) ? T.t[k0 + t] - lij * c[t] : T.t[k0 + t]);
+              asm volatile("" : "+v"(T.t[k0 + t]));  // (pinned here: left alone the scheduler sinks the update to step k and keeps every column read so far in registers, see chol_factor_reg)
+            }
+          }
+        }
+      }
+    }
+  }
+  REAL dg = 1;
+#pragma unroll
+  for (int k = 0; k < NMAX; k++) dg = (k == i) ? T.t[k] : dg;
+  T.inv = valid ? 1 / dg : (REAL)0;
+}
+
 // x = (A)^-1 b for a symmetric positive matrix in LDS (packed lower rows), n <= 16: factor and substitute in registers
 template <int W, typename REAL, int NMAX>
 __device__ __forceinline__ void chol_factor_solve_n(const REAL* A, const REAL* b, REAL* x, int n) {
@@ -741,6 +834,16 @@ __device__ __forceinline__ float mjh_bail_mark(float) { return __builtin_bit_cas
 __device__ __forceinline__ double mjh_bail_mark(double) { return __builtin_bit_cast(double, 0x7ff80005eed5eed5ull); }
 __device__ __forceinline__ bool mjh_is_bail_mark(float x) { return __builtin_bit_cast(unsigned, x) == 0x7fc5eed5u; }
 __device__ __forceinline__ bool mjh_is_bail_mark(double x) { return __builtin_bit_cast(unsigned long long, x) == 0x7ff80005eed5eed5ull; }
+
+// what the register solver reads from leaves that earlier LAUNCHES produced (crb / factor, velocity, the caller's inputs): in the fused constraint + solver
+// kernel these loads are issued at the head of the constraint stage and arrive under its arithmetic
+template <typename REAL, int NMAX>
+struct Sol2Pre {
+  REAL f;                   // qfrc_smooth[l]
+  TriPack<REAL, NMAX> T;    // row and column l of the factor of M (inv is set by the solver)
+  REAL qp[2];               // qpos[l], qpos[l + 32]
+  REAL ac, ad, warm;        // act[l], act_dot[l], qacc_warmstart[l]
+};
 
 // =====================================================================================================================
 // FRIC: the general constraint / solver instantiations (equality, frictionloss, dense limit rows; also max_contact_points);
@@ -1211,7 +1314,8 @@ struct Env {
   }
 
   bool con_inputs_loaded_ = false;  // collision() already fetched what make_constraint() reads (plain instantiation)
-  __device__ __forceinline__ void collision() {
+  template <int PRE_NMAX = 0>
+  __device__ __forceinline__ void collision(Sol2Pre<REAL, (PRE_NMAX > 0 ? PRE_NMAX : 1)>* pre = nullptr) {
     const int l = lane_here();
     if (!FRIC && (KA.stages & 0x78) && M.nefc > 0) {
       // plain instantiation with the rows to follow: qvel, subtree_com and cdof ride in the same round trip as the geom frames -- loaded at the
@@ -1240,6 +1344,7 @@ struct Env {
         row_load<W>(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
       }
     }
+    if constexpr (PRE_NMAX > 0) sol2_prefetch<PRE_NMAX>(*pre);  // fused constraint + solver kernel: requested BEHIND this stage's own inputs (vmcnt is in order: the narrow phase does not wait for them)
     wave_sync();
     for (int p = l; p < M.npair; p += W) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
@@ -1446,6 +1551,7 @@ struct Env {
     k = kk; b = bb; imp = im;
   }
 
+  template <bool CS = false>
   __device__ __forceinline__ void make_constraint() {
     const int l = lane_here();
     // FRIC = false: the plain instantiation (slide / hinge limits and contacts only); equality, frictionloss, ball- and tendon-limit
@@ -1858,8 +1964,10 @@ struct Env {
       }
       if (stage_ad) { ad_stage[r] = -b * jv - k * imp * pos; ad_stage[nefc + r] = 1 / rr; }
       else {
-        if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
-        if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
+        const REAL aref_r = -b * jv - k * imp * pos, D_r = 1 / rr;
+        if (out.efc_aref) out.efc_aref[e * nefc + r] = aref_r;  // lane r <-> row r: coalesced, no staging
+        if (out.efc_D) out.efc_D[e * nefc + r] = D_r;
+        if constexpr (CS) { S.efc_aref()[r] = aref_r; S.efc_D()[r] = D_r; }  // fused kernel: the solver stage takes them from here (over subtree_com / cdof, which nobody reads any more)
       }
     }
     if (stage_ad) {
@@ -3265,6 +3373,39 @@ struct Env {
     if (M.ncon > 0) collision();
     if (KA.stages & 0x78) make_constraint();
   }
+  // the solver's loads that depend on nothing this kernel computes (fused constraint + solver kernel)
+  template <int NMAX>
+  __device__ __forceinline__ void sol2_prefetch(Sol2Pre<REAL, NMAX>& P) {
+    const int l = lane_here();
+    const int nq = M.nq, nv = M.nv, na = M.na;
+    const bool dof = l < nv;
+    P.f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;
+    {
+      const REAL* gL = out.qLD + e * nv * nv;
+#pragma unroll
+      for (int k = 0; k < NMAX; k++) P.T.t[k] = (dof && k < nv) ? (k <= l ? gL[l * nv + k] : gL[k * nv + l]) : (REAL)0;
+    }
+    P.T.inv = 0;
+    const REAL* gq = KA.cur.qpos + e * nq;
+#pragma unroll
+    for (int j = 0; j < 2; j++) P.qp[j] = l + W * j < nq ? gq[l + W * j] : (REAL)0;
+    P.ac = 0; P.ad = 0;
+    if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; P.ac = ga ? ga[e * na + l] : (REAL)0; P.ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
+    P.warm = (dof && KA.warm_src && M.nefc > 0) ? KA.warm_src[e * nv + l] : (REAL)0;
+  }
+  // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the contact rows of efc_J, efc_D / efc_aref and the
+  // narrow phase's distances never leave the arena between the two (the leaves are still stored -- nothing waits for them), and the factor rows, qfrc_smooth
+  // and the state arrive while the constraint stage computes.  Serves models of the plain constraint phase whose dense rows fit one slot per lane.
+  template <int NMAX, int RPL>
+  __device__ __forceinline__ void run_con_sol2() {
+    static_assert(W == 32 && !FRIC && !DIRECT, "plain constraint stage, two environments per wavefront");
+    Sol2Pre<REAL, NMAX> pre;
+    STAMP0();
+    if (M.ncon > 0) collision<NMAX>(&pre); else sol2_prefetch<NMAX>(pre);
+    make_constraint<true>();
+    wave_sync();
+    run_sol2<NMAX, RPL, false, true>(&pre);
+  }
   template <bool FLUID, bool FUSED = false, bool DEFER = false>
   __device__ __forceinline__ void run_vel() {
     STAMP0();
@@ -3309,24 +3450,44 @@ struct Env {
     const int rk = KA.rk_stage;
     if (rk < 0) {  // Euler
       const REAL* qacc = S.qacc();
+      constexpr bool REGSOL = NHI <= 32;  // called by the register solver (its arena: H2 / chol_col); the LDS solvers pass no bounds and keep H / HL / HL_inv
       if (!(M.disableflags & DSBL_EULERDAMP)) {
+        if constexpr (REGSOL && NLO > 16) {
+          // 16 < nv <= NHI: M + dt D factorised and substituted in registers.  Lane i takes row i of the (exactly symmetric) qM leaf as column i -- one coalesced
+          // load per term -- and the right-hand side is its own element; no packed copy, no n x n image of the factor, none of chol_factor_lds's three barriers
+          // per column.  Same operations per element, in the same order, as the LDS path the other solver kernels run.
+          TriPack<REAL, NHI> Hh;
+          const REAL* gM = out.qM + e * nv * nv;
+#pragma unroll
+          for (int k = 0; k < NHI; k++) Hh.t[k] = (l < nv && k <= l) ? gM[k * nv + l] : (REAL)0;
+          const REAL dd = l < nv ? M.timestep * M.dof_damping[l] : (REAL)0;
+          const REAL rhs = l < nv ? S.qfrc_smooth()[l] + (M.nefc ? S.qfrc_constraint()[l] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + l] : (REAL)0)) : (REAL)0;
+#pragma unroll
+          for (int k = 0; k < NHI; k++) Hh.t[k] = (k == l) ? Hh.t[k] + dd : Hh.t[k];
+          chol_pack_big<W, REAL, NHI>(Hh, S.chol_col(), nv);
+          const REAL x = tri_solve<W, REAL, NHI>(Hh, rhs, nv);
+          if (l < nv) S.s_Mgrad()[l] = x;
+          wave_sync();
+        } else {
+        REAL* const Hp = REGSOL ? S.H2() : S.H();
         for (int w = l; w < (nv * (nv + 1)) / 2; w += W) {
           int i, j;
           tri_unpack(w, i, j);
           const REAL mw = out.qM[e * nv * nv + i * nv + j];
-          S.H()[w] = (i == j) ? mw + M.timestep * M.dof_damping[i] : mw;
+          Hp[w] = (i == j) ? mw + M.timestep * M.dof_damping[i] : mw;
         }
         for (int d = l; d < nv; d += W) S.s_grad()[d] = S.qfrc_smooth()[d] + (M.nefc ? S.qfrc_constraint()[d] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + d] : (REAL)0));
         wave_sync();
         if (NLO <= 16 && (NHI <= 16 || nv <= 16)) {
-          if constexpr (NLO <= 16) chol_factor_solve<W, REAL, NLO, (NHI < 16 ? NHI : 16)>(S.H(), S.s_grad(), S.s_Mgrad(), nv);
+          if constexpr (NLO <= 16) chol_factor_solve<W, REAL, NLO, (NHI < 16 ? NHI : 16)>(Hp, S.s_grad(), S.s_Mgrad(), nv);
         } else {
-          if constexpr (NHI > 16) {
+          if constexpr (NHI > 16 && !REGSOL) {
             chol_factor<W, REAL, 16, true>(S.H(), S.HL(), nv);
             chol_inv_diag<W, false>(S.HL(), S.HL_inv(), nv);
             wave_sync();
             chol_solve<W, false>(S.HL(), S.HL_inv(), S.s_grad(), S.s_Mgrad(), nv);
           }
+        }
         }
         qacc = S.s_Mgrad();
       }
@@ -3394,9 +3555,10 @@ struct Env {
     return tri_solve<W, REAL, NMAX>(T, bi, M.nv);
   }
 
-  template <int NMAX, int RPL, bool NEWTON_ONLY = false>
-  __device__ __forceinline__ void run_sol2() {
+  template <int NMAX, int RPL, bool NEWTON_ONLY = false, bool CS = false>
+  __device__ __forceinline__ void run_sol2(const Sol2Pre<REAL, NMAX>* pre = nullptr) {
     static_assert(W == 32 || W == 16, "two or four environments per wavefront");
+    static_assert(!CS || (W == 32 && !NEWTON_ONLY), "the fused constraint + solver kernel runs two environments per wavefront");
     constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
     const int l = lane_here();
     const int nq = M.nq, nv = M.nv, na = M.na, nefc = M.nefc, nl = M.nl, nd = nefc - nl;
@@ -3426,9 +3588,12 @@ struct Env {
       if (!(rows_active > KA.row_lo && rows_active <= KA.row_hi)) return;
     }
     // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
-    const REAL f = (dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0;              // qfrc_smooth
+    const REAL f = CS ? pre->f : ((dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0);              // qfrc_smooth
     TriPack<REAL, NMAX> T;
-    {
+    if constexpr (CS) {
+#pragma unroll
+      for (int k = 0; k < NMAX; k++) T.t[k] = pre->T.t[k];
+    } else {
       // (staging the leaf through LDS with contiguous loads was measured: the strided section shrinks 21 k -> 3 k cycles but the wait only moves
       // to the next load -- this phase's loads are bound by the bytes, 79 MB at B = 4096 -- and the extra registers cost the float32 tier its third wave)
       const REAL* gL = out.qLD + e * nv * nv;
@@ -3455,12 +3620,19 @@ struct Env {
     unsigned short* rdst = reinterpret_cast<unsigned short*>(S.r_dst());  // Data row - nl -> compact dense row, 0xffff = inactive
     const int ndc = nd < KA.row_hi ? nd : KA.row_hi;  // dense rows this tier's arena keeps (r_src, r_fs and efc_Jc are carved for them)
     if (solving) {
+      if constexpr (CS) {  // the constraint stage left qvel (checked) in the arena; the rest was requested at its head
+#pragma unroll
+        for (int j = 0; j < NQS; j++) qp[j] = pre->qp[j];
+        if (dof) qv = S.qvel()[l];
+        ac = pre->ac; ad = pre->ad;
+      } else {
       const REAL* gq = KA.cur.qpos + e * nq;
 #pragma unroll
       for (int j = 0; j < NQS; j++) qp[j] = l + W * j < nq ? gq[l + W * j] : (REAL)0;
       if (dof) qv = (from_in ? in.qvel : KA.cur.qvel)[e * nv + l];
       if (from_in && KA.do_step) qv = checked(qv, (REAL)0);  // _check_state
       if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; ac = ga ? ga[e * na + l] : (REAL)0; ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
+      }
       // the state only feeds the integrator tail: parked in the arena (its own slots, not under the constraint rows)
 #pragma unroll
       for (int j = 0; j < NQS; j++) if (l + W * j < nq) S.qpos()[l + W * j] = qp[j];
@@ -3468,8 +3640,13 @@ struct Env {
       if (l < na) { S.act()[l] = ac; S.act_dot()[l] = ad; }
       if (nefc > 0) {
         const REAL* gJ = out.efc_J + e * nefc * nv;
+        if constexpr (CS) {
+          warm = pre->warm;
+          if (lim) { ldof = M.lim_dof[l]; Dl = S.efc_D()[l]; arl = S.efc_aref()[l]; Jl = S.efc_jl()[l]; }
+        } else {
         if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
         if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
+        }
         if (dof) limrow = M.dof_limrow[2 * l];
         STAMP(81);
         {  // active contacts -> compact row tables: one contact per lane, exclusive prefix sum of the active contacts' row counts
@@ -3484,6 +3661,8 @@ struct Env {
               const int dim = M.con_dim[c];
               rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
               start = M.con_efc_address[c] - nl;
+              if constexpr (CS) act = (S.con_dist()[c] - M.con_includemargin[c]) < 0;
+              else
               act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
             }
             int excl, tot;
@@ -3517,6 +3696,25 @@ struct Env {
       if (nefc > 0) {
         const REAL* gJ = out.efc_J + e * nefc * nv;
         wave_sync();
+        if constexpr (CS) {
+#pragma unroll
+          for (int j = 0; j < RPL; j++) {
+            const int r = l + W * j;
+            if (r < nda) { const int x = rsrc[r]; Dd[j] = S.efc_D()[x]; ard[j] = S.efc_aref()[x]; }
+          }
+          STAMP(83);
+          // The rows are in the arena already, in Data order: the rows of the active contacts are compacted IN PLACE.  A row only ever moves up (its compact index is at
+          // most its source index, both increase with the contact), so walking the compact rows in order -- eight per batch, all reads of a batch ahead of its
+          // writes; one wavefront's LDS operations complete in order -- never overwrites a row that is still to be read.  nv <= 32: one row per pass of the lanes.
+          REAL* const J = S.efc_Jc();
+          for (int r0 = 0; r0 < nda; r0 += 8) {
+            REAL v[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) { const int r = r0 + t < nda ? r0 + t : nda - 1; v[t] = J[(rsrc[r] - nl) * nv + (dof ? l : 0)]; }
+#pragma unroll
+            for (int t = 0; t < 8; t++) if (r0 + t < nda && dof) J[(r0 + t) * nv + l] = v[t];
+          }
+        } else {
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
           const int r = l + W * j;
@@ -3525,6 +3723,7 @@ struct Env {
         STAMP(83);
         // rows of the active contacts of efc_J -> LDS
         gather_rows<16>(S.efc_Jc(), gJ, rsrc, nda * nv);
+        }
       }
     }
     STAMP(70);
@@ -3951,9 +4150,10 @@ struct Env {
 // WT: lanes per environment (32 or 16); WT = 17 is the four-per-wavefront kernel of NEWTON models (16 lanes, Newton-only code: 128 VGPRs + 116 B of scratch instead of + 160 B
 // for the ant's first tier, 227 instead of 243 VGPRs for the mesh scene's; ant 53.6 -> 52.2 us per launch, mesh scene 223.7 -> 219.1 us)
 template <typename REAL, int NMAX, int RPL, int WT>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
-  constexpr int W = WT == 17 ? 16 : WT;
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+  constexpr int W = WT == 17 ? 16 : (WT == 33 ? 32 : WT);
   constexpr bool NEWTON_ONLY = WT == 17;
+  constexpr bool CS = WT == 33;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
@@ -3989,14 +4189,15 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && R
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {
       Env<REAL, W, false> E(lds, K.env_begin + idx, K.flags);
-      E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
+      if constexpr (CS) E.template run_con_sol2<NMAX, RPL>();
+      else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }
     wave_sync();
   }
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 13 && W < 64) ? MJH_KCV32_WAVES : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? MJH_CON64_WAVES : ((sizeof(REAL) == 8 && (PHASE == 12 || PHASE == 13)) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 13 && W < 64) ? MJH_KCV32_WAVES : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? (W < 64 ? 2 : MJH_CON64_WAVES) : ((sizeof(REAL) == 8 && (PHASE == 12 || PHASE == 13)) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each

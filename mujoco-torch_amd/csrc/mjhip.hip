@@ -40,7 +40,7 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 static struct {
   bool on = false;
   int n = 0;                          // launches recorded by the last call
-  int id[MJH_TIMING_MAX];             // 0..8 phase-kernel ids, 9 register solver, 10 convex narrow phase, 11 sensors
+  int id[MJH_TIMING_MAX];             // 0..8 phase-kernel ids, 9 register solver, 10 convex narrow phase, 11 sensors, 12 / 13 fused kinematics (+ crb) + velocity, 14 fused constraint + register solver
   hipEvent_t ev[MJH_TIMING_MAX + 1];  // ev[i] .. ev[i + 1] brackets launch i
 } g_timing;
 static inline void timing_begin(hipStream_t s) { if (g_timing.on) { g_timing.n = 0; (void)hipEventRecord(g_timing.ev[0], s); } }
@@ -73,6 +73,9 @@ struct mjhModel {
   int sol2_it_cap = 0, sol2_ls_cap = 0;    // > 0: that launch leaves long solves (Newton iterations / line-search iterations beyond the caps) to a fallback launch of the LDS solver
   LdsOff off_tier;                         // ... from an arena of its own (32 rows of efc_J instead of all of them)
   int lds_tier = 0;
+  int fuse_cs = 0;                         // constraint stage + register solver + integrator run as ONE kernel (mjh_sol2_kernel<.., 33>, timing id 14) from an arena of its own
+  LdsOff off_cs;
+  int lds_cs = 0;
   int pack2[MJH_NPHASE];                   // phase runs two environments per wavefront
   int pack4[MJH_NPHASE];                   // ... or four (16 lanes each): small models only
   // hipGraph replay: the launch sequence of a (buffers, batch, flags) combination is captured once on a private stream and
@@ -90,7 +93,7 @@ struct mjhModel {
   mutable hipEvent_t split_fork = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
-  int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the END of an environment-major workspace: the first B * cand_reals reals)
+  int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the HEAD of the workspace: its first B * cand_reals reals; the RK4 stage Data and sums follow)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
   DevModel<float> m32;
@@ -530,6 +533,22 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       }
     }
   }
+  {  // constraint stage + register solver in one kernel: plain rows, one dense-row slot per lane, no tiers, nv in (16, 28] (the instantiation that is built).
+     // Measured on the humanoid (MI355X, B = 4096): profiles/r04/notes.md.  MJH_FUSE_CS=0 keeps the two launches.
+    static const bool off = [] { const char* e = getenv("MJH_FUSE_CS"); return e && e[0] == '0'; }();
+    bool mono = true;  // contact rows in contact order (the in-place row compaction walks them upwards)
+    for (int c = 1; c < d->ncon; c++) mono = mono && d->con_efc_address[c] > d->con_efc_address[c - 1];
+    out->fuse_cs = 0;
+    if (!off && out->sol2_nmax == 28 && out->sol2_rpl == 1 && !out->sol2_tiers && !M.con_direct && !M.con_general && !M.topk && d->ncon > 0 && d->nefc > 0 && mono &&
+        d->nv <= 32 && d->nq <= 64 && d->nl <= 32 && d->na <= 32) {
+      const int reals = lds_carve(M, PH_CS, out->off_cs);
+      if (reals > 0 && 2 * reals * (int)sizeof(REAL) <= 64 * 1024) {
+        out->lds_cs = reals * (int)sizeof(REAL);
+        out->fuse_cs = 1;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 33>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_cs));
+      }
+    }
+  }
   out->leaf_count = leaf_counts(d);
   out->work_reals = 0;
   if (d->integrator == INT_RK4) {
@@ -581,11 +600,19 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[2]));
     out->pack2[2] = 1;
   }
+  {  // experiment (MJH_CON2_PACK=1): the plain constraint phase of a mid-size model at two environments per wavefront
+    static const bool con2 = [] { const char* e = getenv("MJH_CON2_PACK"); return e && e[0] == '1'; }();
+    if (con2 && !M.con_direct && !M.con_general && 2 * out->lds_bytes[2] <= 64 * 1024) {
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 2, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_bytes[2]));
+      out->pack2[2] = 1;
+    }
+  }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 8, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));  // plain constraint phase: its contact rows go straight to the leaf, the arena is small enough for two per wavefront
   // CRB: the register Cholesky keeps one matrix row per lane, so nv <= 32 would fit a 32-lane half too; measured on the float64
   // humanoid (nv 27) two per wavefront is SLOWER, 50.2 vs 39.9 us (132 VGPRs: 3 waves / SIMD instead of 4, and every broadcast of the
   // factorisation becomes two v_readlane + a select): opt-in only (MJH_CRB_PACK=1).  float32 small models: +13 % on the ant (round 1).
-  static const bool crb_pack = [] { const char* e = getenv("MJH_CRB_PACK"); return e && e[0] == '1'; }();
+  // (round 4, after the register work of round 3: 35.1 vs 36.5 us, and it is what lets kernel 13 serve the humanoid: default on, MJH_CRB_PACK=0 turns it off)
+  static const bool crb_pack = [] { const char* e = getenv("MJH_CRB_PACK"); return !(e && e[0] == '0'); }();
   if ((sizeof(REAL) == 4 && d->nv <= 16) || (crb_pack && d->nv <= 32 && d->nv > 16)) { SET_PACK(1) }
 #undef SET_PACK
   // small models (every per-body / per-joint / per-dof loop fits 16 lanes): FOUR environments per wavefront in the packed phases.
@@ -614,6 +641,9 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       out->kcv_max_envs = (int64_t)cus * 4 /* SIMDs */ * 2 /* waves per SIMD */ * (out->pack4[1] ? 4 : 2);
+      if (!out->pack4[1]) out->kcv_max_envs = (int64_t)1 << 62;  // two per wavefront (the humanoid, float64): measured at B = 32768 too (652 us against 452 + 218: profiles/r04/notes.md)
+      static const long long kcv_env = [] { const char* e = getenv("MJH_KCV_MAX_ENVS"); return e ? atoll(e) : -1ll; }();  // experiments: the batch bound of kernel 13
+      if (kcv_env >= 0) out->kcv_max_envs = kcv_env;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kcv));
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_kcv));
       if (out->pack4[1]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_kcv));
@@ -655,16 +685,16 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 3 || P == 5 || P == 8 || P == 12 || P == 13);
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 2 || P == 3 || P == 5 || P == 8 || P == 12 || P == 13);
   constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : ((P == 12 || P == 13) ? 0 : P)));  // index into the per-phase packing flags
   const bool can2 = !PACKABLE ? false : (P == 13 ? (bool)m->pack2[1] : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]));  // (13: fuse_kcv holds only when the crb stage packs like the other two)
-  const bool can4 = !PACKABLE ? false : (P == 13 ? (bool)m->pack4[1] : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && m->pack4[PI])));
+  const bool can4 = !PACKABLE ? false : (P == 13 ? (bool)m->pack4[1] : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && P != 2 && m->pack4[PI])));
   if (PACKABLE && can2 && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
     int64_t done = 0;
     int rc = 0;
     if (can4 && a.B >= 4) {
       done = a.B & ~(int64_t)3;
-      if ((rc = launch_range<REAL, P, ((PACKABLE && P != 8) ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
+      if ((rc = launch_range<REAL, P, ((PACKABLE && P != 8 && P != 2) ? 16 : MJH_WAVE)>(m, a, 0, done, stream))) return rc;
     }
     const int64_t even = (a.B - done) & ~(int64_t)1;
     if ((rc = launch_range<REAL, P, (PACKABLE ? 32 : MJH_WAVE)>(m, a, done, even, stream))) return rc;
@@ -741,6 +771,22 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   return 0;
 }
 
+// constraint stage + register solver + integrator in one launch (mjhModel::fuse_cs)
+template <typename REAL>
+int launch_cs(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  a.env_begin = 0; a.env_count = a.B;
+  a.off = m->off_cs;
+  a.lds_reals = m->lds_cs / (int)sizeof(REAL);
+  a.row_lo = -1; a.row_hi = 0x7fffffff;
+  a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
+  const int64_t blocks = (a.B + 1) / 2;
+  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
+  hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
+  HIP_TRY(hipGetLastError());
+  timing_mark(stream, 14);
+  return 0;
+}
+
 // one forward pass = the phases selected by `stages`
 template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
@@ -757,7 +803,8 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     timing_mark(stream, 10);
   }
   if ((st & 0x7e) && !fused_kcv && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
-  if ((st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
+  const bool fused_cs = m->fuse_cs && (st & 0x7c) && (st & 0x40) && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref;  // the whole tail of the pass is asked for: constraint stage and solve share a kernel
+  if (!fused_cs && (st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
   if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
   if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
@@ -766,6 +813,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     timing_mark(stream, 11);
   }
+  if (fused_cs) return launch_cs<REAL>(m, a, stream);
   if ((st & 0x60) && m->sol2_nmax) return launch_sol2<REAL>(m, a, stream);
   if ((st & 0x60) && (rc = (a.M.nf > 0 || a.M.nft > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream))) return rc;  // 0x20: _acceleration's solve lives at the head of the solver phase
   return 0;
@@ -1082,6 +1130,16 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     return rc;
   };
   int64_t a[2] = {0, 0};
+  if (kernel == 14) {  // constraint stage + register solver: the two accounts minus what stays in the arena between them -- the dense rows of efc_J, efc_D / efc_aref, one entry per single-column row, qvel
+    if (!m->fuse_cs) return -2;
+    int64_t k2[2] = {0, 0}, k4[2] = {0, 0};
+    if (io_of(2, k2) != 0 || io_of(4, k4) != 0) return -2;
+    const int64_t R = f64 ? 8 : 4, nv = f64 ? m->m64.nv : m->m32.nv, nefc = f64 ? m->m64.nefc : m->m32.nefc, nl = f64 ? m->m64.nl : m->m32.nl;
+    read_write_bytes[0] = k2[0] + k4[0] - ((nefc - nl) * nv + 2 * nefc + nl + nv) * R;
+    read_write_bytes[1] = k2[1] + k4[1];
+    return 0;
+  }
+  if ((kernel == 2 || kernel == 9) && m->fuse_cs) return -2;  // (a full pass of this model launches kernel 14 instead)
   if (kernel == 12 || kernel == 13) {  // the accounts of the fused stages minus what stays in the arena between them: qpos, cdof, cinert, subtree_com, xipos are not read back (13: nor cinert, cdof by the crb stage)
     int64_t k0[2] = {0, 0}, k3[2] = {0, 0}, k1[2] = {0, 0};
     if (io_of(0, k0) != 0 || io_of(3, k3) != 0 || (kernel == 13 && io_of(1, k1) != 0)) return -2;

@@ -222,6 +222,26 @@ class MjTensorClass(metaclass=_Meta):
             object.__setattr__(self, "_fields", {k: f[k] for k in order if k in f} | {k: v for k, v in f.items() if k not in order})
         return self._fields
 
+    # ---- pickle / copy ----------------------------------------------------------------------
+    # A container's process-local attributes (_PRIVATE: the device-pointer table, cached device blobs, the operator key, stamp caches)
+    # must not travel with it -- neither into another process (torch.save, a spawn / ParallelEnv worker) nor into a copy made by
+    # copy.copy / copy.deepcopy, which would otherwise duplicate ``__dict__`` as it is (a copy with the original's ``_op_key`` would be
+    # stepped with the ORIGINAL's values under torch.vmap / torch.compile).  pickle, copy and deepcopy all go through this pair;
+    # ``_post_init`` runs on the result as it does on every other freshly built instance.
+    def __getstate__(self):
+        state = {k: v for k, v in self.__dict__.items() if k not in _PRIVATE}
+        state["_fields"] = dict(self._all())  # lazily carved leaves of a step's output are materialised first
+        state["_bs"] = tuple(self._bs)
+        pinned = self.__dict__.get("_child_keys")
+        if pinned is not None:
+            state["_child_keys"] = pinned
+        return state
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            object.__setattr__(self, k, v)
+        self._post_init()
+
     def _touch(self, names=None):
         """Bumps the leaf-set version and tells the container's device-pointer table (forward.py) which leaves changed."""
         object.__setattr__(self, "_ver", self.__dict__.get("_ver", 0) + 1)

@@ -194,6 +194,17 @@ class StaticTables:
         self.native_recent = collections.OrderedDict()  # strong references to the few most recently used blobs (native._NATIVE_LRU)
         self.uid = next(_cache_id_counter)  # never reused (unlike id()): keys the host-side plan / pointer caches
 
+    # process-local caches (device blobs, RK4 workspaces) never travel: a pickled / deep-copied tables object starts with empty ones and a
+    # uid of its own (the uid keys caches of THIS process: a loaded value could collide with one handed out here)
+    _LOCAL = ("native", "native_recent", "_workspaces", "uid")
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in self._LOCAL}
+
+    def __setstate__(self, state):
+        self.__init__()
+        self.__dict__.update(state)
+
 
 def _build_tables(m, dtype) -> StaticTables:
     T = StaticTables()

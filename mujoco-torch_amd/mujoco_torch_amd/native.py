@@ -283,8 +283,7 @@ class NativeModel:
         if got != n:
             raise RuntimeError("libmjhip.so leaf table does not match include/mjhip.h")
         self.leaf_counts = np.array(list(buf), dtype=np.int64)  # per-environment element count of every Data leaf, ABI order
-        self._work = {}
-        self._work_clock = 0
+        self._work = {"clock": 0, "bufs": {}}  # replaced by the pool shared through the tables object (get_native_model): the LRU clock lives WITH the pool
 
     def workspace(self, B: int, stream: int = 0):
         """Scratch for RK4 (stage Data + running sums), one per (batch size, stream): two streams stepping the same model
@@ -292,15 +291,17 @@ class NativeModel:
         if self.work_bytes == 0:
             return None
         key = (B, stream)
-        self._work_clock += 1
-        hit = self._work.get(key)
+        pool = self._work
+        bufs = pool["bufs"]
+        pool["clock"] += 1  # one clock per pool: every blob of a tables object ages the entries on the same scale (a per-blob clock made a new blob's fresh entries look oldest)
+        hit = bufs.get(key)
         if hit is not None:
-            hit[1] = self._work_clock
+            hit[1] = pool["clock"]
             return hit[0]
-        if len(self._work) >= 4:  # small LRU: ping-pong between a few batch sizes / streams without re-allocating
-            del self._work[min(self._work, key=lambda k: self._work[k][1])]
+        if len(bufs) >= 4:  # small LRU: ping-pong between a few batch sizes / streams without re-allocating
+            del bufs[min(bufs, key=lambda k: bufs[k][1])]
         w = torch.empty(self.work_bytes * B, dtype=torch.uint8, device=self.device)
-        self._work[key] = [w, self._work_clock]
+        bufs[key] = [w, pool["clock"]]
         return w
 
     def __del__(self):
@@ -333,15 +334,23 @@ def _stamp(m):
         d = c.__dict__
         ver = d.get("_ver", 0)
         ts = d.get("_stamp_ts")
-        if ts is None or ts[0] != ver:
-            lst = []
+        if ts is not None and ts[0] == ver:
+            for w, t0 in ts[2]:
+                if w.data is not t0:  # `unbatched.data = new_tensor` bumps no version counter: the wrapper is re-read every call
+                    ts = (ver, None, None, ts[3] + 1)
+                    break
+        if ts is None or ts[0] != ver or ts[1] is None:
+            lst, wrapped = [], []
             for t in c._fields.values():
                 if isinstance(t, UnbatchedTensor):
+                    if isinstance(t.data, torch.Tensor):
+                        wrapped.append((t, t.data))
                     t = t.data
                 if isinstance(t, torch.Tensor):
                     lst.append(t)
-            ts = (ver, lst)
+            ts = (ver, lst, wrapped, ts[3] if ts is not None else 0)
             object.__setattr__(c, "_stamp_ts", ts)
+        v += ts[3] << 32
         for t in ts[1]:
             v += t._version
     return (m.__dict__.get("_ver", 0), opt, opt.__dict__.get("_ver", 0), stat, stat.__dict__.get("_ver", 0), v)
@@ -391,7 +400,7 @@ def get_native_model(m, device: torch.device, dtype: torch.dtype) -> NativeModel
         nm = NativeModel(desc, keep, torch.device(device.type, key[0]) if key[0] >= 0 else device, dtype)
         # RK4 workspaces are sized by the model's STRUCTURE (leaf counts), not its values: one pool per tables object and (device, dtype), so
         # per-episode domain randomisation (mx.replace(body_mass=...)) re-uses the same scratch instead of growing a pool per blob
-        nm._work = T.__dict__.setdefault("_workspaces", {}).setdefault((key, nm.work_bytes), {})
+        nm._work = T.__dict__.setdefault("_workspaces", {}).setdefault((key, nm.work_bytes), {"clock": 0, "bufs": {}})
         T.native[shared_key] = nm
     # T.native holds blobs weakly: one lives as long as a Model that stepped it (its _native_cache) does, so `mx.replace(body_mass=...)` per
     # episode frees the previous episode's blob with its Model instead of leaking device memory.  The few most recently used ones are also

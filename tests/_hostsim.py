@@ -55,6 +55,9 @@ class _Lib:
         return b"hostsim"
 
 
+REAL_NATIVE_MODEL = native.NativeModel  # the product's class (its host-only methods, e.g. the workspace pool, are tested on the stand-in's instances)
+
+
 class HostSimModel:
     """What ``native.NativeModel`` is to the device: built from the packed descriptor, one per distinct set of model values."""
 
