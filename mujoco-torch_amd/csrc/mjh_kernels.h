@@ -102,22 +102,23 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = n
     if (ca > off) off = ca;
   }
   if (phase_bit == PH_CS) {
-    // Fused constraint + register-solver kernel (plain rows, one dense-row slot per lane, no tiers: the humanoid).  Laid out by hand:
-    //   [qvel | act | act_dot | con_dist | efc_jl]                     live through both stages
-    //   [efc_J == efc_Jc]                                              the contact rows: built by the constraint stage, compacted IN PLACE for the solve (the geom frames of the
+    // Fused constraint + register-solver kernel (plain rows, one contact condim, one dense-row slot per lane, no tiers: the humanoid).  Laid out by hand:
+    //   [qvel | act | act_dot | con_dist | i_con_act | i_crow_act]     live through both stages (the two int tables: active contacts, contact -> compact slot)
+    //   [efc_Jc]                                                       the rows of the ACTIVE contacts, built in compact order by the constraint stage (the geom frames of the
     //                                                                  narrow phase are dead before the rows are built and sit under them, as in PH_CON)
-    //   constraint-only [subtree_com cdof con_pos con_frame | efc_pos efc_invweight]   OVER
-    //   solver-only     [efc_D efc_aref | r_src r_dst r_vs r_vs2 r_pg r_fs qpos]       (efc_D / efc_aref are staged by the aref loop, which no longer reads what lies under them)
+    //   constraint-only [subtree_com cdof con_pos con_frame]           OVER
+    //   solver-only     [efc_D efc_aref | r_vs r_vs2 r_pg r_fs qpos]   (efc_D / efc_aref of the active contacts' rows, compact order: staged by the aref loop, which no longer reads what lies under them)
     //   integrator tail (PH_SOL2T) over the rows, as in PH_SOL2.
-    // Returns -1 when the overlays do not work out for the model (the caller keeps the two launches).
+    // The single-column limit rows travel in registers (lane r <-> row r in both stages).  Returns -1 when the overlays do not work out (the caller keeps the two launches).
     auto ev = [](int c) { return (c + 1) & ~1; };
-    const int nd = m.nefc - m.nl, ns = m.nl;
+    const int nd = m.nefc - m.nl;
     off = 0;
     o.qvel = off; off += ev(m.nv);
     o.act = off; off += ev(m.na);
     o.act_dot = off; off += ev(m.na);
     o.con_dist = off; off += ev(m.ncand);
-    o.efc_jl = off; off += ev(m.nl);
+    o.i_con_act = off; off += ev(m.ncon);   // (ints: one REAL each is enough in both dtypes)
+    o.i_crow_act = off; off += ev(m.ncon);
     const int rows0 = off, nj = ev(nd * m.nv), n3 = ev(3 * m.ngeom), n9 = ev(9 * m.ngeom);
     o.efc_J = o.efc_Jc = rows0;
     if (n3 + n9 > nj) return -1;
@@ -129,15 +130,9 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = n
     o.cdof = ca; ca += ev(6 * m.nv);
     o.con_pos = ca; ca += ev(3 * m.ncand);
     o.con_frame = ca; ca += ev(9 * m.ncand);
-    const int aref_reads = ca;  // from here on: what the aref loop still reads
-    o.efc_pos = ca; ca += ev(ns);
-    o.efc_invweight = ca; ca += ev(ns);
     int sa = ov;
-    o.efc_D = sa; sa += ev(m.nefc);
-    o.efc_aref = sa; sa += ev(m.nefc);
-    if (sa > aref_reads) return -1;
-    o.r_src = sa; sa += ev(nd);
-    o.r_dst = sa; sa += ev((nd + 1) / 2);
+    o.efc_D = sa; sa += ev(nd);
+    o.efc_aref = sa; sa += ev(nd);
     o.r_vs = sa; sa += ev(m.nv);
     o.r_vs2 = sa; sa += ev(m.nv);
     o.r_pg = sa; sa += ev(2 * m.nv);
@@ -149,7 +144,6 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = n
 #define X(n, c, p) if ((p) & PH_SOL2T) { o.n = ta; ta += (((c) + 1) & ~1); }
     MJH_LDS_ARRAYS(X, m)
 #undef X
-    if (ta > qpos_at && ta > off) off = ta;
     if (ta > qpos_at) return -1;  // (the tail must leave the parked qpos alone)
   }
   if (phase_bit == PH_CRB) {
@@ -845,6 +839,15 @@ struct Sol2Pre {
   REAL ac, ad, warm;        // act[l], act_dot[l], qacc_warmstart[l]
 };
 
+// ... and what the constraint stage of that kernel hands to the solver in registers: lane r's single-column limit row, the dense rows of the active contacts
+template <typename REAL>
+struct Sol2Con {
+  REAL jl, Dl, arl;  // the row's one Jacobian entry, efc_D, efc_aref
+  int ldof;          // its column
+  int nda;           // dense rows of the active contacts (compact, in S.efc_Jc())
+  int nact;          // active contacts
+};
+
 // =====================================================================================================================
 // FRIC: the general constraint / solver instantiations (equality, frictionloss, dense limit rows; also max_contact_points);
 // DIRECT: the constraint phase of small models that writes its contact rows straight to the efc_J leaf (kernel 8)
@@ -1344,7 +1347,12 @@ struct Env {
         row_load<W>(S.con_frame(), out.contact_frame, 9 * M.ncon, e);
       }
     }
+#ifndef MJH_CS_PF
+#define MJH_CS_PF 3  /* where the fused constraint + solver kernel requests the solver's inputs from the leaves of earlier launches: 0 behind the narrow phase's own loads (the narrow phase then waits for them, vmcnt is in order: kernel 78.0 - 83.6 us), 1 behind the narrow phase (78.0), 2 behind the contact rows (76.0), 3 behind the whole constraint stage (75.8: requested early they only hold registers -- the constraint stage has little arithmetic to hide them under) */
+#endif
+#if MJH_CS_PF == 0
     if constexpr (PRE_NMAX > 0) sol2_prefetch<PRE_NMAX>(*pre);  // fused constraint + solver kernel: requested BEHIND this stage's own inputs (vmcnt is in order: the narrow phase does not wait for them)
+#endif
     wave_sync();
     for (int p = l; p < M.npair; p += W) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
@@ -1450,6 +1458,14 @@ struct Env {
       const int nc = M.ncon;
       put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
+      if constexpr (PRE_NMAX > 0) return;  // fused constraint + solver kernel: the constant leaves are copied at the kernel's end (contact_const_stores), off the path to the solve
+      contact_const_stores();
+    }
+  }
+  __device__ __forceinline__ void contact_const_stores() {
+    const int l = lane_here();
+    {
+      const int nc = M.ncon;
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
       // (all the reads first, then the stores: a read between two stores waits for the first store to land -- vmcnt is in order -- and the optimiser
       // may not move it up past a store it cannot prove distinct)
@@ -1551,7 +1567,6 @@ struct Env {
     k = kk; b = bb; imp = im;
   }
 
-  template <bool CS = false>
   __device__ __forceinline__ void make_constraint() {
     const int l = lane_here();
     // FRIC = false: the plain instantiation (slide / hinge limits and contacts only); equality, frictionloss, ball- and tendon-limit
@@ -1964,10 +1979,8 @@ struct Env {
       }
       if (stage_ad) { ad_stage[r] = -b * jv - k * imp * pos; ad_stage[nefc + r] = 1 / rr; }
       else {
-        const REAL aref_r = -b * jv - k * imp * pos, D_r = 1 / rr;
-        if (out.efc_aref) out.efc_aref[e * nefc + r] = aref_r;  // lane r <-> row r: coalesced, no staging
-        if (out.efc_D) out.efc_D[e * nefc + r] = D_r;
-        if constexpr (CS) { S.efc_aref()[r] = aref_r; S.efc_D()[r] = D_r; }  // fused kernel: the solver stage takes them from here (over subtree_com / cdof, which nobody reads any more)
+        if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
+        if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
       }
     }
     if (stage_ad) {
@@ -3393,18 +3406,203 @@ struct Env {
     if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; P.ac = ga ? ga[e * na + l] : (REAL)0; P.ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
     P.warm = (dof && KA.warm_src && M.nefc > 0) ? KA.warm_src[e * nv + l] : (REAL)0;
   }
-  // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the contact rows of efc_J, efc_D / efc_aref and the
+  // The constraint stage of the fused kernel: make_constraint() for the plain row set (slide / hinge limits + contacts of ONE condim, nl <= W), with
+  //  * the limit rows in registers, lane r <-> row r, from the joint's position to efc_D / efc_aref (constraint.py:338-372, 683-693);
+  //  * the rows of the ACTIVE contacts only, built in compact order in S.efc_Jc() -- one lane per (active contact, dof), the contact's bodies / dof masks from the
+  //    per-contact tables (DevModel::con_body, con_dmask), as the small-model kernel does; an inactive contact's rows are exact zeros in the reference and in the leaf;
+  //  * efc_D / efc_aref of every row stored to their leaves here (lane <-> row: coalesced), those of the active contacts' rows also staged in compact order for the solve;
+  //  * the efc_J leaf, efc_frictionloss and the constant contact leaves NOT stored here: cs_deferred_stores() writes them behind the solve, where nothing waits for them
+  //    (vmcnt is in order: 11 KB of row stores per environment in front of the solve's qM reads made every wave wait for its own stores to land).
+  // Arithmetic and operation order per value as in make_constraint().
+  template <int NMAX>
+  __device__ __forceinline__ void make_constraint_cs(Sol2Pre<REAL, NMAX>& pre, Sol2Con<REAL>& C) {
+    const int l = lane_here();
+#if MJH_CS_PF >= 2
+    {  // (the limit rows read the normalised qpos from the prefetched registers: that part comes first in these variants)
+      const REAL* gq = KA.cur.qpos + e * M.nq;
+#pragma unroll
+      for (int j = 0; j < 2; j++) pre.qp[j] = l + W * j < M.nq ? gq[l + W * j] : (REAL)0;
+    }
+#endif
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, ncon = M.ncon, rows = M.con_rows;
+    const bool elliptic = M.cone == CONE_ELLIPTIC;
+    if (!KA.state_from_cur && KA.do_step) for (int i = l; i < nv; i += W) S.qvel()[i] = checked(S.qvel()[i], (REAL)0);  // _check_state (same lane wrote it)
+    // ---- limit rows: _instantiate_limit_slide_hinge :338-372, lane r0 <-> row r0 ----
+    REAL lpos = 0, linvw = 0;
+    int lj = 0;
+    C.jl = 0; C.ldof = 0;
+    if (l < nl) {
+      lj = M.lim_jnt[l];
+      C.ldof = M.jnt_dofadr[lj];
+    }
+    {
+      const int qa = l < nl ? M.jnt_qposadr[lj] : 0;
+      // the normalised qpos of this pass sits one element per lane in the prefetched registers: element qa comes across the lanes of this environment's group
+      const int srcl = (int)(lane_id() & ~(W - 1)) + (qa & (W - 1));
+      const REAL q0 = __shfl(pre.qp[0], srcl, MJH_WAVE), q1 = __shfl(pre.qp[1], srcl, MJH_WAVE);
+      const REAL q = qa < W ? q0 : q1;
+      if (l < nl) {
+        const REAL dist_min = q - M.jnt_range[2 * lj], dist_max = M.jnt_range[2 * lj + 1] - q;
+        const REAL val = (REAL)(dist_min < dist_max) * 2 - 1;
+        const REAL pos = (dist_min < dist_max ? dist_min : dist_max) - M.jnt_margin[lj];
+        const REAL active = (REAL)(pos < 0);
+        C.jl = val * active;
+        lpos = pos * active;
+        linvw = M.dof_invweight0[C.ldof];
+      }
+    }
+    // ---- active contacts: compact list and contact -> compact slot ----
+    int* const act_list = reinterpret_cast<int*>(S.i_con_act());
+    int* const slot = reinterpret_cast<int*>(S.i_crow_act());
+    int nact = 0;
+    for (int base = 0; base < ncon; base += W) {
+      const int c = base + l;
+      const bool valid = c < ncon;
+      const bool act = valid && (S.con_dist()[valid ? c : 0] - M.con_includemargin[valid ? c : 0]) < 0;
+      int tot;
+      const int at = sub_prefix_count<W>(act, tot) + nact;
+      if (act) act_list[at] = c;
+      if (valid) slot[c] = act ? at : -1;
+      nact += tot;
+    }
+    C.nact = nact;
+    C.nda = nact * rows;
+    wave_sync();
+    STAMP(23);
+    // ---- rows of the active contacts, compact: _instantiate_contact_* :409-583 ----
+    REAL* const Jc = S.efc_Jc();  // (the geom frames under it are dead: the narrow phase is over)
+    for (int w = l; w < nact * nv; w += W) {
+      int a, d;
+      split_index(w, nv, M.inv_nv, a, d);
+      const int c = act_list[a];
+      const int dim = M.con_dim[c];
+      const int* cb = M.con_body + 4 * c;
+      const int root1 = cb[2], root2 = cb[3];
+      const REAL on1 = (REAL)((M.con_dmask[2 * c] >> d) & 1ull), on2 = (REAL)((M.con_dmask[2 * c + 1] >> d) & 1ull);
+      const REAL* fr = S.con_frame() + 9 * c;
+      const REAL* cpos = S.con_pos() + 3 * c;
+      const REAL* fric = M.con_friction + 5 * c;
+      REAL jp1[3], jr1[3], jp2[3], jr2[3];
+      jac_dof_root(cpos, root2, on2, d, jp2, jr2);
+      jac_dof_root(cpos, root1, on1, d, jp1, jr1);
+      const REAL dp[3] = {jp2[0] - jp1[0], jp2[1] - jp1[1], jp2[2] - jp1[2]};
+      const REAL dr[3] = {jr2[0] - jr1[0], jr2[1] - jr1[1], jr2[2] - jr1[2]};
+      REAL diff[6];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        diff[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2];
+        diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
+      }
+      REAL* const dst = Jc + (a * rows) * nv + d;
+      if (dim == 1) {
+        dst[0] = diff[0];
+      } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
+        const int nedge = 2 * (dim - 1);
+        for (int ed = 0; ed < nedge; ed++) {
+          const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
+          dst[ed * nv] = diff[0] + diff[1 + (ed >> 1)] * f;
+        }
+      } else {  // _instantiate_contact_elliptic :519-583
+        for (int r = 0; r < dim; r++) dst[r * nv] = diff[r];
+      }
+    }
+#if MJH_CS_PF == 2
+    sol2_prefetch<NMAX>(pre);
+#endif
+    wave_sync();
+    STAMP(25);
+    // ---- efc_aref / efc_D of every row (:683-693): lane idx <-> Data row ----
+    C.Dl = 0; C.arl = 0;
+    for (int r = l; r < nefc; r += W) {
+      REAL solref[2], solimp[5];
+      REAL pos = 0, pos_norm = 0, invweight = 0, jv = 0;
+      int crow = -1;
+      if (r < nl) {
+        pos = lpos; pos_norm = lpos; invweight = linvw;
+        solref[0] = M.jnt_solref[2 * lj]; solref[1] = M.jnt_solref[2 * lj + 1];
+#pragma unroll
+        for (int i = 0; i < 5; i++) solimp[i] = M.jnt_solimp[5 * lj + i];
+        jv = 0 + C.jl * S.qvel()[C.ldof];
+      } else {
+        const int q = r - nl, ncr = M.ncrow;
+        const int info = M.crow_info[q];
+        const REAL* P = M.crow_par + q;
+        solref[0] = P[0]; solref[1] = P[ncr];
+#pragma unroll
+        for (int i = 0; i < 5; i++) solimp[i] = P[(2 + i) * ncr];
+        invweight = P[7 * ncr];
+        const int c = info & 0xffff, sub = (info >> 16) & 0xff;
+        const REAL dist = S.con_dist()[c] - P[8 * ncr];
+        const REAL active = (REAL)(dist < 0);
+        if (!(info >> 24)) { pos = dist * active; pos_norm = dist * active; }
+        else { pos = (sub == 0 ? dist : (REAL)0) * active; pos_norm = dist; }
+        if (dist < 0) {
+          crow = slot[c] * rows + sub;
+          jv = dot_seq(Jc + crow * nv, 1, S.qvel(), 1, nv);
+        }  // (an inactive contact's row is all zeros: its product with the finite qvel is 0)
+      }
+      REAL k, b, imp;
+      kbi(solref, solimp, pos_norm, k, b, imp);
+      REAL rr = invweight * (1 - imp) / imp;
+      rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
+      const REAL aref_r = -b * jv - k * imp * pos, D_r = 1 / rr;
+      if (out.efc_aref) out.efc_aref[e * nefc + r] = aref_r;
+      if (out.efc_D) out.efc_D[e * nefc + r] = D_r;
+      if (r < nl) { C.Dl = D_r; C.arl = aref_r; }
+      else if (crow >= 0) { S.efc_aref()[crow] = aref_r; S.efc_D()[crow] = D_r; }  // (over subtree_com / cdof, which nobody reads any more)
+    }
+    STAMP(26);
+  }
+  // the stores the fused kernel keeps for the end: efc_J (single-column rows + the contact rows, the inactive ones as zeros), efc_frictionloss, the constant contact leaves
+  __device__ __forceinline__ void cs_deferred_stores(const Sol2Con<REAL>& C) {
+    const int l = lane_here();
+    const int nv = M.nv, nefc = M.nefc, nl = M.nl, nd = nefc - nl, rows = M.con_rows;
+    rebind();
+    if (out.efc_J) {
+      REAL* gJ = out.efc_J + e * nefc * nv;
+      const bool dof = l < nv;  // nv <= W: one Data row per pass of the lanes, lane d <-> column d (no index arithmetic per element)
+      // single-column rows: lane r holds row r's entry and column
+      for (int r = 0; r < nl; r++) {
+        const int col = sub_read<W>(C.ldof, r);
+        const REAL v = sub_read<W>(C.jl, r);
+        if (dof) gJ[r * nv + l] = (l == col) ? v : (REAL)0;
+      }
+      const int* slot = reinterpret_cast<const int*>(S.i_crow_act());
+      const REAL* Jc = S.efc_Jc();
+      REAL* gC = gJ + nl * nv;
+      for (int c = 0; c < M.ncon; c++) {
+        const int at = slot[c];  // (same address in every lane of the environment: a broadcast read)
+        for (int sub = 0; sub < rows; sub += 4) {
+          REAL v[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) v[t] = (at >= 0 && sub + t < rows && dof) ? Jc[(at * rows + sub + t) * nv + l] : (REAL)0;
+#pragma unroll
+          for (int t = 0; t < 4; t++) if (sub + t < rows && dof) gC[(c * rows + sub + t) * nv + l] = v[t];
+        }
+      }
+    }
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (REAL)0;
+    if (M.ncon > 0) contact_const_stores();
+  }
+  // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the rows of the active contacts, efc_D / efc_aref and the
   // narrow phase's distances never leave the arena between the two (the leaves are still stored -- nothing waits for them), and the factor rows, qfrc_smooth
   // and the state arrive while the constraint stage computes.  Serves models of the plain constraint phase whose dense rows fit one slot per lane.
   template <int NMAX, int RPL>
   __device__ __forceinline__ void run_con_sol2() {
     static_assert(W == 32 && !FRIC && !DIRECT, "plain constraint stage, two environments per wavefront");
     Sol2Pre<REAL, NMAX> pre;
+    Sol2Con<REAL> con;
     STAMP0();
-    if (M.ncon > 0) collision<NMAX>(&pre); else sol2_prefetch<NMAX>(pre);
-    make_constraint<true>();
+    collision<NMAX>(&pre);
+#if MJH_CS_PF == 1
+    sol2_prefetch<NMAX>(pre);
+#endif
+    make_constraint_cs<NMAX>(pre, con);
+#if MJH_CS_PF == 3
+    sol2_prefetch<NMAX>(pre);
+#endif
     wave_sync();
-    run_sol2<NMAX, RPL, false, true>(&pre);
+    run_sol2<NMAX, RPL, false, true>(&pre, &con);
   }
   template <bool FLUID, bool FUSED = false, bool DEFER = false>
   __device__ __forceinline__ void run_vel() {
@@ -3439,6 +3637,15 @@ struct Env {
   // the integrator on the solved accelerations: _euler :313-328, or one stage of _rungekutta4 :331-370.  Reads S.qacc / qpos / qvel /
   // act / act_dot / qfrc_smooth / qfrc_constraint from the arena (both solver kernels leave them there).
   // NLO <= nv <= NHI: what the calling instantiation knows about the model it serves (the register solver: one range of nv per NMAX)
+  // rows of qM for the implicit-damping solve of the register solver's tail (16 < nv <= NMAX), as integrate_tail() takes them: lane i holds row i (entries k <= i)
+  template <int NMAX>
+  __device__ __forceinline__ void load_damping_rows(TriPack<REAL, NMAX>& Hh) {
+    const int l = lane_here();
+    const int nv = M.nv;
+    const REAL* gM = out.qM + e * nv * nv;
+#pragma unroll
+    for (int k = 0; k < NMAX; k++) Hh.t[k] = (l < nv && k <= l) ? gM[k * nv + l] : (REAL)0;
+  }
   template <int NLO = 0, int NHI = (1 << 30)>
   __device__ __forceinline__ void integrate_tail() {
     const int l = lane_here();
@@ -3457,9 +3664,7 @@ struct Env {
           // load per term -- and the right-hand side is its own element; no packed copy, no n x n image of the factor, none of chol_factor_lds's three barriers
           // per column.  Same operations per element, in the same order, as the LDS path the other solver kernels run.
           TriPack<REAL, NHI> Hh;
-          const REAL* gM = out.qM + e * nv * nv;
-#pragma unroll
-          for (int k = 0; k < NHI; k++) Hh.t[k] = (l < nv && k <= l) ? gM[k * nv + l] : (REAL)0;
+          load_damping_rows<NHI>(Hh);
           const REAL dd = l < nv ? M.timestep * M.dof_damping[l] : (REAL)0;
           const REAL rhs = l < nv ? S.qfrc_smooth()[l] + (M.nefc ? S.qfrc_constraint()[l] : (in.qfrc_constraint ? in.qfrc_constraint[e * nv + l] : (REAL)0)) : (REAL)0;
 #pragma unroll
@@ -3556,7 +3761,7 @@ struct Env {
   }
 
   template <int NMAX, int RPL, bool NEWTON_ONLY = false, bool CS = false>
-  __device__ __forceinline__ void run_sol2(const Sol2Pre<REAL, NMAX>* pre = nullptr) {
+  __device__ __forceinline__ void run_sol2(const Sol2Pre<REAL, NMAX>* pre = nullptr, const Sol2Con<REAL>* con = nullptr) {
     static_assert(W == 32 || W == 16, "two or four environments per wavefront");
     static_assert(!CS || (W == 32 && !NEWTON_ONLY), "the fused constraint + solver kernel runs two environments per wavefront");
     constexpr bool NEWT = NMAX <= 16;  // the Newton direction needs H = M + J^T D J factorised per iteration: register Cholesky, n <= 16 (math.py:84)
@@ -3642,13 +3847,15 @@ struct Env {
         const REAL* gJ = out.efc_J + e * nefc * nv;
         if constexpr (CS) {
           warm = pre->warm;
-          if (lim) { ldof = M.lim_dof[l]; Dl = S.efc_D()[l]; arl = S.efc_aref()[l]; Jl = S.efc_jl()[l]; }
+          if (lim) { ldof = con->ldof; Dl = con->Dl; arl = con->arl; Jl = con->jl; }
         } else {
         if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
         if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
         }
         if (dof) limrow = M.dof_limrow[2 * l];
         STAMP(81);
+        if constexpr (CS) nda = con->nda;  // (the constraint stage built the rows in compact order)
+        else
         {  // active contacts -> compact row tables: one contact per lane, exclusive prefix sum of the active contacts' row counts
           const int ncon = M.ncon;
           const bool elliptic = M.cone == CONE_ELLIPTIC;
@@ -3661,8 +3868,6 @@ struct Env {
               const int dim = M.con_dim[c];
               rows = dim == 1 ? 1 : (elliptic ? dim : 2 * (dim - 1));
               start = M.con_efc_address[c] - nl;
-              if constexpr (CS) act = (S.con_dist()[c] - M.con_includemargin[c]) < 0;
-              else
               act = (out.contact_dist[e * ncon + c] - (M.topk ? out.contact_includemargin[e * ncon + c] : M.con_includemargin[c])) < 0;
             }
             int excl, tot;
@@ -3700,20 +3905,9 @@ struct Env {
 #pragma unroll
           for (int j = 0; j < RPL; j++) {
             const int r = l + W * j;
-            if (r < nda) { const int x = rsrc[r]; Dd[j] = S.efc_D()[x]; ard[j] = S.efc_aref()[x]; }
+            if (r < nda) { Dd[j] = S.efc_D()[r]; ard[j] = S.efc_aref()[r]; }
           }
           STAMP(83);
-          // The rows are in the arena already, in Data order: the rows of the active contacts are compacted IN PLACE.  A row only ever moves up (its compact index is at
-          // most its source index, both increase with the contact), so walking the compact rows in order -- eight per batch, all reads of a batch ahead of its
-          // writes; one wavefront's LDS operations complete in order -- never overwrites a row that is still to be read.  nv <= 32: one row per pass of the lanes.
-          REAL* const J = S.efc_Jc();
-          for (int r0 = 0; r0 < nda; r0 += 8) {
-            REAL v[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) { const int r = r0 + t < nda ? r0 + t : nda - 1; v[t] = J[(rsrc[r] - nl) * nv + (dof ? l : 0)]; }
-#pragma unroll
-            for (int t = 0; t < 8; t++) if (r0 + t < nda && dof) J[(r0 + t) * nv + l] = v[t];
-          }
         } else {
 #pragma unroll
         for (int j = 0; j < RPL; j++) {
@@ -4095,8 +4289,21 @@ struct Env {
       }
       if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
         if (lim) out.efc_force[e * nefc + l] = frl;
+        if constexpr (CS) {
+          const int* slot = reinterpret_cast<const int*>(S.i_crow_act());
+          const int rows = M.con_rows;
+          const float inv_rows = 1.0f / (float)rows;
+          for (int r = l; r < nd; r += W) {
+            int c, sub;
+            split_index(r, rows, inv_rows, c, sub);
+            const int at = slot[c];
+            out.efc_force[e * nefc + nl + r] = at >= 0 ? fs[at * rows + sub] : (REAL)0;
+          }
+        } else
         for (int r = l; r < nd; r += W) { const int q = rdst[r]; out.efc_force[e * nefc + nl + r] = q != 0xffff ? fs[q] : (REAL)0; }
       }
+      // (requesting the tail's rows of qM ahead of these stores, into the registers the factor has just left, was measured: 116 -> 240 B of scratch, kernel 78.0 -> 83.6 us)
+      if constexpr (CS) cs_deferred_stores(*con);
     } else {
       if (dof && out.qacc) out.qacc[e * nv + l] = qacc;
     }

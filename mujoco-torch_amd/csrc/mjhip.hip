@@ -540,7 +540,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     for (int c = 1; c < d->ncon; c++) mono = mono && d->con_efc_address[c] > d->con_efc_address[c - 1];
     out->fuse_cs = 0;
     if (!off && out->sol2_nmax == 28 && out->sol2_rpl == 1 && !out->sol2_tiers && !M.con_direct && !M.con_general && !M.topk && d->ncon > 0 && d->nefc > 0 && mono &&
-        d->nv <= 32 && d->nq <= 64 && d->nl <= 32 && d->na <= 32) {
+        M.con_rows > 0 && M.ncrow == d->nefc - d->nl && d->nf == 0 && d->nv <= 32 && d->nq <= 64 && d->nl <= 32 && d->na <= 32) {
       const int reals = lds_carve(M, PH_CS, out->off_cs);
       if (reals > 0 && 2 * reals * (int)sizeof(REAL) <= 64 * 1024) {
         out->lds_cs = reals * (int)sizeof(REAL);
