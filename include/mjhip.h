@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MJH_ABI_VERSION 13
+#define MJH_ABI_VERSION 14
 
 /* ---- dtype / flags ------------------------------------------------------------------- */
 #define MJH_F64 0
@@ -78,7 +78,8 @@ extern "C" {
 #define MJH_MODEL_REALS(X)                                                                       \
   X(timestep) X(impratio) X(tolerance) X(ls_tolerance) X(meaninertia)                            \
   X(gravity_x) X(gravity_y) X(gravity_z)                                                         \
-  X(density) X(viscosity) X(wind_x) X(wind_y) X(wind_z) /* fluid model of passive.py:31-78; all zero = no fluid forces */
+  X(density) X(viscosity) X(wind_x) X(wind_y) X(wind_z) /* fluid model of passive.py:31-78; all zero = no fluid forces */ \
+  X(magnetic_x) X(magnetic_y) X(magnetic_z) /* opt.magnetic: magnetometer sensors (sensor.py:92-94) */
 
 /* const int32_t* arrays (length in comment) */
 #define MJH_MODEL_INT_ARRAYS(X)                                                                  \
@@ -118,11 +119,16 @@ extern "C" {
   X(act_actlimited)   /* nu */                                                                   \
   X(act_actadr)     /* nu */                                                                     \
   X(act_actnum)     /* nu */                                                                     \
-  X(sns_type)       /* nsensor: mjtSensor (accelerometer 1, velocimeter 2, gyro 3, rangefinder 7, jointpos 9, jointvel 10) */ \
+  X(sns_type)       /* nsensor: mjtSensor of the sensors sensor.py evaluates (every type of its three stage functions; the others keep their slots: slot_sensor) */ \
   X(sns_adr)        /* nsensor: first slot in sensordata */                                      \
-  X(sns_objid)      /* nsensor: site id (frame sensors, rangefinder) or qpos / dof address (jointpos / jointvel) */ \
-  X(sns_bodyid)     /* nsensor: body of the site */                                              \
+  X(sns_objid)      /* nsensor: id of the object -- site / body / geom / camera / tendon / actuator id; the qpos address (jointpos, ballquat) or dof address (jointvel, ballangvel, jointactuatorfrc) of a joint */ \
+  X(sns_bodyid)     /* nsensor: body the object rides on (site sensors, frame sensors) */       \
   X(sns_rootid)     /* nsensor: root body of that body */                                        \
+  X(sns_objtype)    /* nsensor: mjtObj of the object: 0 unknown, 1 body (inertial frame), 2 xbody, 5 geom, 6 site, 7 camera (frame sensors, sensor.py:62-74) */ \
+  X(sns_reftype)    /* nsensor: mjtObj of the reference frame of a frame sensor (0 = none) */   \
+  X(sns_refid)      /* nsensor: its id, -1 = none (the value is reported in the world frame) */ \
+  X(sns_refbodyid)  /* nsensor: body of the reference object */                                  \
+  X(sns_refrootid)  /* nsensor: root body of that body */                                        \
   X(sns_datatype)   /* nsensor: mjtDataType (0 real, 1 positive) for the cutoff rule */          \
   X(sns_rfadr)      /* nsensor+1: rangefinders, range into rf_geom; geoms in the reference's evaluation order */ \
   X(rf_geom)        /* geom ids a rangefinder ray is tested against (ray.py:292-325: site's own body excluded, invisible geoms dropped) */ \
@@ -321,6 +327,11 @@ typedef struct mjhModelDesc {
   X(qacc_smooth)      /* nv */                                                                   \
   X(qfrc_constraint)  /* nv */
 
+/* Input-only real leaves that NO stage of the reference writes -- they hold what make_data put there (zeros) or what the caller did -- but its sensor functions
+ * read: cacc (accelerometer, sensor.py:383-392), cfrc_int (force / torque, :399-416), subtree_linvel / subtree_angmom (:261-266).  They trail the struct, outside
+ * the leaf lists above (no kernel writes them, the goldens' key sets do not change); NULL = zeros.  [B, nbody*6], [B, nbody*6], [B, nbody*3], [B, nbody*3]. */
+#define MJH_DATA_EXTRA_IN(X) X(cacc) X(cfrc_int) X(subtree_linvel) X(subtree_angmom)
+
 #define MJH_DATA_I32(X) X(contact_dim) /* ncon */ X(eq_active) /* neq: input, enable / disable each equality constraint (types.py:1103) */
 
 #define MJH_DATA_I64(X)                                                                          \
@@ -338,6 +349,9 @@ typedef struct mjhData {
 #undef X
 #define X(n) int64_t* n;
   MJH_DATA_I64(X)
+#undef X
+#define X(n) const void* n;
+  MJH_DATA_EXTRA_IN(X)
 #undef X
 } mjhData;
 
@@ -402,6 +416,8 @@ const char* mjh_last_error(void);
 
 /* comma-separated field lists in ABI order (lets the binding assert it is in sync) */
 const char* mjh_data_fields(void);
+const char* mjh_data_extra_fields(void); /* ... of the input-only leaves that trail mjhData (MJH_DATA_EXTRA_IN) */
+int mjh_sizeof_data(void);               /* sizeof(mjhData) as the library was built */
 const char* mjh_model_fields(void);
 int mjh_abi_version(void);
 

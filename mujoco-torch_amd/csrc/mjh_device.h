@@ -116,6 +116,7 @@ struct DevModel {
 #undef X
   REAL timestep, impratio, gravity[3];
   REAL density, viscosity, wind[3];  // fluid model (passive.py:31-78)
+  REAL magnetic[3];                  // opt.magnetic (magnetometer sensors)
   int has_fluid;
   int has_gravcomp;  // some body_gravcomp != 0 (device.py:667)
   double meaninertia, tolerance, ls_tolerance;  // python floats in the reference (solver.py:256-265)
@@ -138,6 +139,10 @@ struct DevModel {
   int max_jnt;
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   const int* rf_sensor;                    // nrfq: rangefinder (sns_* index) of entry q of rf_geom
+  const int* rf_site;                      // nrfq: ... its site
+  const int* rf_gtype;                     // nrfq: type of geom rf_geom[q]
+  const REAL* rf_gsize;                    // 3 * nrfq: ... and its size
+  int sns_full;                            // some sensor is of a kind the lean sensor kernel does not carry
   int nrfq;                                // entries of rf_geom = (rangefinder, geom) ray tests per environment
   const int* efc_row_eq;                   // ne: eq_* table entry of an equality row
   int max_depth;

@@ -12,5 +12,5 @@
 #define X_(R, P, W) template __global__ void mjh_phase_kernel<R, P, W>(KArgs<R>);
 #define S_(R, N, RPL, W) template __global__ void mjh_sol2_kernel<R, N, RPL, W>(KArgs<R>);
 #define C_(R) template __global__ void mjh_convex_kernel<R>(KArgs<R>);
-#define N_(R) template __global__ void mjh_sensor_kernel<R>(KArgs<R>);
+#define N_(R) template __global__ void mjh_sensor_kernel<R, 0>(KArgs<R>); template __global__ void mjh_sensor_kernel<R, 1>(KArgs<R>);
 MJH_CAT(MJH_INST_G, MJH_INST_GROUP)(X_, S_, C_, N_, MJH_INST_REAL)

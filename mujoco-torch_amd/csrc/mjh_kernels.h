@@ -167,6 +167,9 @@ struct DevData {  // typed view of mjhData
 #define X(n) int64_t* n;
   MJH_DATA_I64(X)
 #undef X
+#define X(n) const REAL* n;
+  MJH_DATA_EXTRA_IN(X)
+#undef X
 };
 
 // per-environment RK4 bookkeeping rows kept in the caller's workspace ([B, n] each)

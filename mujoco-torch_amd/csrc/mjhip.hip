@@ -23,7 +23,7 @@
 #define X_(R, P, W) extern template __global__ void mjh_phase_kernel<R, P, W>(KArgs<R>);
 #define S_(R, N, RPL, W) extern template __global__ void mjh_sol2_kernel<R, N, RPL, W>(KArgs<R>);
 #define C_(R) extern template __global__ void mjh_convex_kernel<R>(KArgs<R>);
-#define N_(R) extern template __global__ void mjh_sensor_kernel<R>(KArgs<R>);
+#define N_(R) extern template __global__ void mjh_sensor_kernel<R, 0>(KArgs<R>); extern template __global__ void mjh_sensor_kernel<R, 1>(KArgs<R>);
 MJH_INST_ALL(X_, S_, C_, N_, double)
 MJH_INST_ALL(X_, S_, C_, N_, float)
 #undef X_
@@ -91,6 +91,10 @@ struct mjhModel {
   mutable hipStream_t split_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_done[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_fork = nullptr;
+  // the sensor kernel needs nothing of CRB / CON / SOL: it runs on a stream of its own beside them (forked behind the velocity stage, joined at the end of the pass)
+  mutable std::mutex sensor_mutex;
+  mutable hipStream_t sensor_stream = nullptr;
+  mutable hipEvent_t sensor_fork = nullptr, sensor_join = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
   int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the HEAD of the workspace: its first B * cand_reals reals; the RK4 stage Data and sums follow)
@@ -163,6 +167,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   M.impratio = (REAL)d->impratio;
   M.density = (REAL)d->density; M.viscosity = (REAL)d->viscosity;
   M.wind[0] = (REAL)d->wind_x; M.wind[1] = (REAL)d->wind_y; M.wind[2] = (REAL)d->wind_z;
+  M.magnetic[0] = (REAL)d->magnetic_x; M.magnetic[1] = (REAL)d->magnetic_y; M.magnetic[2] = (REAL)d->magnetic_z;
   M.has_fluid = (d->density > 0) || (d->viscosity > 0) || (d->wind_x != 0) || (d->wind_y != 0) || (d->wind_z != 0);
   M.has_gravcomp = 0;
   M.con_general = (d->nf > 0 || d->nft > 0 || d->ne > 0 || d->nlb > 0 || d->nlt > 0 || d->topk) ? 1 : 0;
@@ -340,6 +345,18 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       for (int q = d->sns_rfadr[sidx]; q < d->sns_rfadr[sidx + 1]; q++) owner[q] = sidx;
     M.nrfq = nrf;
     fix.push_back({(const void**)&M.rf_sensor, bb.add(owner.data(), sizeof(int) * owner.size())});
+    std::vector<int> rsite((size_t)nrf + 1, 0), rtype((size_t)nrf + 1, 0);
+    std::vector<REAL> rsize((size_t)3 * nrf + 3, (REAL)0);
+    for (int q = 0; q < nrf; q++) {
+      const int g = d->rf_geom[q];
+      rsite[q] = d->sns_objid[owner[q]]; rtype[q] = d->geom_type[g];
+      for (int i = 0; i < 3; i++) rsize[3 * q + i] = (REAL)d->geom_size[3 * g + i];
+    }
+    fix.push_back({(const void**)&M.rf_site, bb.add(rsite.data(), sizeof(int) * rsite.size())});
+    fix.push_back({(const void**)&M.rf_gtype, bb.add(rtype.data(), sizeof(int) * rtype.size())});
+    fix.push_back({(const void**)&M.rf_gsize, bb.add(rsize.data(), sizeof(REAL) * rsize.size())});
+    M.sns_full = 0;
+    for (int sidx = 0; sidx < d->nsensor; sidx++) { const int t = d->sns_type[sidx]; if (!(t == 1 || t == 2 || t == 3 || t == 7 || t == 9 || t == 10)) M.sns_full = 1; }
   }
   {
     std::vector<int> row_eq((size_t)d->ne + 1, 0);
@@ -795,6 +812,35 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
   const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
   if ((st & 0x7f) && (rc = fused_kcv ? launch_phase<REAL, 13>(m, a, stream) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
+  // Sensors beside the rest of the pass (opt-in: MJH_SENSOR_STREAM=1).  With kinematics + velocity fused everything they read exists behind the first launch; the
+  // kernel is a chain of dependent loads at low occupancy (ant: 40 us of an 880 us step) and shares the chip well with the bandwidth-bound constraint phase.
+  bool sensors_forked = false;
+  {
+    static const bool side = [] { const char* e = getenv("MJH_SENSOR_STREAM"); return e && e[0] == '1'; }();  // opt-in: measured on the ant (B = 16384) 18.58 - 18.65 M beside the pass against 18.58 M in line -- the launches do not overlap in practice
+    const bool want = (st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata;
+    if (side && want && fused_kv && !g_timing.on && !g_stamps) {
+      std::lock_guard<std::mutex> lock(m->sensor_mutex);
+      if (!m->sensor_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->sensor_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->sensor_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->sensor_join, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(m->sensor_fork, stream));
+      HIP_TRY(hipStreamWaitEvent(m->sensor_stream, m->sensor_fork, 0));
+      {
+        const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
+        if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->sensor_stream, a);
+        else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->sensor_stream, a);
+        HIP_TRY(hipGetLastError());
+      }
+      HIP_TRY(hipEventRecord(m->sensor_join, m->sensor_stream));
+      sensors_forked = true;
+    }
+  }
+  struct Join {  // the pass ends with the sensors done, whichever return it takes
+    const mjhModel* m; hipStream_t s; bool on;
+    ~Join() { if (on) (void)hipStreamWaitEvent(s, m->sensor_join, 0); }
+  } join_{m, stream, sensors_forked};
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
     const int64_t items = a.B * a.M.ncvxpair;
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
@@ -807,10 +853,22 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if (!fused_cs && (st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
   if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
-  if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {  // needs only the leaves of KIN and VEL
+  const bool want_sensors = (st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata;  // needs only the leaves of KIN and VEL
+  auto launch_sensors = [&](hipStream_t s_) -> int {
+#ifdef MJH_SENSOR_ABLATE
+    static const int abl = [] { const char* e = getenv("MJH_SENSOR_ABLATE"); return e ? atoi(e) : 0; }();
+    const int keep_flags = a.flags;
+    a.flags |= abl << 8;
+    struct Restore { KArgs<REAL>& a; int f; ~Restore() { a.flags = f; } } restore_{a, keep_flags};
+#endif
     const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-    hipLaunchKernelGGL((mjh_sensor_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
+    if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), s_, a);
+    else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), s_, a);
     HIP_TRY(hipGetLastError());
+    return 0;
+  };
+  if (want_sensors && !sensors_forked) {
+    if ((rc = launch_sensors(stream))) return rc;
     timing_mark(stream, 11);
   }
   if (fused_cs) return launch_cs<REAL>(m, a, stream);
@@ -1023,6 +1081,7 @@ void mjh_model_destroy(mjhModel* m) {
   if (!m) return;
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
+  if (m->sensor_stream) { (void)hipStreamDestroy(m->sensor_stream); (void)hipEventDestroy(m->sensor_fork); (void)hipEventDestroy(m->sensor_join); }
   if (m->split_ready) {
     for (int k = 0; k < 4; k++) { (void)hipStreamDestroy(m->split_stream[k]); (void)hipEventDestroy(m->split_done[k]); }
     (void)hipEventDestroy(m->split_fork);
@@ -1169,6 +1228,16 @@ const char* mjh_data_fields(void) {
   static std::string t = std::string(s).substr(0, sizeof(s) - 2);
   return t.c_str();
 }
+const char* mjh_data_extra_fields(void) {  // the input-only leaves that trail mjhData (MJH_DATA_EXTRA_IN)
+  static const char s[] =
+#define X(n) STR_(n) ","
+      MJH_DATA_EXTRA_IN(X)
+#undef X
+      ;
+  static std::string t = std::string(s).substr(0, sizeof(s) - 2);
+  return t.c_str();
+}
+int mjh_sizeof_data(void) { return (int)sizeof(mjhData); }
 const char* mjh_model_fields(void) {
   static const char s[] =
 #define X(n) STR_(n) ","

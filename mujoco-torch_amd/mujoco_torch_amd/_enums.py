@@ -154,7 +154,8 @@ class CamLightType(enum.IntEnum):
 
 
 class SensorType(enum.IntEnum):
-    """Subset of mjtSensor (3.5.0) that the bundled models declare."""
+    """mjtSensor (3.5.0), the whole list: the MJCF compiler assigns a type to every sensor element; the stepper evaluates the ones the
+    reference's sensor.py does and leaves the slots of the others untouched, as the reference does."""
 
     TOUCH = 0
     ACCELEROMETER = 1
@@ -167,6 +168,56 @@ class SensorType(enum.IntEnum):
     CAMPROJECTION = 8
     JOINTPOS = 9
     JOINTVEL = 10
+    TENDONPOS = 11
+    TENDONVEL = 12
+    ACTUATORPOS = 13
+    ACTUATORVEL = 14
+    ACTUATORFRC = 15
+    JOINTACTFRC = 16
+    TENDONACTFRC = 17
+    BALLQUAT = 18
+    BALLANGVEL = 19
+    JOINTLIMITPOS = 20
+    JOINTLIMITVEL = 21
+    JOINTLIMITFRC = 22
+    TENDONLIMITPOS = 23
+    TENDONLIMITVEL = 24
+    TENDONLIMITFRC = 25
+    FRAMEPOS = 26
+    FRAMEQUAT = 27
+    FRAMEXAXIS = 28
+    FRAMEYAXIS = 29
+    FRAMEZAXIS = 30
+    FRAMELINVEL = 31
+    FRAMEANGVEL = 32
+    FRAMELINACC = 33
+    FRAMEANGACC = 34
+    SUBTREECOM = 35
+    SUBTREELINVEL = 36
+    SUBTREEANGMOM = 37
+    INSIDESITE = 38
+    GEOMDIST = 39
+    GEOMNORMAL = 40
+    GEOMFROMTO = 41
+    CONTACT = 42
+    E_POTENTIAL = 43
+    E_KINETIC = 44
+    CLOCK = 45
+
+
+class ObjType(enum.IntEnum):
+    """mjtObj values the sensors use (reference types.py:465-482)."""
+
+    UNKNOWN = 0
+    BODY = 1
+    XBODY = 2
+    JOINT = 3
+    DOF = 4
+    GEOM = 5
+    SITE = 6
+    CAMERA = 7
+    ACTUATOR = 19
+    TENDON = 18
 
 
 # Sets the stepper supports (reference device.py:919-949 raises for the rest).

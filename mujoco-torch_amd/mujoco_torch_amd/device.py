@@ -136,39 +136,69 @@ def _option(opt, dtype) -> Option:
     )
 
 
-_SNS_SITE = (int(SensorType.ACCELEROMETER), int(SensorType.VELOCIMETER), int(SensorType.GYRO), int(SensorType.RANGEFINDER))
-_SNS_SKIPPED = (int(SensorType.TOUCH),)  # the reference leaves these slots untouched too (sensor.py:420-423)
+_ST = SensorType
+_SNS_SITE = (int(_ST.ACCELEROMETER), int(_ST.VELOCIMETER), int(_ST.GYRO), int(_ST.RANGEFINDER), int(_ST.FORCE), int(_ST.TORQUE), int(_ST.MAGNETOMETER))
+_SNS_FRAME = (int(_ST.FRAMEPOS), int(_ST.FRAMEQUAT), int(_ST.FRAMEXAXIS), int(_ST.FRAMEYAXIS), int(_ST.FRAMEZAXIS), int(_ST.FRAMELINVEL), int(_ST.FRAMEANGVEL))
+_SNS_PLAIN = (int(_ST.TENDONPOS), int(_ST.TENDONVEL), int(_ST.ACTUATORPOS), int(_ST.ACTUATORVEL), int(_ST.ACTUATORFRC), int(_ST.TENDONACTFRC),
+              int(_ST.SUBTREECOM), int(_ST.SUBTREELINVEL), int(_ST.SUBTREEANGMOM), int(_ST.CLOCK))
+# every type one of the reference's three stage functions has a branch for (sensor.py:92-218, 236-333, 373-425): the slots of all others are left
+# untouched there (`else: continue`) and here -- touch, camprojection, the joint / tendon limit sensors, framelinacc / frameangacc, the energies, ...
+_SNS_EVALUATED = frozenset(_SNS_SITE + _SNS_FRAME + _SNS_PLAIN + (int(_ST.JOINTPOS), int(_ST.JOINTVEL), int(_ST.JOINTACTFRC), int(_ST.BALLQUAT), int(_ST.BALLANGVEL)))
+# ... and the ones that read a Data leaf no stage of the reference writes (ABI: MJH_DATA_EXTRA_IN)
+SENSOR_EXTRA_LEAVES = {int(_ST.ACCELEROMETER): "cacc", int(_ST.FORCE): "cfrc_int", int(_ST.TORQUE): "cfrc_int", int(_ST.SUBTREELINVEL): "subtree_linvel", int(_ST.SUBTREEANGMOM): "subtree_angmom"}
 _RAY_GEOM_ORDER = (GeomType.PLANE, GeomType.SPHERE, GeomType.CAPSULE, GeomType.ELLIPSOID, GeomType.CYLINDER, GeomType.BOX)  # ray.py:282-289
 
 
 def _sensor_tables(m) -> dict:
     """Sensors the native stepper evaluates (reference sensor.py:56-440, device.py:381-585), flattened per sensor."""
     ns, nsd = int(getattr(m, "nsensor", 0) or 0), int(getattr(m, "nsensordata", 0) or 0)
-    out = dict(type=[], adr=[], objid=[], bodyid=[], rootid=[], datatype=[], cutoff=[], rfadr=[0], rf_geom=[], slot=-np.ones(nsd, dtype=np.int32))
+    out = dict(type=[], adr=[], objid=[], bodyid=[], rootid=[], objtype=[], reftype=[], refid=[], refbodyid=[], refrootid=[], datatype=[], cutoff=[], rfadr=[0], rf_geom=[],
+               slot=-np.ones(nsd, dtype=np.int32), extra_leaves=())
     if ns == 0 or (int(m.opt.disableflags) & DisableBit.SENSOR):
         return out
-    stype = np.asarray(m.sensor_type)
+    A = lambda name: np.asarray(getattr(m, name))
+    stype, sobj = A("sensor_type"), A("sensor_objid")
+    sobjtype = A("sensor_objtype") if hasattr(m, "sensor_objtype") else np.zeros(ns, dtype=np.int32)
+    sreftype = A("sensor_reftype") if hasattr(m, "sensor_reftype") else np.zeros(ns, dtype=np.int32)
+    srefid = A("sensor_refid") if hasattr(m, "sensor_refid") else -np.ones(ns, dtype=np.int32)
+    body_rootid = A("body_rootid")
+    # body an object of a frame sensor rides on (device.py:525-532; an absent reference reads entry -1 of a one-element table there: the world)
+    body_of = {0: lambda i: 0, 1: lambda i: i, 2: lambda i: i, 5: lambda i: int(A("geom_bodyid")[i]), 6: lambda i: int(A("site_bodyid")[i]), 7: lambda i: int(A("cam_bodyid")[i])}
+    extra = set()
     for i in range(ns):
-        t, oid = int(stype[i]), int(np.asarray(m.sensor_objid)[i])
-        if t in _SNS_SKIPPED:
+        t, oid = int(stype[i]), int(sobj[i])
+        if t not in _SNS_EVALUATED:
             continue
+        if t == int(_ST.TENDONACTFRC) and not hasattr(SensorType, "TENDONACTFRC"):
+            continue
+        obj, body, root, ot, rt, rid, rbody, rroot = oid, 0, 0, int(sobjtype[i]), 0, -1, 0, 0
         if t in _SNS_SITE:
-            body = int(np.asarray(m.site_bodyid)[oid])
-            obj, root = oid, int(np.asarray(m.body_rootid)[body])
-        elif t == int(SensorType.JOINTPOS):
-            obj, body, root = int(np.asarray(m.jnt_qposadr)[oid]), 0, 0
-        elif t == int(SensorType.JOINTVEL):
-            obj, body, root = int(np.asarray(m.jnt_dofadr)[oid]), 0, 0
-        else:
-            raise NotImplementedError(f"sensor type {SensorType(t).name} is not implemented by the native stepper.")
+            body = int(A("site_bodyid")[oid])
+            root = int(body_rootid[body])
+        elif t in (int(_ST.JOINTPOS), int(_ST.BALLQUAT)):
+            obj = int(A("jnt_qposadr")[oid])
+        elif t in (int(_ST.JOINTVEL), int(_ST.BALLANGVEL), int(_ST.JOINTACTFRC)):
+            obj = int(A("jnt_dofadr")[oid])
+        elif t in _SNS_FRAME:
+            rt, rid = int(sreftype[i]), int(srefid[i])
+            if ot not in body_of or rt not in body_of:
+                raise NotImplementedError(f"sensor {i}: frame sensors take body / xbody / geom / site / camera objects (objtype {ot}, reftype {rt})")
+            body = body_of[ot](oid)
+            root = int(body_rootid[body])
+            rbody = body_of[rt](rid) if rid >= 0 else 0
+            rroot = int(body_rootid[rbody])
         k = len(out["type"])
-        dim = int(np.asarray(m.sensor_dim)[i])
-        out["slot"][int(np.asarray(m.sensor_adr)[i]) : int(np.asarray(m.sensor_adr)[i]) + dim] = k
-        out["type"].append(t); out["adr"].append(int(np.asarray(m.sensor_adr)[i])); out["objid"].append(obj)
+        dim = int(A("sensor_dim")[i])
+        out["slot"][int(A("sensor_adr")[i]) : int(A("sensor_adr")[i]) + dim] = k
+        out["type"].append(t); out["adr"].append(int(A("sensor_adr")[i])); out["objid"].append(obj)
         out["bodyid"].append(body); out["rootid"].append(root)
-        out["datatype"].append(int(np.asarray(m.sensor_datatype)[i])); out["cutoff"].append(float(np.asarray(m.sensor_cutoff)[i]))
-        if t == int(SensorType.RANGEFINDER):  # ray.precompute_ray_data(flg_static=True, bodyexclude=site body), type-major order
-            gtype, gbody = np.asarray(m.geom_type), np.asarray(m.geom_bodyid)
+        out["objtype"].append(ot); out["reftype"].append(rt); out["refid"].append(rid); out["refbodyid"].append(rbody); out["refrootid"].append(rroot)
+        # (the reference applies the data type of the FIRST sensor of a type to the whole group, device.py:409: the compiler gives every sensor of a type the same one)
+        out["datatype"].append(int(A("sensor_datatype")[i])); out["cutoff"].append(float(A("sensor_cutoff")[i]))
+        if t in SENSOR_EXTRA_LEAVES:
+            extra.add(SENSOR_EXTRA_LEAVES[t])
+        if t == int(_ST.RANGEFINDER):  # ray.precompute_ray_data(flg_static=True, bodyexclude=site body), type-major order
+            gtype, gbody = A("geom_type"), A("geom_bodyid")
             rgba = np.asarray(getattr(m, "geom_rgba", np.ones((int(m.ngeom), 4))))
             matid = np.asarray(getattr(m, "geom_matid", -np.ones(int(m.ngeom), dtype=np.int32)))
             for gt in _RAY_GEOM_ORDER:
@@ -177,6 +207,7 @@ def _sensor_tables(m) -> dict:
                     if int(gtype[g]) == int(gt) and int(gbody[g]) != body and visible:
                         out["rf_geom"].append(g)
         out["rfadr"].append(len(out["rf_geom"]))
+    out["extra_leaves"] = tuple(sorted(extra))
     return out
 
 

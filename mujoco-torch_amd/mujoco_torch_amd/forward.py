@@ -83,11 +83,13 @@ class _PtrTab:
     """Raw device pointers of one ``Data``'s leaves in ABI order (the ``mjhData`` struct the library takes), kept current
     incrementally: ``dirty`` holds the leaves whose tensor may have changed since the pointer was read."""
 
-    __slots__ = ("struct", "arr", "dirty", "keep", "con", "con_ver", "sig")
+    __slots__ = ("struct", "arr", "xarr", "dirty", "keep", "con", "con_ver", "sig")
 
     def __init__(self):
         self.struct = native.DataPtrs()
-        self.arr = np.frombuffer(self.struct, dtype=np.uint64)  # shares the struct's memory
+        full = np.frombuffer(self.struct, dtype=np.uint64)  # shares the struct's memory
+        self.arr = full[:_NLEAF]
+        self.xarr = full[_NLEAF:]  # the trailing input-only leaves (MJH_DATA_EXTRA_IN): filled per call when a sensor reads them (_extra_inputs)
         self.dirty = set(range(_NLEAF))
         self.keep = {}          # contiguous copies of strided input leaves (re-made every call: the source may be written in place)
         self.con = None
@@ -177,6 +179,30 @@ def _table(d: Data, sig, counts, B: int, dtype, device, dest: bool = False) -> _
         arr[i] = t.data_ptr()
     tab.dirty = again
     return tab
+
+
+_EXTRA_NAMES = native.LISTS["MJH_DATA_EXTRA_IN"]
+_EXTRA_WIDTH = {"cacc": 6, "cfrc_int": 6, "subtree_linvel": 3, "subtree_angmom": 3}
+
+
+def _extra_inputs(tab: _PtrTab, d: Data, names, B: int, nbody: int, dtype, device):
+    """Pointers of the trailing input-only leaves (read per call: four tensors at most).  An absent leaf stays NULL = zeros."""
+    keep = []
+    for n in names:
+        slot = _EXTRA_NAMES.index(n)
+        t = d._fields.get(n)
+        if not isinstance(t, torch.Tensor) or t.numel() == 0:
+            tab.xarr[slot] = 0
+            continue
+        if t.device != device or t.dtype != dtype:
+            raise RuntimeError(f"Data.{n} is {t.dtype} on {t.device}, expected {dtype} on {device}")
+        if t.numel() != B * nbody * _EXTRA_WIDTH[n]:
+            raise ValueError(f"Data.{n} holds {t.numel()} elements (shape {tuple(t.shape)}); a batch of {B} environments of this model needs {B} x {nbody * _EXTRA_WIDTH[n]}")
+        if not t.is_contiguous():
+            t = t.contiguous()
+            keep.append(t)
+        tab.xarr[slot] = t.data_ptr()
+    return keep
 
 
 class _Plan:
@@ -324,7 +350,7 @@ def _run_native(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data
             names = [n for n in names if n != "sensordata"]  # sensors belong to complete forward passes
         plan = _plan(m, d, names, batch, dtype, device, plan_key)
     out_struct = native.DataPtrs()
-    out_arr = np.frombuffer(out_struct, dtype=np.uint64)
+    out_arr = np.frombuffer(out_struct, dtype=np.uint64)[:_NLEAF]
     if out is None:
         slab = torch.empty(plan.total, dtype=torch.uint8, device=device)
         slabs = (slab, torch.empty(plan.total_small, dtype=torch.uint8, device=device))  # the commonly kept state leaves live apart (_SMALL_LEAVES)
@@ -343,6 +369,9 @@ def _run_native(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data
             raise ValueError("out= shares storage with the input on leaves the step writes: the phases read the caller's state "
                              "after the first outputs are written (and RK4 reads it in every stage); use distinct buffers")
     flags = native.FLAG_FIXED_ITERATIONS if fixed_iterations else 0
+    extra = T.sensors["extra_leaves"]
+    if extra:  # Data leaves no stage writes but a sensor of this model reads (cacc, cfrc_int, subtree_linvel / angmom: include/mjhip.h MJH_DATA_EXTRA_IN)
+        keep = _extra_inputs(tab, d, extra, B, int(m.nbody), dtype, device)
     stream, prev = _stream_and_guard(device)
     try:
         work = nm.workspace(B, stream)  # RK4 stages; candidate contacts of max_contact_points over box / mesh pairs; None for most Euler models
@@ -392,7 +421,8 @@ def _run_native(m: Model, d: Data, fixed_iterations: bool, step: bool, out: Data
     f["ncon"], f["nefc"] = _counts(m, device)
     rt = _PtrTab.__new__(_PtrTab)
     rt.struct = native.DataPtrs()
-    rt.arr = np.frombuffer(rt.struct, dtype=np.uint64)
+    full = np.frombuffer(rt.struct, dtype=np.uint64)
+    rt.arr, rt.xarr = full[:_NLEAF], full[_NLEAF:]
     np.copyto(rt.arr, np.where(plan.wmask, out_arr, tab.arr))
     rt.dirty = {i for i in tab.dirty if not plan.wmask[i]}
     rt.keep = {i: t for i, t in tab.keep.items() if not plan.wmask[i]}

@@ -40,6 +40,7 @@ from ._enums import (
     IntegratorType,
     JacobianType,
     JointType,
+    ObjType,
     SensorType,
     SolverType,
     TrnType,
@@ -333,18 +334,51 @@ _CAM_MODES = {
     "targetbody": CamLightType.TARGETBODY,
     "targetbodycom": CamLightType.TARGETBODYCOM,
 }
+# sensor element -> (type, dim, needstage [mjtStage: 1 pos, 2 vel, 3 acc], datatype [mjtDataType: 0 real, 1 positive, 2 axis, 3 quaternion], attachment), as the MuJoCo
+# compiler sets them per sensor type (user_objects.cc, mjCSensor::Compile).  attachment: the attribute that names the object ("frame": objtype / objname + reftype / refname)
 _SENSOR_DIMS = {
-    "touch": (SensorType.TOUCH, 1),
-    "accelerometer": (SensorType.ACCELEROMETER, 3),
-    "velocimeter": (SensorType.VELOCIMETER, 3),
-    "gyro": (SensorType.GYRO, 3),
-    "force": (SensorType.FORCE, 3),
-    "torque": (SensorType.TORQUE, 3),
-    "magnetometer": (SensorType.MAGNETOMETER, 3),
-    "rangefinder": (SensorType.RANGEFINDER, 1),
-    "jointpos": (SensorType.JOINTPOS, 1),
-    "jointvel": (SensorType.JOINTVEL, 1),
+    "touch": (SensorType.TOUCH, 1, 3, 1, "site"),
+    "accelerometer": (SensorType.ACCELEROMETER, 3, 3, 0, "site"),
+    "velocimeter": (SensorType.VELOCIMETER, 3, 2, 0, "site"),
+    "gyro": (SensorType.GYRO, 3, 2, 0, "site"),
+    "force": (SensorType.FORCE, 3, 3, 0, "site"),
+    "torque": (SensorType.TORQUE, 3, 3, 0, "site"),
+    "magnetometer": (SensorType.MAGNETOMETER, 3, 1, 0, "site"),
+    "rangefinder": (SensorType.RANGEFINDER, 1, 1, 0, "site"),
+    "jointpos": (SensorType.JOINTPOS, 1, 1, 0, "joint"),
+    "jointvel": (SensorType.JOINTVEL, 1, 2, 0, "joint"),
+    "tendonpos": (SensorType.TENDONPOS, 1, 1, 0, "tendon"),
+    "tendonvel": (SensorType.TENDONVEL, 1, 2, 0, "tendon"),
+    "actuatorpos": (SensorType.ACTUATORPOS, 1, 1, 0, "actuator"),
+    "actuatorvel": (SensorType.ACTUATORVEL, 1, 2, 0, "actuator"),
+    "actuatorfrc": (SensorType.ACTUATORFRC, 1, 3, 0, "actuator"),
+    "jointactuatorfrc": (SensorType.JOINTACTFRC, 1, 3, 0, "joint"),
+    "tendonactuatorfrc": (SensorType.TENDONACTFRC, 1, 3, 0, "tendon"),
+    "ballquat": (SensorType.BALLQUAT, 4, 1, 3, "joint"),
+    "ballangvel": (SensorType.BALLANGVEL, 3, 2, 0, "joint"),
+    "jointlimitpos": (SensorType.JOINTLIMITPOS, 1, 1, 0, "joint"),
+    "jointlimitvel": (SensorType.JOINTLIMITVEL, 1, 2, 0, "joint"),
+    "jointlimitfrc": (SensorType.JOINTLIMITFRC, 1, 3, 1, "joint"),
+    "tendonlimitpos": (SensorType.TENDONLIMITPOS, 1, 1, 0, "tendon"),
+    "tendonlimitvel": (SensorType.TENDONLIMITVEL, 1, 2, 0, "tendon"),
+    "tendonlimitfrc": (SensorType.TENDONLIMITFRC, 1, 3, 1, "tendon"),
+    "framepos": (SensorType.FRAMEPOS, 3, 1, 0, "frame"),
+    "framequat": (SensorType.FRAMEQUAT, 4, 1, 3, "frame"),
+    "framexaxis": (SensorType.FRAMEXAXIS, 3, 1, 2, "frame"),
+    "frameyaxis": (SensorType.FRAMEYAXIS, 3, 1, 2, "frame"),
+    "framezaxis": (SensorType.FRAMEZAXIS, 3, 1, 2, "frame"),
+    "framelinvel": (SensorType.FRAMELINVEL, 3, 2, 0, "frame"),
+    "frameangvel": (SensorType.FRAMEANGVEL, 3, 2, 0, "frame"),
+    "framelinacc": (SensorType.FRAMELINACC, 3, 3, 0, "frame"),
+    "frameangacc": (SensorType.FRAMEANGACC, 3, 3, 0, "frame"),
+    "subtreecom": (SensorType.SUBTREECOM, 3, 1, 0, "body"),
+    "subtreelinvel": (SensorType.SUBTREELINVEL, 3, 2, 0, "body"),
+    "subtreeangmom": (SensorType.SUBTREEANGMOM, 3, 2, 0, "body"),
+    "e_potential": (SensorType.E_POTENTIAL, 1, 1, 0, None),
+    "e_kinetic": (SensorType.E_KINETIC, 1, 2, 0, None),
+    "clock": (SensorType.CLOCK, 1, 1, 0, None),
 }
+_OBJTYPE_NAMES = {"body": ObjType.BODY, "xbody": ObjType.XBODY, "geom": ObjType.GEOM, "site": ObjType.SITE, "camera": ObjType.CAMERA}
 
 _DEF_SOLREF = np.array([0.02, 1.0])
 _DEF_SOLIMP = np.array([0.9, 0.95, 0.001, 0.5, 2.0])
@@ -1317,25 +1351,54 @@ class _Compiler:
         m.sensor_dim = np.array(dims, dtype=np.int32)
         m.sensor_adr = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32) if sens else np.zeros(0, dtype=np.int32)
         m.nsensordata = int(sum(dims))
-        # object the sensor is attached to (mjtObj: 3 joint, 6 site), stage it needs (mjtStage: 1 pos, 2 vel, 3 acc) and
-        # its data type (mjtDataType: 0 real, 1 positive), as the MuJoCo compiler sets them per sensor type
-        objid, objtype, stage, dtype_ = [], [], [], []
+        lists = {ObjType.BODY: m.names_body, ObjType.XBODY: m.names_body, ObjType.GEOM: m.names_geom, ObjType.SITE: m.names_site, ObjType.CAMERA: m.names_cam}
+
+        def lookup(sn, kind, names, attr):
+            name = sn.get(attr)
+            if name is None or name not in names:
+                raise ValueError(f"sensor <{sn.tag}>: {kind} {name!r} not found")
+            return names.index(name)
+
+        objid, objtype, reftype, refid = [], [], [], []
         for sn in sens:
-            t = sn.tag
-            if t in ("jointpos", "jointvel"):
-                objtype.append(3)
-                objid.append(m.names_jnt.index(sn.get("joint")))
+            attach = _SENSOR_DIMS[sn.tag][4]
+            rt, ri = int(ObjType.UNKNOWN), -1
+            if attach == "site":
+                ot, oi = int(ObjType.SITE), lookup(sn, "site", m.names_site, "site")
+            elif attach == "joint":
+                ot, oi = int(ObjType.JOINT), lookup(sn, "joint", m.names_jnt, "joint")
+                jt = int(m.jnt_type[oi])
+                if sn.tag in ("ballquat", "ballangvel") and jt != int(JointType.BALL):
+                    raise ValueError(f"sensor <{sn.tag}>: joint {sn.get('joint')!r} must be a ball joint")
+                if sn.tag in ("jointpos", "jointvel", "jointlimitpos", "jointlimitvel", "jointlimitfrc") and jt not in (int(JointType.SLIDE), int(JointType.HINGE)):
+                    raise ValueError(f"sensor <{sn.tag}>: joint {sn.get('joint')!r} must be a slide or hinge joint")
+            elif attach == "tendon":
+                ot, oi = int(ObjType.TENDON), lookup(sn, "tendon", getattr(m, "names_tendon", []), "tendon")
+            elif attach == "actuator":
+                ot, oi = int(ObjType.ACTUATOR), lookup(sn, "actuator", getattr(m, "names_actuator", []), "actuator")
+            elif attach == "body":
+                ot, oi = int(ObjType.BODY), lookup(sn, "body", m.names_body, "body")
+            elif attach == "frame":
+                kind = sn.get("objtype")
+                if kind not in _OBJTYPE_NAMES:
+                    raise ValueError(f"sensor <{sn.tag}>: objtype must be one of {sorted(_OBJTYPE_NAMES)}, got {kind!r}")
+                ot = int(_OBJTYPE_NAMES[kind])
+                oi = lookup(sn, kind, lists[_OBJTYPE_NAMES[kind]], "objname")
+                if sn.get("reftype") is not None or sn.get("refname") is not None:
+                    rkind = sn.get("reftype")
+                    if rkind not in _OBJTYPE_NAMES:
+                        raise ValueError(f"sensor <{sn.tag}>: reftype must be one of {sorted(_OBJTYPE_NAMES)}, got {rkind!r}")
+                    rt = int(_OBJTYPE_NAMES[rkind])
+                    ri = lookup(sn, rkind, lists[_OBJTYPE_NAMES[rkind]], "refname")
             else:
-                objtype.append(6)
-                objid.append(m.names_site.index(sn.get("site")))
-            stage.append({"touch": 3, "accelerometer": 3, "force": 3, "torque": 3, "velocimeter": 2, "gyro": 2, "jointvel": 2}.get(t, 1))
-            dtype_.append(1 if t == "touch" else 0)
+                ot, oi = int(ObjType.UNKNOWN), -1
+            objtype.append(ot); objid.append(oi); reftype.append(rt); refid.append(ri)
         m.sensor_objid = np.array(objid, dtype=np.int32)
         m.sensor_objtype = np.array(objtype, dtype=np.int32)
-        m.sensor_needstage = np.array(stage, dtype=np.int32)
-        m.sensor_datatype = np.array(dtype_, dtype=np.int32)
-        m.sensor_reftype = np.zeros(len(sens), dtype=np.int32)
-        m.sensor_refid = -np.ones(len(sens), dtype=np.int32)
+        m.sensor_needstage = np.array([_SENSOR_DIMS[s.tag][2] for s in sens], dtype=np.int32)
+        m.sensor_datatype = np.array([_SENSOR_DIMS[s.tag][3] for s in sens], dtype=np.int32)
+        m.sensor_reftype = np.array(reftype, dtype=np.int32)
+        m.sensor_refid = np.array(refid, dtype=np.int32)
         m.sensor_cutoff = np.array([float(s.get("cutoff", 0.0)) for s in sens], dtype=np.float64)
 
     def _build_equality(self, m):

@@ -44,10 +44,12 @@ def _load_lists():
         text = f.read()
     return {k: _macro_names(text, k) for k in (
         "MJH_MODEL_INTS", "MJH_MODEL_REALS", "MJH_MODEL_INT_ARRAYS", "MJH_MODEL_REAL_ARRAYS",
-        "MJH_DATA_REALS", "MJH_DATA_I32", "MJH_DATA_I64")}
+        "MJH_DATA_REALS", "MJH_DATA_I32", "MJH_DATA_I64", "MJH_DATA_EXTRA_IN")}
 
 
 LISTS = _load_lists()
+with open(HEADER) as _f:
+    ABI_VERSION = int(re.search(r"#define MJH_ABI_VERSION (\d+)", _f.read()).group(1))  # the header is the single source of the version
 
 
 def _make_structs():
@@ -61,7 +63,7 @@ def _make_structs():
     class ModelDesc(ctypes.Structure):
         _fields_ = f
 
-    d = [(n, ctypes.c_void_p) for n in LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"]]
+    d = [(n, ctypes.c_void_p) for n in LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"] + LISTS["MJH_DATA_EXTRA_IN"]]  # (the trailing input-only leaves: NULL unless a sensor reads them)
 
     class DataPtrs(ctypes.Structure):
         _fields_ = d
@@ -108,6 +110,7 @@ def pack_model(m, dtype: torch.dtype):
         meaninertia=float(m.stat.meaninertia), gravity_x=float(grav[0]), gravity_y=float(grav[1]), gravity_z=float(grav[2]),
         density=float(f64(m.opt.density)[0]), viscosity=float(f64(m.opt.viscosity)[0]),
         wind_x=float(f64(m.opt.wind)[0]), wind_y=float(f64(m.opt.wind)[1]), wind_z=float(f64(m.opt.wind)[2]),
+        magnetic_x=float(f64(m.opt.magnetic)[0]), magnetic_y=float(f64(m.opt.magnetic)[1]), magnetic_z=float(f64(m.opt.magnetic)[2]),
     )
     i32 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.int32)).reshape(-1)
     nu = m.nu
@@ -128,7 +131,8 @@ def pack_model(m, dtype: torch.dtype):
         act_ctrllimited=i32(A("actuator_ctrllimited")), act_forcelimited=i32(A("actuator_forcelimited")),
         act_actlimited=i32(A("actuator_actlimited")), act_actadr=i32(A("actuator_actadr")), act_actnum=i32(A("actuator_actnum")),
         sns_type=i32(T.sensors["type"]), sns_adr=i32(T.sensors["adr"]), sns_objid=i32(T.sensors["objid"]), sns_bodyid=i32(T.sensors["bodyid"]),
-        sns_rootid=i32(T.sensors["rootid"]), sns_datatype=i32(T.sensors["datatype"]), sns_rfadr=i32(T.sensors["rfadr"]),
+        sns_rootid=i32(T.sensors["rootid"]), sns_objtype=i32(T.sensors["objtype"]), sns_reftype=i32(T.sensors["reftype"]), sns_refid=i32(T.sensors["refid"]),
+        sns_refbodyid=i32(T.sensors["refbodyid"]), sns_refrootid=i32(T.sensors["refrootid"]), sns_datatype=i32(T.sensors["datatype"]), sns_rfadr=i32(T.sensors["rfadr"]),
         rf_geom=i32(T.sensors["rf_geom"]), slot_sensor=i32(T.sensors["slot"]),
         eq_kind=i32(T.eq['kind']), eq_id=i32(T.eq['id']), eq_obj1=i32(T.eq['obj1']), eq_obj2=i32(T.eq['obj2']), eq_row=i32(T.eq['row']), eq_jadr=i32(T.eq['jadr']),
         topk_slot=i32(T.topk_slot), fric_dof=i32(T.fric_dof), fric_tendon=i32(T.fric_tendon), ten_adr=i32(T.tendon['adr']), ten_dof=i32(T.tendon['dof']), ten_qposadr=i32(T.tendon['qpos']), lim_tendon=i32(T.tendon['lim']), act_trnid=i32([x[1] for x in info]),
@@ -177,7 +181,7 @@ def pack_model(m, dtype: torch.dtype):
         con_solreffriction=f64(st["solreffriction"]), con_solimp=f64(st["solimp"]), convex_vert=cvf("vert"), convex_facenormal=cvf("facenormal"),
     )
     desc = ModelDesc()
-    desc.abi_version = 13
+    desc.abi_version = ABI_VERSION
     keep = []
     for n in LISTS["MJH_MODEL_INTS"]:
         setattr(desc, n, int(ints[n]))
@@ -254,6 +258,9 @@ def check_abi(lib):
     want = LISTS["MJH_DATA_REALS"] + LISTS["MJH_DATA_I32"] + LISTS["MJH_DATA_I64"]
     if data != want:
         raise RuntimeError("libmjhip.so Data field list does not match include/mjhip.h")
+    lib.mjh_data_extra_fields.restype = ctypes.c_char_p
+    if lib.mjh_data_extra_fields().decode().split(",") != LISTS["MJH_DATA_EXTRA_IN"] or int(lib.mjh_sizeof_data()) != ctypes.sizeof(DataPtrs):
+        raise RuntimeError("libmjhip.so mjhData layout (trailing input-only leaves) does not match include/mjhip.h")
     model = lib.mjh_model_fields().decode().split(",")
     wantm = LISTS["MJH_MODEL_INTS"] + LISTS["MJH_MODEL_REALS"] + LISTS["MJH_MODEL_INT_ARRAYS"] + LISTS["MJH_MODEL_REAL_ARRAYS"]
     if model != wantm:

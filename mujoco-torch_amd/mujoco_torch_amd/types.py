@@ -27,6 +27,7 @@ from ._enums import (  # noqa: F401  (re-exported: the reference exposes them fr
     IntegratorType,
     JacobianType,
     JointType,
+    ObjType,
     SensorType,
     SolverType,
     TrnType,

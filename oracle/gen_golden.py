@@ -65,6 +65,11 @@ CASES = {
     # geom type / joint sensors, with cutoffs
     "sensor_rig_f64": ("sensor_rig", {}, "float64", 4, 3, "sensor_rig"),
     "sensor_rig_rk4_f64": ("sensor_rig", {"integrator": 1}, "float64", 2, 2, "sensor_rig"),
+    # ... one of every other type sensor.py evaluates: magnetometer, tendon / actuator / joint-actuator sensors, ball joint sensors, frame sensors in every
+    # object x reference kind, subtree sensors, clock, force / torque / accelerometer / subtree momentum reading the Data leaves no stage writes (set by the recipe), and types the
+    # reference leaves untouched (touch, jointlimitpos, framelinacc, e_potential)
+    "sensor_rig2_f64": ("sensor_rig2", {}, "float64", 4, 3, "sensor_rig2"),
+    "sensor_rig2_rk4_f32": ("sensor_rig2", {"integrator": 1}, "float32", 3, 2, "sensor_rig2"),
     # fluid forces (passive.py:31-78, :158-173): the bundled swimmer (density only) and a variant with viscosity and wind
     "swimmer_f64": ("swimmer", {}, "float64", 2, 3, "generic"),
     "swimmer_viscous_wind_f64": ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, "float64", 2, 2, "generic"),
@@ -132,6 +137,9 @@ CASES = {
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
 
 
+EXTRA_INPUTS = ["sensordata", "cacc", "cfrc_int", "subtree_linvel", "subtree_angmom"]  # inputs only some recipes set (sensor slots the step leaves alone; MJH_DATA_EXTRA_IN)
+
+
 def make_inputs(recipe, lite, env):
     """Seeded per-env input overrides (numpy, float64). ``env`` is the seed index."""
     rng = np.random.RandomState(1000 + env)
@@ -178,6 +186,23 @@ def make_inputs(recipe, lite, env):
         q[7:] += 0.3 * rng.randn(nq - 7)
         out["qpos"] = q
         out["qvel"] = 0.5 * rng.randn(nv)
+    elif recipe == "sensor_rig2":
+        q = lite.qpos0.copy()
+        q[:3] += 0.1 * rng.randn(3) * (env > 0)
+        q[3:7] += 0.2 * rng.randn(4) * (env > 0)
+        q[7:11] += 0.5 * rng.randn(4)          # the ball joint, un-normalised on purpose
+        q[11:] += np.array([0.6, 0.08]) * rng.randn(2)
+        out["qpos"] = q
+        out["qvel"] = 0.6 * rng.randn(nv)
+        out["ctrl"] = np.clip(0.8 * rng.randn(nu), -1.5, 1.5)
+        out["time"] = np.array(0.003 * env)
+        out["sensordata"] = rng.randn(lite.nsensordata)  # the slots of the untouched types keep these
+        # leaves no stage of the reference writes, read by accelerometer / force / torque / subtreelinvel / subtreeangmom: env 0 keeps make_data's zeros
+        if env > 0:
+            out["cacc"] = 0.5 * rng.randn(nb, 6)
+            out["cfrc_int"] = 2.0 * rng.randn(nb, 6)
+            out["subtree_linvel"] = rng.randn(nb, 3)
+            out["subtree_angmom"] = rng.randn(nb, 3)
     elif recipe == "friction_hinge":  # stick (small torque), slip both ways (large torque): reference test/solver_test.py:77-108
         out["qvel"] = np.array([0.0, 0.5, -0.5][env % 3]) * np.ones(nv)
         out["qfrc_applied"] = np.array([0.5, 100.0, -100.0][env % 3]) * np.ones(nv)
@@ -272,6 +297,9 @@ def main(only=None):
                 d = d.to(dtype)
             for n in INPUT_LEAVES:
                 store[f"in/{env}/{n}"] = leaf(d, n).numpy().copy()
+            for n in EXTRA_INPUTS:  # only where the recipe sets them: the other cases' key sets stay as they were
+                if n in inp:
+                    store[f"in/{env}/{n}"] = getattr(d, n).numpy().copy()
             for s in range(nsteps):
                 d = ref.forward.step(mref, d, fixed_iterations=fixed)
                 for n in names:

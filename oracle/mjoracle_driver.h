@@ -178,6 +178,10 @@ static int FN(mjo_run)(const mjhModelDesc* m, const mjhData* in, mjhData* out, i
       w.stage_mode = 0; w.stage_tie_n = 0; w.stage_tie_flip = g_stage_tie_flip;
       w.stat_solves = w.stat_niter = w.stat_ls = w.stat_rows = 0;
       w.tie_on = 0; w.tie_n = 0; w.tie_pairs = 0; w.prim_hint_n = NULL; w.prim_adopted = 0; w0.prim_hint_n = NULL; w0.prim_adopted = 0;
+      w.x_cacc = in->cacc ? (const REAL*)in->cacc + e * 6 * m->nbody : NULL;
+      w.x_cfrc_int = in->cfrc_int ? (const REAL*)in->cfrc_int + e * 6 * m->nbody : NULL;
+      w.x_subtree_linvel = in->subtree_linvel ? (const REAL*)in->subtree_linvel + e * 3 * m->nbody : NULL;
+      w.x_subtree_angmom = in->subtree_angmom ? (const REAL*)in->subtree_angmom + e * 3 * m->nbody : NULL;
       w.eq_active = in->eq_active ? in->eq_active + e * m->neq : eq_zero;
       w0.eq_active = w.eq_active;
       w.hint_dist = g_hint_dist ? (const REAL*)g_hint_dist + e * m->ncon : NULL;

@@ -108,6 +108,7 @@ typedef struct FN(MjoWork) {
   /* rk4 */
   REAL *rk_qpos0, *rk_qvel0, *rk_act0, *rk_qvel, *rk_qacc, *rk_actdot, *rk_kqvel;
   REAL* in_subtree_com;
+  const REAL *x_cacc, *x_cfrc_int, *x_subtree_linvel, *x_subtree_angmom; /* this env's rows of the input-only leaves the sensors read (MJH_DATA_EXTRA_IN), NULL = zeros */
   /* diagnostic: number of line-search candidates that were distinct points with a derivative that is
      pure rounding noise (|deriv_0| < 1e-8 of the initial slope).  Whether such a candidate is
      accepted depends on the sign / exact-zeroness of that noise (solver.py:440-463), so the
@@ -2051,40 +2052,37 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
 
 /* ---- forward (forward.py:373-401) ----------------------------------------------------------------- */
 /* ---- sensors (sensor.py:56-440, ray.py:28-373) ------------------------------------------------------- */
-/* ray functions run in double whatever the Data dtype: the reference keeps the geom sizes of its ray tables in float64
-   (ray.py:317) and torch promotes; with float32 Data its own call raises on the mixed dot products, so float32 +
-   rangefinder is this build's choice: transform in the Data dtype, intersect in double, round the distance. */
-#ifndef MJO_RAY_COMMON_
-#define MJO_RAY_COMMON_
-static double mjo_safe_div(double num, double den) { return num / (den + (den == 0 ? (double)(float)mjMINVAL : 0.0)); }
-static void mjo_ray_quad(double a, double b, double c, double* x0, double* x1) { /* :28-40 */
-  double det = b * b - a * c, det2 = sqrt(det);
-  double r0 = mjo_safe_div(-b - det2, a), r1 = mjo_safe_div(-b + det2, a);
-  *x0 = ((det < mjMINVAL) || (r0 < 0)) ? INFINITY : r0;
-  *x1 = ((det < mjMINVAL) || (r1 < 0)) ? INFINITY : r1;
+/* Ray intersections run in the Data dtype.  The reference keeps the geom sizes of its ray tables in float64 (ray.py:317); with float32 Data its own call
+   raises on the mixed dot products, so float32 + rangefinder has no reference result: this build's choice is float32 throughout (mjh_sensor.h). */
+static REAL FN(ray_safe_div)(REAL num, REAL den) { return num / (den + (den == 0 ? (REAL)(float)mjMINVAL : (REAL)0)); }
+static void FN(ray_quad)(REAL a, REAL b, REAL c, REAL* x0, REAL* x1) { /* :28-40 */
+  REAL det = b * b - a * c, det2 = R_SQRT(det);
+  REAL r0 = FN(ray_safe_div)(-b - det2, a), r1 = FN(ray_safe_div)(-b + det2, a);
+  *x0 = ((det < (REAL)mjMINVAL) || (r0 < 0)) ? INFINITY : r0;
+  *x1 = ((det < (REAL)mjMINVAL) || (r1 < 0)) ? INFINITY : r1;
 }
-static double mjo_dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-static double mjo_ray_geom(int type, const double* size, const double* pnt, const double* vec) {
+static REAL FN(ray_dot3)(const REAL* a, const REAL* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static REAL FN(ray_geom)(int type, const REAL* size, const REAL* pnt, const REAL* vec) {
   if (type == 0) { /* plane :43-57 */
-    double x = -mjo_safe_div(pnt[2], vec[2]);
-    int valid = (vec[2] <= -mjMINVAL) && (x >= 0);
-    for (int i = 0; i < 2; i++) { double p = pnt[i] + x * vec[i]; valid = valid && ((size[i] <= 0) || (fabs(p) <= size[i])); }
+    REAL x = -FN(ray_safe_div)(pnt[2], vec[2]);
+    int valid = (vec[2] <= -(REAL)mjMINVAL) && (x >= 0);
+    for (int i = 0; i < 2; i++) { REAL p = pnt[i] + x * vec[i]; valid = valid && ((size[i] <= 0) || (R_FABS(p) <= size[i])); }
     return valid ? x : INFINITY;
   }
   if (type == 2) { /* sphere :60-69 */
-    double x0, x1;
-    mjo_ray_quad(mjo_dot3(vec, vec), mjo_dot3(vec, pnt), mjo_dot3(pnt, pnt) - size[0] * size[0], &x0, &x1);
+    REAL x0, x1;
+    FN(ray_quad)(FN(ray_dot3)(vec, vec), FN(ray_dot3)(vec, pnt), FN(ray_dot3)(pnt, pnt) - size[0] * size[0], &x0, &x1);
     return isinf(x0) ? x1 : x0;
   }
   if (type == 3) { /* capsule :72-106 */
-    double a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
-    double x0, x1;
-    mjo_ray_quad(a, b, c, &x0, &x1);
-    double x = isinf(x0) ? x1 : x0;
-    x = (fabs(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
+    REAL a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
+    REAL x0, x1;
+    FN(ray_quad)(a, b, c, &x0, &x1);
+    REAL x = isinf(x0) ? x1 : x0;
+    x = (R_FABS(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
     for (int cap = 0; cap < 2; cap++) {
-      double dif[3] = {pnt[0], pnt[1], cap == 0 ? pnt[2] - size[1] : pnt[2] + size[1]};
-      mjo_ray_quad(mjo_dot3(vec, vec), mjo_dot3(vec, dif), mjo_dot3(dif, dif) - size[0] * size[0], &x0, &x1);
+      REAL dif[3] = {pnt[0], pnt[1], cap == 0 ? pnt[2] - size[1] : pnt[2] + size[1]};
+      FN(ray_quad)(FN(ray_dot3)(vec, vec), FN(ray_dot3)(vec, dif), FN(ray_dot3)(dif, dif) - size[0] * size[0], &x0, &x1);
       if (cap == 0) {
         if ((pnt[2] + x0 * vec[2] >= size[1]) && (x0 < x)) x = x0;
         if ((pnt[2] + x1 * vec[2] >= size[1]) && (x1 < x)) x = x1;
@@ -2096,40 +2094,40 @@ static double mjo_ray_geom(int type, const double* size, const double* pnt, cons
     return x;
   }
   if (type == 4) { /* ellipsoid :109-129 */
-    double s[3], sv[3], sp[3];
-    for (int i = 0; i < 3; i++) { s[i] = mjo_safe_div(1, size[i] * size[i]); sv[i] = s[i] * vec[i]; sp[i] = s[i] * pnt[i]; }
-    double x0, x1;
-    mjo_ray_quad(mjo_dot3(sv, vec), mjo_dot3(sv, pnt), mjo_dot3(sp, pnt) - 1, &x0, &x1);
+    REAL s[3], sv[3], sp[3];
+    for (int i = 0; i < 3; i++) { s[i] = FN(ray_safe_div)(1, size[i] * size[i]); sv[i] = s[i] * vec[i]; sp[i] = s[i] * pnt[i]; }
+    REAL x0, x1;
+    FN(ray_quad)(FN(ray_dot3)(sv, vec), FN(ray_dot3)(sv, pnt), FN(ray_dot3)(sp, pnt) - 1, &x0, &x1);
     return isinf(x0) ? x1 : x0;
   }
   if (type == 5) { /* cylinder :235-268 */
-    double a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
-    double x0, x1;
-    mjo_ray_quad(a, b, c, &x0, &x1);
-    double x = isinf(x0) ? x1 : x0;
-    x = (fabs(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
+    REAL a = vec[0] * vec[0] + vec[1] * vec[1], b = vec[0] * pnt[0] + vec[1] * pnt[1], c = (pnt[0] * pnt[0] + pnt[1] * pnt[1]) - size[0] * size[0];
+    REAL x0, x1;
+    FN(ray_quad)(a, b, c, &x0, &x1);
+    REAL x = isinf(x0) ? x1 : x0;
+    x = (R_FABS(pnt[2] + x * vec[2]) <= size[1]) ? x : INFINITY;
     for (int cap = 0; cap < 2; cap++) {
-      double t = mjo_safe_div((cap == 0 ? size[1] : -size[1]) - pnt[2], vec[2]);
-      double p0 = pnt[0] + t * vec[0], p1 = pnt[1] + t * vec[1];
+      REAL t = FN(ray_safe_div)((cap == 0 ? size[1] : -size[1]) - pnt[2], vec[2]);
+      REAL p0 = pnt[0] + t * vec[0], p1 = pnt[1] + t * vec[1];
       if ((t >= 0) && (p0 * p0 + p1 * p1 <= size[0] * size[0]) && (t < x)) x = t;
     }
     return x;
   }
   if (type == 6) { /* box :132-161 */
     static const int iface[6][2] = {{1, 2}, {0, 2}, {0, 1}, {1, 2}, {0, 2}, {0, 1}};
-    double best = INFINITY;
+    REAL best = INFINITY;
     for (int f = 0; f < 6; f++) {
       int ax = f % 3;
-      double x = f < 3 ? mjo_safe_div(size[ax] - pnt[ax], vec[ax]) : -mjo_safe_div(size[ax] + pnt[ax], vec[ax]);
-      double p0 = pnt[iface[f][0]] + x * vec[iface[f][0]], p1 = pnt[iface[f][1]] + x * vec[iface[f][1]];
-      int valid = (fabs(p0) <= size[iface[f][0]]) && (fabs(p1) <= size[iface[f][1]]) && (x >= 0);
+      REAL x = f < 3 ? FN(ray_safe_div)(size[ax] - pnt[ax], vec[ax]) : -FN(ray_safe_div)(size[ax] + pnt[ax], vec[ax]);
+      REAL p0 = pnt[iface[f][0]] + x * vec[iface[f][0]], p1 = pnt[iface[f][1]] + x * vec[iface[f][1]];
+      int valid = (R_FABS(p0) <= size[iface[f][0]]) && (R_FABS(p1) <= size[iface[f][1]]) && (x >= 0);
       if (valid && x < best) best = x;
     }
     return best;
   }
   return INFINITY;
 }
-#endif
+
 
 static REAL FN(sensor_cut)(REAL v, REAL cutoff, int datatype) { /* _apply_cutoff :41-53 */
   if (!(cutoff > 0)) return v;
@@ -2137,14 +2135,112 @@ static REAL FN(sensor_cut)(REAL v, REAL cutoff, int datatype) { /* _apply_cutoff
   if (datatype == 1) return v < cutoff ? v : cutoff;
   return v;
 }
+/* frame of an object of a frame sensor (sensor.py:62-74): position and orientation by mjtObj */
+static void FN(sns_frame)(const FN(MjoWork) * w, int objtype, int id, const REAL** pos, const REAL** mat) {
+  static const REAL zero3[3] = {0, 0, 0}, eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  switch (objtype) {
+    case 1: *pos = w->xipos + 3 * id; *mat = w->ximat + 9 * id; break;
+    case 2: *pos = w->xpos + 3 * id; *mat = w->xmat + 9 * id; break;
+    case 5: *pos = w->geom_xpos + 3 * id; *mat = w->geom_xmat + 9 * id; break;
+    case 6: *pos = w->site_xpos + 3 * id; *mat = w->site_xmat + 9 * id; break;
+    case 7: *pos = w->cam_xpos + 3 * id; *mat = w->cam_xmat + 9 * id; break;
+    default: *pos = zero3; *mat = eye; break;
+  }
+}
+/* orientation of such an object as a quaternion (sensor.py:164-181) */
+static void FN(sns_quat)(const FN(MjoModel) * M, const FN(MjoWork) * w, int objtype, int id, int body, REAL* q) {
+  switch (objtype) {
+    case 2: for (int i = 0; i < 4; i++) q[i] = w->xquat[4 * id + i]; break;
+    case 1: FN(quat_mul)(w->xquat + 4 * id, M->body_iquat + 4 * id, q); break;
+    case 5: FN(quat_mul)(w->xquat + 4 * body, M->geom_quat + 4 * id, q); break;
+    case 6: FN(quat_mul)(w->xquat + 4 * body, M->site_quat + 4 * id, q); break;
+    case 7: FN(quat_mul)(w->xquat + 4 * body, M->cam_quat + 4 * id, q); break;
+    default: q[0] = 1; q[1] = 0; q[2] = 0; q[3] = 0; break;
+  }
+}
 /* value of sensor s, component comp */
 static REAL FN(sensor_value)(const FN(MjoModel) * M, const FN(MjoWork) * w, int s, int comp) {
   const mjhModelDesc* m = M->d;
   int type = m->sns_type[s], obj = m->sns_objid[s], body = m->sns_bodyid[s], root = m->sns_rootid[s];
   if (type == 9) return w->qpos[obj];  /* jointpos */
   if (type == 10) return w->qvel[obj]; /* jointvel */
+  if (type == 11) return w->ten_length[obj];         /* tendonpos :111-112 */
+  if (type == 12) return w->ten_velocity[obj];       /* tendonvel :254-255 */
+  if (type == 13) return w->actuator_length[obj];    /* actuatorpos :113-114 */
+  if (type == 14) return w->actuator_velocity[obj];  /* actuatorvel :256-257 */
+  if (type == 15) return w->actuator_force[obj];     /* actuatorfrc :417-418 */
+  if (type == 16) return w->qfrc_actuator[obj];      /* jointactuatorfrc :419-420 */
+  if (type == 17) { /* tendonactuatorfrc :421-423: force_mask @ actuator_force, the mask picks the actuators acting on the tendon */
+    REAL acc = 0;
+    for (int i = 0; i < m->nu; i++) acc += (REAL)(m->act_trntype[i] == 3 && m->act_trnid[i] == obj) * w->actuator_force[i];
+    return acc;
+  }
+  if (type == 18) { /* ballquat :115-118 */
+    REAL q[4] = {w->qpos[obj], w->qpos[obj + 1], w->qpos[obj + 2], w->qpos[obj + 3]};
+    FN(normalize_n)(q, 4);
+    return q[comp];
+  }
+  if (type == 19) return w->qvel[obj + comp]; /* ballangvel :258-260 */
+  if (type == 35) return w->subtree_com[3 * obj + comp]; /* subtreecom :211-213 */
+  if (type == 36) return w->x_subtree_linvel ? w->x_subtree_linvel[3 * obj + comp] : (REAL)0; /* :261-263: a leaf no stage writes (smooth.subtree_vel does not exist in the reference) */
+  if (type == 37) return w->x_subtree_angmom ? w->x_subtree_angmom[3 * obj + comp] : (REAL)0; /* :264-266 */
+  if (type == 45) return w->time[0]; /* clock :214-215 */
+#define ROT_T(R_, v, o) for (int i_ = 0; i_ < 3; i_++) (o)[i_] = (R_)[i_] * (v)[0] + (R_)[3 + i_] * (v)[1] + (R_)[6 + i_] * (v)[2];
+  if (type >= 26 && type <= 32) { /* frame sensors: object (objtype, obj) seen from the reference object (reftype, refid) or, without one, from the world */
+    int ot = m->sns_objtype[s], rt = m->sns_reftype[s], rid = m->sns_refid[s], rbody = m->sns_refbodyid[s], rroot = m->sns_refrootid[s];
+    const REAL *xpos, *xmat, *rpos, *rmat;
+    FN(sns_frame)(w, ot, obj, &xpos, &xmat);
+    FN(sns_frame)(w, rid >= 0 ? rt : 0, rid >= 0 ? rid : 0, &rpos, &rmat);
+    if (type == 26) { /* framepos :119-138 */
+      if (rid < 0) return xpos[comp];
+      REAL d3[3] = {xpos[0] - rpos[0], xpos[1] - rpos[1], xpos[2] - rpos[2]}, o[3];
+      ROT_T(rmat, d3, o)
+      return o[comp];
+    }
+    if (type >= 28 && type <= 30) { /* frame{x,y,z}axis :139-160 */
+      int k = type - 28;
+      REAL axis[3] = {xmat[k], xmat[3 + k], xmat[6 + k]}, o[3];
+      if (rid < 0) return axis[comp];
+      ROT_T(rmat, axis, o)
+      return o[comp];
+    }
+    if (type == 27) { /* framequat :161-199 */
+      REAL q[4], r[4], ri[4], o[4];
+      FN(sns_quat)(M, w, ot, obj, body, q);
+      if (rid < 0) return q[comp];
+      FN(sns_quat)(M, w, rt, rid, rbody, r);
+      ri[0] = r[0] * (REAL)1; ri[1] = r[1] * (REAL)-1; ri[2] = r[2] * (REAL)-1; ri[3] = r[3] * (REAL)-1; /* quat_inv :264-273 */
+      FN(quat_mul)(ri, q, o);
+      return o[comp];
+    }
+    /* framelinvel / frameangvel :267-328 */
+    const REAL *cv = w->cvel + 6 * body, *cvr = w->cvel + 6 * rbody;
+    if (type == 32) {
+      if (rid < 0) return cv[comp];
+      REAL rel[3] = {cv[0] - cvr[0], cv[1] - cvr[1], cv[2] - cvr[2]}, o[3];
+      ROT_T(rmat, rel, o)
+      return o[comp];
+    }
+    const REAL *sc = w->subtree_com + 3 * root, *scr = w->subtree_com + 3 * rroot;
+    REAL off[3] = {xpos[0] - sc[0], xpos[1] - sc[1], xpos[2] - sc[2]}, c[3], xl[3];
+    FN(cross3)(off, cv, c);
+    for (int i = 0; i < 3; i++) xl[i] = cv[3 + i] - c[i];
+    if (rid < 0) return xl[comp];
+    REAL offr[3] = {rpos[0] - scr[0], rpos[1] - scr[1], rpos[2] - scr[2]}, cr[3], xlr[3], rvec[3] = {xpos[0] - rpos[0], xpos[1] - rpos[1], xpos[2] - rpos[2]}, cw[3], rel[3], o[3];
+    FN(cross3)(offr, cvr, cr);
+    for (int i = 0; i < 3; i++) xlr[i] = cvr[3 + i] - cr[i];
+    FN(cross3)(rvec, cvr, cw);
+    for (int i = 0; i < 3; i++) rel[i] = (xl[i] - xlr[i]) + cw[i];
+    ROT_T(rmat, rel, o)
+    return o[comp];
+  }
   const REAL* rot = w->site_xmat + 9 * obj;
   const REAL* pos = w->site_xpos + 3 * obj;
+  if (type == 6) { /* magnetometer :92-94 */
+    REAL mg[3] = {(REAL)m->magnetic_x, (REAL)m->magnetic_y, (REAL)m->magnetic_z}, o[3];
+    ROT_T(rot, mg, o)
+    return o[comp];
+  }
   if (type == 7) { /* rangefinder: ray along the site's z axis (sensor.py:94-108, ray.py:327-372) */
     REAL vec[3] = {rot[2], rot[5], rot[8]};
     double best = INFINITY;
@@ -2153,29 +2249,38 @@ static REAL FN(sensor_value)(const FN(MjoModel) * M, const FN(MjoWork) * w, int 
       const REAL *gm = w->geom_xmat + 9 * g, *gp = w->geom_xpos + 3 * g;
       REAL d3[3] = {pos[0] - gp[0], pos[1] - gp[1], pos[2] - gp[2]}, lp[3], lv[3];
       for (int i = 0; i < 3; i++) { lp[i] = gm[i] * d3[0] + gm[3 + i] * d3[1] + gm[6 + i] * d3[2]; lv[i] = gm[i] * vec[0] + gm[3 + i] * vec[1] + gm[6 + i] * vec[2]; }
-      double size[3] = {m->geom_size[3 * g], m->geom_size[3 * g + 1], m->geom_size[3 * g + 2]};
-      double dp[3] = {lp[0], lp[1], lp[2]}, dv[3] = {lv[0], lv[1], lv[2]};
-      double x = mjo_ray_geom(m->geom_type[g], size, dp, dv);
+      REAL size[3] = {M->geom_size[3 * g], M->geom_size[3 * g + 1], M->geom_size[3 * g + 2]};
+      double x = (double)FN(ray_geom)(m->geom_type[g], size, lp, lv);
       if (x < best) best = x;
     }
     return isinf(best) ? (REAL)-1 : (REAL)best;
   }
-  const REAL* cvel = w->cvel + 6 * body;
   const REAL* sc = w->subtree_com + 3 * root;
   REAL dif[3] = {pos[0] - sc[0], pos[1] - sc[1], pos[2] - sc[2]};
-#define ROT_T(v, o) for (int i_ = 0; i_ < 3; i_++) (o)[i_] = rot[i_] * (v)[0] + rot[3 + i_] * (v)[1] + rot[6 + i_] * (v)[2];
-  if (type == 3) { REAL o[3]; ROT_T(cvel, o) return o[comp]; } /* gyro :246-251 */
+  if (type == 4 || type == 5) { /* force :399-406, torque :407-416: from Data.cfrc_int, which no stage of the reference writes (smooth.rne_postconstraint does not exist there) */
+    REAL fz[6] = {0, 0, 0, 0, 0, 0}, o[3];
+    const REAL* cf = w->x_cfrc_int ? w->x_cfrc_int + 6 * body : fz;
+    if (type == 4) { ROT_T(rot, cf + 3, o) return o[comp]; }
+    REAL c[3], v[3];
+    FN(cross3)(dif, cf + 3, c);
+    for (int i = 0; i < 3; i++) v[i] = cf[i] - c[i];
+    ROT_T(rot, v, o)
+    return o[comp];
+  }
+  const REAL* cvel = w->cvel + 6 * body;
+  if (type == 3) { REAL o[3]; ROT_T(rot, cvel, o) return o[comp]; } /* gyro :246-251 */
   REAL c[3], v[3], lin[3];
   FN(cross3)(dif, cvel, c);
   for (int i = 0; i < 3; i++) v[i] = cvel[3 + i] - c[i];
-  ROT_T(v, lin)
+  ROT_T(rot, v, lin)
   if (type == 2) return lin[comp]; /* velocimeter :235-245 */
-  /* accelerometer :379-399 with Data.cacc, which no stage of the reference ever writes (zeros from make_data) */
-  REAL ang[3], zero[3] = {0, 0, 0}, ca[3], av[3], acc[3], corr[3];
-  ROT_T(cvel, ang)
-  FN(cross3)(dif, zero, ca);
-  for (int i = 0; i < 3; i++) av[i] = (REAL)0 - ca[i];
-  ROT_T(av, acc)
+  /* accelerometer :379-399 with Data.cacc, which no stage of the reference ever writes (the caller's leaf: zeros from make_data) */
+  REAL ang[3], zero[6] = {0, 0, 0, 0, 0, 0}, ca[3], av[3], acc[3], corr[3];
+  const REAL* cacc = w->x_cacc ? w->x_cacc + 6 * body : zero;
+  ROT_T(rot, cvel, ang)
+  FN(cross3)(dif, cacc, ca);
+  for (int i = 0; i < 3; i++) av[i] = cacc[3 + i] - ca[i];
+  ROT_T(rot, av, acc)
   FN(cross3)(ang, lin, corr);
 #undef ROT_T
   return (acc[comp] + corr[comp]) + 0; /* + gravity term, zero for mujoco >= 3.3.7 (sensor.py:36-38) */

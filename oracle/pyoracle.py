@@ -56,6 +56,19 @@ def data_to_numpy(d):
     return out
 
 
+EXTRA_IN = native.LISTS["MJH_DATA_EXTRA_IN"]  # input-only leaves the sensors read (cacc, cfrc_int, subtree_linvel, subtree_angmom); absent = zeros
+
+
+def extra_inputs(d):
+    """{name: numpy array} of the trailing input-only leaves the Data carries."""
+    out = {}
+    for n in EXTRA_IN:
+        t = d._fields.get(n) if hasattr(d, "_fields") else getattr(d, n, None)
+        if isinstance(t, torch.Tensor) and t.numel():
+            out[n] = np.array(t.detach().cpu().contiguous().numpy(), order="C", copy=True)
+    return out
+
+
 def _ptrs(arrs):
     p = native.DataPtrs()
     for n, a in arrs.items():
@@ -83,7 +96,8 @@ def run(m, d, step=True, stages=native.STAGE_ALL, fixed_iterations=False, nthrea
     batch = tuple(d.qpos.shape[:-1])
     B = int(np.prod(batch)) if batch else 1
     out = {n: np.array(a, copy=True) for n, a in inp.items()}
-    pin, pout = _ptrs(inp), _ptrs(out)
+    extra = extra_inputs(d)  # (kept alive until the call returns: the struct only holds raw addresses)
+    pin, pout = _ptrs({**inp, **extra}), _ptrs(out)
     flags = 1 if fixed_iterations else 0
     dt = 0 if dtype == torch.float64 else 1
     hint = None

@@ -41,6 +41,8 @@ SEEDED_CASES = [
     ("convex_primitives", {}, F32, 32, {}),
     ("sensor_rig", {}, F64, 64, dict(max_alt=0.0)),                             # sensors: IMU, rangefinders, joint sensors
     ("sensor_rig", {"integrator": 1}, F32, 64, {}),                             # ... RK4, float32 (rays intersect in double)
+    ("sensor_rig2", {}, F64, 64, dict(max_alt=0.0)),                            # every other sensor type sensor.py evaluates (frame, tendon, actuator, ball, subtree, clock, force / torque ...)
+    ("sensor_rig2", {"integrator": 1}, F32, 33, dict(tol_sol=2e-4)),            # ... RK4, float32
     ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, F64, 64, dict(max_alt=0.0)),  # fluid forces: density + viscosity + wind
     ("ant_frictionloss", {}, F64, 64, dict(max_alt=0.0)),                       # dof frictionloss rows, Newton
     ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG: stalls across frictionloss zone switches (measured 8.1e-7; Newton one line up: 1e-13)
@@ -117,6 +119,16 @@ def seeded_batch(xml, overrides, dtype, B):
         q[:, 3:7] += torch.tensor(0.2 * rng.randn(B, 4))
         q[:, 7:] += torch.tensor(0.3 * rng.randn(B, mx.nq - 7))
         d = d.replace(qpos=q, qvel=torch.tensor(0.5 * rng.randn(B, mx.nv)))
+    if xml == "sensor_rig2":  # every joint moved (the ball joint's quaternion left un-normalised), the Data leaves no stage writes but sensors read set per environment
+        q = d.qpos.clone()
+        q[:, :3] += torch.tensor(0.1 * rng.randn(B, 3))
+        q[:, 3:11] += torch.tensor(0.3 * rng.randn(B, 8))
+        q[:, 11:] += torch.tensor(np.array([0.6, 0.08]) * rng.randn(B, 2))
+        nb = int(mx.nbody)
+        d = d.replace(qpos=q, qvel=torch.tensor(0.6 * rng.randn(B, mx.nv)), ctrl=torch.tensor(np.clip(0.8 * rng.randn(B, mx.nu), -1.5, 1.5)),
+                      time=torch.tensor(0.003 * np.arange(B, dtype=np.float64)), sensordata=torch.tensor(rng.randn(B, int(mx.nsensordata))),
+                      cacc=torch.tensor(0.5 * rng.randn(B, nb, 6)), cfrc_int=torch.tensor(2.0 * rng.randn(B, nb, 6)),
+                      subtree_linvel=torch.tensor(rng.randn(B, nb, 3)), subtree_angmom=torch.tensor(rng.randn(B, nb, 3)))
     if dtype != torch.float64:
         d = d.to(dtype)
     return mx, d
@@ -128,7 +140,7 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("ant", {}, F64, 1e-8), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, F32, 5e-3), ("ant", {"solver": 1, "cone": 1}, F64, 1e-5),
     ("halfcheetah", {}, F64, 1e-8), ("hopper", {}, F64, 1e-8), ("walker2d", {"integrator": 1}, F64, 1e-8),
     ("swimmer", {"viscosity": 0.05}, F64, 1e-8), ("cartpole", {}, F64, 1e-8), ("satellite_small", {}, F64, 1e-8),
-    ("sensor_rig", {}, F64, 1e-8), ("mesh_contact", {}, F64, 1e-8), ("mesh_contact", {"integrator": 1}, F64, 1e-8), ("convex_primitives", {}, F64, 1e-8),
+    ("sensor_rig", {}, F64, 1e-8), ("sensor_rig2", {}, F64, 1e-8), ("mesh_contact", {}, F64, 1e-8), ("mesh_contact", {"integrator": 1}, F64, 1e-8), ("convex_primitives", {}, F64, 1e-8),
     ("equality_loops", {}, F64, 1e-8), ("equality", {}, F64, 1e-8), ("ball_limits", {}, F64, 1e-8),
     ("tendon_fixed", {}, F64, 1e-8), ("gravcomp_arm", {}, F64, 1e-8), ("gravcomp_arm", {"integrator": 1}, F64, 1e-8), ("ball_free_actuators", {}, F64, 1e-8),
     ("mocap_target", {}, F64, 1e-8), ("pendula", {}, F64, 1e-8), ("pendula", {"integrator": 1, "solver": 1}, F32, 5e-3),
@@ -161,6 +173,10 @@ def fuzz_batch(xml, overrides, dtype, B):
     if mx.neq:
         kw["eq_active"] = torch.tensor(rng.randint(0, 2, size=(B, mx.neq)), dtype=torch.int32) * d.eq_active.clamp(max=1) + d.eq_active * 0
         kw["eq_active"] = torch.where(torch.tensor(rng.rand(B, mx.neq) < 0.3), torch.zeros_like(d.eq_active), d.eq_active)
+    if mx.tables.sensors["extra_leaves"]:  # sensors reading Data leaves no stage writes: every such leaf randomised, like the other inputs
+        for n, w in (("cacc", 6), ("cfrc_int", 6), ("subtree_linvel", 3), ("subtree_angmom", 3)):
+            kw[n] = torch.tensor(rng.randn(B, int(mx.nbody), w))
+        kw["sensordata"] = torch.tensor(rng.randn(B, int(mx.nsensordata)))
     d = d.replace(**kw)
     if dtype != torch.float64:
         d = d.to(dtype)

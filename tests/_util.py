@@ -13,6 +13,7 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 REAL_LEAVES = native.LISTS["MJH_DATA_REALS"]
 INT_LEAVES = native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
+EXTRA_INPUTS = ["sensordata", "cacc", "cfrc_int", "subtree_linvel", "subtree_angmom"]  # inputs only some recordings set (oracle/gen_golden.py)
 INPUT_LEAVES = ["time", "qpos", "qvel", "act", "qacc_warmstart", "ctrl", "qfrc_applied", "xfrc_applied", "qacc", "subtree_com", "mocap_pos", "mocap_quat"]
 
 OUTLIER_CASES = sorted(f[:-4] for f in os.listdir(os.path.join(GOLD, "outliers")) if f.endswith(".npz")) if os.path.isdir(os.path.join(GOLD, "outliers")) else []
@@ -67,6 +68,7 @@ class Golden:
             if self.dtype != torch.float64:
                 d = d.to(self.dtype)
             kw = {n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in INPUT_LEAVES}
+            kw.update({n: torch.from_numpy(self.z[f"in/{e}/{n}"].copy()) for n in EXTRA_INPUTS if f"in/{e}/{n}" in self.z.files})
             return d.replace(**kw)
 
         if env is not None:

@@ -35,8 +35,8 @@ def test_field_lists_match_header(lib):
 
 
 def test_struct_sizes_match_binding(lib):
-    n_data = len(native.LISTS["MJH_DATA_REALS"]) + len(native.LISTS["MJH_DATA_I32"]) + len(native.LISTS["MJH_DATA_I64"])
-    assert ctypes.sizeof(native.DataPtrs) == 8 * n_data
+    n_data = len(native.LISTS["MJH_DATA_REALS"]) + len(native.LISTS["MJH_DATA_I32"]) + len(native.LISTS["MJH_DATA_I64"]) + len(native.LISTS["MJH_DATA_EXTRA_IN"])
+    assert ctypes.sizeof(native.DataPtrs) == 8 * n_data == lib.mjh_sizeof_data()
 
 
 def test_oracle_exports():

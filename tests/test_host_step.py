@@ -36,7 +36,7 @@ def assert_same(got, want, names=REAL_LEAVES + INT_LEAVES):
 
 @pytest.mark.parametrize("xml,overrides,dtype,B", [
     ("humanoid", {"solver": 1}, torch.float64, 5), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 3),
-    ("mesh_contact", {}, torch.float64, 2), ("cartpole", {}, torch.float64, 0), ("pendula", {}, torch.float64, 2),
+    ("mesh_contact", {}, torch.float64, 2), ("cartpole", {}, torch.float64, 0), ("pendula", {}, torch.float64, 2), ("sensor_rig2", {}, torch.float64, 3),
 ])
 def test_step_and_forward_fill_every_leaf_like_the_backend(sim, xml, overrides, dtype, B):
     """The Data returned by step / forward holds, leaf for leaf, what the backend wrote (written leaves) or the caller's
@@ -398,3 +398,31 @@ def test_reassigned_unbatched_leaf_is_seen_by_the_stamp(sim):
         w = mx._fields[wrapped[0]]
         w.data = w.data.clone()
         assert not native._same_stamp(s0, native._stamp(mx))
+
+
+def test_sensors_read_the_data_leaves_no_stage_writes(sim):
+    """force / torque / accelerometer / subtree momentum sensors read Data.cfrc_int / cacc / subtree_linvel / subtree_angmom, which no
+    stage of the reference writes (sensor.py:383-416, 261-266): the caller's values reach the library through the trailing pointers of mjhData."""
+    import xml.etree.ElementTree as ET
+
+    mx = load_model("sensor_rig2")
+    assert mx.tables.sensors["extra_leaves"] == ("cacc", "cfrc_int", "subtree_angmom", "subtree_linvel")
+    d = seeded(mx, 2)
+    base = mt.step(mx, d)
+    nb = int(mx.nbody)
+    rng = np.random.RandomState(3)
+    d2 = d.replace(cfrc_int=torch.tensor(rng.randn(2, nb, 6)), cacc=torch.tensor(rng.randn(2, nb, 6)), subtree_linvel=torch.tensor(rng.randn(2, nb, 3)),
+                   subtree_angmom=torch.tensor(rng.randn(2, nb, 3)).transpose(0, 1).contiguous().transpose(0, 1))  # (one of them strided: copied per call)
+    got = mt.step(mx, d2)
+    assert_same(got, pyoracle.run(mx, d2, step=True))
+    sens = list(ET.parse(mt.test_data_path("sensor_rig2.xml")).getroot().find("sensor"))
+    adr = 0
+    for sn in sens:
+        dim = {"ballquat": 4, "framequat": 4}.get(sn.tag, 1 if sn.tag in ("touch", "jointpos", "jointvel", "tendonpos", "tendonvel", "actuatorpos", "actuatorvel", "actuatorfrc", "jointactuatorfrc",
+                                                                              "tendonactuatorfrc", "jointlimitpos", "e_potential", "clock") else 3)
+        changed = not torch.equal(got.sensordata[:, adr : adr + dim], base.sensordata[:, adr : adr + dim])
+        assert changed == (sn.tag in ("force", "torque", "accelerometer", "subtreelinvel", "subtreeangmom")), sn.tag
+        adr += dim
+    assert adr == int(mx.nsensordata)
+    with pytest.raises(ValueError, match="cfrc_int"):
+        mt.step(mx, d.replace(cfrc_int=torch.zeros(2, nb, 5, dtype=torch.float64)))
