@@ -138,7 +138,62 @@ def _bool(s):
     return s.strip().lower() == "true"
 
 
-_ACT_TAGS = ("motor", "position", "velocity", "general", "intvelocity", "damper", "muscle")
+_ACT_TAGS = ("motor", "position", "velocity", "general", "intvelocity", "damper", "cylinder", "muscle")
+
+
+class _Attrs(dict):
+    """Attribute dict that records which keys the compiler looked at.  Every XML element is read through one of these (its own, or a
+    copy merged with default classes that forwards to it): after the build, an attribute nobody looked at is an attribute this
+    compiler does not honour -- reported instead of silently dropped ("refuse or honour, never ignore")."""
+
+    __slots__ = ("used", "sinks")
+
+    def __init__(self, *args, sinks=(), **kw):
+        super().__init__(*args, **kw)
+        self.used = set()
+        self.sinks = list(sinks)
+
+    def _mark(self, k):
+        self.used.add(k)
+        for s in self.sinks:
+            s._mark(k)
+
+    def __getitem__(self, k):
+        self._mark(k)
+        return dict.__getitem__(self, k)
+
+    def get(self, k, d=None):
+        self._mark(k)
+        return dict.get(self, k, d)
+
+    def __contains__(self, k):
+        self._mark(k)
+        return dict.__contains__(self, k)
+
+    def pop(self, k, *d):
+        self._mark(k)
+        return dict.pop(self, k, *d)
+
+    def mark_all(self):
+        for k in list(dict.keys(self)):
+            self._mark(k)
+
+
+# elements that never reach the physics (skipped with everything below them) ...
+_COSMETIC_ELEMENTS = {"visual", "size", "texture", "material", "skin", "text", "tuple"}
+# ... and attributes that do not either, on any element
+_COSMETIC_ATTRS = {"rgba", "material", "group", "user", "class", "childclass", "name", "fovy", "ipd", "resolution", "focal", "focalpixel", "principal", "principalpixel", "sensorsize",
+                   "orthographic", "directional", "castshadow", "active", "attenuation", "cutoff_light", "exponent", "ambient", "diffuse", "specular", "bulbradius", "intensity", "range_light",
+                   "texcoord", "smoothnormal", "extent", "center", "meansize", "meanmass", "texture"}
+# children each element may have (anything else is refused); None = any child is handled by that section's own check
+_CHILDREN = {
+    "mujoco": {"compiler", "option", "size", "visual", "statistic", "default", "custom", "asset", "worldbody", "contact", "equality", "tendon", "actuator", "sensor", "keyframe"},
+    "option": {"flag"}, "custom": {"numeric", "text", "tuple"}, "asset": {"mesh", "texture", "material", "skin"},
+    "worldbody": {"body", "geom", "site", "camera", "light", "frame"}, "body": {"body", "geom", "site", "camera", "light", "joint", "freejoint", "inertial", "frame"},
+    "frame": {"body", "geom", "site", "camera", "light", "frame"},
+    "contact": {"pair", "exclude"}, "equality": {"connect", "weld", "joint"}, "tendon": {"fixed", "spatial"}, "fixed": {"joint"}, "spatial": {"site", "geom", "pulley"},
+    "actuator": set(_ACT_TAGS), "keyframe": {"key"}, "default": None, "sensor": None,
+}
 
 
 class _Defaults:
@@ -413,6 +468,22 @@ class _Compiler:
         self.lights = []
         self.opt = {}
         self.stat_meaninertia = None
+        self._trackers = {}   # id(element) -> (element, _Attrs of its own attributes)
+        self._consumed = {}   # tag -> attribute names looked at on ANY element of that tag (validates the default classes)
+
+    def _t(self, node):
+        """The tracked attribute dict of an element (one per element)."""
+        hit = self._trackers.get(id(node))
+        if hit is None:
+            hit = (node, _Attrs(node.attrib))
+            self._trackers[id(node)] = hit
+        return hit[1]
+
+    def _merged(self, node, base=None):
+        """A working copy of an element's attributes on top of `base` (default-class values): lookups are recorded on the element."""
+        a = _Attrs(base or {}, sinks=[self._t(node)])
+        a.update(node.attrib)
+        return a
 
     # ---- orientation -------------------------------------------------
     def _ang(self, x):
@@ -466,22 +537,22 @@ class _Compiler:
         cls = node.get("class", childclass or "main")
         if cls not in self.defaults:
             raise ValueError(f"unknown default class {cls!r}")
-        a = dict(self.defaults[cls].get(node.tag))
-        a.pop("__tag__", None)
+        self._t(node).get("class")
+        base = dict(self.defaults[cls].get(node.tag))
+        base.pop("__tag__", None)
         own = dict(node.attrib)
         # an element's own orientation / fromto spec replaces (not merges with) a defaulted one
         orient = ("quat", "axisangle", "euler", "xyaxes", "zaxis")
         if any(k in own for k in orient) or "fromto" in own:
             for k in orient:
-                a.pop(k, None)
-        a.update(own)
-        return a
+                base.pop(k, None)
+        return self._merged(node, base)
 
     # ---- top-level sections -------------------------------------------
     def parse(self):
         root = self.root
         for comp in root.findall("compiler"):
-            c = comp.attrib
+            c = self._t(comp)
             if "angle" in c:
                 self.angle_deg = c["angle"] == "degree"
             if "autolimits" in c:
@@ -503,12 +574,11 @@ class _Compiler:
         for dnode in root.findall("default"):
             self._parse_defaults(dnode, None)
         for st in root.findall("statistic"):
-            if "meaninertia" in st.attrib:
-                self.stat_meaninertia = float(st.get("meaninertia"))
+            if "meaninertia" in self._t(st):
+                self.stat_meaninertia = float(self._t(st).get("meaninertia"))
         for asset in root.findall("asset"):
             for mesh in asset.findall("mesh"):
-                a = dict(self.defaults["main"].get("mesh"))
-                a.update(mesh.attrib)
+                a = self._merged(mesh, dict(self.defaults["main"].get("mesh")))
                 name = a.get("name") or os.path.splitext(os.path.basename(a["file"]))[0]
                 self.meshes[name] = a
         self._parse_option()
@@ -545,7 +615,7 @@ class _Compiler:
             sdf_initpoints=40,
         )
         for on in self.root.findall("option"):
-            a = on.attrib
+            a = self._t(on)
             for k in ("timestep", "density", "viscosity", "impratio", "tolerance", "ls_tolerance", "o_margin"):
                 if k in a:
                     o[k] = float(a[k])
@@ -565,6 +635,8 @@ class _Compiler:
                 o["jacobian"] = {"dense": JacobianType.DENSE, "sparse": JacobianType.SPARSE, "auto": JacobianType.AUTO}[a["jacobian"].lower()]
             for fl in on.findall("flag"):
                 for k, v in fl.attrib.items():
+                    if k in _DISABLE_FLAGS or k in _ENABLE_FLAGS:
+                        self._t(fl).get(k)
                     if k in _DISABLE_FLAGS:
                         if v == "disable":
                             o["disableflags"] |= int(_DISABLE_FLAGS[k])
@@ -578,16 +650,37 @@ class _Compiler:
         self.opt = o
 
     # ---- kinematic tree -------------------------------------------------
-    def _parse_body_children(self, node, body_id, childclass):
+    def _in_frame(self, a, frame):
+        """Pose of an element declared inside <frame> elements, re-expressed in the enclosing body: p' = fp + R(fq) p, q' = fq * q (both endpoints of a fromto)."""
+        if frame is None:
+            return a
+        fp, fq = frame
+        if "fromto" in a:
+            ft = _floats(a["fromto"])
+            p0, p1 = fp + _rotate(ft[:3], fq), fp + _rotate(ft[3:], fq)
+            a["fromto"] = " ".join(repr(float(x)) for x in np.concatenate([p0, p1]))
+            return a
+        q = self._orientation(a)
+        pos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
+        for k in ("quat", "axisangle", "euler", "xyaxes", "zaxis"):
+            a.pop(k, None)
+        a["pos"] = " ".join(repr(float(x)) for x in fp + _rotate(pos, fq))
+        a["quat"] = " ".join(repr(float(x)) for x in _quat_mul(fq, q))
+        return a
+
+    def _parse_body_children(self, node, body_id, childclass, frame=None):
         body = self.bodies[body_id]
         for child in node:
             tag = child.tag
             if tag == "inertial":
-                a = child.attrib
-                body["inertial"] = dict(a)
+                if frame is not None:
+                    raise ValueError("<inertial> belongs to a body, not to a <frame>")
+                body["inertial"] = self._merged(child)
             elif tag in ("joint", "freejoint"):
+                if frame is not None:
+                    raise ValueError("<joint> belongs to a body, not to a <frame>")
                 if tag == "freejoint":
-                    a = dict(child.attrib)
+                    a = self._merged(child)
                     a["type"] = "free"
                 else:
                     a = self._resolve(child, childclass)
@@ -595,31 +688,47 @@ class _Compiler:
                 body["joints"].append(len(self.joints))
                 self.joints.append(a)
             elif tag == "geom":
-                a = self._resolve(child, childclass)
+                a = self._in_frame(self._resolve(child, childclass), frame)
                 a["__body__"] = body_id
                 body["geoms"].append(len(self.geoms))
                 self.geoms.append(a)
             elif tag == "site":
-                a = self._resolve(child, childclass)
+                a = self._in_frame(self._resolve(child, childclass), frame)
                 a["__body__"] = body_id
                 self.sites.append(a)
             elif tag == "camera":
-                a = self._resolve(child, childclass)
+                a = self._in_frame(self._resolve(child, childclass), frame)
                 a["__body__"] = body_id
                 self.cams.append(a)
             elif tag == "light":
                 a = self._resolve(child, childclass)
+                if frame is not None:  # (a light has a position and a direction, no orientation)
+                    fp, fq = frame
+                    a["pos"] = " ".join(repr(float(x)) for x in fp + _rotate(_floats(a["pos"]) if "pos" in a else np.zeros(3), fq))
+                    a["dir"] = " ".join(repr(float(x)) for x in _rotate(_floats(a["dir"]) if "dir" in a else np.array([0.0, 0.0, -1.0]), fq))
                 a["__body__"] = body_id
                 self.lights.append(a)
         for child in node:
+            if child.tag == "frame":  # <frame>: a pure coordinate transformation of what it contains (no body, no dofs); frames nest
+                a = self._t(child)
+                fpos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
+                fquat = self._orientation(a)
+                if frame is not None:
+                    fpos, fquat = frame[0] + _rotate(fpos, frame[1]), _quat_mul(frame[1], fquat)
+                self._parse_body_children(child, body_id, a.get("childclass", childclass), (fpos, fquat))
+        for child in node:
             if child.tag == "body":
-                a = child.attrib
+                a = self._t(child)
                 cc = a.get("childclass", childclass)
+                bpos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
+                bquat = self._orientation(a)
+                if frame is not None:
+                    bpos, bquat = frame[0] + _rotate(bpos, frame[1]), _quat_mul(frame[1], bquat)
                 nb = dict(
                     name=a.get("name", ""),
                     parent=body_id,
-                    pos=_floats(a["pos"]) if "pos" in a else np.zeros(3),
-                    quat=self._orientation(a),
+                    pos=bpos,
+                    quat=bquat,
                     inertial=None,
                     mocap=_bool(a.get("mocap", "false")),
                     gravcomp=float(a.get("gravcomp", 0.0)),
@@ -702,6 +811,7 @@ class _Compiler:
                 jnt_dofadr.append(nv)
                 jnt_bodyid.append(bi)
                 if jt == JointType.FREE:
+                    a.get("pos")  # (a free joint sits at its body's origin whatever the attribute says: MuJoCo ignores it too)
                     jnt_pos.append(np.zeros(3))
                 else:
                     jnt_pos.append(_floats(a["pos"]) if "pos" in a else np.zeros(3))
@@ -841,7 +951,58 @@ class _Compiler:
         _set_const(m, self.stat_meaninertia)
         _equality_set0(m)
         self._auto_spring_damper(m)
+        self._validate_consumed()
         return m
+
+    def _validate_consumed(self):
+        """Refuse or honour, never ignore: every element of the document must be one this compiler handles, and every attribute must have been looked at while
+        it did (cosmetic ones -- colours, materials, camera intrinsics, light properties, rendering groups -- excepted).  MuJoCo's own compiler rejects unknown
+        elements / attributes through its schema; what it accepts and this subset does not model (composite, flex, plugins, hfields, ...) raises here."""
+        root = self.root
+
+        def walk(node, path):
+            allowed = _CHILDREN.get(node.tag, set())
+            for child in node:
+                if child.tag in _COSMETIC_ELEMENTS:
+                    continue
+                if allowed is not None and child.tag not in allowed:
+                    raise NotImplementedError(f"MJCF element <{child.tag}> inside <{node.tag}> is not supported by this compiler ({path})")
+                if node.tag == "default" and child.tag != "default":
+                    continue  # (default-class attributes: checked against what the elements of that tag consumed, below)
+                if child.tag in ("default",):
+                    walk(child, path + "/default")
+                    continue
+                trk = self._trackers.get(id(child))
+                used = trk[1].used if trk is not None else set()
+                self._consumed.setdefault(child.tag, set()).update(used)
+                extra = [k for k in child.attrib if k not in used and k not in _COSMETIC_ATTRS]
+                if child.tag in ("light",):
+                    extra = [k for k in extra if k in ("mode", "target")]  # (lights never reach the physics: only their tracking modes are read)
+                if child.tag in ("statistic",):
+                    extra = []
+                if extra:
+                    raise NotImplementedError(f"MJCF attribute(s) {extra} of <{child.tag} name={child.get('name', '')!r}> are not honoured by this compiler ({path}/{child.tag})")
+                walk(child, path + "/" + child.tag)
+
+        walk(root, "mujoco")
+        # default classes: an attribute given for a tag must be one the compiler reads on elements of that tag (when the model has any)
+        def walk_defaults(node):
+            for child in node:
+                if child.tag == "default":
+                    walk_defaults(child)
+                    continue
+                key = "actuator" if child.tag in _ACT_TAGS else child.tag
+                seen = set()
+                for t, u in self._consumed.items():
+                    if ("actuator" if t in _ACT_TAGS else t) == key:
+                        seen |= u
+                if not seen:
+                    continue
+                extra = [k for k in child.attrib if k not in seen and k not in _COSMETIC_ATTRS]
+                if extra and child.tag != "light":
+                    raise NotImplementedError(f"MJCF default attribute(s) {extra} of <{child.tag}> are not honoured by this compiler")
+        for dn in root.findall("default"):
+            walk_defaults(dn)
 
     def _auto_spring_damper(self, m):
         """joint springdamper="timeconst dampratio": stiffness and damping of the 1-dof mass-spring-damper with the joint's
@@ -981,6 +1142,9 @@ class _Compiler:
         m.geom_matid = -np.ones(ngeom, dtype=np.int32)
         m.geom_sameframe = np.zeros(ngeom, dtype=np.uint8)
         m.geom_fluid = np.zeros((ngeom, 12))
+        for g in G:  # the ellipsoid fluid model (per-geom interaction coefficients) is not modelled: only the inertia-box model of option density / viscosity is
+            if g.get("fluidshape", "none") != "none":
+                raise NotImplementedError("geom fluidshape='ellipsoid' (the ellipsoid fluid-interaction model) is not supported")
         # bounding radius / aabb (setup-only consumers)
         rb = []
         for gi in range(ngeom):
@@ -1138,11 +1302,10 @@ class _Compiler:
         pairs, excl = [], []
         for cn in self.root.findall("contact"):
             for p in cn.findall("pair"):
-                a = dict(self.defaults[p.get("class", "main")].get("pair"))
-                a.update(p.attrib)
+                a = self._merged(p, dict(self.defaults[self._t(p).get("class", "main")].get("pair")))
                 pairs.append(a)
             for e in cn.findall("exclude"):
-                excl.append(e.attrib)
+                excl.append(self._t(e))
         rows = []
         for a in pairs:
             g1, g2 = m.names_geom.index(a["geom1"]), m.names_geom.index(a["geom2"])
@@ -1210,9 +1373,9 @@ class _Compiler:
             for node in an:
                 if node.tag not in _ACT_TAGS:
                     raise NotImplementedError(f"actuator <{node.tag}> not supported")
-                a = dict(self.defaults[node.get("class", "main")].get(node.tag))
-                a.pop("__tag__", None)
-                a.update(node.attrib)
+                base = dict(self.defaults[self._t(node).get("class", "main")].get(node.tag))
+                base.pop("__tag__", None)
+                a = self._merged(node, base)
                 a["__tag__"] = node.tag
                 acts.append(a)
         nu = len(acts)
@@ -1279,6 +1442,16 @@ class _Compiler:
                 m.actuator_gainprm[i, 0] = kp
                 m.actuator_biastype[i] = BiasType.AFFINE
                 m.actuator_biasprm[i, :3] = [0.0, -kp, -kv]
+            elif tag == "cylinder":  # pneumatic / hydraulic cylinder (MuJoCo XML reference): dyntype filter, gaintype fixed (area), biastype affine
+                area = float(a.get("area", 1.0))
+                if "diameter" in a:
+                    area = math.pi / 4.0 * float(a["diameter"]) ** 2
+                m.actuator_dyntype[i] = DynType.FILTER
+                m.actuator_dynprm[i, 0] = float(a.get("timeconst", 1.0))
+                m.actuator_gainprm[i, 0] = area
+                m.actuator_biastype[i] = BiasType.AFFINE
+                bias = _floats(a.get("bias", "0 0 0"))
+                m.actuator_biasprm[i, : len(bias[:3])] = bias[:3]
             elif tag == "damper":  # force = -kv * velocity * ctrl (affine gain on the velocity), ctrl >= 0
                 kv = float(a.get("kv", 1.0))
                 m.actuator_gaintype[i] = GainType.AFFINE
@@ -1354,7 +1527,7 @@ class _Compiler:
         lists = {ObjType.BODY: m.names_body, ObjType.XBODY: m.names_body, ObjType.GEOM: m.names_geom, ObjType.SITE: m.names_site, ObjType.CAMERA: m.names_cam}
 
         def lookup(sn, kind, names, attr):
-            name = sn.get(attr)
+            name = self._t(sn).get(attr)
             if name is None or name not in names:
                 raise ValueError(f"sensor <{sn.tag}>: {kind} {name!r} not found")
             return names.index(name)
@@ -1369,9 +1542,9 @@ class _Compiler:
                 ot, oi = int(ObjType.JOINT), lookup(sn, "joint", m.names_jnt, "joint")
                 jt = int(m.jnt_type[oi])
                 if sn.tag in ("ballquat", "ballangvel") and jt != int(JointType.BALL):
-                    raise ValueError(f"sensor <{sn.tag}>: joint {sn.get('joint')!r} must be a ball joint")
+                    raise ValueError(f"sensor <{sn.tag}>: joint {self._t(sn).get('joint')!r} must be a ball joint")
                 if sn.tag in ("jointpos", "jointvel", "jointlimitpos", "jointlimitvel", "jointlimitfrc") and jt not in (int(JointType.SLIDE), int(JointType.HINGE)):
-                    raise ValueError(f"sensor <{sn.tag}>: joint {sn.get('joint')!r} must be a slide or hinge joint")
+                    raise ValueError(f"sensor <{sn.tag}>: joint {self._t(sn).get('joint')!r} must be a slide or hinge joint")
             elif attach == "tendon":
                 ot, oi = int(ObjType.TENDON), lookup(sn, "tendon", getattr(m, "names_tendon", []), "tendon")
             elif attach == "actuator":
@@ -1379,13 +1552,13 @@ class _Compiler:
             elif attach == "body":
                 ot, oi = int(ObjType.BODY), lookup(sn, "body", m.names_body, "body")
             elif attach == "frame":
-                kind = sn.get("objtype")
+                kind = self._t(sn).get("objtype")
                 if kind not in _OBJTYPE_NAMES:
                     raise ValueError(f"sensor <{sn.tag}>: objtype must be one of {sorted(_OBJTYPE_NAMES)}, got {kind!r}")
                 ot = int(_OBJTYPE_NAMES[kind])
                 oi = lookup(sn, kind, lists[_OBJTYPE_NAMES[kind]], "objname")
-                if sn.get("reftype") is not None or sn.get("refname") is not None:
-                    rkind = sn.get("reftype")
+                if self._t(sn).get("reftype") is not None or self._t(sn).get("refname") is not None:
+                    rkind = self._t(sn).get("reftype")
                     if rkind not in _OBJTYPE_NAMES:
                         raise ValueError(f"sensor <{sn.tag}>: reftype must be one of {sorted(_OBJTYPE_NAMES)}, got {rkind!r}")
                     rt = int(_OBJTYPE_NAMES[rkind])
@@ -1399,7 +1572,7 @@ class _Compiler:
         m.sensor_datatype = np.array([_SENSOR_DIMS[s.tag][3] for s in sens], dtype=np.int32)
         m.sensor_reftype = np.array(reftype, dtype=np.int32)
         m.sensor_refid = np.array(refid, dtype=np.int32)
-        m.sensor_cutoff = np.array([float(s.get("cutoff", 0.0)) for s in sens], dtype=np.float64)
+        m.sensor_cutoff = np.array([float(self._t(s).get("cutoff", 0.0)) for s in sens], dtype=np.float64)
 
     def _build_equality(self, m):
         """<equality>: connect / weld / joint (body form; site form is compiled to site ids like MuJoCo does).
@@ -1422,9 +1595,9 @@ class _Compiler:
         for i, node in enumerate(nodes):
             if node.tag not in kinds:
                 raise NotImplementedError(f"equality type <{node.tag}> is outside this build's MJCF subset (connect, weld, joint)")
-            a = dict(self.defaults[node.get("class", "main")].get("equality"))
-            a.pop("__tag__", None)
-            a.update(node.attrib)
+            base = dict(self.defaults[self._t(node).get("class", "main")].get("equality"))
+            base.pop("__tag__", None)
+            a = self._merged(node, base)
             m.names_eq.append(a.get("name", ""))
             m.eq_type[i] = kinds[node.tag]
             m.eq_active0[i] = _bool(a.get("active", "true"))
@@ -1484,20 +1657,41 @@ class _Compiler:
         m.tendon_solimp_fri = np.tile(_DEF_SOLIMP, (nt, 1)).reshape(nt, 5)
         wrap_type, wrap_objid, wrap_prm = [], [], []
         for i, node in enumerate(nodes):
-            if node.tag != "fixed":
-                raise NotImplementedError("only <fixed> tendons are inside this build's MJCF subset (spatial tendons need wrapping)")
-            a = dict(self.defaults[node.get("class", "main")].get("tendon"))
-            a.pop("__tag__", None)
-            a.update(node.attrib)
+            if node.tag not in ("fixed", "spatial"):
+                raise NotImplementedError(f"tendon <{node.tag}> is not an MJCF tendon element (fixed, spatial)")
+            base = dict(self.defaults[self._t(node).get("class", "main")].get("tendon"))
+            base.pop("__tag__", None)
+            a = self._merged(node, base)
             m.names_tendon.append(a.get("name", ""))
             m.tendon_adr[i] = len(wrap_type)
-            for jn in node.findall("joint"):
-                j = m.names_jnt.index(jn.get("joint"))
+            if node.tag == "spatial":
+                # <spatial>: the path as MuJoCo's wrap objects -- site (mjWRAP_SITE 3), sphere / cylinder geom with an optional side site (4 / 5), pulley (2).
+                # device_put carries site-only paths in the form the reference evaluates them (zero length and Jacobian, smooth.py:470-497) and refuses the rest.
+                for wn in node:
+                    w = self._t(wn)
+                    if wn.tag == "site":
+                        wrap_type.append(3); wrap_objid.append(m.names_site.index(w["site"])); wrap_prm.append(0.0)
+                    elif wn.tag == "geom":
+                        g = m.names_geom.index(w["geom"])
+                        gt = int(m.geom_type[g])
+                        if gt not in (int(GeomType.SPHERE), int(GeomType.CYLINDER)):
+                            raise ValueError("a tendon wraps sphere or cylinder geoms")
+                        wrap_type.append(4 if gt == int(GeomType.SPHERE) else 5); wrap_objid.append(g)
+                        wrap_prm.append(float(m.names_site.index(w["sidesite"])) if "sidesite" in w else -1.0)
+                    elif wn.tag == "pulley":
+                        wrap_type.append(2); wrap_objid.append(-1); wrap_prm.append(float(w["divisor"]))
+                    else:
+                        raise NotImplementedError(f"<spatial> tendon child <{wn.tag}>")
+                for k in ("width",):
+                    a.get(k)  # (rendering only)
+            for jn in (node.findall("joint") if node.tag == "fixed" else []):
+                jt = self._t(jn)
+                j = m.names_jnt.index(jt.get("joint"))
                 if int(m.jnt_type[j]) not in (int(JointType.SLIDE), int(JointType.HINGE)):
                     raise ValueError("fixed tendons act on slide / hinge joints")
                 wrap_type.append(1)  # mjWRAP_JOINT
                 wrap_objid.append(j)
-                wrap_prm.append(float(jn.get("coef")))
+                wrap_prm.append(float(jt.get("coef")))
             m.tendon_num[i] = len(wrap_type) - int(m.tendon_adr[i])
             has_range = "range" in a
             if has_range:
@@ -1533,13 +1727,13 @@ class _Compiler:
         m.nuserdata = 0
         adr, data, nadr, names = [], [], [], b""
         for n in nums:
-            vals = _floats(n.get("data", "0"))
-            size = int(n.get("size", len(vals)))
+            vals = _floats(self._t(n).get("data", "0"))
+            size = int(self._t(n).get("size", len(vals)))
             vals = (list(vals) + [0.0] * size)[:size]
             adr.append(len(data))
             data.extend(vals)
             nadr.append(len(names))
-            names += n.get("name", "").encode("utf-8") + b"\x00"
+            names += self._t(n).get("name", "").encode("utf-8") + b"\x00"
         m.numeric_adr = np.array(adr, dtype=np.int32)
         m.numeric_size = np.array([int(n.get("size", len(_floats(n.get("data", "0"))))) for n in nums], dtype=np.int32)
         m.numeric_data = np.array(data, dtype=np.float64)
@@ -1553,16 +1747,16 @@ class _Compiler:
         m.key_qvel = np.zeros((m.nkey, m.nv))
         m.key_ctrl = np.zeros((m.nkey, m.nu))
         m.key_time = np.zeros(m.nkey)
-        m.names_key = [k.get("name", "") for k in keys]
+        m.names_key = [self._t(k).get("name", "") for k in keys]
         for i, k in enumerate(keys):
-            if "qpos" in k.attrib:
-                m.key_qpos[i] = _floats(k.get("qpos"))
-            if "qvel" in k.attrib:
-                m.key_qvel[i] = _floats(k.get("qvel"))
-            if "ctrl" in k.attrib:
-                m.key_ctrl[i] = _floats(k.get("ctrl"))
-            if "time" in k.attrib:
-                m.key_time[i] = float(k.get("time"))
+            if "qpos" in self._t(k):
+                m.key_qpos[i] = _floats(self._t(k).get("qpos"))
+            if "qvel" in self._t(k):
+                m.key_qvel[i] = _floats(self._t(k).get("qvel"))
+            if "ctrl" in self._t(k):
+                m.key_ctrl[i] = _floats(self._t(k).get("ctrl"))
+            if "time" in self._t(k):
+                m.key_time[i] = float(self._t(k).get("time"))
 
 
 # --------------------------------------------------------------------------
@@ -1693,7 +1887,23 @@ def _set_const(m, stat_meaninertia=None):
     ten_J = np.zeros((m.ntendon, nv))
     for t in range(m.ntendon):
         a, n = int(m.tendon_adr[t]), int(m.tendon_num[t])
-        for w_ in range(a, a + n):
+        if n and int(m.wrap_type[a]) != 1:
+            # a spatial tendon (mj_tendon at qpos0): over site-only paths the length is the sum of the segment lengths and the Jacobian the sum of
+            # (J_site[k+1] - J_site[k]) . direction; paths with wrapping geoms or pulleys are left at zero here -- device_put refuses them anyway
+            if all(int(m.wrap_type[w_]) == 3 for w_ in range(a, a + n)):
+                site_x = lambda sid: xpos[int(m.site_bodyid[sid])] + xmat[int(m.site_bodyid[sid])] @ m.site_pos[sid]
+                for w_ in range(a, a + n - 1):
+                    s0, s1 = int(m.wrap_objid[w_]), int(m.wrap_objid[w_ + 1])
+                    p0, p1 = site_x(s0), site_x(s1)
+                    seg = p1 - p0
+                    ln = float(np.linalg.norm(seg))
+                    m.tendon_length0[t] += ln
+                    if ln > 1e-15 and nv:
+                        j0, _ = _body_jac(m, int(m.site_bodyid[s0]), p0, xpos, xmat, xanchor, xaxis)
+                        j1, _ = _body_jac(m, int(m.site_bodyid[s1]), p1, xpos, xmat, xanchor, xaxis)
+                        ten_J[t] += (seg / ln) @ (j1 - j0)
+        else:
+          for w_ in range(a, a + n):
             j = int(m.wrap_objid[w_])
             ten_J[t, int(m.jnt_dofadr[j])] += m.wrap_prm[w_]
             m.tendon_length0[t] += m.wrap_prm[w_] * m.qpos0[int(m.jnt_qposadr[j])]
@@ -1763,9 +1973,42 @@ def _equality_set0(m):
 _XML_COMMENT = re.compile(r"<!--.*?-->", re.S)
 
 
+def _expand_includes(node, cur_dir, main_dir, seen):
+    """<include file=...>: the children of the included document's <mujoco> root take the place of the element (MuJoCo XML reference).  The path is looked up
+    relative to the INCLUDING file, then relative to the main model file; a missing file, a repeated file or a non-MJCF root is an error, never a silent skip."""
+    for i, child in enumerate(list(node)):
+        if child.tag != "include":
+            _expand_includes(child, cur_dir, main_dir, seen)
+            continue
+        name = child.get("file")
+        if not name:
+            raise ValueError("<include> needs a file attribute")
+        cands = [os.path.join(cur_dir, name), os.path.join(main_dir, name)]
+        path = next((c for c in cands if os.path.isfile(c)), None)
+        if path is None:
+            raise FileNotFoundError(f"<include file={name!r}>: not found (looked in {cur_dir} and {main_dir})")
+        real = os.path.realpath(path)
+        if real in seen:
+            raise ValueError(f"<include file={name!r}>: the file is included more than once")
+        seen.add(real)
+        with open(path) as f:
+            sub = ET.fromstring(_XML_COMMENT.sub("", f.read()))
+        if sub.tag != "mujoco":
+            raise ValueError(f"<include file={name!r}>: the root element must be <mujoco>, got <{sub.tag}>")
+        _expand_includes(sub, os.path.dirname(os.path.abspath(path)), main_dir, seen)
+        pos = list(node).index(child)
+        node.remove(child)
+        for k, c in enumerate(list(sub)):
+            node.insert(pos + k, c)
+
+
 def from_xml_string(xml: str, base_dir: str = ".") -> MjModelLite:
     # MuJoCo's parser tolerates "--" inside comments (ASCII tables in bundled models); expat does not: drop comments first
-    return _Compiler(ET.fromstring(_XML_COMMENT.sub("", xml)), base_dir).build()
+    root = ET.fromstring(_XML_COMMENT.sub("", xml))
+    if root.tag != "mujoco":
+        raise ValueError(f"not an MJCF document: root element <{root.tag}>")
+    _expand_includes(root, base_dir, base_dir, set())
+    return _Compiler(root, base_dir).build()
 
 
 def from_xml_path(path: str) -> MjModelLite:

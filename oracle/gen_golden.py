@@ -99,6 +99,8 @@ CASES = {
     # Jacobian row (smooth.py:470-497, device.py:850).  The fixed-tendon model with t1 (limited, spring, damper) and t4 (spring) retyped to
     # site wraps: their limit row, passive force and constants stay in the model, their kinematics read zero.
     "tendon_spatial_degenerate_f64": ("tendon_fixed", {"model.wrap_type": [3, 3, 1, 1, 1, 1, 1, 3]}, "float64", 3, 3, "tendon"),
+    # ... the same two tendons declared as <spatial> in the XML: the compiler produces the site wraps and the qpos0 constants
+    "tendon_spatial_f64": ("tendon_spatial", {}, "float64", 3, 3, "tendon"),
     # tendon armature (smooth.py:500-522): qM gains J^T diag(armature) J, off the kinematic tree's sparsity pattern
     "tendon_armature_f64": ("tendon_armature", {}, "float64", 3, 3, "tendon"),
     "tendon_armature_cg_rk4_f32": ("tendon_armature", {"integrator": 1, "solver": 1}, "float32", 2, 2, "tendon"),

@@ -284,3 +284,90 @@ def test_weld_with_an_explicit_relpose_is_stored_as_given():
     assert np.allclose(scaled.eq_data[0, 3:10], [0.1, 0.2, 0.3, 1, 0, 0, 0]) and np.allclose(scaled.eq_data[0, 0:3], [0, 0, 0.05])
     zero = mt.mjcf.from_xml_string(xml.format(rp='relpose="9 9 9 0 0 0 0"'))  # all-zero quaternion: ignored
     assert np.allclose(zero.eq_data, derived.eq_data)
+
+
+_PROBE = ('<mujoco><worldbody><body name="b"><joint name="j" type="hinge" axis="0 1 0"/><geom name="g" size="0.1"/><site name="s1" pos="0.3 0 0"/></body>'
+          '<site name="s2" pos="0 0 1"/>%s</worldbody>%s</mujoco>')
+
+
+def _compile(tmp_path, world="", rest="", files=None):
+    for n, t in (files or {}).items():
+        (tmp_path / n).parent.mkdir(parents=True, exist_ok=True)
+        (tmp_path / n).write_text(t)
+    (tmp_path / "m.xml").write_text(_PROBE % (world, rest))
+    return mt.mjcf.from_xml_path(str(tmp_path / "m.xml"))
+
+
+def test_mjcf_refuses_what_it_does_not_honour(tmp_path):
+    """the compiler used to drop what it did not know -- a missing <include>, unknown top-level elements, <composite>,
+    unknown attributes -- and compile "successfully" to a different model.  Refuse or honour, never ignore."""
+    assert _compile(tmp_path).nbody == 2
+    with pytest.raises(FileNotFoundError, match="x.xml"):
+        _compile(tmp_path, rest='<include file="x.xml"/>')
+    for rest in ("<deformable/>", "<extension/>", "<custom><frobnicate/></custom>", '<equality><flex/></equality>'):
+        with pytest.raises(NotImplementedError, match="not supported|outside this build"):
+            _compile(tmp_path, rest=rest)
+    for world in ('<composite type="grid"/>', '<replicate count="3"><geom size="0.1"/></replicate>', '<flexcomp/>', '<body><plugin/></body>'):
+        with pytest.raises(NotImplementedError, match="not supported"):
+            _compile(tmp_path, world=world)
+    with pytest.raises(NotImplementedError, match="foo"):
+        _compile(tmp_path, world='<geom size="0.1" foo="1"/>')
+    with pytest.raises(NotImplementedError, match="fluidshape"):
+        _compile(tmp_path, world='<geom size="0.1" fluidshape="ellipsoid"/>')
+    with pytest.raises(NotImplementedError, match="bogus"):
+        _compile(tmp_path, rest='<default><geom bogus="1"/></default>')
+    with pytest.raises(NotImplementedError, match="springref2"):
+        _compile(tmp_path, world='<body><joint springref2="1"/><geom size="0.1"/></body>')
+    # cosmetic elements / attributes are not physics: accepted
+    m = _compile(tmp_path, world='<geom size="0.1" rgba="1 0 0 1" material="x" group="2"/><light pos="0 0 3" diffuse="1 1 1"/><camera name="c" fovy="40"/>',
+                 rest='<visual><global fovy="3"/><quality shadowsize="2"/></visual><asset><texture name="t" type="2d" builtin="flat" width="8" height="8"/><material name="x"/></asset>')
+    assert m.ngeom == 2 and m.ncam == 1 and m.nlight == 1
+
+
+def test_mjcf_include_is_expanded_relative_to_the_including_file(tmp_path):
+    files = {"parts/act.xml": '<mujoco><include file="more.xml"/><actuator><motor name="m1" joint="j"/></actuator></mujoco>',
+             "parts/more.xml": '<mujoco><actuator><position name="p1" joint="j" kp="3"/></actuator></mujoco>'}
+    m = _compile(tmp_path, rest='<include file="parts/act.xml"/>', files=files)
+    assert m.nu == 2 and m.names_actuator == ["p1", "m1"]
+    with pytest.raises(ValueError, match="more than once"):
+        _compile(tmp_path, rest='<include file="parts/more.xml"/><include file="parts/more.xml"/>', files=files)
+    with pytest.raises(ValueError, match="root element"):
+        _compile(tmp_path, rest='<include file="bad.xml"/>', files={"bad.xml": "<worldbody/>"})
+
+
+def test_mjcf_frames_compose_poses(tmp_path):
+    """<frame>: a pure coordinate transformation of its contents (geoms, sites, cameras, bodies; nested)."""
+    m = _compile(tmp_path, world='<frame pos="1 0 0" euler="0 0 90"><geom name="fg" size="0.1" pos="1 0 0"/><frame pos="0 0 1"><site name="fs" pos="0 1 0"/></frame>'
+                                 '<body name="fb" pos="0 1 0" euler="0 0 90"><geom size="0.1" fromto="0 0 0 1 0 0"/></body></frame>')
+    g = m.names_geom.index("fg")
+    np.testing.assert_allclose(m.geom_pos[g], [1, 1, 0], atol=1e-12)            # (1,0,0) rotated by 90 deg about z, then shifted
+    np.testing.assert_allclose(m.site_pos[m.names_site.index("fs")], [0, 0, 1], atol=1e-12)
+    b = m.names_body.index("fb")
+    np.testing.assert_allclose(m.body_pos[b], [0, 0, 0], atol=1e-12)
+    np.testing.assert_allclose(np.abs(m.body_quat[b]), [0, 0, 0, 1], atol=1e-12)  # two quarter turns about z
+    with pytest.raises(ValueError, match="belongs to a body"):
+        _compile(tmp_path, world='<frame><joint/></frame>')
+
+
+def test_mjcf_spatial_tendons_and_the_cylinder_shortcut(tmp_path):
+    """<spatial> site paths compile to MuJoCo's wrap objects with their qpos0 constants; device_put carries them in the reference's (degenerate) form.  <cylinder>: filter dynamics, fixed gain = area, affine bias (MuJoCo XML reference)."""
+    m = _compile(tmp_path, rest='<tendon><spatial name="t" range="0 2" stiffness="3"><site site="s1"/><site site="s2"/></spatial></tendon>'
+                                '<actuator><cylinder name="c" joint="j" diameter="0.1" timeconst="0.5" bias="1 2 3"/><cylinder joint="j" area="2"/></actuator>')
+    assert list(m.wrap_type) == [3, 3] and list(m.wrap_objid) == [m.names_site.index("s1"), m.names_site.index("s2")]
+    np.testing.assert_allclose(m.tendon_length0, [np.sqrt(0.3 ** 2 + 1.0)], rtol=1e-12)
+    assert m.tendon_invweight0[0] > 0 and np.allclose(m.tendon_lengthspring[0], m.tendon_length0[0])
+    assert int(m.actuator_dyntype[0]) == int(mt.DynType.FILTER) and int(m.actuator_biastype[0]) == int(mt.BiasType.AFFINE) and int(m.actuator_gaintype[0]) == int(mt.GainType.FIXED)
+    np.testing.assert_allclose(m.actuator_gainprm[0, 0], np.pi / 4 * 0.01)
+    np.testing.assert_allclose(m.actuator_dynprm[0, 0], 0.5)
+    np.testing.assert_allclose(m.actuator_biasprm[0, :3], [1, 2, 3])
+    np.testing.assert_allclose([m.actuator_gainprm[1, 0], m.actuator_dynprm[1, 0]], [2.0, 1.0])
+    mx = mt.device_put(m)
+    assert int(mx.ntendon) == 1
+    wrapped = _compile(tmp_path, world='<geom name="w" type="sphere" size="0.05" pos="0.2 0 0.5"/>',
+                       rest='<tendon><spatial><site site="s1"/><geom geom="w"/><site site="s2"/></spatial></tendon>')
+    assert list(wrapped.wrap_type) == [3, 4, 3]
+    assert int(mt.device_put(wrapped).ntendon) == 1   # (carried like every tendon whose first wrap is not a joint wrap: zero length / Jacobian at run time, as in the reference)
+    with pytest.raises(NotImplementedError, match="mixing"):
+        bad = _compile(tmp_path, rest='<tendon><fixed><joint joint="j" coef="1"/></fixed></tendon>')
+        bad.wrap_type = np.array([1, 3], dtype=np.int32); bad.wrap_objid = np.array([0, 0], dtype=np.int32); bad.wrap_prm = np.array([1.0, 0.0]); bad.tendon_num = np.array([2], dtype=np.int32); bad.nwrap = 2
+        mt.device_put(bad)
