@@ -38,11 +38,11 @@ SEEDED_CASES = [
     ("mesh_contact", {"solver": 1, "cone": 1}, F64, 32, dict(tol_sol=1e-5)),
     ("convex_meshes", {}, F64, 32, dict(max_alt=0.0)),
     ("convex_primitives", {}, F64, 32, dict(max_alt=0.0)),
-    ("convex_primitives", {}, F32, 32, {}),
+    ("convex_primitives", {}, F32, 32, dict(tol_sol=2e-4)),                      # measured 1.5e-5 (profiles/r04/notes.md: every float32 bound below is 10 x the measured worst of three steps)
     ("sensor_rig", {}, F64, 64, dict(max_alt=0.0)),                             # sensors: IMU, rangefinders, joint sensors
-    ("sensor_rig", {"integrator": 1}, F32, 64, {}),                             # ... RK4, float32 (rays intersect in double)
+    ("sensor_rig", {"integrator": 1}, F32, 64, dict(tol_sol=6e-5)),             # ... RK4, float32 (measured 6.1e-6)
     ("sensor_rig2", {}, F64, 64, dict(max_alt=0.0)),                            # every other sensor type sensor.py evaluates (frame, tendon, actuator, ball, subtree, clock, force / torque ...)
-    ("sensor_rig2", {"integrator": 1}, F32, 33, dict(tol_sol=2e-4)),            # ... RK4, float32
+    ("sensor_rig2", {"integrator": 1}, F32, 33, dict(tol_sol=2e-4)),            # ... RK4, float32 (measured 1.6e-5)
     ("swimmer", {"viscosity": 0.05, "wind": [0.3, -0.2, 0.1]}, F64, 64, dict(max_alt=0.0)),  # fluid forces: density + viscosity + wind
     ("ant_frictionloss", {}, F64, 64, dict(max_alt=0.0)),                       # dof frictionloss rows, Newton
     ("ant_frictionloss", {"solver": 1}, F64, 64, dict(tol_sol=1e-5)),           # ... CG: stalls across frictionloss zone switches (measured 8.1e-7; Newton one line up: 1e-13)
@@ -61,14 +61,14 @@ SEEDED_CASES = [
     ("tendon_fixed", {"solver": 1}, F64, 64, dict(max_alt=0.0)),
     ("tendon_armature", {}, F64, 64, dict(max_alt=0.0)),                          # tendon armature: qM += J^T diag(armature) J off the tree's sparsity pattern
     ("capsules_topk", {}, F64, 64, dict(max_alt=0.0)),                           # max_contact_points: 13 candidates, the 5 closest kept per environment
-    ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, {}),
+    ("capsules_topk", {"integrator": 1, "cone": 1}, F32, 64, dict(tol_sol=5e-5)),  # measured 4.9e-6
     ("boxes_topk", {}, F64, 48, dict(max_alt=0.0)),                               # ... over box candidates: the convex narrow phase hands 22 candidates to the selection through the workspace
-    ("boxes_topk", {"integrator": 1, "cone": 1}, F32, 33, {}),
+    ("boxes_topk", {"integrator": 1, "cone": 1}, F32, 33, dict(tol_sol=1.5e-4)),  # measured 1.4e-5
     ("capsules_topk", {"solver": 1, "iterations": 100, "ls_iterations": 50}, F64, 33, dict(tol_sol=1e-5)),  # ... through the register solver (CG stall accuracy)
     ("centipede", {}, F64, 24, dict(max_alt=0.0)),                                # 72 dofs / 74 bodies (jacobian=dense): multi-word dof masks, more dofs than lanes in the LDS solver
-    ("centipede", {"integrator": 1}, F32, 17, {}),
+    ("centipede", {"integrator": 1}, F32, 17, dict(tol_sol=6e-5)),                # measured 5.5e-6
     ("muscle_arm", {}, F64, 64, dict(max_alt=0.0)),                               # muscle actuators: activation dynamics, force-length-velocity gain, passive bias
-    ("muscle_arm", {"integrator": 1}, F32, 33, {}),
+    ("muscle_arm", {"integrator": 1}, F32, 33, dict(tol_sol=2e-5)),              # measured 2.0e-6
     ("tendon_friction", {}, F64, 64, dict(max_alt=0.0)),                         # tendon + dof frictionloss rows, Newton
     ("tendon_friction", {"solver": 1, "integrator": 1}, F64, 32, dict(tol_sol=1e-5)),  # ... CG (stall accuracy, see above), RK4
     # CG models served by the register solver (mjh_sol2_kernel: two environments per wavefront): Euler with the eulerdamp re-solve,
@@ -84,6 +84,14 @@ SEEDED_CASES = [
     # iterations = 2, 3).  They are covered by their converged twins above and by the one-solve BASELINE configuration.)
     ("humanoid", {"solver": 1, "disableflags": 0}, F64, 1, dict(max_alt=1.0)),     # eulerdamp on (the XML disables it), a single environment
 ]
+
+
+def seeded_tol_sol(xml, overrides, dtype):
+    """The solver bound tests/_cases.py states for a seeded configuration (its `tol_sol`, else the dtype's default)."""
+    for x, ov, dt, _, bounds in SEEDED_CASES:
+        if x == xml and ov == overrides and dt == dtype:
+            return bounds.get("tol_sol", TOL_SOL[dtype])
+    return TOL_SOL[dtype]
 
 
 def case_id(c):

@@ -182,6 +182,19 @@ def gpu_out_to_numpy(d):
 PRE_SOLVER = [n for n in REAL_LEAVES if n not in SOLVER_LEAVES]
 
 
+STATE_ELEMENTWISE = ("qpos", "qvel", "qacc")
+
+
+def elementwise_err(got, want):
+    """Worst element of max_i |got_i - want_i| / max(|want_i|, 1e-3 * |want|max): the max-norm metric (rel_err) checks an entry a thousand times smaller than
+    its leaf's largest to 1e-5 of itself; this one holds every entry to the tolerance down to 1e-3 of the leaf's scale."""
+    g, w = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(want, dtype=np.float64).reshape(-1)
+    if w.size == 0:
+        return 0.0
+    scale = np.maximum(np.abs(w), 1e-3 * max(float(np.abs(w).max()), 1e-3))
+    return float((np.abs(g - w) / scale).max())
+
+
 def compare_with_oracle(model, d_cpu, got, step=True, **kw):
     """HIP outputs `got` (dict of numpy, batched) vs the oracle on the same inputs, without judging: per-leaf errors of the leaves
     upstream of the solver (natural oracle run), integer equality, and per environment the solver-leaf error against the
@@ -202,15 +215,18 @@ def compare_with_oracle(model, d_cpu, got, step=True, **kw):
     need = set(SOLVER_LEAVES) | {"efc_force"}
     env_of = (lambda a, e: {n: a[n][e] for n in need}) if batched else (lambda a, e: {n: a[n] for n in need})
     leaf_nat = {n: 0.0 for n in SOLVER_LEAVES}
+    elem_best = np.zeros(B)  # element-wise error of the state leaves on each environment's accepted branch
     for e in range(B):
         ge = env_of(got, e)
         errs = [solver_err(ge, env_of(a, e)) for a in alts]
         err_nat[e], err_best[e], which[e] = errs[0], min(errs), int(np.argmin(errs))
+        be = env_of(alts[int(which[e])], e)
+        elem_best[e] = max(elementwise_err(ge[n], be[n]) for n in STATE_ELEMENTWISE)
         ne = env_of(nat, e)
         for n in SOLVER_LEAVES:
             leaf_nat[n] = max(leaf_nat[n], rel_err(ge[n], ne[n], solver_floor(n, ne)))
     return dict(pre=pre, pre_worst=max(pre.values()) if pre else 0.0, ints_ok=ints_ok, err_nat=err_nat, err_best=err_best, which=which,
-                n_alts=len(alts), tie_pairs=tie_pairs, leaf_nat=leaf_nat, alts=alts, knife=knife)
+                n_alts=len(alts), tie_pairs=tie_pairs, leaf_nat=leaf_nat, alts=alts, knife=knife, elem_best=elem_best)
 
 
 def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, max_tie_frac=1.0, band=None, **kw):
@@ -248,6 +264,10 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
     B = len(c["err_best"])
     worst_env = int(np.argmax(c["err_best"]))
     assert c["err_best"].max() <= tol_solver, f"{what} env {worst_env}: solver outputs match no admissible oracle branch: best {c['err_best'][worst_env]:.3e}, natural {c['err_nat'][worst_env]:.3e}"
+    if d_cpu.qpos.dtype == torch.float64 and band is None:
+        # ... and ELEMENT-wise on the state leaves (qpos, qvel, qacc): every entry within the tolerance of max(|entry|, 1e-3 of its leaf's largest)
+        we = int(np.argmax(c["elem_best"]))
+        assert c["elem_best"].max() <= tol_solver, f"{what} env {we}: a state entry is {c['elem_best'][we]:.3e} off its own magnitude on the accepted branch (bound {tol_solver:g})"
     alt = c["err_nat"] > tol_solver
     need_alt = int(alt.sum())
     # a non-natural branch is only admissible where the reference's own result is implementation-defined: the natural oracle run

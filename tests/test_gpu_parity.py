@@ -11,7 +11,7 @@ import torch
 
 import mujoco_torch_amd as mt
 import pyoracle
-from _cases import FUZZ_BAND, FUZZ_CASES, FUZZ_TOL_PRE, SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, fuzz_batch, seeded_batch
+from _cases import FUZZ_BAND, FUZZ_CASES, FUZZ_TOL_PRE, SEEDED_CASES, TOL_PRE, TOL_SOL, case_id, fuzz_batch, seeded_batch, seeded_tol_sol
 from _util import (solve_cost, solver_err, OUTLIER_CASES, compare_with_oracle, load_outlier, policy_spread, CASE_TOL_SOL, SOLVER_FLOOR, GOLDEN_CASES, INT_LEAVES, PRE_SOLVER, REAL_LEAVES, SOLVER_LEAVES, Golden, assert_ints_equal,
                    assert_leaves_close, check_against_oracle, gpu_out_to_numpy, leaf, load_model, rel_err)
 
@@ -714,7 +714,8 @@ def test_configs_3_and_5_full_size_batch_properties(xml, overrides, B, oracle_li
         if a.is_floating_point():
             assert torch.isfinite(a).all(), n
     first = mt.step(mdev, base.to("cuda"))
-    frac, worst = check_against_oracle(mx, base, gpu_out_to_numpy(first), TOL_PRE[dtype], TOL_SOL[dtype], what=f"{xml} full size", nthreads=4)
+    # the per-configuration float32 bounds of tests/_cases.py (ant 5e-6, mesh scene 5e-4: measured 3e-7 / 3e-5), not the blanket float32 tolerance
+    frac, worst = check_against_oracle(mx, base, gpu_out_to_numpy(first), TOL_PRE[dtype], seeded_tol_sol(xml, overrides, dtype), what=f"{xml} full size", nthreads=4)
     print(f"{xml} B={B}: worst solver rel err of the first 128 environments {worst:.2e}")
 
 

@@ -2,7 +2,8 @@
 oracle on the BASELINE configs (2: humanoid f64 Euler+CG, 3: ant f32 RK4+Newton elliptic, 5: mesh scene f32 Newton; config 4 is
 config 2's model) in the bench's input recipe, three consecutive steps.  Writes gpurun_out/parity.json (copied to profiles/<round>/).
 
-Errors are max-norm per leaf: |got - want|max / max(|want|max, floor) (tests/_util.rel_err), NOT element-wise.  Solver-dependent
+Errors are max-norm per leaf: |got - want|max / max(|want|max, floor) (tests/_util.rel_err), NOT element-wise -- except `state_leaves_elementwise_*`:
+worst entry of qpos / qvel / qacc against max(|entry|, 1e-3 of its leaf's largest) on the accepted branch (tests/_util.elementwise_err).  Solver-dependent
 leaves are reported twice: against the oracle's natural run and against the closest admissible branch per environment.
 MJX / MuJoCo-C parity is unpinned in this container (no mujoco / jax wheel): the oracle is pinned by the reference's own Python
 (tests/golden, oracle/gen_golden.py).
@@ -46,6 +47,7 @@ for name, (xml, ov, dt, B) in CONFIGS.items():
             best[n] = max(rel_err(got[n][e], c["alts"][int(c["which"][e])][n][e], solver_floor(n, {"efc_force": c["alts"][int(c["which"][e])]["efc_force"][e]})) for e in range(B))
         steps.append({"pre_solver_leaves": {n: c["pre"][n] for n in PRE_SOLVER}, "integer_leaves_bit_exact": bool(c["ints_ok"]),
                       "solver_leaves_vs_natural_oracle_run": c["leaf_nat"], "solver_leaves_on_accepted_branch": best,
+                      "state_leaves_elementwise_on_accepted_branch": float(c["elem_best"].max()),
                       "envs_on_non_natural_branch": float((c["err_nat"] > (1e-8 if dt == torch.float64 else 2e-3)).mean()),
                       "envs_with_noise_candidates": float((c["knife"] > 0).mean())})
         dg = og
@@ -53,6 +55,7 @@ for name, (xml, ov, dt, B) in CONFIGS.items():
     out["summary"][name] = {"dtype": str(dt)[6:], "max_pre_solver": max(max(s["pre_solver_leaves"].values()) for s in steps),
                             "max_solver_on_accepted_branch": max(max(s["solver_leaves_on_accepted_branch"].values()) for s in steps),
                             "max_state_qpos_qvel_on_accepted_branch": max(max(s["solver_leaves_on_accepted_branch"][k] for k in ("qpos", "qvel")) for s in steps),
+                            "max_state_elementwise_on_accepted_branch": max(s["state_leaves_elementwise_on_accepted_branch"] for s in steps),
                             "integer_leaves_bit_exact": all(s["integer_leaves_bit_exact"] for s in steps),
                             "max_fraction_on_non_natural_branch": max(s["envs_on_non_natural_branch"] for s in steps)}
     print(name, json.dumps(out["summary"][name]), flush=True)
