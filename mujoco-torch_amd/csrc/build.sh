@@ -46,10 +46,10 @@ LOG="$(mktemp)"
 cat "$OBJ"/inst_*.log "$OBJ/mjhip.log" > "$LOG"
 grep -E "error|warning: " "$LOG" || true
 NFUNC=$(grep -c "Function Name:" "$LOG" || true)
-NKERN=$(grep "Function Name:" "$LOG" | grep -cE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" || true)
+NKERN=$(grep "Function Name:" "$LOG" | grep -cE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel|mjh_sort_kernel" || true)
 if [ "$NFUNC" != "$NKERN" ]; then
   echo "build.sh: device functions were not inlined into the kernels:" >&2
-  grep "Function Name:" "$LOG" | grep -vE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel" >&2
+  grep "Function Name:" "$LOG" | grep -vE "mjh_phase_kernel|mjh_sol2_kernel|mjh_convex_kernel|mjh_sensor_kernel|mjh_reset_kernel|mjh_sort_kernel" >&2
   exit 1
 fi
 grep -E "Function Name|VGPRs:|ScratchSize|Occupancy" "$LOG" | sed 's/.*remark: *//' | paste - - - - | sed 's/\[-Rpass[^]]*\]//g' | sort > "${OUT%.so}.resource_usage.txt"

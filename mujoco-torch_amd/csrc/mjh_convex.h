@@ -30,15 +30,35 @@ struct CvxView {
 };
 
 // argmax (SGN = +1) / argmin (SGN = -1) over the wave; ties -> lowest index.  Every lane returns the winner.
+// "Best" is the minimum of a total order on (value, index) pairs, so any reduction tree gives the same winner.  Four DPP steps (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror) leave each 16-lane row's best in all of its lanes; the four rows are then combined from v_readlane broadcasts.  No LDS-pipe
+// round trip: the __shfl_xor butterfly this replaces was six dependent ds_bpermute pairs per call (~1.4 k cycles each, ten calls on the box-mesh pair's path).
+template <int CTRL> __device__ __forceinline__ int dpp_move_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int SGN, typename REAL>
+__device__ __forceinline__ void argbest_combine(REAL& v, int& idx, REAL ov, int oi) {
+  const bool better = SGN > 0 ? (ov > v) : (ov < v);
+  if (better || (ov == v && oi < idx)) { v = ov; idx = oi; }
+}
 template <int SGN, typename REAL>
 __device__ __forceinline__ void wave_argbest(REAL& v, int& idx) {
+#ifdef MJH_NO_DPP
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     const REAL ov = __shfl_xor(v, o, MJH_WAVE);
     const int oi = __shfl_xor(idx, o, MJH_WAVE);
-    const bool better = SGN > 0 ? (ov > v) : (ov < v);
-    if (better || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    argbest_combine<SGN>(v, idx, ov, oi);
   }
+#else
+  { const REAL ov = dpp_move<0xB1>(v); const int oi = dpp_move_int<0xB1>(idx); argbest_combine<SGN>(v, idx, ov, oi); }
+  { const REAL ov = dpp_move<0x4E>(v); const int oi = dpp_move_int<0x4E>(idx); argbest_combine<SGN>(v, idx, ov, oi); }
+  { const REAL ov = dpp_move<0x141>(v); const int oi = dpp_move_int<0x141>(idx); argbest_combine<SGN>(v, idx, ov, oi); }
+  { const REAL ov = dpp_move<0x140>(v); const int oi = dpp_move_int<0x140>(idx); argbest_combine<SGN>(v, idx, ov, oi); }
+  REAL bv = read_lane(v, 0);
+  int bi = read_lane(idx, 0);
+#pragma unroll
+  for (int r = 1; r < 4; r++) argbest_combine<SGN>(bv, bi, read_lane(v, 16 * r), read_lane(idx, 16 * r));
+  v = bv; idx = bi;
+#endif
 }
 template <int SGN, typename REAL>
 __device__ __forceinline__ void lane_best(REAL& bv, int& bi, REAL v, int i) {
@@ -321,7 +341,7 @@ struct CvxPair {
     wave_argbest<-1>(ebv, ebi);
     const int owner = ebi % MJH_WAVE;  // lane k % 64 handled edge k
 #pragma unroll
-    for (int i = 0; i < 3; i++) { ecl[i] = __shfl(ecl[i], owner, MJH_WAVE); ccl[i] = __shfl(ccl[i], owner, MJH_WAVE); }
+    for (int i = 0; i < 3; i++) { ecl[i] = read_lane(ecl[i], owner); ccl[i] = read_lane(ccl[i], owner); }  // (owner is wave-uniform: a v_readlane, not an LDS-pipe shuffle)
     wave_sync();
     REAL cl[2][3];
     const bool mask = clip_edge_to_planes(pts[0], pts[1], face, en, K, cl[0], cl[1]);
@@ -430,16 +450,31 @@ struct CvxPair {
       // running extremes as hardware max / min from +-infinity (one instruction each; the same values as compare-and-keep for finite projections)
       const REAL inf = (REAL)INFINITY;
       REAL amax0 = -inf, amin0 = inf, bmax0 = -inf, bmin0 = inf, amax1 = -inf, amin1 = inf, bmax1 = -inf, bmin1 = inf;
-      for (int v = 0; v < V1; v++) {
-        const REAL x = v1[3 * v], y = v1[3 * v + 1], z = v1[3 * v + 2];
-        const REAL s0 = (ax0[0] * x + ax0[1] * y) + ax0[2] * z, s1 = (ax1[0] * x + ax1[1] * y) + ax1[2] * z;
-        amax0 = r_max(amax0, s0); amin0 = r_min(amin0, s0); amax1 = r_max(amax1, s1); amin1 = r_min(amin1, s1);
-      }
-      for (int v = 0; v < V2; v++) {
-        const REAL x = v2[3 * v], y = v2[3 * v + 1], z = v2[3 * v + 2];
-        const REAL s0 = (ax0[0] * x + ax0[1] * y) + ax0[2] * z, s1 = (ax1[0] * x + ax1[1] * y) + ax1[2] * z;
-        bmax0 = r_max(bmax0, s0); bmin0 = r_min(bmin0, s0); bmax1 = r_max(bmax1, s1); bmin1 = r_min(bmin1, s1);
-      }
+      // Four vertices per trip: their twelve coordinates are requested together (one LDS round trip instead of four -- the loop was one exposed ds_read latency per
+      // vertex) and their extremes are folded as a tree before they meet the running ones (a max / min whose operand came round the loop is canonicalised first:
+      // one extra instruction per accumulator and trip, now per four vertices).  max / min are exact and order-independent: the same values as the one-by-one scan.
+      auto project = [&](const REAL* vv, int nvx, REAL& mx0, REAL& mn0, REAL& mx1, REAL& mn1) {
+        int v = 0;
+        for (; v + 4 <= nvx; v += 4) {
+          REAL c[12], s0[4], s1[4];
+#pragma unroll
+          for (int t = 0; t < 12; t++) c[t] = vv[3 * v + t];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            s0[t] = (ax0[0] * c[3 * t] + ax0[1] * c[3 * t + 1]) + ax0[2] * c[3 * t + 2];
+            s1[t] = (ax1[0] * c[3 * t] + ax1[1] * c[3 * t + 1]) + ax1[2] * c[3 * t + 2];
+          }
+          mx0 = r_max(mx0, r_max(r_max(s0[0], s0[1]), r_max(s0[2], s0[3]))); mn0 = r_min(mn0, r_min(r_min(s0[0], s0[1]), r_min(s0[2], s0[3])));
+          mx1 = r_max(mx1, r_max(r_max(s1[0], s1[1]), r_max(s1[2], s1[3]))); mn1 = r_min(mn1, r_min(r_min(s1[0], s1[1]), r_min(s1[2], s1[3])));
+        }
+        for (; v < nvx; v++) {
+          const REAL x = vv[3 * v], y = vv[3 * v + 1], z = vv[3 * v + 2];
+          const REAL s0 = (ax0[0] * x + ax0[1] * y) + ax0[2] * z, s1 = (ax1[0] * x + ax1[1] * y) + ax1[2] * z;
+          mx0 = r_max(mx0, s0); mn0 = r_min(mn0, s0); mx1 = r_max(mx1, s1); mn1 = r_min(mn1, s1);
+        }
+      };
+      project(v1, V1, amax0, amin0, amax1, amin1);
+      project(v2, V2, bmax0, bmin0, bmax1, bmin1);
       {
         const REAL d1 = amax0 - bmin0, d2 = bmax0 - amin0;
         REAL d = d1 < d2 ? d1 : d2;
@@ -457,10 +492,10 @@ struct CvxPair {
     if (ba < 0) { bd = (REAL)1e30; ba = CVX_NONE; }
     wave_argbest<-1>(bd, ba);
     const int owner = ba % MJH_WAVE;
-    const int best_sign = __shfl(bsign, owner, MJH_WAVE);
+    const int best_sign = read_lane(bsign, owner);
     REAL best_axis[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++) best_axis[i] = __shfl(baxis[i], owner, MJH_WAVE);
+    for (int i = 0; i < 3; i++) best_axis[i] = read_lane(baxis[i], owner);
     const bool is_edge = ba >= F1 + F2;
     // faces most aligned / most opposed to the axis: lanes over faces
     REAL v_amax = 0, v_amin = 0, v_bmax = 0, v_bmin = 0;

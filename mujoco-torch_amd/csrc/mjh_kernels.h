@@ -214,6 +214,8 @@ struct KArgs {
   int scan_marks;       // register solver, second tier: waves scan 64 environments' marks each and serve the marked ones (instead of one wave per environment pair counting rows)
   int fallback_only;    // LDS solver launch: serve only the environments the register solver flagged (mjh_bail_mark in out.qacc)
   int row_lo, row_hi;   // register solver tiers: this launch serves the environments with row_lo < (dense rows of their active contacts) <= row_hi
+  const int* sol_perm;  // register solver, four environments per wavefront: environment served by each (wave, lane group) slot, sorted by the previous step's iteration counts (NULL: identity)
+  int* sol_key;         // ... and where this step's count of an environment goes (NULL: not recorded)
   unsigned long long* stamps;  // diagnostic builds (-DMJH_STAMPS): [B, 128] s_memtime stamps, else unused
 };
 template <typename REAL>
@@ -4275,6 +4277,7 @@ struct Env {
         if (need_grad) grad = dof ? (Ma - f) - qfrc : (REAL)0;  // _update_gradient :359-376, the part cond reads (its preconditioned half: next loop head)
         niter++; it++;
       }
+      if (W == 16 && KA.sol_key && l == 0) { const int k = 6 * niter + ls_total; KA.sol_key[e] = k < 63 ? k : 63; }  // ~ the solve's cost: a Newton iteration (Hessian build + factorisation) weighs about six line-search iterations
       if (bail) {  // nothing of this environment's solve is kept: the mark hands it to the fallback launch, which writes every output of the phase
         if (l == 0) out.qacc[e * nv] = mjh_bail_mark((REAL)0);
         return;
@@ -4398,7 +4401,10 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {
-      Env<REAL, W, false> E(lds, K.env_begin + idx, K.flags);
+      // W = 16: the four environments of a wave run until the slowest has converged.  They are drawn from a list sorted by the previous step's iteration counts
+      // (mjh_sort_kernel), so that long solves share waves; which environments share a wave changes nothing in any of them.
+      const int64_t env = (W == 16 && K.sol_perm) ? (int64_t)K.sol_perm[idx] : idx;
+      Env<REAL, W, false> E(lds, K.env_begin + env, K.flags);
       if constexpr (CS) E.template run_con_sol2<NMAX, RPL>();
       else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }

@@ -35,3 +35,20 @@ __global__ __launch_bounds__(256) void mjh_reset_kernel(ResetArgs a) {
     for (int i = threadIdx.x; i < L.words; i += blockDim.x) dst[i] = src[i];
   }
 }
+
+
+// Counting sort of the environments by the iteration-count key the register solver left last step (any int: clipped to 0..63), slowest first: `perm[slot]` = environment
+// served by that slot of the solver's four-per-wavefront launch.  One workgroup; the order inside a bucket is whatever the atomics give -- which environments share a wave
+// has no effect on any environment's result.  Garbage keys (a fresh workspace) still give a valid permutation.
+__global__ __launch_bounds__(1024) void mjh_sort_kernel(const int* key, int* perm, long long B) {
+  __shared__ int hist[64];
+  __shared__ int base[64];
+  const int t = threadIdx.x;
+  if (t < 64) hist[t] = 0;
+  __syncthreads();
+  for (long long e = t; e < B; e += 1024) { const unsigned k = (unsigned)key[e]; atomicAdd(&hist[k > 63u ? 63 : (int)k], 1); }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int k = 63; k >= 0; k--) { base[k] = acc; acc += hist[k]; } }
+  __syncthreads();
+  for (long long e = t; e < B; e += 1024) { const unsigned k = (unsigned)key[e]; perm[atomicAdd(&base[k > 63u ? 63 : (int)k], 1)] = (int)e; }
+}

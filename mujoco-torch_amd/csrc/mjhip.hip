@@ -97,6 +97,7 @@ struct mjhModel {
   mutable hipEvent_t sensor_fork = nullptr, sensor_join = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
+  int64_t sort_reals = 0;                  // ... of which the register solver's environment list and iteration-count keys (two ints per environment, at the very head)
   int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the HEAD of the workspace: its first B * cand_reals reals; the RK4 stage Data and sums follow)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
@@ -580,6 +581,15 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   }
   out->cand_reals = (d->topk && M.ncvxpair > 0) ? 13 * (int64_t)d->ncand : 0;  // candidate contacts of the convex narrow phase (dist, pos, frame)
   out->work_reals += out->cand_reals;
+  {  // register solver at four environments per wavefront with solves of uneven length (Newton): two ints per environment at the head of the workspace -- the solver's
+     // slot -> environment list of this step and the iteration-count key each environment leaves for the next one.
+    // Measured (MI355X, profiles/r04/notes.md): the mesh scene's solver phase 203.1 us with the list against 203.9 us without -- last step's counts do not predict this
+    // step's (which environments take the long line searches changes from step to step) -- and the one-workgroup sort costs 14.6 us at B = 8192, 30.7 us at B = 16384:
+    // opt-in (MJH_SOL2_SORT=1), off by default.
+    static const bool on = [] { const char* e = getenv("MJH_SOL2_SORT"); return e && e[0] == '1'; }();
+    out->sort_reals = (on && out->sol2_w16_rpl && d->solver == SOL_NEWTON) ? (int64_t)(8 / sizeof(REAL)) : 0;
+    out->work_reals += out->sort_reals;
+  }
 
   void* dev = nullptr;
   HIP_TRY(hipMalloc(&dev, bb.host.size() + 16));
@@ -658,7 +668,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       int dev = 0, cus = 256;
       if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       out->kcv_max_envs = (int64_t)cus * 4 /* SIMDs */ * 2 /* waves per SIMD */ * (out->pack4[1] ? 4 : 2);
-      if (!out->pack4[1]) out->kcv_max_envs = (int64_t)1 << 62;  // two per wavefront (the humanoid, float64): measured at B = 32768 too (652 us against 452 + 218: profiles/r04/notes.md)
+      out->kcv_max_envs = (int64_t)1 << 62;  // round 4: at every batch size -- the humanoid (two per wavefront) at B = 32768: 652 us against 452 + 218; the ant (four per wavefront) at B = 16384, two rounds: 93.6 us against 75.8 + 21.8 (profiles/r04/notes.md)
       static const long long kcv_env = [] { const char* e = getenv("MJH_KCV_MAX_ENVS"); return e ? atoll(e) : -1ll; }();  // experiments: the batch bound of kernel 13
       if (kcv_env >= 0) out->kcv_max_envs = kcv_env;
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_kcv));
@@ -902,6 +912,19 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
     return fail(-22, "models with convex pairs need out.geom_xpos/geom_xmat and out.contact_dist/pos/frame");
   hipStream_t s = (hipStream_t)stream;
   REAL* w = (REAL*)work;
+  if (m->sort_reals > 0) {
+    if (work) {
+      int* perm = (int*)work;
+      int* key = perm + B;
+      if ((a.stages & 0x40) && B >= 8) {  // this step's list from last step's keys (a forward pass without a solve leaves both alone)
+        hipLaunchKernelGGL(mjh_sort_kernel, dim3(1), dim3(1024), 0, s, (const int*)key, perm, (long long)B);
+        HIP_TRY(hipGetLastError());
+        timing_mark(s, 15);
+        a.sol_perm = perm; a.sol_key = key;
+      }
+    }
+    w += m->sort_reals * B;
+  }
   if (m->cand_reals > 0 && (a.stages & 0x7c)) {  // max_contact_points over box / mesh pairs: the candidates live at the head of the workspace
     if (!work) return fail(-22, "max_contact_points with box / mesh pairs needs a workspace of mjh_model_work_bytes(m) * B bytes");
     a.cand = w;

@@ -1,0 +1,8 @@
+#!/bin/bash
+run() { tag=$1; wl=$2; shift 2; env "$@" python3 bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline --no-other-workloads --no-long-run 2>/dev/null | python3 tools/benchline.py "$tag"; }
+run mesh_sort mesh MJH_X=0
+run mesh_nosort mesh MJH_SOL2_SORT=0
+run mesh_sort mesh MJH_X=0
+run ant_sort ant MJH_X=0
+run ant_nosort ant MJH_SOL2_SORT=0
+timeout 1200 python -m pytest tests -m gpu -x -q -k "mesh or ant or config" 2>&1 | tail -4
