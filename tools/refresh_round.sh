@@ -2,13 +2,13 @@
 # GPU box: regenerates every measured artefact of a round under gpurun_out/<round>/ (copy to profiles/<round>/ afterwards):
 # rocprofv3 kernel stats, PMC traffic (stamped with the library fingerprint bench.py checks), parity report, counter calibration,
 # and the bench lines of the three BASELINE workloads.  Usage: MJH_GIT_COMMIT=<sha> bash tools/refresh_round.sh r03
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 uptime > $O/host_load.txt  # the boxes' hosts are shared: a loaded host starves the calling thread of the drop-in loop (profiles/r03/notes.md)
 bash tools/fetch_calib.sh 2>&1 | grep -E "FETCH_SIZE|WRITE_SIZE" > $O/fetch_calibration.txt
 for w in humanoid ant mesh; do
-  bash tools/prof_kernels.sh $w 100 > $O/kernel_stats_$w.txt 2>&1
+  bash tools/prof_kernels.sh $w 200 > $O/kernel_stats_$w.txt 2>&1
   cp gpurun_out/${w}_kernel_stats.csv $O/${w}_kernel_stats.csv
   bash tools/hbm_traffic.sh $w > /dev/null 2>&1
 done
