@@ -6,8 +6,9 @@ Why: the reference's published batched mode is ``torch.compile(torch.vmap(lambda
 (plain ``torch.vmap``), it calls ``torch.ops.mujoco_torch_amd.step_leaves`` instead of the ctypes path:
 
 * the operator takes the Data leaves in ABI order (``include/mjhip.h`` X-macro lists; an absent leaf is an empty tensor), the Model as a
-  process-unique integer (``Model._op_key``, resolved through a weak registry -- an operator cannot take a container) and the call's
-  flags; it returns the leaves the call writes, in ``forward._written_names`` order;
+  process-unique number in a 0-dim int64 TENSOR (``Model._op_key_t``, resolved through a weak registry -- an operator cannot take a container; as a tensor it is an
+  input of a traced graph, so ``mx.replace(body_mass=...)`` per episode steps the new values WITHOUT a recompile), the structure id ``tables.uid`` as a string (the
+  graph's constant: shape propagation runs on any Model of that structure) and the call's flags; it returns the leaves the call writes, in ``forward._written_names`` order;
 * its eager implementation rebuilds a ``Data`` around the tensors and runs the very same ``forward._run`` (the native batch);
 * ``register_fake`` gives the output shapes (batch dims of ``qpos`` + the per-environment shape of each leaf), so Inductor / AOT see an
   ordinary opaque node;
@@ -22,7 +23,7 @@ from __future__ import annotations
 import torch
 
 from . import native
-from .types import _MODELS_BY_KEY
+from .types import _MODELS_BY_KEY, _MODELS_BY_UID
 
 _NAMES = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
 _NREAL = len(native.LISTS["MJH_DATA_REALS"])
@@ -31,10 +32,20 @@ _QPOS = _NAMES.index("qpos")
 _TEMPLATES = {}  # tables uid -> an unbatched make_data(m): the fields outside the ABI and the per-environment shape of every leaf
 
 
-def _model(key: int):
-    m = _MODELS_BY_KEY.get(key)
+def _model(key) -> "Model":
+    """The Model whose VALUES this call steps: the operator receives its process-unique number as a 0-dim int64 tensor (an input of the traced graph, not a constant)."""
+    m = _MODELS_BY_KEY.get(int(key))
     if m is None:
-        raise RuntimeError("mujoco_torch_amd::step_leaves: the Model this call was traced with no longer exists")
+        raise RuntimeError("mujoco_torch_amd::step_leaves: the Model this call was made with no longer exists")
+    return m
+
+
+def _structure(uid: str):
+    """Any live Model of that structure (tables.uid, as the string the graph carries: an int that changes between calls is made a symbolic
+    shape by Dynamo's automatic dynamism, a string stays a guarded constant): what shape propagation needs does not depend on values."""
+    m = _MODELS_BY_UID.get(uid)
+    if m is None:
+        raise RuntimeError("mujoco_torch_amd::step_leaves: no Model of the structure this call was traced with exists any more")
     return m
 
 
@@ -64,10 +75,13 @@ def out_names(m, do_step: bool, stages: int):
 
 
 @torch.library.custom_op("mujoco_torch_amd::step_leaves", mutates_args=())
-def step_leaves(leaves: list[torch.Tensor], model_key: int, fixed_iterations: bool, do_step: bool, stages: int) -> list[torch.Tensor]:
+def step_leaves(leaves: list[torch.Tensor], model_key: torch.Tensor, struct_uid: str, fixed_iterations: bool, do_step: bool, stages: int) -> list[torch.Tensor]:
     from .forward import _run_native
 
     m = _model(model_key)
+    if m._struct_uid != struct_uid:
+        raise RuntimeError("mujoco_torch_amd::step_leaves: the Model handed to the traced step has another structure than the one it was traced with "
+                           "(different XML / cone / disabled constraints): trace a step of its own for it")
     tmpl = _template(m)
     top, con = {}, {}
     for n, t in zip(_NAMES, leaves):
@@ -99,8 +113,8 @@ def step_leaves(leaves: list[torch.Tensor], model_key: int, fixed_iterations: bo
 
 
 @step_leaves.register_fake
-def _(leaves, model_key, fixed_iterations, do_step, stages):
-    m = _model(model_key)
+def _(leaves, model_key, struct_uid, fixed_iterations, do_step, stages):
+    m = _structure(struct_uid)
     tmpl = _template(m)
     qpos = leaves[_QPOS]
     batch = tuple(qpos.shape[:-1])
@@ -112,12 +126,12 @@ def _(leaves, model_key, fixed_iterations, do_step, stages):
     return outs
 
 
-def _step_leaves_vmap(info, in_dims, leaves, model_key, fixed_iterations, do_step, stages):
+def _step_leaves_vmap(info, in_dims, leaves, model_key, struct_uid, fixed_iterations, do_step, stages):
     B = info.batch_size
     moved = []
     for t, bd in zip(leaves, in_dims[0]):
         moved.append(t.unsqueeze(0).expand(B, *t.shape) if bd is None else t.movedim(bd, 0))
-    outs = step_leaves(moved, model_key, fixed_iterations, do_step, stages)
+    outs = step_leaves(moved, model_key, struct_uid, fixed_iterations, do_step, stages)
     return outs, [0] * len(outs)
 
 
@@ -134,7 +148,7 @@ def run_through_op(m, d, fixed_iterations: bool, do_step: bool, stages: int):
         path = native.DATA_PATH[n]
         t = getattr(con if len(path) == 2 else d, path[-1], None)
         leaves.append(t if isinstance(t, torch.Tensor) else _ABSENT)
-    outs = torch.ops.mujoco_torch_amd.step_leaves(leaves, m._op_key, fixed_iterations, do_step, stages)
+    outs = torch.ops.mujoco_torch_amd.step_leaves(leaves, m._op_key_t, m._struct_uid, fixed_iterations, do_step, stages)
     top, cn = {}, {}
     names = out_names(m, do_step, stages)
     for i in range(len(names)):

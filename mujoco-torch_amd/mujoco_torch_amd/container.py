@@ -58,7 +58,7 @@ class UnbatchedTensor:
 
 
 # host-side attributes that belong to ONE container instance and are never inherited by containers derived from it
-_PRIVATE = ("_fields", "_bs", "_ver", "_child_keys", "_lazy", "_ptab", "_native_cache", "_order", "_op_key", "_stamp_ts")
+_PRIVATE = ("_fields", "_bs", "_ver", "_child_keys", "_lazy", "_ptab", "_native_cache", "_order", "_op_key", "_op_key_t", "_struct_uid", "_stamp_ts")
 
 
 def _carve(spec):

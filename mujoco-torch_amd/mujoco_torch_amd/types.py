@@ -105,6 +105,7 @@ MODEL_FIELDS = (
 
 _MODEL_KEYS = itertools.count(1)
 _MODELS_BY_KEY = weakref.WeakValueDictionary()
+_MODELS_BY_UID = weakref.WeakValueDictionary()  # tables.uid -> the most recent live Model of that structure (any of them serves shape propagation)
 
 
 class Model(MjTensorClass):
@@ -152,6 +153,14 @@ class Model(MjTensorClass):
         # and finds the Model again through a weak registry -- a custom op cannot take a container
         object.__setattr__(self, "_op_key", next(_MODEL_KEYS))
         _MODELS_BY_KEY[self._op_key] = self
+        # ... and hands the SAME number over as a tensor: a traced graph takes a tensor attribute of a closed-over object as an INPUT (no guard on its value), where the int
+        # would be burnt in as a constant -- a `mx.replace(body_mass=...)` per episode would then recompile the step every episode.  The graph's only
+        # constant is the STRUCTURE id (tables.uid, shared by every value-only copy), which is all the shape propagation needs.
+        object.__setattr__(self, "_op_key_t", torch.tensor(self._op_key, dtype=torch.int64))
+        T = self.__dict__.get("_tables")
+        if T is not None:
+            object.__setattr__(self, "_struct_uid", f"u{T.uid}")  # (a plain attribute: code traced by Dynamo reads it without going through `__dict__`)
+            _MODELS_BY_UID[f"u{T.uid}"] = self
 
 
 # attach the by-name leaves as annotations so they are real fields

@@ -426,3 +426,28 @@ def test_sensors_read_the_data_leaves_no_stage_writes(sim):
     assert adr == int(mx.nsensordata)
     with pytest.raises(ValueError, match="cfrc_int"):
         mt.step(mx, d.replace(cfrc_int=torch.zeros(2, nb, 5, dtype=torch.float64)))
+
+
+def test_value_only_model_edits_do_not_retrace_the_compiled_step(sim):
+    """the operator took the Model as a Python int, a constant of the traced graph -- every `mx.replace(body_mass=...)` (per-episode domain
+    randomisation) recompiled the step until Dynamo's recompile limit.  The graph's constant is now the STRUCTURE id; the Model's values travel as a tensor input."""
+    import torch._dynamo as dynamo
+
+    mx = load_model("hopper")
+    d = seeded(mx, 3)
+    holder = {"m": mx}
+    dynamo.reset()
+    counter = dynamo.testing.CompileCounter()
+    step = torch.compile(lambda x: mt.step(holder["m"], x), fullgraph=True, backend=counter)
+    base = step(d)
+    assert torch.equal(base.qpos, mt.step(mx, d).qpos)
+    frames = counter.frame_count
+    for k in range(3):
+        holder["m"] = mx.replace(body_mass=mx.body_mass * (1.5 + 0.1 * k))
+        got = step(d)
+        assert torch.equal(got.qpos, mt.step(holder["m"], d).qpos) and not torch.equal(got.qpos, base.qpos)
+    assert counter.frame_count == frames, f"value-only Model edits retraced the step ({counter.frame_count - frames} times)"
+    other = load_model("halfcheetah")                                   # another structure: its own trace, checked at run time
+    holder["m"] = other
+    d2 = seeded(other, 3)
+    assert torch.equal(step(d2).qpos, mt.step(other, d2).qpos)
