@@ -33,6 +33,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=0, help="environments per GPU (default: the workload's)")
     ap.add_argument("--workload", default="humanoid", choices=["humanoid", "humanoid32k", "ant", "mesh", "cartpole"])
+    ap.add_argument("--dtype", default="", choices=["", "f32", "f64"], help="override the workload's dtype (experiments: e.g. the float64 twin of config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="N > 1 humanoid runs also time BASELINE config 4 (32768 envs/GPU); skip it")
     ap.add_argument("--no-other-workloads", action="store_true", help="the default humanoid run also times BASELINE configs 3 (ant) and 5 (mesh scene); skip them")
@@ -263,6 +264,9 @@ def setup_workload(key, B, device, rank):
     wl = WORKLOADS[key]
     B = B or wl["batch"]
     dtype = wl["dtype"]
+    if ARGS is not None and getattr(ARGS, "dtype", "") and key == ARGS.workload:
+        dtype = torch.float64 if ARGS.dtype == "f64" else torch.float32
+        wl = dict(wl, dtype=dtype, name=wl["name"] + f" [dtype overridden: {ARGS.dtype}]")
     lite = mt.mjcf.from_xml_path(mt.test_data_path(wl["xml"] + ".xml"))
     for k, v in wl["overrides"].items():
         setattr(lite.opt, k, v)

@@ -459,10 +459,23 @@ struct CvxPair {
           REAL c[12], s0[4], s1[4];
 #pragma unroll
           for (int t = 0; t < 12; t++) c[t] = vv[3 * v + t];
+          if constexpr (sizeof(REAL) == 4) {
+            // float32: the two axes of the lane ride in the two halves of packed registers -- three v_pk_mul_f32 and two v_pk_add_f32 per vertex for BOTH projections
+            // (the compiler's own pairing left the additions scalar: 16 v_add_f32 per trip).  Each half is the same (a x + b y) + c z expression, rounded the same way.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            const f2 ax = {(float)ax0[0], (float)ax1[0]}, ay = {(float)ax0[1], (float)ax1[1]}, az = {(float)ax0[2], (float)ax1[2]};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const f2 x = {(float)c[3 * t], (float)c[3 * t]}, y = {(float)c[3 * t + 1], (float)c[3 * t + 1]}, z = {(float)c[3 * t + 2], (float)c[3 * t + 2]};
+              const f2 sv = (ax * x + ay * y) + az * z;
+              s0[t] = (REAL)sv[0]; s1[t] = (REAL)sv[1];
+            }
+          } else {
 #pragma unroll
           for (int t = 0; t < 4; t++) {
             s0[t] = (ax0[0] * c[3 * t] + ax0[1] * c[3 * t + 1]) + ax0[2] * c[3 * t + 2];
             s1[t] = (ax1[0] * c[3 * t] + ax1[1] * c[3 * t + 1]) + ax1[2] * c[3 * t + 2];
+          }
           }
           mx0 = r_max(mx0, r_max(r_max(s0[0], s0[1]), r_max(s0[2], s0[3]))); mn0 = r_min(mn0, r_min(r_min(s0[0], s0[1]), r_min(s0[2], s0[3])));
           mx1 = r_max(mx1, r_max(r_max(s1[0], s1[1]), r_max(s1[2], s1[3]))); mn1 = r_min(mn1, r_min(r_min(s1[0], s1[1]), r_min(s1[2], s1[3])));
