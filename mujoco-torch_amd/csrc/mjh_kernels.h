@@ -194,6 +194,7 @@ template <typename REAL>
 struct KArgs {
   DevModel<REAL> M;
   LdsOff off;          // arena of this launch's phase
+  LdsOff off2;         // whole-pass kernel (mjh_sol2_kernel<.., 34>): the arena layout of its second half (constraint stage + solver: PH_CS); `off` is its first half's (PH_KCV)
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
   StatePtrs<REAL> nxt; // where an RK stage writes the next stage's state (workspace Data)
@@ -4363,10 +4364,11 @@ struct Env {
 // WT: lanes per environment (32 or 16); WT = 17 is the four-per-wavefront kernel of NEWTON models (16 lanes, Newton-only code: 128 VGPRs + 116 B of scratch instead of + 160 B
 // for the ant's first tier, 227 instead of 243 VGPRs for the mesh scene's; ant 53.6 -> 52.2 us per launch, mesh scene 223.7 -> 219.1 us)
 template <typename REAL, int NMAX, int RPL, int WT>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
-  constexpr int W = WT == 17 ? 16 : (WT == 33 ? 32 : WT);
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && WT != 34 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+  constexpr int W = WT == 17 ? 16 : ((WT == 33 || WT == 34) ? 32 : WT);
   constexpr bool NEWTON_ONLY = WT == 17;
-  constexpr bool CS = WT == 33;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
+  constexpr bool CS = WT == 33 || WT == 34;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
+  constexpr bool ALL = WT == 34;             // WT = 34: ... and kinematics + crb / factor + velocity in front of that: the whole forward pass + integrator of an environment in one kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
@@ -4405,6 +4407,24 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
       // (mjh_sort_kernel), so that long solves share waves; which environments share a wave changes nothing in any of them.
       const int64_t env = (W == 16 && K.sol_perm) ? (int64_t)K.sol_perm[idx] : idx;
       Env<REAL, W, false> E(lds, K.env_begin + env, K.flags);
+      if constexpr (ALL) {
+        // The two halves of the pass used to be two launches (kernels 13 and 14): a device-wide barrier between them -- the slowest wave of the first, the launch, and
+        // every wave of the second requesting its inputs at the same moment.  Here an environment's wave goes straight on: what the second half reads of the first
+        // (geom frames, subtree_com, cdof, the factor, qM, qfrc_smooth, the normalised qpos) it reads back from the leaves THIS wave has just stored -- behind a
+        // release / acquire pair at the scope of its own CU -- through the arena layout of the second half.
+        E.template run_kin<false>();
+        wave_sync();
+        E.template crb_factor<true>();
+        wave_sync();
+        E.template run_vel<false, true>();
+        // (workgroup scope = this CU: its waves share ONE write-through L1, so a wave's loads see its own landed stores; agent scope would write back and invalidate the
+        //  XCD's L2 on every wave -- measured: 228.9 us against 167 us for the two launches)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        wave_sync();
+        E.S.off = &K.off2;
+        E.template run_con_sol2<NMAX, RPL>();
+      } else
       if constexpr (CS) E.template run_con_sol2<NMAX, RPL>();
       else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }

@@ -73,6 +73,8 @@ struct mjhModel {
   int sol2_it_cap = 0, sol2_ls_cap = 0;    // > 0: that launch leaves long solves (Newton iterations / line-search iterations beyond the caps) to a fallback launch of the LDS solver
   LdsOff off_tier;                         // ... from an arena of its own (32 rows of efc_J instead of all of them)
   int lds_tier = 0;
+  int fuse_all = 0;                        // ... and the whole pass as ONE kernel (mjh_sol2_kernel<.., 34>, timing id 16): kernel 13's stages in front of kernel 14's, one arena of max(lds_kcv, lds_cs)
+  int lds_all = 0;
   int fuse_cs = 0;                         // constraint stage + register solver + integrator run as ONE kernel (mjh_sol2_kernel<.., 33>, timing id 14) from an arena of its own
   LdsOff off_cs;
   int lds_cs = 0;
@@ -691,6 +693,20 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
 #undef SET_SOL2W
     }
   }
+  {  // the whole pass in one kernel: models both fused kernels serve at two environments per wavefront, without convex pairs or sensors (their kernels sit between the two halves).
+    // Measured (MI355X, humanoid B = 4096, three A / B pairs in one call, profiles/r04/notes.md): 166.8 - 170.5 us in one launch against 91.7 - 93.1 + 76.4 - 76.7 in two
+    // (23.5 - 24.3 M against 24.1 - 24.6 M env-steps/s): the one function is allocated 256 VGPRs + 304 B of scratch where the halves take 198 + 0 and 256 + 120 B, and that
+    // costs what the missing device-wide barrier saves.  Opt-in (MJH_FUSE_ALL=1).
+    static const bool on = [] { const char* e = getenv("MJH_FUSE_ALL"); return e && e[0] == '1'; }();
+    out->fuse_all = 0;
+    if (on && out->fuse_cs && out->fuse_kcv && out->pack2[1] && !out->pack4[1] && M.ncvxpair == 0 && d->nsensor == 0) {
+      out->lds_all = out->lds_kcv > out->lds_cs ? out->lds_kcv : out->lds_cs;
+      if (2 * out->lds_all <= 64 * 1024) {
+        out->fuse_all = 1;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 34>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_all));
+      }
+    }
+  }
   return 0;
 }
 
@@ -814,11 +830,28 @@ int launch_cs(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   return 0;
 }
 
+// the whole pass in one launch (mjhModel::fuse_all)
+template <typename REAL>
+int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  a.env_begin = 0; a.env_count = a.B;
+  a.off = m->off_kcv; a.off2 = m->off_cs;
+  a.lds_reals = m->lds_all / (int)sizeof(REAL);
+  a.row_lo = -1; a.row_hi = 0x7fffffff;
+  a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
+  const int64_t blocks = (a.B + 1) / 2;
+  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
+  hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 34>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
+  HIP_TRY(hipGetLastError());
+  timing_mark(stream, 16);
+  return 0;
+}
+
 // one forward pass = the phases selected by `stages`
 template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
+  if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
   const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
   const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
   if ((st & 0x7f) && (rc = fused_kcv ? launch_phase<REAL, 13>(m, a, stream) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
@@ -1195,6 +1228,14 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
   return (int)all.size();
 }
 
+static thread_local bool g_io_inner = false;
+static int mjh_model_kernel_io_impl(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
+  const bool prev = g_io_inner;
+  g_io_inner = true;
+  const int rc = mjh_model_kernel_io(m, kernel, read_write_bytes);
+  g_io_inner = prev;
+  return rc;
+}
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   if (!m || !read_write_bytes) return fail(-22, "null argument");
   if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
@@ -1212,6 +1253,15 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     return rc;
   };
   int64_t a[2] = {0, 0};
+  if (kernel == 16) {  // the whole pass in one launch: the accounts of kernels 13 and 14 (what the second half reads of the first it still reads from the leaves)
+    if (!m->fuse_all) return -2;
+    int64_t a13[2] = {0, 0}, a14[2] = {0, 0};
+    const mjhModel* mm = m;
+    if (mjh_model_kernel_io_impl(mm, 13, a13) != 0 || mjh_model_kernel_io_impl(mm, 14, a14) != 0) return -2;
+    read_write_bytes[0] = a13[0] + a14[0]; read_write_bytes[1] = a13[1] + a14[1];
+    return 0;
+  }
+  if ((kernel == 13 || kernel == 14) && m->fuse_all && !g_io_inner) return -2;
   if (kernel == 14) {  // constraint stage + register solver: the two accounts minus what stays in the arena between them -- the dense rows of efc_J, efc_D / efc_aref, one entry per single-column row, qvel
     if (!m->fuse_cs) return -2;
     int64_t k2[2] = {0, 0}, k4[2] = {0, 0};

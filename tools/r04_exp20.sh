@@ -1,0 +1,8 @@
+#!/bin/bash
+run() { tag=$1; wl=$2; shift 2; env "$@" python3 bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline --no-other-workloads --no-long-run 2>/dev/null | python3 tools/benchline.py "$tag"; }
+run h_all humanoid MJH_X=0
+run h_two humanoid MJH_FUSE_ALL=0
+run h_all humanoid MJH_X=0
+run h32k_all humanoid32k MJH_X=0
+run h32k_two humanoid32k MJH_FUSE_ALL=0
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "humanoid or config" 2>&1 | tail -4
