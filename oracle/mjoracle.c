@@ -16,6 +16,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>

@@ -1973,7 +1973,15 @@ static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx)
       for (int q = 0; q < 3; q++) {
         FN(LSPoint)* cd = cands[q];
         if (R_FABS(cd->d0) < noise && cd->alpha != lo.alpha && cd->alpha != hi.alpha) {
-          if (w->knife_policy >= 0) {
+          if (w->knife_policy >= (1 << 30)) {
+            /* "every Newton candidate that lands on the root rounds to exactly zero": only derivatives at the rounding floor of their own sum (a few ulp of
+               |d0(0)|), not the wider noise band -- bisection points that approach the root stay what they are */
+#ifdef REAL_IS_FLOAT
+            if (R_FABS(cd->d0) < (REAL)4e-6 * R_FABS(p0.d0)) cd->d0 = 0;
+#else
+            if (R_FABS(cd->d0) < (REAL)1e-14 * R_FABS(p0.d0)) cd->d0 = 0;
+#endif
+          } else if (w->knife_policy >= 0) {
             if (w->knife < w->knife_policy) cd->d0 = 0;                       /* "rounded to exactly zero": rejected */
             else if (w->knife == w->knife_policy && cd->d0 == 0) cd->d0 = -noise * (REAL)1e-6; /* "not exactly zero": accepted */
           }
@@ -1989,10 +1997,12 @@ static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx)
     int s5 = FN(ls_swap)(hi.d0, mid.d0, nb); if (s5) hi = mid;
     int s6 = FN(ls_swap)(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
     swap = s1 | s2 | s3 | s4 | s5 | s6;
+    if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo]     ls %d: lo_next (a %.17g d0 %.6e) hi_next (a %.17g d0 %.6e) mid (a %.17g d0 %.6e) swaps %d%d%d%d%d%d -> lo (a %.17g d0 %.6e) hi (a %.17g d0 %.6e)\n", ls_iter, (double)lo_next.alpha, (double)lo_next.d0, (double)hi_next.alpha, (double)hi_next.d0, (double)mid.alpha, (double)mid.d0, s1, s2, s3, s4, s5, s6, (double)lo.alpha, (double)lo.d0, (double)hi.alpha, (double)hi.d0);
     ls_iter++;
   }
   REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
   REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
+  if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo]   ls: iters %d early %d p0 (d0 %.6e d1 %.6e cost %.17g) p1 (a %.17g d0 %.6e) lo (a %.17g d0 %.6e cost %.17g) hi (a %.17g d0 %.6e cost %.17g) gtol %.3e alpha %.17g improved %g\n", ls_iter, early, (double)p0.d0, (double)p0.d1, (double)p0.cost, (double)p1.alpha, (double)p1.d0, (double)lo.alpha, (double)lo.d0, (double)lo.cost, (double)hi.alpha, (double)hi.d0, (double)hi.cost, (double)gtol, (double)alpha, (double)improved);
   for (int d = 0; d < nv; d++) {
     w->s_qacc[d] = w->s_qacc[d] + improved * w->s_search[d] * alpha;
     w->s_Ma[d] = w->s_Ma[d] + improved * w->s_mv[d] * alpha;
@@ -2027,6 +2037,7 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
       int done = c.niter >= m->iterations;
       done |= improvement < (REAL)m->tolerance;
       done |= gradient < (REAL)m->tolerance;
+      if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo] it %d cost %.17g improvement %.6e gradient %.6e done %d qacc0 %.17g\n", c.niter, (double)c.cost, (double)improvement, (double)gradient, done, (double)w->s_qacc[0]);
       if (done) break;
     }
     /* body :510-524 */

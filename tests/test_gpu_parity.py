@@ -640,6 +640,23 @@ def test_pinned_campaign_outliers(name, oracle_lib):
       on every pre-solver leaf, lie inside that band, and match at 1e-8 once the same solve is allowed to converge."""
     mx, d, meta = load_outlier(name)
     got = gpu_out_to_numpy(mt.step(mx.to("cuda"), d.to("cuda")))
+    if "_r04_" in name:
+        # round 4, tools/fuzz_parity.py 2048 5: five of 358 400 environment-steps matched no outcome of the batch enumeration.  Each is pinned with the rule of
+        # check_against_oracle that accounts for it (DESIGN.md section 4, "campaign tail"): "branch" = an enumerated stage-tie outcome (the element-wise figure had been
+        # taken from the wrong branch), "deep" = a noise candidate beyond the 14th decides, "band" = a capped Newton solve inside the oracle's own spread, "f64" = the
+        # float32 oracle is itself further from the float64 solution than the tolerance, "cost" = same objective value to the solver's own stopping tolerance.
+        from _cases import FUZZ_BAND, FUZZ_TOL_PRE
+
+        d2 = torch.stack([d, d])
+        got2 = {n: np.stack([got[n], got[n]]) for n in got}
+        tail = {}
+        tol = 5e-3 if meta["dtype"] == "float32" else 1e-8
+        check_against_oracle(mx, d2, got2, FUZZ_TOL_PRE[d.qpos.dtype], tol, what=name, band=FUZZ_BAND.get(meta["xml"]), tail_rules=True, tail_out=tail)
+        if meta["rule"] in tail:
+            assert tail[meta["rule"]] == 2, (meta["rule"], tail)
+        else:
+            assert sum(tail.values()) == 0, tail
+        return
     if "_rk4_" in name:
         check_against_oracle(mx, d, got, 1e-9, 1e-8, what=name)
         return

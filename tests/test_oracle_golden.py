@@ -1,5 +1,6 @@
 """The CPU oracle (oracle/mjoracle.c) against golden vectors recorded from the reference's own
 Python step (oracle/gen_golden.py).  This is what pins the oracle; CPU-only."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -89,3 +90,31 @@ def test_iteration_capped_newton_states_are_implementation_defined(name, oracle_
     mx2, d2, _ = load_outlier(name, dict(iterations=100, ls_iterations=50, tolerance=1e-12))
     spread2, _ = policy_spread(mx2, d2)
     assert spread2 < 1e-8, spread2
+
+
+@pytest.mark.parametrize("name", [c for c in OUTLIER_CASES if "_r04_" in c])
+def test_campaign_tail_rules_on_recorded_outputs(name, oracle_lib):
+    """The five environment-steps of the round-4 campaign (2048 environments x 5 steps x 35 cases) that matched no outcome of the batch enumeration, with the outputs the
+    HIP step produced for them (recorded on the GPU box, `got/*`): each must be accepted by the rule recorded with it and by no weaker path -- the checker's tail rules
+    are exercised here without a GPU (tests/test_gpu_parity.py::test_pinned_campaign_outliers runs the live step through the same check)."""
+    import json
+
+    from _cases import FUZZ_BAND, FUZZ_TOL_PRE
+    from _util import GOLD, check_against_oracle
+
+    mx, d, meta = load_outlier(name)
+    z = np.load(os.path.join(GOLD, "outliers", name + ".npz"))
+    got2 = {k[4:]: np.stack([z[k], z[k]]) for k in z.files if k.startswith("got/")}
+    d2 = torch.stack([d, d])
+    tol = 5e-3 if meta["dtype"] == "float32" else 1e-8
+    kw = dict(what=name, band=FUZZ_BAND.get(meta["xml"]))
+    tail = {}
+    check_against_oracle(mx, d2, got2, FUZZ_TOL_PRE[d.qpos.dtype], tol, tail_rules=True, tail_out=tail, **kw)
+    if meta["rule"] in ("f64", "cost"):
+        assert tail[meta["rule"]] == 2, tail
+        with pytest.raises(AssertionError):  # ... and without the tail rules it is the mismatch the campaign reported
+            check_against_oracle(mx, d2, got2, FUZZ_TOL_PRE[d.qpos.dtype], tol, **kw)
+    elif meta["rule"] == "deep":
+        assert tail["deep"] == 2 and tail["f64"] == 0 and tail["cost"] == 0, tail
+    else:
+        assert tail["f64"] == 0 and tail["cost"] == 0, tail

@@ -31,13 +31,13 @@ for xml, ov, dt, tol_sol in CASES:
     try:
         mx, d = fuzz_batch(xml, ov, dt, B)
         mdev, dg = mx.to("cuda"), d.to("cuda")
-        fracs = []
+        fracs, tail = [], {}
         for s in range(STEPS):
             og = mt.step(mdev, dg)
-            frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dt], tol_sol, what=f"{xml} step{s}", nthreads=16, band=FUZZ_BAND.get(xml))
+            frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dt], tol_sol, what=f"{xml} step{s}", nthreads=16, band=FUZZ_BAND.get(xml), tail_rules=True, tail_out=tail)
             fracs.append((round(frac, 3), float(f"{worst:.1e}")))
             dg = og
-        print(f"ok   {xml:22s} {str(ov):55s} {str(dt)[6:]:8s} B={B} (alt-branch frac, worst solver err) per step: {fracs}  [{time.time() - t0:.0f}s]", flush=True)
+        print(f"ok   {xml:22s} {str(ov):55s} {str(dt)[6:]:8s} B={B} (alt-branch frac, worst solver err) per step: {fracs}  tail {tail}  [{time.time() - t0:.0f}s]", flush=True)
     except Exception as ex:  # noqa: BLE001
         bad += 1
         print(f"FAIL {xml} {ov} {dt}: {str(ex)[:600]}", flush=True)
