@@ -2,7 +2,7 @@
 seeded unit tests: joint angles, un-normalised quaternions, velocities, controls, applied forces, warm starts) are stepped on the
 GPU and checked leaf by leaf against the CPU oracle.  Prints one line per (model, dtype) and exits non-zero on a mismatch.
 
-    python tools/fuzz_parity.py [B] [steps]
+    python tools/fuzz_parity.py [B] [steps] [case indices into tests/_cases.py FUZZ_CASES, comma-separated]
 """
 import os
 import sys
@@ -25,8 +25,11 @@ STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 from _cases import FUZZ_BAND, FUZZ_CASES as CASES, FUZZ_TOL_PRE as TOL_PRE  # noqa: E402  (the bounds of the in-suite campaign, tests/test_gpu_parity.py::test_differential_campaign)
 import _util  # noqa: E402
 
+ONLY = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None
 bad = 0
-for xml, ov, dt, tol_sol in CASES:
+for ci, (xml, ov, dt, tol_sol) in enumerate(CASES):
+    if ONLY is not None and ci not in ONLY:
+        continue
     t0 = time.time()
     try:
         mx, d = fuzz_batch(xml, ov, dt, B)
