@@ -173,6 +173,7 @@ struct DevModel {
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
   int con_rows;                            // constraint rows of every contact when they all have the same number (one condim), else 0
   int sol2_row_cap;                        // only while the arena of the register solver's first tier is carved (mjhip.hip): dense rows it keeps; 0 otherwise
+  int sol2_hs;                             // non-zero: the register solver builds the Newton Hessian with block matrix instructions (float32, nv <= 16)
   // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
   // everything a row needs with ONE table read indexed by its own row number instead of a chain row -> contact -> geom -> body
   const REAL* crow_par;                    // 9 * ncrow, parameter-major [k * ncrow + q]: solref (2, friction rows of elliptic cones resolved), solimp (5), invweight, includemargin of contact row q

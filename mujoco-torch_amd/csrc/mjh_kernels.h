@@ -854,6 +854,14 @@ struct Sol2Con {
   int nact;          // active contacts
 };
 
+#ifndef MJH_HROWS
+#define MJH_HROWS 4
+#endif
+// lane c of every quad (4 consecutive lanes) broadcast to the quad's four lanes (DPP quad_perm [c, c, c, c])
+template <int C> __device__ __forceinline__ float quad_bcast(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C * 0x55, 0xf, 0xf, false));
+}
+
 // =====================================================================================================================
 // FRIC: the general constraint / solver instantiations (equality, frictionloss, dense limit rows; also max_contact_points);
 // DIRECT: the constraint phase of small models that writes its contact rows straight to the efc_J leaf (kernel 8)
@@ -4085,7 +4093,11 @@ struct Env {
         REAL acc[NMAX];
 #pragma unroll
         for (int k = 0; k < NMAX; k++) acc[k] = 0;
-        if (dof && limrow >= 0) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
+        // (measured, MI355X: mesh scene, nv 12, up to 80 rows: solver phase 206 -> 195 us; ant, nv 8, <= 32 rows: 48.3 -> 49.4 us -- eight-dof models keep the vector path)
+        constexpr bool MFMA_H = sizeof(REAL) == 4 && NEWT && (NMAX % 4) == 0 && NMAX >= 12;
+        bool by_mfma = false;
+        if constexpr (MFMA_H) by_mfma = M.sol2_hs != 0;
+        if (dof && limrow >= 0 && !by_mfma) {  // a single-column row only touches its own diagonal entry, and it precedes the contact rows
 #pragma unroll
           for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[ndc + limrow];
         }
@@ -4093,7 +4105,64 @@ struct Env {
         // r = g, g + G, ... (a counted loop whose LDS reads pipeline; a row outside the quadratic set has weight 0 and adds (J * 0) * J = +-0),
         // then the groups' partial sums are added across lanes.  One lane per dof walking every row was a quarter of the lanes doing
         // four times the trips.
-        {
+        if constexpr (MFMA_H) {
+          if (by_mfma) {
+            // J^T diag(w) J on the matrix cores: v_mfma_f32_4x4x1 is 16 independent 4 x 4 outer-product accumulations, block b fed by lanes 4 b .. 4 b + 3 -- an
+            // environment's W lanes own W / 4 blocks and nothing of another environment's lanes enters them, so the instruction sits in this per-environment
+            // (divergent) code like any other (checked on the device: lanes outside EXEC keep their destination registers, tools/micro/mfma_exec.hip).  Block q owns
+            // rows 4 q .. 4 q + 3 of H: lane p of the block supplies A[p] = J[r][4 q + p] * w[r] once per row and B[p] = J[r][4 tj + p] for each column tile tj, and
+            // receives column 4 tj + p of the block's four rows (register t = row 4 q + t); rows r in order, NMAX / 4 instructions per row.  Lane i = 4 q + p needs
+            // row i, i.e. register p of every lane of its own block: a 4 x 4 transpose inside each quad, done with quad_perm broadcasts and selects -- nothing goes
+            // through LDS (a staging square cost the mesh scene one of its seven workgroups per CU).  Against the vector path (one lane per dof walking every row:
+            // 1 + 2 NMAX vector instructions and NMAX + 1 LDS reads per row) this is one multiply, 2 + NMAX / 4 LDS reads and NMAX / 4 matrix instructions per row.  The
+            // products are fused multiply-adds here and separate multiplies and adds there: the Hessian differs in its last bits (it only steers the search direction).
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            constexpr int TS = NMAX / 4;
+            const int q = l >> 2, p = l & 3;
+            const bool qon = q < TS;
+            const int ia = qon ? 4 * q + p : nv, ca = ia < nv ? ia : 0;  // (columns past nv: a clamped address and a zero after the read -- no branch around an LDS read, as in the vector path)
+            int cb[TS];
+            bool bon[TS];
+            f4v hacc[TS];
+#pragma unroll
+            for (int tj = 0; tj < TS; tj++) { bon[tj] = 4 * tj + p < nv; cb[tj] = bon[tj] ? 4 * tj + p : 0; hacc[tj] = (f4v){0.f, 0.f, 0.f, 0.f}; }
+            // MJH_HROWS rows per trip, their reads requested together (a row past nda: row 0 with weight 0); the accumulation stays in row order
+            for (int r = 0; r < nda; r += MJH_HROWS) {
+              float ja[MJH_HROWS], jb[MJH_HROWS][TS], w[MJH_HROWS];
+#pragma unroll
+              for (int u = 0; u < MJH_HROWS; u++) {
+                const bool row_in = r + u < nda;
+                const int rr = row_in ? r + u : 0;
+                const REAL* jr = Jc + rr * nv;
+                const float wr = (float)fs[rr];
+                w[u] = row_in ? wr : 0.f;
+                ja[u] = (float)jr[ca];
+#pragma unroll
+                for (int tj = 0; tj < TS; tj++) jb[u][tj] = (float)jr[cb[tj]];
+              }
+#pragma unroll
+              for (int u = 0; u < MJH_HROWS; u++) {
+                const float a = (ia < nv ? ja[u] : 0.f) * w[u] * 1.f;
+#pragma unroll
+                for (int tj = 0; tj < TS; tj++) hacc[tj] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, bon[tj] ? jb[u][tj] : 0.f, hacc[tj], 0, 0, 0);
+              }
+            }
+#define MJH_QUAD_COL(tj, c)                                                                                                                                         \
+            {                                                                                                                                                       \
+              const float x0 = quad_bcast<c>(hacc[tj][0]), x1 = quad_bcast<c>(hacc[tj][1]), x2 = quad_bcast<c>(hacc[tj][2]), x3 = quad_bcast<c>(hacc[tj][3]);       \
+              const float v = p == 0 ? x0 : (p == 1 ? x1 : (p == 2 ? x2 : x3));                                                                                      \
+              acc[4 * tj + c] = (dof && 4 * tj + c <= l) ? (REAL)v : (REAL)0;                                                                                        \
+            }
+#pragma unroll
+            for (int tj = 0; tj < TS; tj++) { MJH_QUAD_COL(tj, 0) MJH_QUAD_COL(tj, 1) MJH_QUAD_COL(tj, 2) MJH_QUAD_COL(tj, 3) }
+#undef MJH_QUAD_COL
+            if (dof && limrow >= 0) {
+#pragma unroll
+              for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[ndc + limrow];
+            }
+          }
+        }
+        if (!by_mfma) {
           constexpr int G = NEWT ? W / NMAX : 1;
           static_assert(G == 1 || (NMAX & (NMAX - 1)) == 0, "several lane groups need a power-of-two NMAX");
           const int hg = NEWT ? l / NMAX : 0, hi = NEWT ? l - hg * NMAX : l;  // (lanes past the last group run the loop on rows nobody reads)

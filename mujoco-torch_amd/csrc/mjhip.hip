@@ -468,6 +468,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   fix.push_back({(const void**)&M.dof_limrow, bb.add(dof_limrow.data(), sizeof(int) * dof_limrow.size())});
   M.max_depth = max_depth;
   M.sol_qm_lds = (d->nefc > 0 && d->iterations > 4) ? 1 : 0;  // one pass over qM per solver iteration: from LDS when there are many
+  {  // register solver, Newton, float32: J^T diag(w) J on the matrix cores (v_mfma_f32_4x4x1, 16 independent 4 x 4 blocks: each environment's lanes feed only their own blocks).  MJH_SOL2_MFMA=0: vector path
+    static const bool mfma_off = [] { const char* e = getenv("MJH_SOL2_MFMA"); return e && e[0] == '0'; }();
+    M.sol2_hs = (!mfma_off && sizeof(REAL) == 4 && d->solver == SOL_NEWTON && d->nv <= 16 && d->nefc > 0) ? 1 : 0;
+  }
   // convex pairs and the LDS scratch their wave needs (layout in mjh_convex.h)
   std::vector<int> cvx_pairs;
   int cvx_reals = 0;
