@@ -155,6 +155,7 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("frictionloss_dof", {}, F64, 1e-8), ("ant_frictionloss", {}, F64, 1e-8),
     ("muscle_arm", {}, F64, 1e-8), ("tendon_armature", {}, F64, 1e-8), ("tendon_friction", {}, F64, 1e-8), ("capsules_topk", {}, F64, 1e-8),
     ("centipede", {}, F64, 1e-8), ("tendon_spatial", {}, F64, 1e-8),
+    ("mesh_contact", {}, F32, 5e-3),  # BASELINE config 5's model and dtype: the packed Newton tier with the Hessian on the matrix cores (round 4)
 ]
 # float32 cases of the campaign: near-degenerate contact normals amplify eps under these perturbations (pre-solver 1e-3); qfrc_constraint /
 # efc_force of the ant cancel forces of ~1e5, the dynamics leaves carry the comparison there
