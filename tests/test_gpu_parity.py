@@ -289,6 +289,45 @@ print("split ok")
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_matrix_core_hessian_against_the_vector_path(tmp_path):
+    """Float32 Newton models with 12 - 16 dofs build the Hessian of the packed solver tier with v_mfma_f32_4x4x1 blocks (MJH_SOL2_MFMA=0: vector units).  On the SAME inputs
+    -- one step of the seeded mesh-scene batch (BASELINE config 5's recipe) and one of the campaign's heavily perturbed batch -- the two paths must agree to float32 solver
+    noise, and must NOT be bit-identical (fused multiply-adds against separate multiplies and adds: identical bits would mean the switch selects nothing).  Trajectories are not
+    compared: resting boxes are chaotic (a 1e-6 difference after one step flips a manifold selection in the next and moves qacc by O(1): measured while writing this test)."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from _cases import fuzz_batch, seeded_batch
+out = {}
+for tag, (mx, d) in (("seeded", seeded_batch("mesh_contact", {}, torch.float32, 256)), ("fuzz", fuzz_batch("mesh_contact", {}, torch.float32, 512))):
+    og = mt.step(mx.to("cuda"), d.to("cuda"))
+    for n in ("qacc", "qvel", "qpos", "efc_force"):
+        out[f"{tag}/{n}"] = getattr(og, n).cpu().numpy()
+np.savez(sys.argv[1], **out)
+print("saved")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, val in (("mfma", "1"), ("valu", "0")):
+        path = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", code, path], cwd=root, env=dict(os.environ, MJH_SOL2_MFMA=val), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "saved" in r.stdout, r.stdout + r.stderr
+        res[tag] = dict(np.load(path))
+    worst, same = {"seeded": 0.0, "fuzz": 0.0}, True
+    for k in res["mfma"]:
+        a, b = res["mfma"][k].astype(np.float64), res["valu"][k].astype(np.float64)
+        worst[k.split("/")[0]] = max(worst[k.split("/")[0]], float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-3)))
+        same = same and np.array_equal(res["mfma"][k], res["valu"][k])
+    assert worst["seeded"] <= 5e-4, worst   # config 5's float32 bound (tests/_cases.py); measured 3.8e-6
+    assert worst["fuzz"] <= 5e-3, worst     # the campaign's float32 bound
+    assert not same, "MJH_SOL2_MFMA selected nothing: both runs are bit-identical"
+
+
 def test_batch_beyond_the_launch_grid_cap():
     """B = 2^20 + 5 cartpoles (the launch grid is capped at 2^20 workgroups, the kernels loop over the rest; two environments
     per wavefront in the packed phases and an odd tail): every environment equals its twin in an 8-environment batch."""
