@@ -1291,7 +1291,13 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
 }
 
 int64_t mjh_model_work_bytes(const mjhModel* m) { return m ? m->work_reals * (m->dtype == MJH_F64 ? 8 : 4) : 0; }
-int mjh_model_lds_bytes(const mjhModel* m, int phase) { return (m && phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0; }  // phase 5: the register solver's arena
+int mjh_model_lds_bytes(const mjhModel* m, int phase) {  // phase 5: the register solver's arena; 16 / 17 / 18: its packed first tier, the fused kinematics + crb + velocity kernel, the fused constraint + solver kernel (per environment)
+  if (!m) return 0;
+  if (phase == 16) return m->lds_tier;
+  if (phase == 17) return m->lds_kcv;
+  if (phase == 18) return m->lds_cs;
+  return (phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0;
+}
 const char* mjh_last_error(void) { return g_err.c_str(); }
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
 
