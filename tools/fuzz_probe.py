@@ -1,5 +1,5 @@
 """GPU box: one saved campaign environment (tools/fuzz_triage.py) stepped under a grid of iteration caps, to find the solver iteration / line-search iteration at which
-the GPU and the oracle part ways.   python tools/fuzz_probe.py triage_tmp/NAME.pt   -> gpurun_out/triage/NAME.probe.pt = {(iterations, ls_iterations): qacc}"""
+the GPU and the oracle part ways.   python tools/fuzz_probe.py triage_tmp/NAME.pt   (copy gpurun_out/triage/NAME.pt into triage_tmp/ first: git-ignored, but it travels to the box)   -> gpurun_out/triage/NAME.probe.pt = {(iterations, ls_iterations): qacc}"""
 import os
 import sys
 
