@@ -282,6 +282,9 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
       enumerated): an environment beyond tol_solver is still accepted when the natural run met noise candidates there and its
       error is within ``band`` x the spread of the oracle's own enumerated outcomes for that environment, i.e. inside the
       reference's implementation-defined band (tests/test_oracle_golden.py pins that such bands collapse once the solve converges).
+    * ``tail_rules`` (the large differential campaign only, DESIGN.md section 4 "the campaign's tail"): an environment that still matches nothing is put through the
+      evidence rules below -- last-bit sensitivity of the oracle itself (`ulp`, `ulp_band`), the float64 yardstick for float32 (`f64`), equal objective value (`cost`), and the
+      conditioning-aware bound on a contact normal between coincident points (`frame_cond`); ``tail_out`` receives the number of environments each rule accepted.
     Returns (fraction of environments on a non-natural line-search branch, worst solver-leaf error on the accepted branch)."""
     c = compare_with_oracle(model, d_cpu, got, step=step, **kw)
     c["tail"] = {"deep": 0, "f64": 0, "cost": 0}  # environments accepted by the rules below (reported by the campaign)
@@ -295,8 +298,6 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
                                       **{k: v for k, v in kw.items() if k != "tie_pairs"})
             if one["err_best"][0] < c["err_best"][e]:
                 c["err_best"][e], c["elem_best"][e] = one["err_best"][0], one["elem_best"][0]  # (the element-wise figure belongs to the branch that was accepted)
-                c["alts_env"] = c.get("alts_env", {})
-                c["alts_env"][int(e)] = one["alts"]
                 c["tail"]["deep"] += int(one["err_best"][0] <= tol_solver)
     if tail_rules and d_cpu.qpos.ndim > 1 and step:
         need = set(SOLVER_LEAVES) | {"efc_force"}
