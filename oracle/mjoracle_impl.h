@@ -36,6 +36,16 @@
 #define DSBL_EULERDAMP (1 << 15)
 #define INT_EULER 0
 #define INT_RK4 1
+
+/* MJO_TRACE=1: the solver prints its iterations and line searches to stderr (triage of campaign environments, tools/fuzz_triage.py); read once */
+#ifndef MJO_TRACE_HELPER
+#define MJO_TRACE_HELPER
+static int mjo_trace_flag = -1;
+static inline int mjo_trace_on(void) {
+  if (mjo_trace_flag < 0) mjo_trace_flag = getenv("MJO_TRACE") != NULL;
+  return mjo_trace_flag;
+}
+#endif
 #define SOL_CG 1
 #define SOL_NEWTON 2
 #define CONE_ELLIPTIC 1
@@ -1997,12 +2007,12 @@ static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx)
     int s5 = FN(ls_swap)(hi.d0, mid.d0, nb); if (s5) hi = mid;
     int s6 = FN(ls_swap)(hi.d0, lo_next.d0, nb); if (s6) hi = lo_next;
     swap = s1 | s2 | s3 | s4 | s5 | s6;
-    if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo]     ls %d: lo_next (a %.17g d0 %.6e) hi_next (a %.17g d0 %.6e) mid (a %.17g d0 %.6e) swaps %d%d%d%d%d%d -> lo (a %.17g d0 %.6e) hi (a %.17g d0 %.6e)\n", ls_iter, (double)lo_next.alpha, (double)lo_next.d0, (double)hi_next.alpha, (double)hi_next.d0, (double)mid.alpha, (double)mid.d0, s1, s2, s3, s4, s5, s6, (double)lo.alpha, (double)lo.d0, (double)hi.alpha, (double)hi.d0);
+    if (mjo_trace_on()) fprintf(stderr, "[mjo]     ls %d: lo_next (a %.17g d0 %.6e) hi_next (a %.17g d0 %.6e) mid (a %.17g d0 %.6e) swaps %d%d%d%d%d%d -> lo (a %.17g d0 %.6e) hi (a %.17g d0 %.6e)\n", ls_iter, (double)lo_next.alpha, (double)lo_next.d0, (double)hi_next.alpha, (double)hi_next.d0, (double)mid.alpha, (double)mid.d0, s1, s2, s3, s4, s5, s6, (double)lo.alpha, (double)lo.d0, (double)hi.alpha, (double)hi.d0);
     ls_iter++;
   }
   REAL improved = (REAL)((lo.cost < p0.cost) || (hi.cost < p0.cost));
   REAL alpha = lo.cost < hi.cost ? lo.alpha : hi.alpha;
-  if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo]   ls: iters %d early %d p0 (d0 %.6e d1 %.6e cost %.17g) p1 (a %.17g d0 %.6e) lo (a %.17g d0 %.6e cost %.17g) hi (a %.17g d0 %.6e cost %.17g) gtol %.3e alpha %.17g improved %g\n", ls_iter, early, (double)p0.d0, (double)p0.d1, (double)p0.cost, (double)p1.alpha, (double)p1.d0, (double)lo.alpha, (double)lo.d0, (double)lo.cost, (double)hi.alpha, (double)hi.d0, (double)hi.cost, (double)gtol, (double)alpha, (double)improved);
+  if (mjo_trace_on()) fprintf(stderr, "[mjo]   ls: iters %d early %d p0 (d0 %.6e d1 %.6e cost %.17g) p1 (a %.17g d0 %.6e) lo (a %.17g d0 %.6e cost %.17g) hi (a %.17g d0 %.6e cost %.17g) gtol %.3e alpha %.17g improved %g\n", ls_iter, early, (double)p0.d0, (double)p0.d1, (double)p0.cost, (double)p1.alpha, (double)p1.d0, (double)lo.alpha, (double)lo.d0, (double)lo.cost, (double)hi.alpha, (double)hi.d0, (double)hi.cost, (double)gtol, (double)alpha, (double)improved);
   for (int d = 0; d < nv; d++) {
     w->s_qacc[d] = w->s_qacc[d] + improved * w->s_search[d] * alpha;
     w->s_Ma[d] = w->s_Ma[d] + improved * w->s_mv[d] * alpha;
@@ -2037,7 +2047,7 @@ static void FN(solve)(const FN(MjoModel) * M, FN(MjoWork) * w, int fixed_iterati
       int done = c.niter >= m->iterations;
       done |= improvement < (REAL)m->tolerance;
       done |= gradient < (REAL)m->tolerance;
-      if (getenv("MJO_TRACE")) fprintf(stderr, "[mjo] it %d cost %.17g improvement %.6e gradient %.6e done %d qacc0 %.17g\n", c.niter, (double)c.cost, (double)improvement, (double)gradient, done, (double)w->s_qacc[0]);
+      if (mjo_trace_on()) fprintf(stderr, "[mjo] it %d cost %.17g improvement %.6e gradient %.6e done %d qacc0 %.17g\n", c.niter, (double)c.cost, (double)improvement, (double)gradient, done, (double)w->s_qacc[0]);
       if (done) break;
     }
     /* body :510-524 */
