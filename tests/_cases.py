@@ -156,6 +156,7 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
     ("muscle_arm", {}, F64, 1e-8), ("tendon_armature", {}, F64, 1e-8), ("tendon_friction", {}, F64, 1e-8), ("capsules_topk", {}, F64, 1e-8),
     ("centipede", {}, F64, 1e-8), ("tendon_spatial", {}, F64, 1e-8),
     ("mesh_contact", {}, F32, 5e-3),  # BASELINE config 5's model and dtype: the packed Newton tier with the Hessian on the matrix cores (round 4)
+    ("mesh_contact_arm", {}, F32, 5e-3), ("mesh_contact_arm", {}, F64, 1e-8),  # 15 dofs, condim 6 + 3 contacts, hinge limits: the 16-wide instantiations of that tier (four tile rows)
 ]
 # float32 cases of the campaign: near-degenerate contact normals amplify eps under these perturbations (pre-solver 1e-3); qfrc_constraint /
 # efc_force of the ant cancel forces of ~1e5, the dynamics leaves carry the comparison there
