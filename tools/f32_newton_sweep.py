@@ -1,5 +1,5 @@
 """GPU box: float32 Newton steps of every bundled model whose packed solver tier builds its Hessian on the matrix cores (9 - 16 dofs; nv < NMAX and NMAX = 16 included),
-heavily perturbed batches against the float32 oracle -- the campaign's check at the campaign's float32 bound.   python tools/f32_newton_sweep.py [B] [steps]"""
+heavily perturbed batches against the float32 oracle -- the campaign's check at the campaign's float32 bound.   python tools/f32_newton_sweep.py [B] [steps]    (SWEEP_ELLIPTIC=1: elliptic cones)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in ("mujoco-torch_amd", "oracle", "tests"): sys.path.insert(0, os.path.join(ROOT, p))
@@ -12,7 +12,7 @@ STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 bad = 0
 for xml in ("ball_free_actuators", "gravcomp_arm", "halfcheetah", "walker2d", "mocap_target", "sensor_rig2", "tendon_fixed", "mesh_contact", "mesh_contact_arm"):
     try:
-        mx, d = fuzz_batch(xml, {"solver": 2}, torch.float32, B)
+        mx, d = fuzz_batch(xml, dict({"solver": 2}, **({"cone": 1} if os.environ.get("SWEEP_ELLIPTIC") else {})), torch.float32, B)
         mdev, dg = mx.to("cuda"), d.to("cuda")
         res, tail = [], {}
         for s in range(STEPS):
