@@ -94,7 +94,7 @@ def test_iteration_capped_newton_states_are_implementation_defined(name, oracle_
 
 @pytest.mark.parametrize("name", [c for c in OUTLIER_CASES if "_r04_" in c])
 def test_campaign_tail_rules_on_recorded_outputs(name, oracle_lib):
-    """The environment-steps of the round-4 campaigns (36 cases x 2048 environments x 5 steps, x 4096 x 4) that matched no outcome of the batch enumeration, with the
+    """The environment-steps of the round-4 campaigns (38 cases x 2048 environments x 5 steps, x 4096 x 4) that matched no outcome of the batch enumeration, with the
     outputs the HIP step produced for them (recorded on the GPU box, `got/*`): each must be accepted by the rule recorded with it -- the checker's tail rules are
     exercised here without a GPU (tests/test_gpu_parity.py::test_pinned_campaign_outliers runs the live step through the same check)."""
     import json
