@@ -4432,8 +4432,11 @@ struct Env {
 // The register solver's kernel: two environments per wavefront; an odd last environment leaves the second half of its wave idle.
 // WT: lanes per environment (32 or 16); WT = 17 is the four-per-wavefront kernel of NEWTON models (16 lanes, Newton-only code: 128 VGPRs + 116 B of scratch instead of + 160 B
 // for the ant's first tier, 227 instead of 243 VGPRs for the mesh scene's; ant 53.6 -> 52.2 us per launch, mesh scene 223.7 -> 219.1 us)
+#ifndef MJH_SOL2_F64_WAVES
+#define MJH_SOL2_F64_WAVES 1  /* float64 instantiations for <= 16 dofs (the twins of configs 3 / 5): at two waves per SIMD they spilled 80 - 600 B per lane to scratch memory; at ONE the unified register file holds the overflow in AGPRs (24 - 150 of them, no scratch).  Measured (MI355X, solver phase): mesh scene float64 B = 4096 190.6 -> 186.9 us, B = 16384 501 -> 463 us; ant float64 29.3 -> 28.3 / 54.9 -> 53.8 us */
+#endif
 template <typename REAL, int NMAX, int RPL, int WT>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && WT != 34 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : 2) mjh_sol2_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && WT != 34 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : ((sizeof(REAL) == 8 && NMAX <= 16) ? MJH_SOL2_F64_WAVES : 2)) mjh_sol2_kernel(KArgs<REAL> args) {
   constexpr int W = WT == 17 ? 16 : ((WT == 33 || WT == 34) ? 32 : WT);
   constexpr bool NEWTON_ONLY = WT == 17;
   constexpr bool CS = WT == 33 || WT == 34;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
