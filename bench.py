@@ -258,7 +258,7 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r04"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
+PROFILE_ROUND = "r05"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
 
 
 def setup_workload(key, B, device, rank):
@@ -393,6 +393,14 @@ def main(args):
             dist.init_process_group(backend)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    # which device every rank drives: one rank per GPU means `world` distinct (host, device uuid / index) pairs
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": device.index, "device_name": torch.cuda.get_device_name(device), "visible_devices": torch.cuda.device_count(),
+          "uuid": str(getattr(props, "uuid", "")), "cus": props.multi_processor_count, "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
 
     wl, B, dtype, mx, mdev, loop = setup_workload(args.workload, args.batch, device, rank)
     loop.bufs, loop.cur = [loop.d.clone(), loop.d.clone()], 0   # the out= loop starts from the same state (solver work depends on it)
@@ -457,6 +465,8 @@ def main(args):
             "roofline": roof,
             "device_allocations_in_timed_region": allocs_in_region,  # hipMalloc calls of torch's caching allocator between the two synchronizes (each one stalls the host for ~1 ms at these sizes)
         }
+        line["ranks"] = ranks
+        line["one_device_per_rank"] = len({(r["uuid"] or r["device_index"]) for r in ranks}) == world  # false only under the one-GPU test hook (MJH_BENCH_SHARE_GPU=1)
         if per_rank is not None:
             line["per_rank_ms_per_step"] = per_rank  # every rank's own K steps, fastest and slowest (the bracket above is max-reduced)
         if long_run is not None:

@@ -405,6 +405,10 @@ int mjh_model_lds_bytes(const mjhModel* m, int phase);
 int mjh_debug_phase_timing(int enable);
 int mjh_debug_phase_times(float* ms, int* kernel_ids, int max);
 
+/* diagnostic builds only (-DMJH_STAMPS, tools/stamps.py): device buffer the kernels write their s_memtime section stamps into; NULL turns
+ * them off.  The shipped library is built without MJH_STAMPS: the pointer is stored and nothing reads it. */
+void mjh_debug_set_stamps(void* dev_ptr);
+
 /* global-memory bytes ONE launch of kernel `kernel` (ids as above) reads and writes per environment in a step: the library's own
  * account of its loads / stores through the Data leaves (csrc/mjh_io.h) -- the per-kernel "algorithmic bytes" of the roofline.
  * read_write_bytes[0] = read, [1] = written.  RK4 models: the mean over the four stage launches of a step (stages 1..3 write a private

@@ -94,9 +94,6 @@ struct mjhModel {
   mutable hipEvent_t split_done[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_fork = nullptr;
   // the sensor kernel needs nothing of CRB / CON / SOL: it runs on a stream of its own beside them (forked behind the velocity stage, joined at the end of the pass)
-  mutable std::mutex sensor_mutex;
-  mutable hipStream_t sensor_stream = nullptr;
-  mutable hipEvent_t sensor_fork = nullptr, sensor_join = nullptr;
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
   int64_t sort_reals = 0;                  // ... of which the register solver's environment list and iteration-count keys (two ints per environment, at the very head)
@@ -859,35 +856,6 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
   const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
   if ((st & 0x7f) && (rc = fused_kcv ? launch_phase<REAL, 13>(m, a, stream) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
-  // Sensors beside the rest of the pass (opt-in: MJH_SENSOR_STREAM=1).  With kinematics + velocity fused everything they read exists behind the first launch; the
-  // kernel is a chain of dependent loads at low occupancy (ant: 40 us of an 880 us step) and shares the chip well with the bandwidth-bound constraint phase.
-  bool sensors_forked = false;
-  {
-    static const bool side = [] { const char* e = getenv("MJH_SENSOR_STREAM"); return e && e[0] == '1'; }();  // opt-in: measured on the ant (B = 16384) 18.58 - 18.65 M beside the pass against 18.58 M in line -- the launches do not overlap in practice
-    const bool want = (st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata;
-    if (side && want && fused_kv && !g_timing.on && !g_stamps) {
-      std::lock_guard<std::mutex> lock(m->sensor_mutex);
-      if (!m->sensor_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&m->sensor_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&m->sensor_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->sensor_join, hipEventDisableTiming));
-      }
-      HIP_TRY(hipEventRecord(m->sensor_fork, stream));
-      HIP_TRY(hipStreamWaitEvent(m->sensor_stream, m->sensor_fork, 0));
-      {
-        const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-        if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->sensor_stream, a);
-        else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->sensor_stream, a);
-        HIP_TRY(hipGetLastError());
-      }
-      HIP_TRY(hipEventRecord(m->sensor_join, m->sensor_stream));
-      sensors_forked = true;
-    }
-  }
-  struct Join {  // the pass ends with the sensors done, whichever return it takes
-    const mjhModel* m; hipStream_t s; bool on;
-    ~Join() { if (on) (void)hipStreamWaitEvent(s, m->sensor_join, 0); }
-  } join_{m, stream, sensors_forked};
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
     const int64_t items = a.B * a.M.ncvxpair;
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
@@ -914,7 +882,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipGetLastError());
     return 0;
   };
-  if (want_sensors && !sensors_forked) {
+  if (want_sensors) {  // (round 4's opt-in side stream for this launch is gone: it raced the integrator tail's write of out.qpos, which jointpos / ballquat sensors read, and measured no gain -- profiles/r04/notes.md)
     if ((rc = launch_sensors(stream))) return rc;
     timing_mark(stream, 11);
   }
@@ -1022,6 +990,9 @@ void offset_data(const mjhModel* m, const DevModel<REAL>& M, const mjhData* src,
   const int64_t ncon = M.ncon, neq = M.neq;
   const int64_t int_bytes[] = {4 * ncon, 4 * neq, 8 * ncon, 8 * ncon, 16 * ncon, 8 * ncon};  // contact_dim, eq_active | geom1, geom2, geom, efc_address
   for (size_t k = 0; k < 6; k++) if (p[nreal + k]) p[nreal + k] += (size_t)begin * (size_t)int_bytes[k];
+  const int64_t extra_reals[] = {6 * (int64_t)M.nbody, 6 * (int64_t)M.nbody, 3 * (int64_t)M.nbody, 3 * (int64_t)M.nbody};  // MJH_DATA_EXTRA_IN: cacc, cfrc_int, subtree_linvel, subtree_angmom (input-only, may be NULL)
+  static_assert(sizeof(mjhData) / sizeof(void*) >= 10, "mjhData: leaves + six integer leaves + four input-only leaves");
+  for (size_t k = 0; k < 4; k++) if (p[nreal + 6 + k]) p[nreal + 6 + k] += (size_t)begin * (size_t)extra_reals[k] * sizeof(REAL);
 }
 
 template <typename REAL>
@@ -1141,7 +1112,6 @@ void mjh_model_destroy(mjhModel* m) {
   if (!m) return;
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
-  if (m->sensor_stream) { (void)hipStreamDestroy(m->sensor_stream); (void)hipEventDestroy(m->sensor_fork); (void)hipEventDestroy(m->sensor_join); }
   if (m->split_ready) {
     for (int k = 0; k < 4; k++) { (void)hipStreamDestroy(m->split_stream[k]); (void)hipEventDestroy(m->split_done[k]); }
     (void)hipEventDestroy(m->split_fork);

@@ -203,6 +203,9 @@ class SensorType(enum.IntEnum):
     E_POTENTIAL = 43
     E_KINETIC = 44
     CLOCK = 45
+    TACTILE = 46
+    PLUGIN = 47
+    USER = 48
 
 
 class ObjType(enum.IntEnum):

@@ -5,7 +5,7 @@ Why: the reference's published batched mode is ``torch.compile(torch.vmap(lambda
 ``fullgraph=True`` nothing may graph-break either.  So when ``step`` is reached by Dynamo, or its Data holds functorch batched tensors
 (plain ``torch.vmap``), it calls ``torch.ops.mujoco_torch_amd.step_leaves`` instead of the ctypes path:
 
-* the operator takes the Data leaves in ABI order (``include/mjhip.h`` X-macro lists; an absent leaf is an empty tensor), the Model as a
+* the operator takes the Data leaves in ABI order (``include/mjhip.h`` X-macro lists, then the input-only ``MJH_DATA_EXTRA_IN`` leaves; an absent leaf is an empty tensor), the Model as a
   process-unique number in a 0-dim int64 TENSOR (``Model._op_key_t``, resolved through a weak registry -- an operator cannot take a container; as a tensor it is an
   input of a traced graph, so ``mx.replace(body_mass=...)`` per episode steps the new values WITHOUT a recompile), the structure id ``tables.uid`` as a string (the
   graph's constant: shape propagation runs on any Model of that structure) and the call's flags; it returns the leaves the call writes, in ``forward._written_names`` order;
@@ -23,12 +23,16 @@ from __future__ import annotations
 import torch
 
 from . import native
-from .types import _MODELS_BY_KEY, _MODELS_BY_UID
+from .types import _MODELS_BY_KEY, structure_model
 
 _NAMES = native.LISTS["MJH_DATA_REALS"] + native.LISTS["MJH_DATA_I32"] + native.LISTS["MJH_DATA_I64"]
 _NREAL = len(native.LISTS["MJH_DATA_REALS"])
 _INT_DTYPE = {n: torch.int32 for n in native.LISTS["MJH_DATA_I32"]} | {n: torch.int64 for n in native.LISTS["MJH_DATA_I64"]}
 _QPOS = _NAMES.index("qpos")
+# Input-only leaves that trail the ABI struct (cacc, cfrc_int, subtree_linvel, subtree_angmom: no stage writes them, sensors read them --
+# include/mjhip.h MJH_DATA_EXTRA_IN).  They ride behind the ABI leaves in the operator's list so that a vmapped / traced call hands the
+# CALLER's batched values to the native step (rebuilt from the unbatched template they failed the size check and were dropped).
+_XNAMES = native.LISTS["MJH_DATA_EXTRA_IN"]
 _TEMPLATES = {}  # tables uid -> an unbatched make_data(m): the fields outside the ABI and the per-environment shape of every leaf
 
 
@@ -43,7 +47,7 @@ def _model(key) -> "Model":
 def _structure(uid: str):
     """Any live Model of that structure (tables.uid, as the string the graph carries: an int that changes between calls is made a symbolic
     shape by Dynamo's automatic dynamism, a string stays a guarded constant): what shape propagation needs does not depend on values."""
-    m = _MODELS_BY_UID.get(uid)
+    m = structure_model(uid)
     if m is None:
         raise RuntimeError("mujoco_torch_amd::step_leaves: no Model of the structure this call was traced with exists any more")
     return m
@@ -83,7 +87,10 @@ def step_leaves(leaves: list[torch.Tensor], model_key: torch.Tensor, struct_uid:
         raise RuntimeError("mujoco_torch_amd::step_leaves: the Model handed to the traced step has another structure than the one it was traced with "
                            "(different XML / cone / disabled constraints): trace a step of its own for it")
     tmpl = _template(m)
-    top, con = {}, {}
+    top, con = {n: None for n in _XNAMES}, {}  # an absent input-only leaf is NULL (zeros) for the kernels -- never the template's unbatched copy
+    for n, t in zip(_XNAMES, leaves[len(_NAMES):]):
+        if t.numel() != 0:
+            top[n] = t
     for n, t in zip(_NAMES, leaves):
         if t.numel() == 0 and t.dim() == 1 and native.data_field_tensor(tmpl, n) is not None and native.data_field_tensor(tmpl, n).numel() != 0:
             continue  # placeholder of a leaf the caller's Data did not carry: keep the template's
@@ -147,6 +154,9 @@ def run_through_op(m, d, fixed_iterations: bool, do_step: bool, stages: int):
     for n in _NAMES:
         path = native.DATA_PATH[n]
         t = getattr(con if len(path) == 2 else d, path[-1], None)
+        leaves.append(t if isinstance(t, torch.Tensor) else _ABSENT)
+    for n in _XNAMES:
+        t = getattr(d, n, None)
         leaves.append(t if isinstance(t, torch.Tensor) else _ABSENT)
     outs = torch.ops.mujoco_torch_amd.step_leaves(leaves, m._op_key_t, m._struct_uid, fixed_iterations, do_step, stages)
     top, cn = {}, {}

@@ -548,8 +548,8 @@ def device_put(value, *, dtype: torch.dtype | None = None):
     T.source = value
     T.structure_key = (int(value.opt.cone), int(value.opt.disableflags) & (0b11111 | (1 << 13)), int(value.opt.jacobian))  # native._structure_key
     object.__setattr__(m, "_tables", T)
-    from .types import _MODELS_BY_UID
+    from .types import _register_structure
 
-    _MODELS_BY_UID[f"u{T.uid}"] = m
+    _register_structure(f"u{T.uid}", m)
     object.__setattr__(m, "_struct_uid", f"u{T.uid}")
     return m

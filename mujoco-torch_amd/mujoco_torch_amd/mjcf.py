@@ -381,6 +381,17 @@ _GEOM_TYPES = {
     "box": GeomType.BOX,
     "mesh": GeomType.MESH,
 }
+
+
+def _geom_type(name, what="geom"):
+    """mjtGeom of a type attribute; what MuJoCo has and this build does not (sdf) is refused by name (it surfaced as a bare KeyError)."""
+    if name not in _GEOM_TYPES:
+        if name == "sdf":
+            raise NotImplementedError(f'{what} type="sdf" (signed-distance-field geoms need plugins) is not supported')
+        raise ValueError(f"unknown {what} type {name!r}")
+    return _GEOM_TYPES[name]
+
+
 _JOINT_TYPES = {"free": JointType.FREE, "ball": JointType.BALL, "slide": JointType.SLIDE, "hinge": JointType.HINGE}
 _CAM_MODES = {
     "fixed": CamLightType.FIXED,
@@ -400,6 +411,7 @@ _SENSOR_DIMS = {
     "torque": (SensorType.TORQUE, 3, 3, 0, "site"),
     "magnetometer": (SensorType.MAGNETOMETER, 3, 1, 0, "site"),
     "rangefinder": (SensorType.RANGEFINDER, 1, 1, 0, "site"),
+    "camprojection": (SensorType.CAMPROJECTION, 2, 1, 0, "site+camera"),  # (the reference's sensor_pos has no branch for it: the slot keeps the caller's value, sensor.py:196)
     "jointpos": (SensorType.JOINTPOS, 1, 1, 0, "joint"),
     "jointvel": (SensorType.JOINTVEL, 1, 2, 0, "joint"),
     "tendonpos": (SensorType.TENDONPOS, 1, 1, 0, "tendon"),
@@ -432,7 +444,12 @@ _SENSOR_DIMS = {
     "e_potential": (SensorType.E_POTENTIAL, 1, 1, 0, None),
     "e_kinetic": (SensorType.E_KINETIC, 1, 2, 0, None),
     "clock": (SensorType.CLOCK, 1, 1, 0, None),
+    "user": (SensorType.USER, None, None, 0, "user"),  # dim / needstage / datatype / object from the element; evaluated by a user callback in MuJoCo, by nobody in the reference (slot untouched)
 }
+_STAGE_NAMES = {"pos": 1, "vel": 2, "acc": 3}
+_DATATYPE_NAMES = {"real": 0, "positive": 1, "axis": 2, "quaternion": 3}
+_USER_OBJTYPES = {"body": ObjType.BODY, "xbody": ObjType.XBODY, "joint": ObjType.JOINT, "geom": ObjType.GEOM, "site": ObjType.SITE, "camera": ObjType.CAMERA,
+                  "tendon": ObjType.TENDON, "actuator": ObjType.ACTUATOR}
 _OBJTYPE_NAMES = {"body": ObjType.BODY, "xbody": ObjType.XBODY, "geom": ObjType.GEOM, "site": ObjType.SITE, "camera": ObjType.CAMERA}
 
 _DEF_SOLREF = np.array([0.02, 1.0])
@@ -668,8 +685,15 @@ class _Compiler:
         a["quat"] = " ".join(repr(float(x)) for x in _quat_mul(fq, q))
         return a
 
-    def _parse_body_children(self, node, body_id, childclass, frame=None):
+    def _parse_body_children(self, node, body_id, childclass, frame=None, pending=None):
+        """One pass over the children IN DOCUMENT ORDER, as MuJoCo expands them: a <frame> is visited in place (its geoms / sites / cameras / lights take their
+        ids between those of the body's direct children around it) and the child bodies -- direct ones and those nested in frames -- are created in the order
+        they appear (frames used to be visited in a second loop, so a model interleaving frames with direct children got other ids than the
+        MuJoCo-compiled model the reference's device_put consumes)."""
         body = self.bodies[body_id]
+        top = pending is None
+        if top:
+            pending = []  # (element, attributes, childclass, enclosing frame) of the child bodies, in document order
         for child in node:
             tag = child.tag
             if tag == "inertial":
@@ -708,36 +732,37 @@ class _Compiler:
                     a["dir"] = " ".join(repr(float(x)) for x in _rotate(_floats(a["dir"]) if "dir" in a else np.array([0.0, 0.0, -1.0]), fq))
                 a["__body__"] = body_id
                 self.lights.append(a)
-        for child in node:
-            if child.tag == "frame":  # <frame>: a pure coordinate transformation of what it contains (no body, no dofs); frames nest
+            elif tag == "frame":  # <frame>: a pure coordinate transformation of what it contains (no body, no dofs); frames nest
                 a = self._t(child)
                 fpos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
                 fquat = self._orientation(a)
                 if frame is not None:
                     fpos, fquat = frame[0] + _rotate(fpos, frame[1]), _quat_mul(frame[1], fquat)
-                self._parse_body_children(child, body_id, a.get("childclass", childclass), (fpos, fquat))
-        for child in node:
-            if child.tag == "body":
+                self._parse_body_children(child, body_id, a.get("childclass", childclass), (fpos, fquat), pending)
+            elif tag == "body":
                 a = self._t(child)
-                cc = a.get("childclass", childclass)
-                bpos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
-                bquat = self._orientation(a)
-                if frame is not None:
-                    bpos, bquat = frame[0] + _rotate(bpos, frame[1]), _quat_mul(frame[1], bquat)
-                nb = dict(
-                    name=a.get("name", ""),
-                    parent=body_id,
-                    pos=bpos,
-                    quat=bquat,
-                    inertial=None,
-                    mocap=_bool(a.get("mocap", "false")),
-                    gravcomp=float(a.get("gravcomp", 0.0)),
-                    id=len(self.bodies),
-                    joints=[],
-                    geoms=[],
-                )
-                self.bodies.append(nb)
-                self._parse_body_children(child, nb["id"], cc)
+                pending.append((child, a, a.get("childclass", childclass), frame))
+        if not top:
+            return
+        for child, a, cc, fr in pending:
+            bpos = _floats(a["pos"]) if "pos" in a else np.zeros(3)
+            bquat = self._orientation(a)
+            if fr is not None:
+                bpos, bquat = fr[0] + _rotate(bpos, fr[1]), _quat_mul(fr[1], bquat)
+            nb = dict(
+                name=a.get("name", ""),
+                parent=body_id,
+                pos=bpos,
+                quat=bquat,
+                inertial=None,
+                mocap=_bool(a.get("mocap", "false")),
+                gravcomp=float(a.get("gravcomp", 0.0)),
+                id=len(self.bodies),
+                joints=[],
+                geoms=[],
+            )
+            self.bodies.append(nb)
+            self._parse_body_children(child, nb["id"], cc)
 
     # ---- build ---------------------------------------------------------
     def build(self) -> MjModelLite:
@@ -1075,7 +1100,7 @@ class _Compiler:
         m.geom_dataid = -np.ones(ngeom, dtype=np.int32)
         f = lambda g, k, d: float(g.get(k, d))
         for gi, g in enumerate(G):
-            t = _GEOM_TYPES[g.get("type", "sphere")]
+            t = _geom_type(g.get("type", "sphere"))
             size = np.zeros(3)
             if "size" in g:
                 s = _floats(g["size"])
@@ -1240,7 +1265,7 @@ class _Compiler:
         m.nsite = len(S)
         m.names_site = [s.get("name", "") for s in S]
         m.site_bodyid = np.array([remap[s["__body__"]] for s in S], dtype=np.int32)
-        m.site_type = np.array([int(_GEOM_TYPES[s.get("type", "sphere")]) for s in S], dtype=np.int32)
+        m.site_type = np.array([int(_geom_type(s.get("type", "sphere"), "site")) for s in S], dtype=np.int32)
         spos, squat, ssize = [], [], []
         for s in S:
             pos = _floats(s["pos"]) if "pos" in s else np.zeros(3)
@@ -1519,7 +1544,25 @@ class _Compiler:
                     raise NotImplementedError(f"sensor <{node.tag}> not supported")
                 sens.append(node)
         m.nsensor = len(sens)
-        dims = [_SENSOR_DIMS[s.tag][1] for s in sens]
+        def user_attr(sn, key, table, default):
+            v = self._t(sn).get(key)
+            if v is None:
+                return default
+            if v not in table:
+                raise ValueError(f"sensor <user>: {key} must be one of {sorted(table)}, got {v!r}")
+            return table[v]
+
+        def spec(sn, k):  # dim, needstage, datatype of one element (<user> carries its own: dim is required, needstage defaults to acc, datatype to real)
+            if sn.tag != "user":
+                return _SENSOR_DIMS[sn.tag][k]
+            if k == 1:
+                dim = self._t(sn).get("dim")
+                if dim is None or int(dim) < 0:
+                    raise ValueError("sensor <user>: a non-negative dim is required")
+                return int(dim)
+            return user_attr(sn, "needstage", _STAGE_NAMES, 3) if k == 2 else user_attr(sn, "datatype", _DATATYPE_NAMES, 0)
+
+        dims = [spec(s, 1) for s in sens]
         m.sensor_type = np.array([int(_SENSOR_DIMS[s.tag][0]) for s in sens], dtype=np.int32)
         m.sensor_dim = np.array(dims, dtype=np.int32)
         m.sensor_adr = np.concatenate([[0], np.cumsum(dims)[:-1]]).astype(np.int32) if sens else np.zeros(0, dtype=np.int32)
@@ -1538,6 +1581,20 @@ class _Compiler:
             rt, ri = int(ObjType.UNKNOWN), -1
             if attach == "site":
                 ot, oi = int(ObjType.SITE), lookup(sn, "site", m.names_site, "site")
+            elif attach == "site+camera":  # camprojection: the site is the object, the camera the reference (user_objects.cc)
+                ot, oi = int(ObjType.SITE), lookup(sn, "site", m.names_site, "site")
+                rt, ri = int(ObjType.CAMERA), lookup(sn, "camera", m.names_cam, "camera")
+            elif attach == "user":  # optional object
+                kind, name = self._t(sn).get("objtype"), self._t(sn).get("objname")
+                if (kind is None) != (name is None):
+                    raise ValueError("sensor <user>: objtype and objname go together")
+                ot, oi = int(ObjType.UNKNOWN), -1
+                if kind is not None:
+                    if kind not in _USER_OBJTYPES:
+                        raise ValueError(f"sensor <user>: objtype must be one of {sorted(_USER_OBJTYPES)}, got {kind!r}")
+                    names = {ObjType.JOINT: m.names_jnt, ObjType.TENDON: getattr(m, "names_tendon", []), ObjType.ACTUATOR: getattr(m, "names_actuator", [])}
+                    ot = int(_USER_OBJTYPES[kind])
+                    oi = lookup(sn, kind, names.get(_USER_OBJTYPES[kind]) if _USER_OBJTYPES[kind] in names else lists[_USER_OBJTYPES[kind]], "objname")
             elif attach == "joint":
                 ot, oi = int(ObjType.JOINT), lookup(sn, "joint", m.names_jnt, "joint")
                 jt = int(m.jnt_type[oi])
@@ -1568,8 +1625,8 @@ class _Compiler:
             objtype.append(ot); objid.append(oi); reftype.append(rt); refid.append(ri)
         m.sensor_objid = np.array(objid, dtype=np.int32)
         m.sensor_objtype = np.array(objtype, dtype=np.int32)
-        m.sensor_needstage = np.array([_SENSOR_DIMS[s.tag][2] for s in sens], dtype=np.int32)
-        m.sensor_datatype = np.array([_SENSOR_DIMS[s.tag][3] for s in sens], dtype=np.int32)
+        m.sensor_needstage = np.array([spec(s, 2) for s in sens], dtype=np.int32)
+        m.sensor_datatype = np.array([spec(s, 3) for s in sens], dtype=np.int32)
         m.sensor_reftype = np.array(reftype, dtype=np.int32)
         m.sensor_refid = np.array(refid, dtype=np.int32)
         m.sensor_cutoff = np.array([float(self._t(s).get("cutoff", 0.0)) for s in sens], dtype=np.float64)

@@ -105,7 +105,28 @@ MODEL_FIELDS = (
 
 _MODEL_KEYS = itertools.count(1)
 _MODELS_BY_KEY = weakref.WeakValueDictionary()
-_MODELS_BY_UID = weakref.WeakValueDictionary()  # tables.uid -> the most recent live Model of that structure (any of them serves shape propagation)
+_MODELS_BY_UID = {}  # tables.uid -> WeakSet of the live Models of that structure (any of them serves shape propagation: `structure_model`)
+
+
+def _register_structure(uid: str, m) -> None:
+    """Every live Model of a structure is a member: the entry must outlive any ONE of them (as a WeakValueDictionary holding the newest
+    Model only, the entry vanished when a value-only copy -- `tmp = mx.replace(body_mass=...)` -- was collected while `mx` itself was still in use)."""
+    s = _MODELS_BY_UID.get(uid)
+    if s is None:
+        if len(_MODELS_BY_UID) > 256:  # structures whose Models are all gone
+            for k in [k for k, v in _MODELS_BY_UID.items() if len(v) == 0]:
+                del _MODELS_BY_UID[k]
+        s = _MODELS_BY_UID[uid] = weakref.WeakSet()
+    s.add(m)
+
+
+def structure_model(uid: str):
+    """Any live Model of that structure, or None."""
+    s = _MODELS_BY_UID.get(uid)
+    if s:
+        for m in s:
+            return m
+    return None
 
 
 class Model(MjTensorClass):
@@ -160,7 +181,7 @@ class Model(MjTensorClass):
         T = self.__dict__.get("_tables")
         if T is not None:
             object.__setattr__(self, "_struct_uid", f"u{T.uid}")  # (a plain attribute: code traced by Dynamo reads it without going through `__dict__`)
-            _MODELS_BY_UID[f"u{T.uid}"] = self
+            _register_structure(f"u{T.uid}", self)
 
 
 # attach the by-name leaves as annotations so they are real fields

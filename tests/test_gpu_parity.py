@@ -268,10 +268,13 @@ import numpy as np, torch, mujoco_torch_amd as mt
 from mujoco_torch_amd import native
 from _util import load_model, REAL_LEAVES, INT_LEAVES
 for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
-                    ("mesh_contact", {}, torch.float32), ("sensor_rig", {}, torch.float64), ("equality_loops", {}, torch.float64)):
+                    ("mesh_contact", {}, torch.float32), ("sensor_rig", {}, torch.float64), ("equality_loops", {}, torch.float64), ("sensor_rig2", {}, torch.float64)):
     mx = load_model(xml, ov, dt)
     B = 203                                              # slices of 68, 68, 67: odd tail, two-per-wave phases stay paired
     d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+    if xml == "sensor_rig2":                             # ADVICE r04: the input-only leaves its sensors read (cacc, cfrc_int, subtree_*) follow their slice too
+        rng, nb = np.random.RandomState(1), int(mx.nbody)
+        d = d.replace(cacc=torch.tensor(rng.randn(B, nb, 6)), cfrc_int=torch.tensor(rng.randn(B, nb, 6)), subtree_linvel=torch.tensor(rng.randn(B, nb, 3)), subtree_angmom=torch.tensor(rng.randn(B, nb, 3)))
     if dt != torch.float64: d = d.to(dt)
     mdev = mx.to("cuda")
     dg = d.to("cuda")
@@ -370,6 +373,32 @@ def test_vmap_idiom_is_one_native_batch():
     assert torch.equal(got.qvel, want.qvel)
     two = torch.vmap(torch.vmap(lambda x: mt.step(mdev, x)))(torch.stack([dg[:4], dg[4:8]]))   # nested maps: one native batch of 2 x 4
     assert tuple(two.qpos.shape) == (2, 4, mx.nq) and torch.equal(two.qpos.reshape(8, -1), mt.step(mdev, dg[:8].clone()).qpos)
+
+
+@pytest.mark.parametrize("xml,overrides,dtype", [("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32), ("sensor_rig2", {}, torch.float64)])
+def test_vmap_and_compile_carry_the_input_only_sensor_leaves(xml, overrides, dtype):
+    """`torch.vmap(step)` / `torch.compile(vmap(step))` of models whose sensors read cacc / cfrc_int / subtree_linvel / subtree_angmom
+    (ant = BASELINE config 3, the sensor rigs) raised, and caller-set values of those leaves were dropped: they are operator inputs now.  Bit-equal to the direct call."""
+    from mujoco_torch_amd import native
+
+    mx = load_model(xml, overrides, dtype)
+    B, nb = 8, int(mx.nbody)
+    rng = np.random.RandomState(5)
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * rng.randn(B, mx.nv)))
+    d2 = d.replace(cacc=torch.tensor(rng.randn(B, nb, 6)), cfrc_int=torch.tensor(rng.randn(B, nb, 6)), subtree_linvel=torch.tensor(rng.randn(B, nb, 3)),
+                   subtree_angmom=torch.tensor(rng.randn(B, nb, 3)))
+    mdev = mx.to("cuda")
+    outs = []
+    for x in (d, d2):
+        xg = (x.to(dtype) if dtype != torch.float64 else x).to("cuda")
+        want = mt.step(mdev, xg)
+        for wrap in (torch.vmap(lambda y: mt.step(mdev, y)), torch.compile(torch.vmap(lambda y: mt.step(mdev, y)), fullgraph=True)):
+            got = wrap(xg)
+            for n in REAL_LEAVES + INT_LEAVES:
+                assert torch.equal(native.data_field_tensor(got, n), native.data_field_tensor(want, n)), n
+            assert torch.equal(got.cacc, xg.cacc)
+        outs.append(want.sensordata)
+    assert not torch.equal(outs[0], outs[1])
 
 
 def test_fullgraph_compile_of_vmap_step_is_the_native_batch():
@@ -603,6 +632,33 @@ def test_two_ranks_on_one_device_step_the_product():
            "--master-port", "29531", os.path.join(root, "tests", "mp_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "MP_OK" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
+def test_bench_gpus_2_on_one_shared_device():
+    """`python bench.py --gpus 2` end to end as the driver launches the multi-GPU bench -- the parent spawns torch.distributed.run as a child before any
+    HIP call, two ranks step their own shards (here both on cuda:0 over gloo: RCCL refuses two ranks on one device), rank 0 prints ONE line with the whole-job value,
+    the per-rank spread, which device every rank drove and BASELINE config 4's share."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MJH_BENCH_BACKEND="gloo", MJH_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-other-workloads", "--no-long-run"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=root)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert res.returncode == 0 and len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 2 * line["config"]["envs_per_gpu"] == 8192
+    assert abs(line["value"] - 8192 * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
+    pr = line["per_rank_ms_per_step"]
+    assert 0 < pr["min"] <= pr["max"] <= line["ms_per_step"] * 1.001
+    assert [r["rank"] for r in line["ranks"]] == [0, 1] and all(r["visible_devices"] >= 1 and r["device_name"] for r in line["ranks"])
+    assert line["one_device_per_rank"] is False                       # (the test hook: both ranks on cuda:0 -- the driver's run must say true)
+    c4 = line["config4"]
+    assert c4["envs_per_gpu"] == 32768 and c4["global_batch"] == 65536 and c4["steps"] >= 20 and c4["value"] > 0
+    assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line  # the CPU leg runs at N = 1 only
 
 
 def test_config4_batch_properties():

@@ -432,6 +432,7 @@ def test_value_only_model_edits_do_not_retrace_the_compiled_step(sim):
     """the operator took the Model as a Python int, a constant of the traced graph -- every `mx.replace(body_mass=...)` (per-episode domain
     randomisation) recompiled the step until Dynamo's recompile limit.  The graph's constant is now the STRUCTURE id; the Model's values travel as a tensor input."""
     import torch._dynamo as dynamo
+    import torch._dynamo.testing  # noqa: F401  (a submodule: not imported by `import torch._dynamo` alone)
 
     mx = load_model("hopper")
     d = seeded(mx, 3)
@@ -451,3 +452,70 @@ def test_value_only_model_edits_do_not_retrace_the_compiled_step(sim):
     holder["m"] = other
     d2 = seeded(other, 3)
     assert torch.equal(step(d2).qpos, mt.step(other, d2).qpos)
+
+
+@pytest.mark.parametrize("xml,overrides", [("ant", {"integrator": 1, "solver": 2, "cone": 1}), ("sensor_rig2", {})])
+def test_vmap_and_compile_carry_the_input_only_sensor_leaves(sim, xml, overrides):
+    """models whose sensors read cacc / cfrc_int / subtree_linvel / subtree_angmom (ant: BASELINE config 3; the sensor rigs) raised
+    under `torch.vmap(step)` / `torch.compile(vmap(step))` -- the operator rebuilt those leaves from the UNBATCHED template -- and a caller's values for them
+    were dropped.  They are operator inputs now: results equal the direct call with zeros, with caller-set values, and with the leaves absent."""
+    mx = load_model(xml, overrides)
+    B = 4
+    d = seeded(mx, B)
+    nb = int(mx.nbody)
+    rng = np.random.RandomState(5)
+    d2 = d.replace(cacc=torch.tensor(rng.randn(B, nb, 6)), cfrc_int=torch.tensor(rng.randn(B, nb, 6)), subtree_linvel=torch.tensor(rng.randn(B, nb, 3)),
+                   subtree_angmom=torch.tensor(rng.randn(B, nb, 3)))
+    for x in (d, d2):
+        want = mt.step(mx, x)
+        assert_same(want, pyoracle.run(mx, x, step=True))
+        for wrap in (torch.vmap(lambda y: mt.step(mx, y)), torch.compile(torch.vmap(lambda y: mt.step(mx, y)), fullgraph=True),
+                     torch.compile(lambda y: mt.step(mx, y), fullgraph=True)):
+            got = wrap(x)
+            assert_same(got, {n: leaf(want, n).numpy() for n in REAL_LEAVES + INT_LEAVES})
+            assert torch.equal(got.cacc, x.cacc) and torch.equal(got.subtree_angmom, x.subtree_angmom)     # untouched leaves stay the caller's
+            assert torch.equal(wrap(got).sensordata, mt.step(mx, want).sensordata)
+    assert not torch.equal(mt.step(mx, d2).sensordata, mt.step(mx, d).sensordata)                            # (the values matter: they were dropped before)
+    cacc = torch.tensor(rng.randn(nb, 6))                                                                  # a closed-over, unmapped input-only leaf is broadcast
+    got = torch.vmap(lambda y: mt.step(mx, y.replace(cacc=cacc)))(d)
+    assert torch.equal(got.sensordata, mt.step(mx, d.replace(cacc=cacc.expand(B, nb, 6).clone())).sensordata)
+
+
+def test_structure_registry_outlives_collected_value_only_copies(sim):
+    """the structure registry held only the NEWEST Model of a structure, weakly -- when that value-only copy was collected the entry went
+    with it and the next trace / recompile of a step of the ORIGINAL raised 'no Model of the structure ... exists any more'."""
+    import gc
+
+    from mujoco_torch_amd import compile_op
+
+    mx = load_model("hopper")
+    tmp = mx.replace(body_mass=mx.body_mass * 1.5)
+    assert compile_op._structure(mx._struct_uid) is not None
+    del tmp
+    gc.collect()
+    assert compile_op._structure(mx._struct_uid) is mx
+    d = seeded(mx, 2)
+    want = mt.step(mx, d)
+    torch._dynamo.reset()
+    got = torch.compile(torch.vmap(lambda x: mt.step(mx, x)), fullgraph=True)(d)   # a fresh trace: register_fake looks the structure up
+    assert torch.equal(got.qpos, want.qpos)
+    uid = mx._struct_uid
+    del mx, got, want, d
+    gc.collect()
+    with pytest.raises(RuntimeError, match="no Model of the structure"):
+        compile_op._structure(uid)
+
+
+def test_unevaluated_sensor_slots_keep_the_callers_values(sim, tmp_path):
+    """<camprojection> / <user> sensors (compiled since round 5) belong to the types sensor.py has no branch for: their sensordata slots pass through the step."""
+    (tmp_path / "m.xml").write_text(
+        '<mujoco><worldbody><camera name="cam" pos="0 -1 1"/><body name="b"><joint name="j" type="hinge" axis="0 1 0"/><geom size="0.1" pos="0.2 0 0"/><site name="s1" pos="0.3 0 0"/></body></worldbody>'
+        '<sensor><jointpos joint="j"/><camprojection site="s1" camera="cam"/><user dim="3" needstage="vel"/><jointvel joint="j"/></sensor></mujoco>')
+    mx = mt.device_put(mt.mjcf.from_xml_path(str(tmp_path / "m.xml")))
+    d = seeded(mx, 3)
+    sd = torch.tensor(np.random.RandomState(2).randn(3, int(mx.nsensordata)))
+    d = d.replace(sensordata=sd.clone())
+    got = mt.step(mx, d)
+    assert_same(got, pyoracle.run(mx, d, step=True))
+    assert torch.equal(got.sensordata[:, 1:6], sd[:, 1:6])                                   # camprojection (2) + user (3): untouched
+    assert not torch.equal(got.sensordata[:, 0], sd[:, 0]) and not torch.equal(got.sensordata[:, 6], sd[:, 6])   # jointpos / jointvel: evaluated
