@@ -22,8 +22,8 @@
 #define MJH_INST_G14(X, S, C, N, R) S(R, 16, 2, 17) S(R, 16, 5, 17)
 #define MJH_INST_G12(X, S, C, N, R) X(R, 13, 64) X(R, 13, 32) X(R, 13, 16)  /* kinematics + crb + velocity in one launch */
 #define MJH_INST_G15(X, S, C, N, R) X(R, 2, 32)  /* plain constraint phase, two environments per wavefront (mid-size models) */
-#define MJH_INST_G16(X, S, C, N, R) S(R, 28, 1, 33)  /* constraint stage + register solver + integrator in one kernel (W = 33: 32 lanes, fused) */
-#define MJH_INST_G17(X, S, C, N, R) S(R, 28, 1, 34)  /* the whole pass -- kinematics + crb + velocity + constraint stage + register solver + integrator -- in one kernel (W = 34) */
+#define MJH_INST_G16(X, S, C, N, R) S(R, 28, 1, 33) S(R, 28, 1, 35)  /* constraint stage + register solver + integrator in one kernel (W = 33: 32 lanes, fused; W = 35: the same for opt.iterations == 1) */
+#define MJH_INST_G17(X, S, C, N, R) S(R, 28, 1, 34) S(R, 28, 1, 36)  /* the whole pass -- kinematics + crb + velocity + constraint stage + register solver + integrator -- in one kernel (W = 34) */
 #define MJH_INST_NGROUPS 18
 
 #define MJH_INST_ALL(X, S, C, N, R)                                                                                              \

@@ -3601,7 +3601,7 @@ struct Env {
   // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the rows of the active contacts, efc_D / efc_aref and the
   // narrow phase's distances never leave the arena between the two (the leaves are still stored -- nothing waits for them), and the factor rows, qfrc_smooth
   // and the state arrive while the constraint stage computes.  Serves models of the plain constraint phase whose dense rows fit one slot per lane.
-  template <int NMAX, int RPL>
+  template <int NMAX, int RPL, bool ONE = false>
   __device__ __forceinline__ void run_con_sol2() {
     static_assert(W == 32 && !FRIC && !DIRECT, "plain constraint stage, two environments per wavefront");
     Sol2Pre<REAL, NMAX> pre;
@@ -3616,7 +3616,7 @@ struct Env {
     sol2_prefetch<NMAX>(pre);
 #endif
     wave_sync();
-    run_sol2<NMAX, RPL, false, true>(&pre, &con);
+    run_sol2<NMAX, RPL, false, true, ONE>(&pre, &con);
   }
   template <bool FLUID, bool FUSED = false, bool DEFER = false>
   __device__ __forceinline__ void run_vel() {
@@ -3774,7 +3774,7 @@ struct Env {
     return tri_solve<W, REAL, NMAX>(T, bi, M.nv);
   }
 
-  template <int NMAX, int RPL, bool NEWTON_ONLY = false, bool CS = false>
+  template <int NMAX, int RPL, bool NEWTON_ONLY = false, bool CS = false, bool ONE = false>
   __device__ __forceinline__ void run_sol2(const Sol2Pre<REAL, NMAX>* pre = nullptr, const Sol2Con<REAL>* con = nullptr) {
     static_assert(W == 32 || W == 16, "two or four environments per wavefront");
     static_assert(!CS || (W == 32 && !NEWTON_ONLY), "the fused constraint + solver kernel runs two environments per wavefront");
@@ -4228,7 +4228,7 @@ struct Env {
       // (iteration caps: measured slower than letting the packed tier finish its solves, profiles/r03/notes.md -- compiled in only with -DMJH_SOL2_CAPS, so the kernels do not carry their bookkeeping)
       const int it_cap = MJH_SOL2_CAPS_ON ? KA.it_cap : 0, ls_cap = MJH_SOL2_CAPS_ON ? KA.ls_cap : 0;
       for (;;) {
-        if (M.iterations == 1) { if (it >= 1) break; }
+        if (ONE || M.iterations == 1) { if (it >= 1) break; }  // (ONE: the launch has checked opt.iterations == 1 -- a compile-time trip count of one)
         else if (fixed) { if (it >= M.iterations) break; }
         else {  // cond :501-508
           const REAL gg = sub_sum<W>(grad * grad);
@@ -4240,7 +4240,7 @@ struct Env {
           if (done) break;
         }
         if (it_cap > 0 && (it >= it_cap || ls_total >= ls_cap)) { bail = true; break; }  // another iteration is due: the fallback launch redoes this solve from its inputs
-        const bool need_grad = !(it + 1 >= M.iterations);
+        const bool need_grad = ONE ? false : !(it + 1 >= M.iterations);
         {  // search direction of this iteration: -H^-1 grad (Newton), -M^-1 grad at the start, Polak-Ribiere afterwards (CG, :519-523)
           const REAL Mg = precondition(grad);
           if (first_dir || newton) {
@@ -4436,11 +4436,12 @@ struct Env {
 #define MJH_SOL2_F64_WAVES 1  /* float64 instantiations for <= 16 dofs (the twins of configs 3 / 5): at two waves per SIMD they spilled 80 - 600 B per lane to scratch memory; at ONE the unified register file holds the overflow in AGPRs (24 - 150 of them, no scratch).  Measured (MI355X, solver phase): mesh scene float64 B = 4096 190.6 -> 186.9 us, B = 16384 501 -> 463 us; ant float64 29.3 -> 28.3 / 54.9 -> 53.8 us */
 #endif
 template <typename REAL, int NMAX, int RPL, int WT>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT != 33 && WT != 34 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : ((sizeof(REAL) == 8 && NMAX <= 16) ? MJH_SOL2_F64_WAVES : 2)) mjh_sol2_kernel(KArgs<REAL> args) {
-  constexpr int W = WT == 17 ? 16 : ((WT == 33 || WT == 34) ? 32 : WT);
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT < 33 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : ((sizeof(REAL) == 8 && NMAX <= 16) ? MJH_SOL2_F64_WAVES : 2)) mjh_sol2_kernel(KArgs<REAL> args) {
+  constexpr int W = WT == 17 ? 16 : (WT >= 33 ? 32 : WT);
   constexpr bool NEWTON_ONLY = WT == 17;
-  constexpr bool CS = WT == 33 || WT == 34;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
-  constexpr bool ALL = WT == 34;             // WT = 34: ... and kinematics + crb / factor + velocity in front of that: the whole forward pass + integrator of an environment in one kernel
+  constexpr bool ONE = WT == 35 || WT == 36;             // WT = 35: WT = 33 for models with opt.iterations == 1 (the humanoid benchmark, solver.py:534-535): the solver loop's body is straight-line code -- the factor of M is dead behind the one preconditioning step instead of crossing the line search in 56 VGPRs
+  constexpr bool CS = WT >= 33;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
+  constexpr bool ALL = WT == 34 || WT == 36;  // WT = 34 (36: its one-iteration form, as 35 is to 33): ... and kinematics + crb / factor + velocity in front of that: the whole forward pass + integrator of an environment in one kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: two (32 lanes each) or, for nv <= 16, four (16 lanes each)
@@ -4495,9 +4496,9 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wave_sync();
         E.S.off = &K.off2;
-        E.template run_con_sol2<NMAX, RPL>();
+        E.template run_con_sol2<NMAX, RPL, ONE>();
       } else
-      if constexpr (CS) E.template run_con_sol2<NMAX, RPL>();
+      if constexpr (CS) E.template run_con_sol2<NMAX, RPL, ONE>();
       else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }
     wave_sync();

@@ -567,6 +567,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
         out->lds_cs = reals * (int)sizeof(REAL);
         out->fuse_cs = 1;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 33>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_cs));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 35>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_cs));
       }
     }
   }
@@ -698,13 +699,19 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     // Measured (MI355X, humanoid B = 4096, three A / B pairs in one call, profiles/r04/notes.md): 166.8 - 170.5 us in one launch against 91.7 - 93.1 + 76.4 - 76.7 in two
     // (23.5 - 24.3 M against 24.1 - 24.6 M env-steps/s): the one function is allocated 256 VGPRs + 304 B of scratch where the halves take 198 + 0 and 256 + 120 B, and that
     // costs what the missing device-wide barrier saves.  Opt-in (MJH_FUSE_ALL=1).
-    static const bool on = [] { const char* e = getenv("MJH_FUSE_ALL"); return e && e[0] == '1'; }();
+    // Round 5: for models with opt.iterations == 1 (the humanoid benchmark) the one-iteration instantiation (W = 36: the solver loop is straight-line code, the factor of M
+    // dies behind its one preconditioning step) takes 256 VGPRs + 52 B where the generic one takes 256 + 304 B, and the single launch wins at every batch size: B = 4096
+    // 155.0 - 155.9 us against 91.0 + 71.0 - 71.6 in two launches (25.5 - 25.7 M against 25.0 - 25.2 M env-steps/s), B = 32768 1162 us against 657 + 577 (27.8 - 28.1 M against
+    // 26.4 M; profiles/r05/notes.md).  Default on for those models (MJH_FUSE_ALL=0: off); still opt-in (MJH_FUSE_ALL=1) for the others.
+    static const int sw = [] { const char* e = getenv("MJH_FUSE_ALL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    const bool on = sw == 1 || (sw == -1 && d->iterations == 1);
     out->fuse_all = 0;
     if (on && out->fuse_cs && out->fuse_kcv && out->pack2[1] && !out->pack4[1] && M.ncvxpair == 0 && d->nsensor == 0) {
       out->lds_all = out->lds_kcv > out->lds_cs ? out->lds_kcv : out->lds_cs;
       if (2 * out->lds_all <= 64 * 1024) {
         out->fuse_all = 1;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 34>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_all));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 36>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_all));
       }
     }
   }
@@ -825,7 +832,9 @@ int launch_cs(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
+  static const bool one_off = [] { const char* e = getenv("MJH_CS_ONE"); return e && e[0] == '0'; }();  // (A / B switch: MJH_CS_ONE=0 launches the generic instantiation for one-iteration models too)
+  if (a.M.iterations == 1 && !one_off) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 35>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);  // opt.iterations == 1 (solver.py:534-535: the loop body runs exactly once): straight-line solver code
+  else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
   HIP_TRY(hipGetLastError());
   timing_mark(stream, 14);
   return 0;
@@ -841,7 +850,8 @@ int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 34>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
+  if (a.M.iterations == 1) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 36>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
+  else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 34>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
   HIP_TRY(hipGetLastError());
   timing_mark(stream, 16);
   return 0;
