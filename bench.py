@@ -114,9 +114,10 @@ KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kern
                9: "mjh_sol2_kernel<{r}, NMAX, RPL> (solve / integrate: register solver, two environments per wavefront)", 10: "mjh_convex_kernel<{r}>", 11: "mjh_sensor_kernel<{r}>",
                12: "mjh_phase_kernel<{r}, 12, W> (kinematics + velocity in one launch)",
                13: "mjh_phase_kernel<{r}, 13, W> (kinematics + crb / factor + velocity in one launch)",
-               14: "mjh_sol2_kernel<{r}, 28, 1, 33> (collision / constraint + register solver + integrator in one launch)",
+               14: "mjh_sol2_kernel<{r}, 28, 1, 33 | 35> (collision / constraint + register solver + integrator in one launch)",
                15: "mjh_sort_kernel (environments ordered by last step's solver iteration counts)",
-               16: "mjh_sol2_kernel<{r}, 28, 1, 34> (the whole pass in one launch: kinematics + crb / factor + velocity + collision / constraint + register solver + integrator)"}
+               16: "mjh_sol2_kernel<{r}, 28, 1, 34 | 36> (the whole pass in one launch: kinematics + crb / factor + velocity + collision / constraint + register solver + integrator; 36: opt.iterations == 1)",
+               17: "mjh_phase_kernel<{r}, 17, W> (kernel 13 on two wavefronts per workgroup: kinematics, then velocity beside crb / factor)"}
 
 
 def kernel_algorithmic_bytes(nm):
@@ -125,7 +126,7 @@ def kernel_algorithmic_bytes(nm):
     import ctypes
 
     out = {}
-    for k in range(17):
+    for k in range(18):
         rw = (ctypes.c_int64 * 2)()
         if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
             out[k] = (int(rw[0]), int(rw[1]))

@@ -48,21 +48,22 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
 #define PH_SOL2P 128 /* ... after the state the tail integrates, which is parked for the whole phase                           */
 #define PH_KINVEL 256 /* arena of the fused kinematics + velocity kernel (12): the arrays both phases use, then the kinematics-only and the velocity-only arrays OVER each other */
 #define PH_KCV 512  /* arena of the fused kinematics + crb + velocity kernel (13): what kinematics and velocity share, then the kinematics-only, the crb-only and the velocity-only arrays OVER each other */
+#define PH_KCV2 2048 /* arena of the two-wave form of kernel 13 (mjh_phase_kernel<.., 17, W>): kinematics, then the velocity stage on the first wave BESIDE the crb / factor stage on a second one -- the crb-only arrays get a region of their own */
 #define PH_CS 1024  /* arena of the fused constraint + register-solver kernel (mjh_cs_kernel): the contact rows of efc_J stay where the constraint stage built them */
 #define MJH_NPHASE 5
 #define MJH_NARENA 6  /* arenas carved per model: the five phases + the register solver */
 #define MJH_LDS_ARRAYS(X, m)                                                                                   \
   X(qpos, m.nq, PH_KIN | PH_VEL | PH_SOL | PH_SOL2P) X(qpos_con, m.con_general ? m.nq : 0, PH_CON) /* general constraint phase only */ X(qvel, m.nv, PH_CON | PH_VEL | PH_SOL | PH_SOL2P)                     \
   X(act, m.na, PH_VEL | PH_SOL | PH_SOL2P)                                                                                \
-  X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, 9 * m.nbody, PH_KIN)                      \
-  X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, 9 * m.nbody, PH_KIN)                                         \
+  X(xpos, 3 * m.nbody, PH_KIN) X(xquat, 4 * m.nbody, PH_KIN) X(xmat, m.lds_diet ? 0 : 9 * m.nbody, PH_KIN)                      \
+  X(xipos, 3 * m.nbody, PH_KIN | PH_VEL) X(ximat, m.lds_diet ? 0 : 9 * m.nbody, PH_KIN)                                         \
   X(xanchor, 3 * m.njnt, PH_KIN) X(xaxis, 3 * m.njnt, PH_KIN)                                                  \
   X(jquat, 4 * m.njnt, PH_KIN) /* per-joint local rotation (or slide offset), computed before the chain walk */ \
   X(geom_xpos, 3 * m.ngeom, 0) X(geom_xmat, 9 * m.ngeom, 0) /* PH_CON, aliased over efc_J (dead before the rows are built): see lds_carve */ \
   X(subtree_com, 3 * m.nbody, PH_KIN | PH_CON | PH_VEL) X(cinert, 10 * m.nbody, PH_KIN | PH_CRB | PH_VEL)      \
   X(crb, 10 * m.nbody, PH_CRB) X(cdof, 6 * m.nv, PH_KIN | PH_CRB | PH_CON | PH_VEL)                            \
   X(cdof_dot, 6 * m.nv, PH_VEL) X(cvel, 6 * m.nbody, PH_VEL) X(cacc, 6 * m.nbody, PH_VEL)                      \
-  X(cfrc, 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
+  X(cfrc, m.lds_diet ? 0 : 6 * m.nbody, PH_VEL) X(crb_cdof, 6 * m.nv, PH_CRB) X(sub_mass, m.nbody, PH_KIN)                      \
   X(sub_pos, 3 * m.nbody, PH_KIN)                                                                              \
   X(qMp, m.nv * (m.nv + 1) / 2, PH_CRB) /* lower triangle, packed rows */                                      \
   X(qLD, m.nv * m.nv, 0) /* PH_CRB only, aliased over the dead arrays when the factor is written: see lds_carve */ \
@@ -78,7 +79,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
   X(H2, (!(m.disableflags & DSBL_EULERDAMP) && m.nv <= 16) ? m.nv * (m.nv + 1) / 2 : 0, PH_SOL2T) X(chol_col, (!(m.disableflags & DSBL_EULERDAMP) && m.nv > 16) ? 64 : 0, PH_SOL2T) \
   X(con_dist, m.ncand, PH_CON) X(con_pos, 3 * m.ncand, PH_CON) X(con_frame, 9 * m.ncand, PH_CON) /* candidate contacts (== the contacts unless max_contact_points selects) */ \
   X(i_con_src, m.topk ? m.ncon : 0, PH_CON) /* top-k: candidate kept in each contact slot (ints) */                  \
-  X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(i_con_act, m.con_direct ? m.ncon : 0, PH_CON) X(i_crow_act, m.con_direct ? m.nefc - m.nl : 0, PH_CON) /* small models: compact list of the active contacts, per-row activity (ints) */ X(efc_D, m.nefc, PH_SOL)                                            \
+  X(efc_J, m.con_general ? m.nefc * m.nv : (m.con_direct ? 0 : (m.nefc - m.nl) * m.nv), PH_CON) /* plain instantiation: contact rows only, none when they go straight to the leaf (con_direct) */ X(efc_jl, m.con_general ? 0 : m.nl, PH_CON) /* plain: contact rows only + the limit rows' single entries */ X(i_con_act, m.con_direct ? m.ncon : 0, PH_CON) X(i_crow_act, m.con_direct ? (m.crow_by_con ? m.ncon : m.nefc - m.nl) : 0, PH_CON) /* small models: compact list of the active contacts; activity per contact row -- per CONTACT where dense row q is contact q / con_rows: 480 B less for the ant, whose 5200 B arena fitted 15 two-environment workgroups per CU, i.e. THREE rounds of waves at B = 16384 (30 + 30 + 4 environments per CU) instead of two (ints) */ X(efc_D, m.nefc, PH_SOL)                                            \
   X(efc_Jc, MJH_JC_ROWS(m) * m.nv, PH_SOL | PH_SOL2) /* dense rows of the contacts (sol2_row_cap: the register solver's first tier keeps 32 of them) */                                   \
   X(efc_Jl, m.nf + m.nl, PH_SOL) /* the single non-zero of each frictionloss / joint-limit row (column crow_dof[r]) */ \
   X(efc_fl, m.nf + m.nft, PH_SOL) /* frictionloss of the dof- and tendon-friction rows */                \
@@ -89,7 +90,7 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
   X(act_length, m.nu, PH_VEL) X(act_velocity, m.nu, PH_VEL) X(act_force, m.nu, PH_VEL) X(act_rot, m.act_has_rot ? 3 * m.nu : 0, PH_VEL) X(ten_len, m.ntendon, PH_VEL) X(ten_frc, m.ntendon, PH_VEL)                         \
   X(act_dot, m.na, PH_VEL | PH_SOL | PH_SOL2P)                                                                            \
   X(qfrc_bias, m.nv, PH_VEL) X(qfrc_passive, m.nv, PH_VEL) X(qfrc_actuator, m.nv, PH_VEL) X(qfrc_gravcomp, m.has_gravcomp ? m.nv : 0, PH_VEL)                      \
-  X(qfrc_smooth, m.nv, PH_VEL | PH_SOL | PH_SOL2T) X(qacc_smooth, m.nv, PH_VEL | PH_SOL)                                  \
+  X(qfrc_smooth, m.nv, PH_VEL | PH_SOL | PH_SOL2T) X(qacc_smooth, m.nv, PH_SOL) /* (the velocity stage never touched it: _acceleration's solve sits at the head of the solver phase) */                                  \
   X(qacc_warm, m.nv, PH_SOL) X(qacc, m.nv, PH_SOL | PH_SOL2T) X(qfrc_constraint, m.nv, PH_SOL | PH_SOL2T)                            \
   X(s_qacc, m.nv, PH_SOL) X(s_qfrc, m.nv, PH_SOL) X(s_Ma, m.nv, PH_SOL) X(s_grad, m.nv, PH_SOL | PH_SOL2T)                \
   X(s_Mgrad, m.nv, PH_SOL | PH_SOL2T) X(s_search, m.nv, PH_SOL) X(s_mv, m.nv, PH_SOL | PH_SOL2T) X(s_pgrad, m.nv, PH_SOL | PH_SOL2T)            \
@@ -172,6 +173,8 @@ struct DevModel {
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
   int con_rows;                            // constraint rows of every contact when they all have the same number (one condim), else 0
+  int lds_diet;                            // small models (four environments per wavefront): xmat / ximat are stored from registers and recomputed from xquat where read again, the subtree force sums fold into qfrc_bias -- the arena of kernel 13 drops from 3064 to 2272 B for the ant, i.e. 16 four-environment workgroups per CU fit (one round of waves at B = 16384 instead of two)
+  int crow_by_con;                         // ... and the contact rows are in contact order, no gaps: dense row q belongs to contact q / con_rows (the small-model constraint phase then keeps its activity flags per CONTACT)
   int sol2_row_cap;                        // only while the arena of the register solver's first tier is carved (mjhip.hip): dense rows it keeps; 0 otherwise
   int sol2_hs;                             // non-zero: the register solver builds the Newton Hessian with block matrix instructions (float32, nv <= 16)
   // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
@@ -186,16 +189,19 @@ struct DevModel {
 };
 
 // ---- wave helpers --------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x; }
+// lane of this thread inside its wavefront.  Workgroups are one wavefront (launch bound 64: the mask folds away) except the two-wave form of kernel 13 (mjh_phase_kernel<.., 17, W>)
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (MJH_WAVE - 1)); }
 
 // LDS visibility point for a single-wave workgroup (s_waitcnt + barrier; the barrier is free for 1 wave).
 // A workgroup is one wavefront: what a "barrier" has to order is the LDS traffic of its lanes.  __syncthreads() carries a workgroup-scope
 // fence over GLOBAL memory too, i.e. s_waitcnt vmcnt(0): every barrier behind a burst of leaf stores stalled the wave until L2 had taken all of
 // them (the stores of one phase are 60 - 80 MB per launch, issued by all waves at the same moment) -- 10 of the fused kinematics + velocity
 // kernel's 75 us on the humanoid.  The fences below are restricted to the LDS address space; the stores drain behind the arithmetic that follows.
+// (round 5: no s_barrier instruction between the fences.  For a one-wave workgroup the hardware treats it as a no-op anyway -- a wave's LDS operations complete in issue order --
+// and the two-wave form of kernel 13 needs the stage functions' internal sync points to stay INSIDE a wave: a real barrier there would pair up with the other wave's.)
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 // ... and the full barrier, for the one place where a wave reads back through L2 what it has just stored (the small-model constraint phase)
@@ -255,13 +261,13 @@ __device__ __forceinline__ void split_index(int w, int n, float inv_n, int& q, i
 }
 
 // ---- sub-wave helpers: W lanes (64 or 32) serve one environment, 64 / W environments share a wavefront ----------------
-template <int W> __device__ __forceinline__ int sub_lane() { return (W == MJH_WAVE) ? (int)threadIdx.x : (int)(threadIdx.x & (W - 1)); }
+template <int W> __device__ __forceinline__ int sub_lane() { return (W == MJH_WAVE) ? lane_id() : (int)(threadIdx.x & (W - 1)); }
 // any() over the lanes of this environment
 template <int W>
 __device__ __forceinline__ bool sub_any(bool p) {
   if (W == MJH_WAVE) return __any(p) != 0;
   const unsigned long long m = __ballot(p);
-  const int sh = (int)(threadIdx.x & ~(W - 1));
+  const int sh = lane_id() & ~(W - 1);
   return ((m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1))) != 0;
 }
 // number of lanes below this one in the environment's lane group whose predicate holds, and the group's total: one ballot and two
@@ -269,7 +275,7 @@ __device__ __forceinline__ bool sub_any(bool p) {
 template <int W>
 __device__ __forceinline__ int sub_prefix_count(bool p, int& total) {
   const unsigned long long m = __ballot(p);
-  const int sh = (int)(threadIdx.x & ~(W - 1)), l = (int)(threadIdx.x & (W - 1));
+  const int sh = lane_id() & ~(W - 1), l = (int)(threadIdx.x & (W - 1));
   const unsigned long long g = (m >> sh) & ((W >= 64) ? ~0ull : ((1ull << W) - 1));
   total = __popcll(g);
   return __popcll(g & ((1ull << l) - 1ull));
@@ -282,9 +288,9 @@ __device__ __forceinline__ T sub_read(T v, int k) {
   if (W == MJH_WAVE) return read_lane(v, k);
   if (W == 32) {
     const T a = read_lane(v, k), b = read_lane(v, 32 + k);
-    return threadIdx.x < 32 ? a : b;
+    return lane_id() < 32 ? a : b;
   }
-  return __shfl(v, (int)(threadIdx.x & ~(W - 1)) + k, MJH_WAVE);
+  return __shfl(v, (lane_id() & ~(W - 1)) + k, MJH_WAVE);
 }
 // value of lane K (0..15) of each 16-lane DPP row, in every lane of that row: three DPP moves, no LDS-pipe round trip and no SGPR hop.
 // quad_perm [a, a, a, a] leaves lane 4 q + a in all lanes of quad q; row_half_mirror (lane i <- lane 7 - i of its half) copies the quad that

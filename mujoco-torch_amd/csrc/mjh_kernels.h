@@ -101,6 +101,27 @@ inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = n
     off = ka > va ? ka : va;
     if (ca > off) off = ca;
   }
+  if (phase_bit == PH_KCV2) {
+    // two-wave kinematics -> {velocity || crb / factor}: [what kinematics and velocity share | kinematics-only OVER velocity-only (as PH_KINVEL) | crb-only arrays, the factor over them]
+    // -- the crb wave reads cinert / cdof of the shared part and writes nothing outside its own region, so the velocity wave's arrays are never under it
+    int s0 = 0;
+#define X(n, c, p) if (((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = s0; s0 += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    int ka = s0, va = s0;
+#define X(n, c, p) if (((p) & PH_KIN) && !((p) & PH_VEL)) { o.n = ka; ka += (((c) + 1) & ~1); } else if (!((p) & PH_KIN) && ((p) & PH_VEL)) { o.n = va; va += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    const int c0 = ka > va ? ka : va;
+    int ca = c0;
+#define X(n, c, p) if (((p) & PH_CRB) && !((p) & (PH_KIN | PH_VEL))) { o.n = ca; ca += (((c) + 1) & ~1); }
+    MJH_LDS_ARRAYS(X, m)
+#undef X
+    const int nn = ((m.nv * m.nv + 1) & ~1);
+    if (m.nv <= 32) { o.qLD = c0; if (ca < c0 + nn) ca = c0 + nn; }
+    else { o.qLD = ca; ca += nn; }
+    off = ca;
+  }
   if (phase_bit == PH_CS) {
     // Fused constraint + register-solver kernel (plain rows, one contact condim, one dense-row slot per lane, no tiers: the humanoid).  Laid out by hand:
     //   [qvel | act | act_dot | con_dist | i_con_act | i_crow_act]     live through both stages (the two int tables: active contacts, contact -> compact slot)
@@ -937,8 +958,8 @@ struct Env {
   }
 
   __device__ __forceinline__ void frame_stores() {
-    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); put(out.xmat, S.xmat(), 9 * M.nbody);
-    put(out.xipos, S.xipos(), 3 * M.nbody); put(out.ximat, S.ximat(), 9 * M.nbody);
+    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); if (!M.lds_diet) put(out.xmat, S.xmat(), 9 * M.nbody);  // (lds_diet: the two matrices went out from the registers that formed them)
+    put(out.xipos, S.xipos(), 3 * M.nbody); if (!M.lds_diet) put(out.ximat, S.ximat(), 9 * M.nbody);
     put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
   }
   __device__ __forceinline__ void com_stores() {
@@ -1047,8 +1068,22 @@ struct Env {
       for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
 #pragma unroll
       for (int i = 0; i < 4; i++) S.xquat()[4 * b + i] = quat[i];
+      if (M.lds_diet) {  // the two 3 x 3 frames are not staged: stored from here, formed again from xquat where com_pos reads them (the same operations on the same inputs)
+        REAL xm[9], xim[9];
+        quat_to_mat(quat, xm);
+        local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, xim);
+        if (out.xmat) {
+#pragma unroll
+          for (int i = 0; i < 9; i++) out.xmat[(e * M.nbody + b) * 9 + i] = xm[i];
+        }
+        if (out.ximat) {
+#pragma unroll
+          for (int i = 0; i < 9; i++) out.ximat[(e * M.nbody + b) * 9 + i] = xim[i];
+        }
+      } else {
       quat_to_mat(quat, S.xmat() + 9 * b);
       local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, S.ximat() + 9 * b);
+      }
     }
     wave_sync();
     STAMP(2);
@@ -1160,7 +1195,12 @@ struct Env {
       const REAL* rc = S.subtree_com() + 3 * M.body_rootid[b];
       const REAL off[3] = {S.xipos()[3 * b] - rc[0], S.xipos()[3 * b + 1] - rc[1], S.xipos()[3 * b + 2] - rc[2]};
       const REAL mass = M.body_mass[b];
-      const REAL* xi = S.ximat() + 9 * b;
+      REAL xi[9];  // (a register copy either way: a pointer that may address a private array OR the arena would put the array in scratch memory)
+      if (M.lds_diet) { REAL q_[4]; quat_mul(S.xquat() + 4 * b, M.body_iquat + 4 * b, q_); quat_to_mat(q_, xi); }  // support.local_to_global's orientation half, as the kinematics formed it
+      else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) xi[i] = S.ximat()[9 * b + i];
+      }
       const REAL* inr = M.body_inertia + 3 * b;
       const REAL h[3][3] = {{0, -off[2], off[1]}, {off[2], 0, -off[0]}, {-off[1], off[0], 0}};
       REAL I[3][3];
@@ -1189,8 +1229,15 @@ struct Env {
           for (int r = 0; r < 3; r++) for (int k = 0; k < 6; k++) S.cdof()[6 * (d + r) + k] = (k == 3 + r) ? (REAL)1 : (REAL)0;
           d += 3;
         }
+        REAL xmb[9];
+        if (M.lds_diet) quat_to_mat(S.xquat() + 4 * b, xmb);
+        else {
+#pragma unroll
+          for (int i = 0; i < 9; i++) xmb[i] = S.xmat()[9 * b + i];
+        }
+#pragma unroll
         for (int r = 0; r < 3; r++) {
-          const REAL a[3] = {S.xmat()[9 * b + r], S.xmat()[9 * b + 3 + r], S.xmat()[9 * b + 6 + r]};
+          const REAL a[3] = {xmb[r], xmb[3 + r], xmb[6 + r]};
           REAL c[3];
           cross3(a, off, c);
           for (int k = 0; k < 3; k++) { S.cdof()[6 * (d + r) + k] = a[k]; S.cdof()[6 * (d + r) + 3 + k] = c[k]; }
@@ -1270,7 +1317,7 @@ struct Env {
     put(out.crb, S.crb(), 10 * nb);
     wave_sync();
     STAMP(15);
-    chol_factor<W, REAL, 32, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve)
+    chol_factor<W, REAL, (W == 16 ? 16 : 32), true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve).  (Four environments per wavefront: nv <= 16 -- the 24 / 28 / 32-row register variants are not compiled in)
     STAMP(16);
     put(out.qLD, S.qLD(), nv * nv);
     STAMP(17);
@@ -1771,7 +1818,8 @@ struct Env {
         int tot;
         const int before = sub_prefix_count<W>(act, tot);
         if (act) act_list[nact + before] = c;
-        for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
+        if (M.crow_by_con) { if (c < ncon) row_act[c] = act ? 1 : 0; }  // (dense row q is contact q / con_rows: one flag per contact)
+        else for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
         nact += tot;
       }
       nact_contacts = nact;
@@ -1780,6 +1828,7 @@ struct Env {
       // RK4 stages 1..3 write a private workspace Data whose only reader is this stage's solver phase, and that gathers the rows of the ACTIVE
       // contacts only (load_solver_inputs / run_sol2): the zero rows, and further down D / aref of the inactive rows, are not written there
       const bool scratch_stage = KA.rk_stage > 0;
+      const float inv_rows_ = 1.0f / (float)(M.con_rows > 0 ? M.con_rows : 1);
       if (!scratch_stage) {
         constexpr int VW = 16 / (int)sizeof(REAL);  // elements per 16-byte store
         typedef REAL zvec __attribute__((ext_vector_type(VW)));
@@ -1792,13 +1841,17 @@ struct Env {
           for (int w = l; w < nd * gpr; w += W) {
             int q, g;
             split_index(w, gpr, 1.0f / (float)gpr, q, g);
-            if (!row_act[q]) reinterpret_cast<zvec*>(Jdst)[w] = z;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+            int qc = q, unused_;
+            if (M.crow_by_con) split_index(q, M.con_rows, inv_rows_, qc, unused_);
+            if (!row_act[qc]) reinterpret_cast<zvec*>(Jdst)[w] = z;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
           }
         } else
         for (int w = l; w < nd * nv; w += W) {
           int q, d;
           split_index(w, nv, M.inv_nv, q, d);
-          if (!row_act[q]) Jdst[w] = 0;
+          int qc = q, unused_;
+          if (M.crow_by_con) split_index(q, M.con_rows, inv_rows_, qc, unused_);
+          if (!row_act[qc]) Jdst[w] = 0;
         }
       }
       for (int w = l; w < nact * nv; w += W) {
@@ -2454,6 +2507,19 @@ struct Env {
     }
     wave_sync();
     STAMP(36);
+    if (M.lds_diet) {  // no cfrc array: the lane of a dof forms its body's six subtree sums itself (same terms, same order) and projects them
+      for (int d = l; d < nv; d += W) {
+        const int b = M.dof_bodyid[d], end = M.body_subtree_end[b];
+        REAL s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          REAL acc = 0;
+          for (int bb = end - 1; bb >= b; bb--) acc += S.cacc()[6 * bb + k];
+          s += S.cdof()[6 * d + k] * acc;
+        }
+        S.qfrc_bias()[d] = s;
+      }
+    } else {
     for (int w = l; w < nb * 6; w += W) {  // subtree sums of the body forces
       const int b = w / 6, k = w - 6 * b;
       const int end = M.body_subtree_end[b];
@@ -2469,6 +2535,7 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < 6; k++) s += S.cdof()[6 * d + k] * cf[k];
       S.qfrc_bias()[d] = s;
+    }
     }
     wave_sync();
     STAMP(38);
@@ -4419,7 +4486,10 @@ struct Env {
 #define MJH_KV32_WAVES 2  /* float32 fused kinematics + velocity kernel, packed: a lower bound -- the kernel needs ~122 VGPRs since the stage functions stopped sharing hoisted address arithmetic (round 2: 256) and runs four waves per SIMD: the ant's B = 16384 is one round.  Requesting the caller's cold ctrl / applied-force rows at the kernel's head instead of at their use: 129 VGPRs, humanoid -0.7 us, ant +2.4 us: not kept */
 #endif
 #ifndef MJH_KCV32_WAVES
-#define MJH_KCV32_WAVES 2  /* float32 fused kinematics + crb + velocity kernel, packed: 173 VGPRs; at three waves per SIMD (168 + 20 B of scratch) the ant ran it in 99.7 us instead of 95.7, at four (128 + 112 B) in 104.5 */
+#define MJH_KCV32_WAVES 4  /* round 5: 137 VGPRs once the crb stage of the four-per-wavefront instantiation stopped compiling the 24 / 28 / 32-row register Cholesky variants it can never run (nv <= 16): 128 + 24 B at four waves per SIMD.  Rounds 1 - 4, when those variants set the allocation: float32 fused kinematics + crb + velocity kernel, packed: 173 VGPRs; at three waves per SIMD (168 + 20 B of scratch) the ant ran it in 99.7 us instead of 95.7, at four (128 + 112 B) in 104.5 */
+#endif
+#ifndef MJH_KCV2_WAVES
+#define MJH_KCV2_WAVES 4  /* two-wave kernel 13 of packed float32 models: two workgroups of two waves per SIMD pair -- the point of the kernel is to be at four waves per SIMD where kernel 13 (169 VGPRs) sits at two */
 #endif
 #ifndef MJH_CON64_WAVES
 #define MJH_CON64_WAVES 4  /* float64 plain constraint phase: 128 VGPRs + ~108 B of scratch buys the fourth wave per SIMD (16 environments per CU) */
@@ -4506,11 +4576,11 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
 }
 
 template <typename REAL, int PHASE, int W>
-__global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 13 && W < 64) ? MJH_KCV32_WAVES : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? (W < 64 ? 2 : MJH_CON64_WAVES) : ((sizeof(REAL) == 8 && (PHASE == 12 || PHASE == 13)) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
+__global__ void __launch_bounds__((PHASE == 17 ? 2 * MJH_WAVE : MJH_WAVE), ((sizeof(REAL) == 4 && PHASE == 17 && W < 64) ? MJH_KCV2_WAVES : (sizeof(REAL) == 4 && PHASE == 8) ? MJH_CON32D_WAVES : (sizeof(REAL) == 4 && PHASE == 4) ? MJH_SOL32_WAVES : (sizeof(REAL) == 4 && (PHASE == 6 || ((PHASE == 0 || PHASE == 3) && W < 64))) ? 3 : (sizeof(REAL) == 4 && PHASE == 13 && W < 64) ? MJH_KCV32_WAVES : (sizeof(REAL) == 4 && PHASE == 12 && W < 64) ? MJH_KV32_WAVES : ((sizeof(REAL) == 4 && PHASE == 1) ? (W < 64 ? MJH_CRB32P_WAVES : 4) : ((sizeof(REAL) == 8 && PHASE == 2) ? (W < 64 ? 2 : MJH_CON64_WAVES) : ((sizeof(REAL) == 8 && (PHASE == 12 || PHASE == 13)) ? 2 : ((sizeof(REAL) == 8 && PHASE == 1 && W == 64) ? 4 : 1)))))) mjh_phase_kernel(KArgs<REAL> args) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const KArgs<REAL>& K = kargs<REAL>();
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
-  const int sub = (W == MJH_WAVE) ? 0 : (int)(threadIdx.x / W);  // folded away for a whole-wave environment: everything stays scalar
+  const int sub = (W == MJH_WAVE) ? 0 : (int)((threadIdx.x & (MJH_WAVE - 1)) / W);  // (PHASE 17: two wavefronts per workgroup share the arenas of the same NSUB environments)  // folded away for a whole-wave environment: everything stays scalar
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
   for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
     Env<REAL, W, PHASE == 6 || PHASE == 7, PHASE == 8> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
@@ -4520,6 +4590,17 @@ __global__ void __launch_bounds__(MJH_WAVE, ((sizeof(REAL) == 4 && PHASE == 8) ?
     else if (PHASE == 3) E.template run_vel<false>();
     else if (PHASE == 5) E.template run_vel<true>();  // velocity phase of models with fluid forces (density / viscosity / wind)
     else if (PHASE == 13) { E.template run_kin<false>(); wave_sync(); E.template crb_factor<true>(); wave_sync(); E.template run_vel<false, true>(); }  // ... and the crb / factor stage between them (small models: the three stages of one RK4 stage are one launch)
+    else if (PHASE == 17) {
+      // Kernel 13 on TWO wavefronts per workgroup (small float32 models): crb / factor and velocity both depend on the kinematics only (forward.py:73-99), so behind
+      // the kinematics stage the first wave goes on with the velocity stage while a second one -- idle at the barrier until then -- runs crb / factor on cinert / cdof in the shared
+      // arena (PH_KCV2: its own arrays are a region of their own).  The serial chain of an environment is KIN + max(VEL, CRB) instead of KIN + CRB + VEL.
+      const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+      if (role == 0) E.template run_kin<false>();
+      wave_sync(); __builtin_amdgcn_s_barrier(); wave_sync();  // (an LDS-only fence on both sides: __syncthreads() would also wait for the kinematics stage's leaf stores to land)
+      if (role == 0) E.template run_vel<false, true>();
+      else E.template crb_factor<true>();
+      wave_sync(); __builtin_amdgcn_s_barrier();               // the next block of the grid-stride loop reuses the arenas
+    }
     else if (PHASE == 12) { E.template run_kin<true>(); wave_sync(); E.template run_vel<false, true, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
     wave_sync();

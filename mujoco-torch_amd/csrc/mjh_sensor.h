@@ -288,7 +288,10 @@ __device__ __forceinline__ REAL sensor_value(int64_t e, int s, int comp, const d
 }
 
 template <typename REAL, int FULL>
-__global__ __launch_bounds__(MJH_WAVE) void mjh_sensor_kernel(KArgs<REAL> args) {
+#ifndef MJH_SENSOR32_WAVES
+#define MJH_SENSOR32_WAVES 8  /* float32 lean instantiation: 70 VGPRs are seven waves per SIMD = 28 one-environment workgroups per CU -- three rounds of waves for the ant's 64 environments per CU (28 + 28 + 8); 64 VGPRs are two */
+#endif
+__global__ __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && FULL == 0) ? MJH_SENSOR32_WAVES : 1) void mjh_sensor_kernel(KArgs<REAL> args) {
   // rangefinders dominate: their (sensor, geom) ray tests are spread over the lanes first (ant: 8 sensors x 13 geoms = two
   // trips instead of 13 dependent tests on 8 lanes), then every sensordata slot is produced by one lane
   extern __shared__ double rf_x[];

@@ -66,6 +66,10 @@ struct mjhModel {
   int fuse_kcv = 0;                        // ... and the crb / factor stage between them: ONE kernel (13) for the three (models whose crb stage packs like the other two)
   LdsOff off_kcv;
   int lds_kcv = 0;
+  LdsOff off_kcv2;                         // ... and of its two-wave form (mjh_phase_kernel<.., 17, W>, timing id 17: PH_KCV2)
+  int lds_kcv2 = 0;
+  int kcv2 = 0;                            // a step launches the two-wave form instead of kernel 13 ...
+  int64_t kcv2_max_envs = 0;               // ... while the batch is at most this many environments (one round of its workgroups)
   int64_t kcv_max_envs = 0;                // ... while the batch is ONE round of that kernel's waves (it needs more registers than either of its parts: two waves per SIMD)
   int sol2_tiers = 0;                      // 1: a first launch with ONE row slot per lane serves the environments whose active contacts fit 32 dense rows
   int sol2_w16_rpl = 0;                    // > 0: that first launch runs FOUR environments per wavefront (16 lanes each, nv <= 16) with this many row slots per lane
@@ -93,6 +97,10 @@ struct mjhModel {
   mutable hipStream_t split_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_done[4] = {nullptr, nullptr, nullptr, nullptr};
   mutable hipEvent_t split_fork = nullptr;
+  mutable std::mutex dag_mutex;            // MJH_DAG=1 (experiment): crb / factor and velocity kernels beside the constraint phase on two internal streams
+  mutable bool dag_ready = false;
+  mutable hipStream_t dag_stream[2] = {nullptr, nullptr};
+  mutable hipEvent_t dag_fork = nullptr, dag_done[2] = {nullptr, nullptr};
   // the sensor kernel needs nothing of CRB / CON / SOL: it runs on a stream of its own beside them (forked behind the velocity stage, joined at the end of the pass)
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
@@ -198,6 +206,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   const int NW = nv > 64 ? (nv + 63) / 64 : 1;  // 64-bit words per dof mask
   M.mask_words = NW;
   M.big = nv > 64 ? 1 : 0;
+  {  // small plain models (the ones that run four environments per wavefront, no optional physics): a leaner arena (DevModel::lds_diet).  MJH_LDS_DIET=0: off
+    static const bool diet_off = [] { const char* e = getenv("MJH_LDS_DIET"); return e && e[0] == '0'; }();
+    M.lds_diet = (!diet_off && d->nbody <= 16 && d->njnt <= 16 && nv <= 16 && !M.has_fluid && !M.has_gravcomp && d->ntendon == 0) ? 1 : 0;
+  }
   if (M.big) M.con_general = 1;  // the general constraint kernel (7) reads multi-word masks; so does the optional-physics velocity kernel (5)
   if (M.big) M.con_direct = 0;
   std::vector<int> depth(nb, 0), sub_end(nb, 0);
@@ -280,6 +292,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       const int dim = d->con_dim[c], rows = dim == 1 ? 1 : (d->cone == CONE_ELLIPTIC ? dim : 2 * (dim - 1));
       if (c == 0) M.con_rows = rows; else if (rows != M.con_rows) { M.con_rows = 0; break; }
     }
+    M.crow_by_con = (M.con_rows > 0 && ncrow == d->ncon * M.con_rows) ? 1 : 0;
+    for (int c = 0; c < d->ncon && M.crow_by_con; c++) if (d->con_efc_address[c] != first + c * M.con_rows) M.crow_by_con = 0;
     const bool elliptic = d->cone == CONE_ELLIPTIC;
     std::vector<REAL> par((size_t)9 * (ncrow > 0 ? ncrow : 1), (REAL)0);
     std::vector<int> info((size_t)(ncrow > 0 ? ncrow : 1), 0);
@@ -680,6 +694,27 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       if (out->pack4[1]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 13, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_kcv));
     }
   }
+  {  // kernel 13 on two wavefronts per workgroup (velocity beside crb / factor): packed float32 models.  MJH_KCV2=0 / 1 forces it off / on (also for float64, two per wavefront).
+    static const int sw = [] { const char* e = getenv("MJH_KCV2"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
+    out->kcv2 = 0;
+    if (out->fuse_kcv && sw != 0 && (sw == 1 || (sizeof(REAL) == 4 && out->pack4[1]))) {
+      out->lds_kcv2 = lds_carve(M, PH_KCV2, out->off_kcv2) * (int)sizeof(REAL);
+      const int per_wg = (out->pack4[1] ? 4 : 2) * out->lds_kcv2;
+      if (per_wg <= 64 * 1024) {
+        out->kcv2 = 1;
+        // The two-wave form pays while the whole batch is resident at once: two wavefronts per workgroup at four per SIMD are 8 workgroups per CU (and their arenas must fit the
+        // CU's 160 KB).  Past that it runs more rounds of waves than kernel 13 (which fits 16 one-wave workgroups) and loses.  Measured (MI355X, profiles/r05/notes.md): mesh scene
+        // B = 8192 37.5 us against 46.0; ant B = 8192 46.1 against 54.5; ant B = 16384 (two rounds against one) 101 against 62.
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int wgs = 160 * 1024 / per_wg;
+        if (wgs > 8) wgs = 8;
+        out->kcv2_max_envs = sw == 1 ? ((int64_t)1 << 62) : (int64_t)cus * wgs * (out->pack4[1] ? 4 : 2);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 17, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_kcv2));
+        if (out->pack4[1]) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 17, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * out->lds_kcv2));
+      }
+    }
+  }
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 6, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[4]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 7, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[2]));
   HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_phase_kernel<REAL, 5, MJH_WAVE>), hipFuncAttributeMaxDynamicSharedMemorySize, out->lds_bytes[3]));
@@ -722,24 +757,24 @@ template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
   constexpr int NSUB = MJH_WAVE / W;
-  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : ((P == 7 || P == 8) ? 2 : P));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
-  const int arena_bytes = P == 13 ? m->lds_kcv : (P == 12 ? m->lds_kv : m->lds_bytes[(P == 12 || P == 13) ? 0 : A]);
-  a.off = P == 13 ? m->off_kcv : (P == 12 ? m->off_kv : m->off[(P == 12 || P == 13) ? 0 : A]);
+  constexpr int A = P == 5 ? 3 : (P == 6 ? 4 : ((P == 7 || P == 8) ? 2 : (P == 17 ? 0 : P)));  // kernels 5 / 6: velocity phase with fluid forces, solver phase with frictionloss rows
+  const int arena_bytes = P == 17 ? m->lds_kcv2 : (P == 13 ? m->lds_kcv : (P == 12 ? m->lds_kv : m->lds_bytes[(P == 12 || P == 13) ? 0 : A]));
+  a.off = P == 17 ? m->off_kcv2 : (P == 13 ? m->off_kcv : (P == 12 ? m->off_kv : m->off[(P == 12 || P == 13) ? 0 : A]));
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = arena_bytes / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);
+  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(P == 17 ? 2 * MJH_WAVE : MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);  // (17: a second wavefront per workgroup runs the crb / factor stage)
   HIP_TRY(hipGetLastError());
   timing_mark(stream, P);
   return 0;
 }
 template <typename REAL, int P>
 int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
-  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 2 || P == 3 || P == 5 || P == 8 || P == 12 || P == 13);
-  constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : ((P == 12 || P == 13) ? 0 : P)));  // index into the per-phase packing flags
-  const bool can2 = !PACKABLE ? false : (P == 13 ? (bool)m->pack2[1] : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]));  // (13: fuse_kcv holds only when the crb stage packs like the other two)
-  const bool can4 = !PACKABLE ? false : (P == 13 ? (bool)m->pack4[1] : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && P != 2 && m->pack4[PI])));
+  constexpr bool PACKABLE = (P == 0 || P == 1 || P == 2 || P == 3 || P == 5 || P == 8 || P == 12 || P == 13 || P == 17);
+  constexpr int PI = !PACKABLE ? 0 : (P == 5 ? 3 : (P == 8 ? 2 : ((P == 12 || P == 13 || P == 17) ? 0 : P)));  // index into the per-phase packing flags
+  const bool can2 = !PACKABLE ? false : ((P == 13 || P == 17) ? (bool)m->pack2[1] : (P == 12 ? (m->pack2[0] && m->pack2[3] && 2 * m->lds_kv <= 64 * 1024) : (bool)m->pack2[PI]));  // (13: fuse_kcv holds only when the crb stage packs like the other two)
+  const bool can4 = !PACKABLE ? false : ((P == 13 || P == 17) ? (bool)m->pack4[1] : (P == 12 ? (m->pack4[0] && m->pack4[3] && 4 * m->lds_kv <= 64 * 1024) : (P != 8 && P != 2 && m->pack4[PI])));
   if (PACKABLE && can2 && a.B >= 2) {  // groups of four / pairs of environments, then the odd one on its own
     int64_t done = 0;
     int rc = 0;
@@ -749,9 +784,9 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     }
     const int64_t even = (a.B - done) & ~(int64_t)1;
     if ((rc = launch_range<REAL, P, (PACKABLE ? 32 : MJH_WAVE)>(m, a, done, even, stream))) return rc;
-    return launch_range<REAL, P, MJH_WAVE>(m, a, done + even, a.B - done - even, stream);
+    return launch_range<REAL, (P == 17 ? 13 : P), MJH_WAVE>(m, a, done + even, a.B - done - even, stream);  // (the odd environment: one per wavefront -- the two-wave form only exists packed, kernel 13 serves it)
   }
-  return launch_range<REAL, P, MJH_WAVE>(m, a, 0, a.B, stream);
+  return launch_range<REAL, (P == 17 ? 13 : P), MJH_WAVE>(m, a, 0, a.B, stream);
 }
 
 // the solver phase through the register solver: two (or, first tier of a small model, four) environments per wavefront
@@ -863,9 +898,47 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
   if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
+  // MJH_DAG=1 (experiment): kinematics -> {crb / factor || velocity (+ sensors) || convex + constraint phase} -> solver, the two side branches on internal
+  // streams forked from and joined into the caller's.  Needs the stand-alone kernels: run with MJH_FUSE_KV=0 (and so no kernel 13 / whole-pass kernel).  profiles/r05/notes.md has the numbers.
+  static const bool dag = [] { const char* e = getenv("MJH_DAG"); return e && e[0] == '1'; }();
+  if (dag && !m->fuse_kv && (st & 0x7f) == 0x7f && !g_timing.on && !g_stamps) {
+    {
+      std::lock_guard<std::mutex> lock(m->dag_mutex);
+      if (!m->dag_ready) {
+        for (int k = 0; k < 2; k++) { HIP_TRY(hipStreamCreateWithFlags(&m->dag_stream[k], hipStreamNonBlocking)); HIP_TRY(hipEventCreateWithFlags(&m->dag_done[k], hipEventDisableTiming)); }
+        HIP_TRY(hipEventCreateWithFlags(&m->dag_fork, hipEventDisableTiming));
+        m->dag_ready = true;
+      }
+    }
+    if ((rc = launch_phase<REAL, 0>(m, a, stream))) return rc;
+    HIP_TRY(hipEventRecord(m->dag_fork, stream));
+    HIP_TRY(hipStreamWaitEvent(m->dag_stream[0], m->dag_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(m->dag_stream[1], m->dag_fork, 0));
+    if ((rc = launch_phase<REAL, 1>(m, a, m->dag_stream[0]))) return rc;
+    HIP_TRY(hipEventRecord(m->dag_done[0], m->dag_stream[0]));
+    if ((rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, m->dag_stream[1]) : launch_phase<REAL, 3>(m, a, m->dag_stream[1]))) return rc;
+    if (a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {
+      const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
+      if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->dag_stream[1], a);
+      else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->dag_stream[1], a);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(m->dag_done[1], m->dag_stream[1]));
+    if (a.M.ncvxpair > 0) {
+      const int64_t items = a.B * a.M.ncvxpair;
+      const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
+      hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
+      HIP_TRY(hipGetLastError());
+    }
+    if ((a.M.ncon > 0 || a.M.nefc > 0) && (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
+    HIP_TRY(hipStreamWaitEvent(stream, m->dag_done[0], 0));
+    HIP_TRY(hipStreamWaitEvent(stream, m->dag_done[1], 0));
+    if (m->sol2_nmax) return launch_sol2<REAL>(m, a, stream);
+    return (a.M.nf > 0 || a.M.nft > 0 || a.M.ne > 0 || a.M.nlb > 0 || a.M.nlt > 0) ? launch_phase<REAL, 6>(m, a, stream) : launch_phase<REAL, 4>(m, a, stream);
+  }
   const bool fused_kv = m->fuse_kv && (st & 0x70);  // the velocity phase is asked for: it rides with the kinematics (it needs nothing of CRB / CON)
   const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
-  if ((st & 0x7f) && (rc = fused_kcv ? launch_phase<REAL, 13>(m, a, stream) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
+  if ((st & 0x7f) && (rc = fused_kcv ? ((m->kcv2 && a.B <= m->kcv2_max_envs) ? launch_phase<REAL, 17>(m, a, stream) : launch_phase<REAL, 13>(m, a, stream)) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
     const int64_t items = a.B * a.M.ncvxpair;
     const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
@@ -1122,6 +1195,7 @@ void mjh_model_destroy(mjhModel* m) {
   if (!m) return;
   for (auto& g : m->graphs) (void)hipGraphExecDestroy(g.exec);
   if (m->capture_stream) (void)hipStreamDestroy(m->capture_stream);
+  if (m->dag_ready) { for (int k = 0; k < 2; k++) { (void)hipStreamDestroy(m->dag_stream[k]); (void)hipEventDestroy(m->dag_done[k]); } (void)hipEventDestroy(m->dag_fork); }
   if (m->split_ready) {
     for (int k = 0; k < 4; k++) { (void)hipStreamDestroy(m->split_stream[k]); (void)hipEventDestroy(m->split_done[k]); }
     (void)hipEventDestroy(m->split_fork);
@@ -1223,6 +1297,7 @@ static int mjh_model_kernel_io_impl(const mjhModel* m, int kernel, int64_t* read
 int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   if (!m || !read_write_bytes) return fail(-22, "null argument");
   if ((kernel == 9) != (m->sol2_nmax != 0) && (kernel == 9 || kernel == 4 || kernel == 6)) return -2;  // the solver phase runs as ONE of kernels 4 / 6 / 9
+  if (kernel == 17) { if (!m->kcv2) return -2; const bool prev = g_io_inner; g_io_inner = true; const int rc = mjh_model_kernel_io(m, 13, read_write_bytes); g_io_inner = prev; return rc; }  // the two-wave form of kernel 13 moves the same bytes
   if (kernel == 13 && !m->fuse_kcv) return -2;  // (a model with kernel 13 reports both accounts: which one a step launches depends on the batch)
   if ((kernel == 12) != (m->fuse_kv != 0) && (kernel == 12 || kernel == 0 || kernel == 3)) return -2;  // kinematics + velocity: ONE kernel (12) or two (0, 3)
   const bool f64 = m->dtype == MJH_F64;
@@ -1276,6 +1351,7 @@ int mjh_model_lds_bytes(const mjhModel* m, int phase) {  // phase 5: the registe
   if (phase == 16) return m->lds_tier;
   if (phase == 17) return m->lds_kcv;
   if (phase == 18) return m->lds_cs;
+  if (phase == 19) return m->lds_kcv2;
   return (phase >= 0 && phase < MJH_NARENA) ? m->lds_bytes[phase] : 0;
 }
 const char* mjh_last_error(void) { return g_err.c_str(); }
