@@ -649,8 +649,8 @@ __global__ __launch_bounds__(MJH_WAVE, sizeof(REAL) == 4 ? MJH_CVX32_WAVES : 1) 
   extern __shared__ unsigned char cvx_smem[];
   REAL* lds = reinterpret_cast<REAL*>(cvx_smem);
   const int npc = M.ncvxpair;
-  const int64_t total = KA.B * npc;
-  for (int64_t item = blockIdx.x; item < total; item += gridDim.x) {
+  {  // one workgroup per (environment, pair): no grid-stride loop (the host launches per 2^22 items, KArgs::env_begin = first item) -- see mjh_phase_kernel
+    const int64_t item = KA.env_begin + blockIdx.x;
     const int64_t env = item / npc;
     const int pair = M.cvx_pairs[(int)(item - env * npc)];
     CvxPair<REAL>(lds, env, pair).run();

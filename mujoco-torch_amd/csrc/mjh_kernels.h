@@ -827,9 +827,9 @@ template <int W, typename REAL, int MAXREG, bool APACKED>
 __device__ __forceinline__ void chol_factor(const REAL* A, REAL* L, int n) {
   if (n <= 8) chol_factor_reg<W, APACKED, REAL, 8>(A, L, n);
   else if (n <= 16) chol_factor_reg<W, APACKED, REAL, 16>(A, L, n);
-  else if (MAXREG >= 32 && n <= 24) chol_factor_reg<W, APACKED, REAL, 24>(A, L, n);
-  else if (MAXREG >= 32 && n <= 28) chol_factor_reg<W, APACKED, REAL, 28>(A, L, n);
-  else if (MAXREG >= 32 && n <= 32) chol_factor_reg<W, APACKED, REAL, 32>(A, L, n);
+  else if (MAXREG >= 24 && n <= 24) { if constexpr (MAXREG >= 24) chol_factor_reg<W, APACKED, REAL, 24>(A, L, n); }
+  else if (MAXREG >= 28 && n <= 28) { if constexpr (MAXREG >= 28) chol_factor_reg<W, APACKED, REAL, 28>(A, L, n); }
+  else if (MAXREG >= 32 && n <= 32) { if constexpr (MAXREG >= 32) chol_factor_reg<W, APACKED, REAL, 32>(A, L, n); }
   else chol_factor_lds<W, APACKED>(A, L, n);
 }
 
@@ -1257,7 +1257,8 @@ struct Env {
   }
 
   // ---- crb + make_m + factor_m (smooth.py:291-332, support.make_m :50-80) ------------------------------------------------------------
-  template <bool FUSED = false>
+  // MAXN: the largest nv the calling instantiation serves (the register Cholesky variants for more rows are not compiled: they would set the kernel's register allocation without ever running)
+  template <bool FUSED = false, int MAXN = (W == 16 ? 16 : 32)>
   __device__ __forceinline__ void crb_factor() {
     const int l = lane_here();
     const int nb = M.nbody, nv = M.nv;
@@ -1317,7 +1318,7 @@ struct Env {
     put(out.crb, S.crb(), 10 * nb);
     wave_sync();
     STAMP(15);
-    chol_factor<W, REAL, (W == 16 ? 16 : 32), true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve).  (Four environments per wavefront: nv <= 16 -- the 24 / 28 / 32-row register variants are not compiled in)
+    chol_factor<W, REAL, MAXN, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve).  (Four environments per wavefront: nv <= 16 -- the 24 / 28 / 32-row register variants are not compiled in)
     STAMP(16);
     put(out.qLD, S.qLD(), nv * nv);
     STAMP(17);
@@ -4543,7 +4544,10 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     }
     return;
   }
-  for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {
+  // One workgroup per NSUB environments, no grid-stride loop (the host launches per 2^20 workgroups): nothing is live across the body for a next trip -- with the loop the whole-pass
+  // kernel took 256 VGPRs + 48 B of scratch, without it 153 (see mjh_phase_kernel)
+  const int64_t blk = blockIdx.x;
+  {
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {
       // W = 16: the four environments of a wave run until the slowest has converged.  They are drawn from a list sorted by the previous step's iteration counts
@@ -4557,7 +4561,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
         // release / acquire pair at the scope of its own CU -- through the arena layout of the second half.
         E.template run_kin<false>();
         wave_sync();
-        E.template crb_factor<true>();
+        E.template crb_factor<true, NMAX>();
         wave_sync();
         E.template run_vel<false, true>();
         // (workgroup scope = this CU: its waves share ONE write-through L1, so a wave's loads see its own landed stores; agent scope would write back and invalidate the
@@ -4571,7 +4575,6 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
       if constexpr (CS) E.template run_con_sol2<NMAX, RPL, ONE>();
       else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
     }
-    wave_sync();
   }
 }
 
@@ -4582,7 +4585,10 @@ __global__ void __launch_bounds__((PHASE == 17 ? 2 * MJH_WAVE : MJH_WAVE), ((siz
   constexpr int NSUB = MJH_WAVE / W;  // environments per wavefront: W lanes each, their own LDS arena each
   const int sub = (W == MJH_WAVE) ? 0 : (int)((threadIdx.x & (MJH_WAVE - 1)) / W);  // (PHASE 17: two wavefronts per workgroup share the arenas of the same NSUB environments)  // folded away for a whole-wave environment: everything stays scalar
   REAL* lds = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals;
-  for (int64_t blk = blockIdx.x; blk * NSUB < K.env_count; blk += gridDim.x) {  // env_count is a multiple of NSUB (host)
+  // One workgroup per NSUB environments, no grid-stride loop (the host cuts batches past 2^20 workgroups into several launches): with a loop around the body the optimiser keeps
+  // whatever is loop-invariant -- addresses, kernarg-derived values of EVERY stage -- in registers across the whole body (round 5: the whole-pass kernel went 256 VGPRs + 48 B -> 153 without it)
+  {
+    const int64_t blk = blockIdx.x;  // env_count is a multiple of NSUB and the grid covers it exactly (host)
     Env<REAL, W, PHASE == 6 || PHASE == 7, PHASE == 8> E(lds, K.env_begin + blk * NSUB + sub, K.flags);
     if (PHASE == 0) E.template run_kin<false>();
     else if (PHASE == 1) E.run_crb();

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && FULL == 0) ? MJH_SE
   // trips instead of 13 dependent tests on 8 lanes), then every sensordata slot is produced by one lane
   extern __shared__ double rf_x[];
   const int nsd = M.nsensordata, nrf = M.nrfq;
-  for (int64_t e = blockIdx.x; e < KA.B; e += gridDim.x) {
+  {  // one workgroup per environment, no grid-stride loop (the host launches per 2^20 environments)
+    const int64_t e = KA.env_begin + blockIdx.x;
 #ifdef MJH_SENSOR_ABLATE
     if (!(KA.flags & 0x100))
 #endif
@@ -321,7 +322,6 @@ __global__ __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && FULL == 0) ? MJH_SE
       }
       out.sensordata[e * nsd + k] = v;
     }
-    wave_sync();  // the next environment of this workgroup reuses rf_x
   }
 }
 

@@ -763,9 +763,12 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = arena_bytes / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
-  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-  hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(P == 17 ? 2 * MJH_WAVE : MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);  // (17: a second wavefront per workgroup runs the crb / factor stage)
-  HIP_TRY(hipGetLastError());
+  for (int64_t b0 = 0; b0 < blocks; b0 += (int64_t)1 << 20) {  // the kernels have no grid-stride loop: one launch per 2^20 workgroups
+    const int64_t grid = blocks - b0 < (int64_t)1 << 20 ? blocks - b0 : (int64_t)1 << 20;
+    a.env_begin = begin + b0 * NSUB; a.env_count = grid * NSUB;
+    hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(P == 17 ? 2 * MJH_WAVE : MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);  // (17: a second wavefront per workgroup runs the crb / factor stage)
+    HIP_TRY(hipGetLastError());
+  }
   timing_mark(stream, P);
   return 0;
 }
@@ -795,8 +798,10 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.env_begin = 0; a.env_count = a.B;
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
-#define GO(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 32>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a)
-#define GOW(N, R) do { if (a.M.solver == SOL_NEWTON) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 17>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a); else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)grid4), dim3(MJH_WAVE), lds, stream, a); } while (0)  /* 17: the Newton-only code of the four-per-wavefront tier */
+  // (the kernels have no grid-stride loop: one launch per 2^20 workgroups of NS environments each; the marks-scanning second tier keeps its own walk)
+#define CHUNKED(NS, LAUNCH) do { if (a.scan_marks) { a.env_begin = 0; a.env_count = a.B; const int64_t g_ = grid; (void)g_; LAUNCH(grid); } else for (int64_t e0_ = 0; e0_ < a.B; e0_ += ((int64_t)NS << 20)) { const int64_t n_ = a.B - e0_ < ((int64_t)NS << 20) ? a.B - e0_ : ((int64_t)NS << 20); a.env_begin = e0_; a.env_count = n_; LAUNCH((n_ + NS - 1) / NS); } a.env_begin = 0; a.env_count = a.B; } while (0)
+#define GO(N, R) do { auto L_ = [&](int64_t g) { hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 32>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); }; CHUNKED(2, L_); } while (0)
+#define GOW(N, R) do { auto L_ = [&](int64_t g) { if (a.M.solver == SOL_NEWTON) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 17>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); }; CHUNKED(4, L_); } while (0)  /* 17: the Newton-only code of the four-per-wavefront tier */
   const int nd = a.M.nefc - a.M.nf - a.M.nl;
   bool second = true;
   const bool marks = m->sol2_tiers && a.cur.qacc != nullptr;  // the first tier marks what it leaves, the second scans the marks (needs the qacc leaf)
@@ -853,6 +858,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
 #undef GO
 #undef GOW
+#undef CHUNKED
   timing_mark(stream, 9);  // both tiers under one mark: the solver phase
   return 0;
 }
@@ -865,11 +871,14 @@ int launch_cs(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.lds_reals = m->lds_cs / (int)sizeof(REAL);
   a.row_lo = -1; a.row_hi = 0x7fffffff;
   a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
-  const int64_t blocks = (a.B + 1) / 2;
-  const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   static const bool one_off = [] { const char* e = getenv("MJH_CS_ONE"); return e && e[0] == '0'; }();  // (A / B switch: MJH_CS_ONE=0 launches the generic instantiation for one-iteration models too)
-  if (a.M.iterations == 1 && !one_off) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 35>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);  // opt.iterations == 1 (solver.py:534-535: the loop body runs exactly once): straight-line solver code
-  else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
+  for (int64_t e0 = 0; e0 < a.B; e0 += (int64_t)2 << 20) {  // (no grid-stride loop in the kernels: one launch per 2^20 workgroups)
+    const int64_t n = a.B - e0 < ((int64_t)2 << 20) ? a.B - e0 : ((int64_t)2 << 20), grid = (n + 1) / 2;
+    a.env_begin = e0; a.env_count = n;
+    if (a.M.iterations == 1 && !one_off) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 35>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);  // opt.iterations == 1 (solver.py:534-535: the loop body runs exactly once): straight-line solver code
+    else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
+  }
+  a.env_begin = 0; a.env_count = a.B;
   HIP_TRY(hipGetLastError());
   timing_mark(stream, 14);
   return 0;
@@ -892,12 +901,39 @@ int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   return 0;
 }
 
+// convex narrow phase: one wavefront per (environment, pair); sensors: one per environment.  No grid-stride loops in the kernels: one launch per 2^22 items / 2^20 environments
+template <typename REAL>
+int launch_convex(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  const int64_t items = a.B * a.M.ncvxpair;
+  for (int64_t i0 = 0; i0 < items; i0 += (int64_t)1 << 22) {
+    const int64_t grid = items - i0 < (int64_t)1 << 22 ? items - i0 : (int64_t)1 << 22;
+    a.env_begin = i0;  // (first ITEM of this launch)
+    hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
+    HIP_TRY(hipGetLastError());
+  }
+  a.env_begin = 0;
+  return 0;
+}
+template <typename REAL>
+int launch_sensor_kernel(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  (void)m;
+  for (int64_t e0 = 0; e0 < a.B; e0 += (int64_t)1 << 20) {
+    const int64_t grid = a.B - e0 < (int64_t)1 << 20 ? a.B - e0 : (int64_t)1 << 20;
+    a.env_begin = e0;
+    if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
+    else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
+    HIP_TRY(hipGetLastError());
+  }
+  a.env_begin = 0;
+  return 0;
+}
+
 // one forward pass = the phases selected by `stages`
 template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
-  if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
+  if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.B <= ((int64_t)1 << 21) /* one workgroup per pair: the kernel has no grid-stride loop */ && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
   // MJH_DAG=1 (experiment): kinematics -> {crb / factor || velocity (+ sensors) || convex + constraint phase} -> solver, the two side branches on internal
   // streams forked from and joined into the caller's.  Needs the stand-alone kernels: run with MJH_FUSE_KV=0 (and so no kernel 13 / whole-pass kernel).  profiles/r05/notes.md has the numbers.
   static const bool dag = [] { const char* e = getenv("MJH_DAG"); return e && e[0] == '1'; }();
@@ -918,17 +954,11 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     HIP_TRY(hipEventRecord(m->dag_done[0], m->dag_stream[0]));
     if ((rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, m->dag_stream[1]) : launch_phase<REAL, 3>(m, a, m->dag_stream[1]))) return rc;
     if (a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {
-      const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-      if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->dag_stream[1], a);
-      else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), m->dag_stream[1], a);
-      HIP_TRY(hipGetLastError());
+      if ((rc = launch_sensor_kernel<REAL>(m, a, m->dag_stream[1]))) return rc;
     }
     HIP_TRY(hipEventRecord(m->dag_done[1], m->dag_stream[1]));
     if (a.M.ncvxpair > 0) {
-      const int64_t items = a.B * a.M.ncvxpair;
-      const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
-      hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
-      HIP_TRY(hipGetLastError());
+      if ((rc = launch_convex<REAL>(m, a, stream))) return rc;
     }
     if ((a.M.ncon > 0 || a.M.nefc > 0) && (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
     HIP_TRY(hipStreamWaitEvent(stream, m->dag_done[0], 0));
@@ -940,10 +970,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const bool fused_kcv = fused_kv && m->fuse_kcv && (st & 0x7e) && a.B <= m->kcv_max_envs;  // ... and so does the crb / factor stage (small models)
   if ((st & 0x7f) && (rc = fused_kcv ? ((m->kcv2 && a.B <= m->kcv2_max_envs) ? launch_phase<REAL, 17>(m, a, stream) : launch_phase<REAL, 13>(m, a, stream)) : (fused_kv ? launch_phase<REAL, 12>(m, a, stream) : launch_phase<REAL, 0>(m, a, stream)))) return rc;
   if ((st & 0x7c) && a.M.ncvxpair > 0) {  // convex narrow phase: one wave per (environment, pair); needs only the geom frames of PH_KIN
-    const int64_t items = a.B * a.M.ncvxpair;
-    const int64_t grid = items < (int64_t)1 << 22 ? items : (int64_t)1 << 22;
-    hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
-    HIP_TRY(hipGetLastError());
+    if ((rc = launch_convex<REAL>(m, a, stream))) return rc;
     timing_mark(stream, 10);
   }
   if ((st & 0x7e) && !fused_kcv && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
@@ -959,11 +986,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
     a.flags |= abl << 8;
     struct Restore { KArgs<REAL>& a; int f; ~Restore() { a.flags = f; } } restore_{a, keep_flags};
 #endif
-    const int64_t grid = a.B < (int64_t)1 << 20 ? a.B : (int64_t)1 << 20;
-    if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), s_, a);
-    else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), s_, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_sensor_kernel<REAL>(m, a, s_);
   };
   if (want_sensors) {  // (round 4's opt-in side stream for this launch is gone: it raced the integrator tail's write of out.qpos, which jointpos / ballquat sensors read, and measured no gain -- profiles/r04/notes.md)
     if ((rc = launch_sensors(stream))) return rc;
@@ -1008,7 +1031,7 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
         hipLaunchKernelGGL(mjh_sort_kernel, dim3(1), dim3(1024), 0, s, (const int*)key, perm, (long long)B);
         HIP_TRY(hipGetLastError());
         timing_mark(s, 15);
-        a.sol_perm = perm; a.sol_key = key;
+        if (B <= ((int64_t)4 << 20)) { a.sol_perm = perm; a.sol_key = key; }  // (the list indexes the whole batch: one launch of the packed tier)
       }
     }
     w += m->sort_reals * B;
