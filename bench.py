@@ -272,6 +272,10 @@ def setup_workload(key, B, device, rank):
     lite = mt.mjcf.from_xml_path(mt.test_data_path(wl["xml"] + ".xml"))
     for k, v in wl["overrides"].items():
         setattr(lite.opt, k, v)
+    for kv in filter(None, os.environ.get("BENCH_OPT", "").split(",")):  # experiments only, e.g. BENCH_OPT=iterations=3 (the line's config.workload says so)
+        k, v = kv.split("=")
+        setattr(lite.opt, k, type(getattr(lite.opt, k))(float(v)))
+        wl = dict(wl, name=wl["name"] + f" [BENCH_OPT {kv}]")
     mx = mt.device_put(lite, dtype=None if dtype == torch.float64 else dtype)
     mdev = mx.to(device)
     # different seeds per rank: independent environments, no collective on the data path

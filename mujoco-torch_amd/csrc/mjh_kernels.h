@@ -3887,11 +3887,13 @@ struct Env {
 #pragma unroll
       for (int k = 0; k < NMAX; k++) T.t[k] = (dof && k < nv) ? (k <= l ? gL[l * nv + k] : gL[k * nv + l]) : (REAL)0;
     }
-    REAL mrow[NEWT ? NMAX : 1];  // row d of qM (Newton models: nv <= 16): M products and the Hessian start from registers
-    if (NEWT) {  // qM is exactly symmetric: row d is read as column d, one coalesced load per term
+    // (MROW for the one-iteration instantiations of the big CG models too -- to save the two passes over qM through L2 -- was tried in round 5: 153 VGPRs -> 256 + 324 B of scratch)
+    constexpr bool MROW = NEWT;
+    REAL mrow[MROW ? NMAX : 1];  // row d of qM (Newton models: nv <= 16): M products and the Hessian start from registers
+    if (MROW) {  // qM is exactly symmetric: row d is read as column d, one coalesced load per term
       const REAL* gM = out.qM + e * nv * nv;
 #pragma unroll
-      for (int k = 0; k < (NEWT ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[k * nv + l] : (REAL)0;
+      for (int k = 0; k < (MROW ? NMAX : 1); k++) mrow[k] = (dof && k < nv && solving && nefc > 0) ? gM[k * nv + l] : (REAL)0;
     }
     STAMP(80);
     constexpr int NQS = 64 / W;  // qpos slots per lane (nq <= 64)
@@ -4027,9 +4029,9 @@ struct Env {
       // read from L2 -- it is symmetric, so row d is read as column d, coalesced -- nine rows in flight per trip.  Terms in column order.
       auto mul_M2 = [&](const REAL* a, const REAL* b, REAL& o1, REAL& o2, bool two) {
         REAL s1 = 0, s2 = 0;
-        if (NEWT) {
+        if (MROW) {
 #pragma unroll
-          for (int k = 0; k < (NEWT ? NMAX : 1); k++) {  // (no `k < nv` branch around the reads: columns past nv read a clamped address and meet mrow = 0)
+          for (int k = 0; k < (MROW ? NMAX : 1); k++) {  // (no `k < nv` branch around the reads: columns past nv read a clamped address and meet mrow = 0)
             const int kc = k < nv ? k : 0;
             s1 += mrow[k] * a[kc]; s2 += mrow[k] * b[kc];  // callers with one vector pass it twice: the second read is the same address
           }

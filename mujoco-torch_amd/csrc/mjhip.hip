@@ -739,7 +739,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     // 155.0 - 155.9 us against 91.0 + 71.0 - 71.6 in two launches (25.5 - 25.7 M against 25.0 - 25.2 M env-steps/s), B = 32768 1162 us against 657 + 577 (27.8 - 28.1 M against
     // 26.4 M; profiles/r05/notes.md).  Default on for those models (MJH_FUSE_ALL=0: off); still opt-in (MJH_FUSE_ALL=1) for the others.
     static const int sw = [] { const char* e = getenv("MJH_FUSE_ALL"); return !e ? -1 : (e[0] == '1' ? 1 : 0); }();
-    const bool on = sw == 1 || (sw == -1 && d->iterations == 1);
+    const bool on = sw != 0;  // (round 5, second half: without the kernels' grid-stride loops the generic instantiation takes 228 VGPRs and no scratch either: default on for every model both fused kernels serve)
     out->fuse_all = 0;
     if (on && out->fuse_cs && out->fuse_kcv && out->pack2[1] && !out->pack4[1] && M.ncvxpair == 0 && d->nsensor == 0) {
       out->lds_all = out->lds_kcv > out->lds_cs ? out->lds_kcv : out->lds_cs;
@@ -753,6 +753,13 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   return 0;
 }
 
+// Workgroups per launch.  The kernels run ONE unit of work per workgroup (no grid-stride loop), so a batch past this many is cut into several launches.  2^20 by default;
+// MJH_MAX_GRID_LOG2 lowers it so that the tests reach the multi-launch paths at small batches.
+static int64_t max_grid() {
+  static const int64_t g = [] { const char* e = getenv("MJH_MAX_GRID_LOG2"); int v = e ? atoi(e) : 20; return (int64_t)1 << (v < 0 ? 0 : (v > 20 ? 20 : v)); }();
+  return g;
+}
+
 template <typename REAL, int P, int W>
 int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count, hipStream_t stream) {
   if (count <= 0) return 0;
@@ -763,8 +770,8 @@ int launch_range(const mjhModel* m, KArgs<REAL>& a, int64_t begin, int64_t count
   a.env_begin = begin; a.env_count = count;
   a.lds_reals = arena_bytes / (int)sizeof(REAL);
   const int64_t blocks = count / NSUB;
-  for (int64_t b0 = 0; b0 < blocks; b0 += (int64_t)1 << 20) {  // the kernels have no grid-stride loop: one launch per 2^20 workgroups
-    const int64_t grid = blocks - b0 < (int64_t)1 << 20 ? blocks - b0 : (int64_t)1 << 20;
+  for (int64_t b0 = 0; b0 < blocks; b0 += max_grid()) {  // the kernels have no grid-stride loop: one launch per 2^20 workgroups
+    const int64_t grid = blocks - b0 < max_grid() ? blocks - b0 : max_grid();
     a.env_begin = begin + b0 * NSUB; a.env_count = grid * NSUB;
     hipLaunchKernelGGL((mjh_phase_kernel<REAL, P, W>), dim3((unsigned)grid), dim3(P == 17 ? 2 * MJH_WAVE : MJH_WAVE), (size_t)(NSUB * arena_bytes), stream, a);  // (17: a second wavefront per workgroup runs the crb / factor stage)
     HIP_TRY(hipGetLastError());
@@ -799,7 +806,7 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   // (the kernels have no grid-stride loop: one launch per 2^20 workgroups of NS environments each; the marks-scanning second tier keeps its own walk)
-#define CHUNKED(NS, LAUNCH) do { if (a.scan_marks) { a.env_begin = 0; a.env_count = a.B; const int64_t g_ = grid; (void)g_; LAUNCH(grid); } else for (int64_t e0_ = 0; e0_ < a.B; e0_ += ((int64_t)NS << 20)) { const int64_t n_ = a.B - e0_ < ((int64_t)NS << 20) ? a.B - e0_ : ((int64_t)NS << 20); a.env_begin = e0_; a.env_count = n_; LAUNCH((n_ + NS - 1) / NS); } a.env_begin = 0; a.env_count = a.B; } while (0)
+#define CHUNKED(NS, LAUNCH) do { if (a.scan_marks) { a.env_begin = 0; a.env_count = a.B; const int64_t g_ = grid; (void)g_; LAUNCH(grid); } else for (int64_t e0_ = 0; e0_ < a.B; e0_ += NS * max_grid()) { const int64_t n_ = a.B - e0_ < NS * max_grid() ? a.B - e0_ : NS * max_grid(); a.env_begin = e0_; a.env_count = n_; LAUNCH((n_ + NS - 1) / NS); } a.env_begin = 0; a.env_count = a.B; } while (0)
 #define GO(N, R) do { auto L_ = [&](int64_t g) { hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 32>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); }; CHUNKED(2, L_); } while (0)
 #define GOW(N, R) do { auto L_ = [&](int64_t g) { if (a.M.solver == SOL_NEWTON) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 17>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 16>), dim3((unsigned)g), dim3(MJH_WAVE), lds, stream, a); }; CHUNKED(4, L_); } while (0)  /* 17: the Newton-only code of the four-per-wavefront tier */
   const int nd = a.M.nefc - a.M.nf - a.M.nl;
@@ -872,8 +879,8 @@ int launch_cs(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   a.row_lo = -1; a.row_hi = 0x7fffffff;
   a.mark_leftover = 0; a.scan_marks = 0; a.it_cap = a.ls_cap = 0;
   static const bool one_off = [] { const char* e = getenv("MJH_CS_ONE"); return e && e[0] == '0'; }();  // (A / B switch: MJH_CS_ONE=0 launches the generic instantiation for one-iteration models too)
-  for (int64_t e0 = 0; e0 < a.B; e0 += (int64_t)2 << 20) {  // (no grid-stride loop in the kernels: one launch per 2^20 workgroups)
-    const int64_t n = a.B - e0 < ((int64_t)2 << 20) ? a.B - e0 : ((int64_t)2 << 20), grid = (n + 1) / 2;
+  for (int64_t e0 = 0; e0 < a.B; e0 += 2 * max_grid()) {  // (no grid-stride loop in the kernels: one launch per 2^20 workgroups)
+    const int64_t n = a.B - e0 < 2 * max_grid() ? a.B - e0 : 2 * max_grid(), grid = (n + 1) / 2;
     a.env_begin = e0; a.env_count = n;
     if (a.M.iterations == 1 && !one_off) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 35>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);  // opt.iterations == 1 (solver.py:534-535: the loop body runs exactly once): straight-line solver code
     else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 33>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_cs), stream, a);
@@ -905,8 +912,8 @@ int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 template <typename REAL>
 int launch_convex(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t items = a.B * a.M.ncvxpair;
-  for (int64_t i0 = 0; i0 < items; i0 += (int64_t)1 << 22) {
-    const int64_t grid = items - i0 < (int64_t)1 << 22 ? items - i0 : (int64_t)1 << 22;
+  for (int64_t i0 = 0; i0 < items; i0 += 4 * max_grid()) {
+    const int64_t grid = items - i0 < 4 * max_grid() ? items - i0 : 4 * max_grid();
     a.env_begin = i0;  // (first ITEM of this launch)
     hipLaunchKernelGGL((mjh_convex_kernel<REAL>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)m->cvx_lds_bytes, stream, a);
     HIP_TRY(hipGetLastError());
@@ -917,8 +924,8 @@ int launch_convex(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 template <typename REAL>
 int launch_sensor_kernel(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   (void)m;
-  for (int64_t e0 = 0; e0 < a.B; e0 += (int64_t)1 << 20) {
-    const int64_t grid = a.B - e0 < (int64_t)1 << 20 ? a.B - e0 : (int64_t)1 << 20;
+  for (int64_t e0 = 0; e0 < a.B; e0 += max_grid()) {
+    const int64_t grid = a.B - e0 < max_grid() ? a.B - e0 : max_grid();
     a.env_begin = e0;
     if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
     else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
@@ -933,7 +940,7 @@ template <typename REAL>
 int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   int rc = 0;
   const int st = a.stages;
-  if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.B <= ((int64_t)1 << 21) /* one workgroup per pair: the kernel has no grid-stride loop */ && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
+  if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.B <= 2 * max_grid() /* one workgroup per pair: the kernel has no grid-stride loop */ && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
   // MJH_DAG=1 (experiment): kinematics -> {crb / factor || velocity (+ sensors) || convex + constraint phase} -> solver, the two side branches on internal
   // streams forked from and joined into the caller's.  Needs the stand-alone kernels: run with MJH_FUSE_KV=0 (and so no kernel 13 / whole-pass kernel).  profiles/r05/notes.md has the numbers.
   static const bool dag = [] { const char* e = getenv("MJH_DAG"); return e && e[0] == '1'; }();
@@ -1031,7 +1038,7 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
         hipLaunchKernelGGL(mjh_sort_kernel, dim3(1), dim3(1024), 0, s, (const int*)key, perm, (long long)B);
         HIP_TRY(hipGetLastError());
         timing_mark(s, 15);
-        if (B <= ((int64_t)4 << 20)) { a.sol_perm = perm; a.sol_key = key; }  // (the list indexes the whole batch: one launch of the packed tier)
+        if (B <= 4 * max_grid()) { a.sol_perm = perm; a.sol_key = key; }  // (the list indexes the whole batch: one launch of the packed tier)
       }
     }
     w += m->sort_reals * B;

@@ -292,6 +292,49 @@ print("split ok")
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_batches_past_one_launch_are_cut_on_the_host():
+    """The kernels run one unit of work per workgroup (no grid-stride loops since round 5): a batch of more than 2^20 workgroups is cut into several launches by the host.
+    MJH_MAX_GRID_LOG2=3 brings that limit down to 8 workgroups, so a batch of 203 environments takes every multi-launch path -- packed / paired / odd-tail phase kernels, both
+    solver tiers, the fused constraint + solver kernel, the convex and sensor kernels, RK4 -- and must equal the one-launch result bit for bit, every leaf."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+from _util import load_model, REAL_LEAVES, INT_LEAVES
+out = {}
+for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("humanoid", {"solver": 1, "iterations": 3}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
+                    ("mesh_contact", {}, torch.float32), ("sensor_rig2", {}, torch.float64), ("equality_loops", {}, torch.float64), ("centipede", {}, torch.float64)):
+    mx = load_model(xml, ov, dt)
+    B = 203
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+    if dt != torch.float64: d = d.to(dt)
+    mdev = mx.to("cuda")
+    got = mt.step(mdev, mt.step(mdev, d.to("cuda")))
+    out[xml + str(sorted(ov.items()))] = {n: native.data_field_tensor(got, n).cpu() for n in REAL_LEAVES + INT_LEAVES}
+torch.save(out, sys.argv[1])
+print("ran")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    import torch as _t
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("one", {}), ("cut", {"MJH_MAX_GRID_LOG2": "3"})):
+            f = os.path.join(td, tag + ".pt")
+            r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ran" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            res[tag] = _t.load(f)
+    for case in res["one"]:
+        for n, t in res["one"][case].items():
+            assert _t.equal(t, res["cut"][case][n]) or (t.is_floating_point() and _t.equal(_t.nan_to_num(t), _t.nan_to_num(res["cut"][case][n]))), (case, n)
+
+
 def test_matrix_core_hessian_against_the_vector_path(tmp_path):
     """Float32 Newton models with 12 - 16 dofs build the Hessian of the packed solver tier with v_mfma_f32_4x4x1 blocks (MJH_SOL2_MFMA=0: vector units).  On the SAME inputs
     -- one step of the seeded mesh-scene batch (BASELINE config 5's recipe) and one of the campaign's heavily perturbed batch -- the two paths must agree to float32 solver
