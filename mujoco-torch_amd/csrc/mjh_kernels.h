@@ -229,6 +229,8 @@ struct KArgs {
   int do_step;
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
+  REAL* hs;             // small models with one contact condim (DevModel::crow_by_con): per-environment hand-over of the constraint phase to the register solver (workspace, hs_reals each): [nda | contact -> compact slot (ncon) | efc_D (nd) | efc_aref (nd) | efc_J rows (nd * nv)] of the ACTIVE contacts' rows in compact order, so that the solver's loads are ONE round of fixed addresses instead of contact_dist -> compaction -> D / aref gather -> row gather (four dependent trips: 45 % of the ant's solver kernel).  NULL: the solver reads the leaves
+  int hs_reals;
   REAL* cand;           // max_contact_points over convex pairs: candidate contacts of the convex narrow phase, [B, ncand] dist | [B, ncand, 3] pos | [B, ncand, 9] frame (workspace)
   const REAL* warm_src; // [B, nv] warm start of this pass: the caller's, or the previous RK stage's solution
   int it_cap, ls_cap;   // > 0: the register solver leaves an environment to the fallback launch (LDS solver, one environment per wavefront) once its solve has run it_cap Newton iterations or ls_cap line-search iterations: the long solves of a batch are few, and inside a shared wavefront every one of them holds three other environments' lanes
@@ -1795,6 +1797,8 @@ struct Env {
     }
     const bool elliptic = M.cone == CONE_ELLIPTIC;
     int nact_contacts = 0;  // small models: active contacts of this environment (compact list in S.i_con_act())
+    REAL* hs = nullptr;     // ... and their hand-over to the register solver (KArgs::hs), when this launch has one
+    REAL* hsJ = nullptr;
     if constexpr (!FRIC && DIRECT) {
       // Small models (rows straight to the leaf).  (A) one lane per contact: which contacts are active, as a compact list and as a per-row flag; (B) the rows of the
       // inactive contacts are zeroed by a straight loop over the block (no table reads); (C) one lane per (ACTIVE contact, dof) forms the
@@ -1819,12 +1823,19 @@ struct Env {
         int tot;
         const int before = sub_prefix_count<W>(act, tot);
         if (act) act_list[nact + before] = c;
-        if (M.crow_by_con) { if (c < ncon) row_act[c] = act ? 1 : 0; }  // (dense row q is contact q / con_rows: one flag per contact)
+        if (M.crow_by_con) { if (c < ncon) row_act[c] = act ? nact + before + 1 : 0; }  // (dense row q is contact q / con_rows: one entry per contact -- 0 = inactive, else its place in the compact list + 1)
         else for (int r = 0; r < rows; r++) row_act[row0 + r] = act ? 1 : 0;
         nact += tot;
       }
       nact_contacts = nact;
       wave_sync();
+      // hand-over to the register solver (KArgs::hs): the count, then contact -> compact slot
+      if (KA.hs && M.crow_by_con) hs = KA.hs + e * KA.hs_reals;
+      if (hs) {
+        if (l == 0) hs[0] = (REAL)(nact * M.con_rows);
+        for (int c = l; c < ncon; c += W) hs[1 + c] = (REAL)(row_act[c] - 1);
+      }
+      if (hs) hsJ = hs + 1 + ncon + 2 * nd;
       REAL* const Jdst = out.efc_J + (e * nefc + nl) * nv;  // row 0 = first contact row
       // RK4 stages 1..3 write a private workspace Data whose only reader is this stage's solver phase, and that gathers the rows of the ACTIVE
       // contacts only (load_solver_inputs / run_sol2): the zero rows, and further down D / aref of the inactive rows, are not written there
@@ -1877,16 +1888,22 @@ struct Env {
           diff[r] = fr[3 * r] * dp[0] + fr[3 * r + 1] * dp[1] + fr[3 * r + 2] * dp[2];
           diff[3 + r] = fr[3 * r] * dr[0] + fr[3 * r + 1] * dr[1] + fr[3 * r + 2] * dr[2];
         }
+        // RK4 stages 1..3 with a hand-over: the solver reads the compact copy only -- the workspace leaf is not written
+        REAL* const dstA = (hsJ && scratch_stage && !MJH_SOL2_CAPS_ON) ? nullptr : Jdst + row0 * nv + d;  // (a build with the iteration caps hands capped solves to the LDS solver, which reads the leaves)
+        REAL* const dstB = hsJ ? hsJ + (a * M.con_rows) * nv + d : nullptr;
         if (dim == 1) {
-          Jdst[row0 * nv + d] = diff[0];
+          if (dstA) dstA[0] = diff[0];
+          if (dstB) dstB[0] = diff[0];
         } else if (!elliptic) {  // _instantiate_contact_pyramidal :454-516
           const int nedge = 2 * (dim - 1);
           for (int ed = 0; ed < nedge; ed++) {
             const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
-            Jdst[(row0 + ed) * nv + d] = diff[0] + diff[1 + (ed >> 1)] * f;
+            const REAL v = diff[0] + diff[1 + (ed >> 1)] * f;
+            if (dstA) dstA[ed * nv] = v;
+            if (dstB) dstB[ed * nv] = v;
           }
         } else {  // _instantiate_contact_elliptic :519-583
-          for (int r = 0; r < dim; r++) Jdst[(row0 + r) * nv + d] = diff[r];
+          for (int r = 0; r < dim; r++) { if (dstA) dstA[r * nv] = diff[r]; if (dstB) dstB[r * nv] = diff[r]; }
         }
       }
     } else
@@ -1957,6 +1974,7 @@ struct Env {
       REAL solref[2], solimp[5];
       REAL pos = 0, pos_norm = 0, invweight = 0;
       bool con_row_active = false;
+      int hs_row = -1;
       if (r < ns) { pos = S.efc_pos()[r]; pos_norm = FRIC ? S.efc_pos_norm()[r] : pos; invweight = S.efc_invweight()[r]; }
       if (r < ne) {
         const int id = M.eq_id[M.efc_row_eq[r]];
@@ -1991,6 +2009,7 @@ struct Env {
         const REAL active = (REAL)(dist < 0);
         con_row_active = dist < 0;
         if (KA.rk_stage > 0 && !con_row_active) continue;  // workspace Data of an RK4 stage: nobody reads D / aref of an inactive row (see above)
+        if (hs && con_row_active) hs_row = (reinterpret_cast<const int*>(S.i_crow_act())[c] - 1) * M.con_rows + sub;  // this row's place in the hand-over
         if (!(info >> 24)) { pos = dist * active; pos_norm = dist * active; }
         else { pos = (sub == 0 ? dist : (REAL)0) * active; pos_norm = dist; }
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here
@@ -2034,7 +2053,7 @@ struct Env {
       else {
         // this wave stored the row above and the barrier drained the stores to L2.  Agent-scope loads read L2 past the CU's L1,
         // where a line shared with a neighbouring environment's rows could have been cached before this wave's stores landed.
-        const REAL* jr = out.efc_J + (e * nefc + r) * nv;
+        const REAL* jr = (hs_row >= 0 && !MJH_SOL2_CAPS_ON) ? hsJ + hs_row * nv : out.efc_J + (e * nefc + r) * nv;  // (RK4 stages 1..3 with a hand-over keep the row there only)
         REAL s = 0;
         int k = 0;
         for (; k + 4 <= nv; k += 4) {
@@ -2045,10 +2064,13 @@ struct Env {
         for (; k < nv; k++) s += __hip_atomic_load(jr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * S.qvel()[k];
         jv = s;
       }
-      if (stage_ad) { ad_stage[r] = -b * jv - k * imp * pos; ad_stage[nefc + r] = 1 / rr; }
+      const REAL aref_r = -b * jv - k * imp * pos, D_r = 1 / rr;
+      if (hs_row >= 0) { hs[1 + M.ncon + hs_row] = D_r; hs[1 + M.ncon + (nefc - nl) + hs_row] = aref_r; }
+      if (hs_row >= 0 && KA.rk_stage > 0 && !MJH_SOL2_CAPS_ON) continue;  // (stages 1..3: the solver reads the hand-over, nobody the workspace leaves of a contact row)
+      if (stage_ad) { ad_stage[r] = aref_r; ad_stage[nefc + r] = D_r; }
       else {
-        if (out.efc_aref) out.efc_aref[e * nefc + r] = -b * jv - k * imp * pos;  // lane r <-> row r: coalesced, no staging
-        if (out.efc_D) out.efc_D[e * nefc + r] = 1 / rr;
+        if (out.efc_aref) out.efc_aref[e * nefc + r] = aref_r;  // lane r <-> row r: coalesced, no staging
+        if (out.efc_D) out.efc_D[e * nefc + r] = D_r;
       }
     }
     if (stage_ad) {
@@ -3903,6 +3925,7 @@ struct Env {
     REAL Dl = 0, arl = 0, Jl = 0, Dd[RPL], ard[RPL];
     int ldof = 0, limrow = -1;
     int nda = 0;  // dense rows of the ACTIVE contacts of this environment (the rows of inactive contacts are exact zeros throughout, see Env::nrow_)
+    const REAL* hsp = nullptr;  // this environment's hand-over from the constraint phase (KArgs::hs), when there is one
 #pragma unroll
     for (int j = 0; j < RPL; j++) { Dd[j] = 0; ard[j] = 0; }
     int* rsrc = reinterpret_cast<int*>(S.r_src());  // compact dense row -> Data row
@@ -3938,8 +3961,26 @@ struct Env {
         }
         if (dof) limrow = M.dof_limrow[2 * l];
         STAMP(81);
+        if constexpr (!CS) if (KA.hs && M.crow_by_con) hsp = KA.hs + e * KA.hs_reals;
         if constexpr (CS) nda = con->nda;  // (the constraint stage built the rows in compact order)
-        else
+        else if (hsp) {
+          // The constraint phase handed the active contacts' rows over in compact order (KArgs::hs): every address below is fixed, so the whole solver input is ONE round of loads --
+          // the count, the contact -> slot table (for the Data-order efc_force store at the end), D / aref of this lane's rows; the rows themselves follow behind the tier test.
+          const int ncon = M.ncon, rows = M.con_rows;
+          nda = (int)hsp[0];
+#pragma unroll
+          for (int j = 0; j < RPL; j++) {
+            const int r = l + W * j;
+            if (r < ndc) { Dd[j] = hsp[1 + ncon + r]; ard[j] = hsp[1 + ncon + nd + r]; }
+          }
+          for (int c = l; c < ncon; c += W) {
+            const int at = (int)hsp[1 + c];
+            const int start = c * rows;
+            for (int k = 0; k < rows; k++) rdst[start + k] = at >= 0 ? (unsigned short)(at * rows + k) : (unsigned short)0xffff;
+          }
+#pragma unroll
+          for (int j = 0; j < RPL; j++) if (!(l + W * j < nda)) { Dd[j] = 0; ard[j] = 0; }  // (past the count: whatever an earlier step left there)
+        } else
         {  // active contacts -> compact row tables: one contact per lane, exclusive prefix sum of the active contacts' row counts
           const int ncon = M.ncon;
           const bool elliptic = M.cone == CONE_ELLIPTIC;
@@ -3992,6 +4033,19 @@ struct Env {
             if (r < nda) { Dd[j] = S.efc_D()[r]; ard[j] = S.efc_aref()[r]; }
           }
           STAMP(83);
+        } else if (hsp) {
+          STAMP(83);
+          // the rows of the active contacts, already compact: a contiguous copy, sixteen loads in flight per trip
+          const REAL* hJ = hsp + 1 + M.ncon + 2 * nd;
+          REAL* dJ = S.efc_Jc();
+          const int n = nda * nv;
+          for (int i0 = 0; i0 < n; i0 += 16 * W) {
+            REAL v[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) { const int i = i0 + t * W + l; v[t] = i < n ? hJ[i] : (REAL)0; }
+#pragma unroll
+            for (int t = 0; t < 16; t++) { const int i = i0 + t * W + l; if (i < n) dJ[i] = v[t]; }
+          }
         } else {
 #pragma unroll
         for (int j = 0; j < RPL; j++) {

@@ -105,6 +105,7 @@ struct mjhModel {
   int cvx_lds_bytes;                       // LDS scratch of one (environment, convex pair) wave
   int64_t work_reals;                      // per-environment REALs of workspace: RK4 stage Data and sums + the convex candidates of max_contact_points (0 for most Euler models)
   int64_t sort_reals = 0;                  // ... of which the register solver's environment list and iteration-count keys (two ints per environment, at the very head)
+  int64_t hs_reals = 0;                    // ... of which the constraint phase's hand-over to the register solver (KArgs::hs): small models with one contact condim
   int64_t cand_reals = 0;                  // ... of which the candidate contacts (at the HEAD of the workspace: its first B * cand_reals reals; the RK4 stage Data and sums follow)
   std::vector<int64_t> leaf_count;         // per-env element count of every real Data leaf, ABI order
   DevModel<double> m64;
@@ -597,6 +598,14 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) out->work_reals += out->leaf_count[i];
     out->work_reals += 4 * (int64_t)d->nv + 2 * (int64_t)d->na;  // qvel0, kqvel(unused), sum_qvel, sum_qacc, act0, sum_actdot
   }
+  {  // hand-over of the small-model constraint phase (kernel 8) to the register solver: [count | contact -> slot | D | aref | rows] of the active contacts' rows, compact.  MJH_HANDOVER=0: off
+    static const bool off = [] { const char* e = getenv("MJH_HANDOVER"); return e && e[0] == '0'; }();
+    const int64_t nd = (int64_t)d->nefc - d->nl;
+    // Measured (MI355X, profiles/r05/notes.md): ant (RK4: stages 1..3 write the hand-over INSTEAD of their workspace leaves) solver phase 44.7 -> 42.3 us per stage, constraint phase unchanged;
+    // mesh scene (Euler: the leaves AND the hand-over) solver 197.9 -> 194.4 us but constraint phase 47.2 -> 52.0: RK4 models only.
+    out->hs_reals = (!off && d->integrator == INT_RK4 && M.con_direct && M.crow_by_con && out->sol2_nmax && !out->fuse_cs && nd > 0) ? ((1 + (int64_t)d->ncon + 2 * nd + nd * d->nv + 3) & ~(int64_t)3) : 0;
+    out->work_reals += out->hs_reals;
+  }
   out->cand_reals = (d->topk && M.ncvxpair > 0) ? 13 * (int64_t)d->ncand : 0;  // candidate contacts of the convex narrow phase (dist, pos, frame)
   out->work_reals += out->cand_reals;
   {  // register solver at four environments per wavefront with solves of uneven length (Newton): two ints per environment at the head of the workspace -- the solver's
@@ -1042,6 +1051,10 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
       }
     }
     w += m->sort_reals * B;
+  }
+  if (m->hs_reals > 0) {  // (without a workspace the solver reads the leaves, as it always did)
+    if (work) { a.hs = w; a.hs_reals = (int)m->hs_reals; }
+    w += m->hs_reals * B;
   }
   if (m->cand_reals > 0 && (a.stages & 0x7c)) {  // max_contact_points over box / mesh pairs: the candidates live at the head of the workspace
     if (!work) return fail(-22, "max_contact_points with box / mesh pairs needs a workspace of mjh_model_work_bytes(m) * B bytes");
