@@ -880,6 +880,9 @@ struct Sol2Con {
 #ifndef MJH_HROWS
 #define MJH_HROWS 4
 #endif
+#ifndef MJH_INCR_H_PERIOD
+#define MJH_INCR_H_PERIOD 8  /* Newton, incremental Hessian: every so many builds of a solve the Hessian is rebuilt from all rows (bounds the drift of the add / subtract updates) */
+#endif
 // lane c of every quad (4 consecutive lanes) broadcast to the quad's four lanes (DPP quad_perm [c, c, c, c])
 template <int C> __device__ __forceinline__ float quad_bcast(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C * 0x55, 0xf, 0xf, false));
@@ -4204,9 +4207,70 @@ struct Env {
       qfrc = constraint_qfrc();
       STAMP(72);
       // M^-1 grad (CG) or H^-1 grad with H = M + J^T diag(D active) J factorised in registers (Newton, solver.py:359-376)
+      // Newton, incremental Hessian (round 5): between two iterations of a solve only the rows whose `active` flag flipped change
+      // H = M + J^T diag(D active) J (solver.py:359-376).  The un-factored row of H stays in registers (Hraw) with the activity bits of this lane's rows at the last build (hact);
+      // later builds add / subtract the flipped rows only (a compact list of them in the arena, the same lane-group accumulation as the full build) and every MJH_INCR_H_PERIOD-th build is
+      // a full one again.  Tolerance-level, not bit-level, parity: the sums differ from the reference's full rebuild in their last bits (as the matrix-core build already does).
+      // (instantiations for more than 8 dofs only: the 8-dof tier -- the ant's -- sits at its 128-VGPR bound and would spill 80 B more for it: 52 -> 132 B)
+      constexpr bool INCR = NEWT && NMAX > 8;
+      REAL Hraw[INCR ? NMAX : 1];
+      unsigned hact = 0;
+      int hbuilds = 0;  // builds of this solve so far (the same in every environment of a wave that is still iterating)
+      const bool incr_on = INCR && M.sol2_incr != 0;
       auto precondition = [&](REAL grad) -> REAL {
         if (!newton) return tri_solve2<NMAX>(T, grad);
         TriPack<REAL, NMAX> H;
+        unsigned hnow = 0;
+        if (INCR) {
+#pragma unroll
+          for (int j = 0; j < RPL; j++) if (l + W * j < nda && jad[j] < 0) hnow |= 1u << j;
+          if (lim && jal < 0) hnow |= 1u << 31;
+        }
+        const bool incr = incr_on && hbuilds > 0 && (hbuilds % MJH_INCR_H_PERIOD) != 0;
+        if (INCR && incr) {
+          const unsigned flip = hnow ^ hact;
+          int* const flist = reinterpret_cast<int*>(S.r_src());  // (the row-source table is dead once the solver's inputs are loaded)
+          int nfl = 0;
+#pragma unroll
+          for (int j = 0; j < RPL; j++) {
+            const int r = l + W * j;
+            const bool f = r < nda && ((flip >> j) & 1u);
+            if (r < nda) fs[r] = f ? ((hnow >> j) & 1u ? Dd[j] : -Dd[j]) : (REAL)0;  // the row's weight CHANGE
+            int tot;
+            const int at = sub_prefix_count<W>(f, tot) + nfl;
+            if (f) flist[at] = r;
+            nfl += tot;
+          }
+          if (lim) fs[ndc + l] = (flip >> 31) ? ((hnow >> 31) ? (Jl * Dl * (REAL)1) * Jl : -((Jl * Dl * (REAL)1) * Jl)) : (REAL)0;
+          wave_sync();
+          REAL acc[NMAX];
+#pragma unroll
+          for (int k = 0; k < NMAX; k++) acc[k] = 0;
+          if (dof && limrow >= 0) {
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) if (k == l) acc[k] += fs[ndc + limrow];
+          }
+          constexpr int G = NEWT ? W / NMAX : 1;
+          const int hg = NEWT ? l / NMAX : 0, hi = NEWT ? l - hg * NMAX : l;
+          for (int q = hg; q < nfl; q += G) {
+            const int r = flist[q];
+            const REAL* jr = Jc + r * nv;
+            const REAL ji = (hi < nv ? jr[hi] : (REAL)0) * fs[r] * (REAL)1;
+            REAL jk[NMAX];
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) jk[k] = jr[k < nv ? k : 0];
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) acc[k] += ji * jk[k];
+          }
+#pragma unroll
+          for (int o = NMAX; o < NMAX * G; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NMAX; k++) acc[k] += __shfl_xor(acc[k], o, W);
+          }
+#pragma unroll
+          for (int k = 0; k < (INCR ? NMAX : 1); k++) { Hraw[k] = (k <= l) ? Hraw[k] + acc[k] : (REAL)0; H.t[k] = Hraw[k]; }
+          wave_sync();
+        } else {
         // weights of the rows in the quadratic set, staged for broadcast reads (fs is rewritten by the next constraint_qfrc)
 #pragma unroll
         for (int j = 0; j < RPL; j++) if (l + W * j < nda) fs[l + W * j] = jad[j] < 0 ? Dd[j] : (REAL)0;
@@ -4311,7 +4375,13 @@ struct Env {
         }
 #pragma unroll
         for (int k = 0; k < NMAX; k++) H.t[k] = (k <= l) ? H.t[k] + acc[k] : (REAL)0;
+        if (INCR && incr_on) {
+#pragma unroll
+          for (int k = 0; k < (INCR ? NMAX : 1); k++) Hraw[k] = H.t[k];
+        }
         wave_sync();
+        }
+        hact = hnow; hbuilds++;
         STAMP(73);
         // register Cholesky (math.small_cholesky :117-127, pivots clamped at 1e-12) leaving row AND column l of L in lane l
 #pragma unroll

@@ -483,6 +483,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   {  // register solver, Newton, float32: J^T diag(w) J on the matrix cores (v_mfma_f32_4x4x1, 16 independent 4 x 4 blocks: each environment's lanes feed only their own blocks).  MJH_SOL2_MFMA=0: vector path
     static const bool mfma_off = [] { const char* e = getenv("MJH_SOL2_MFMA"); return e && e[0] == '0'; }();
     M.sol2_hs = (!mfma_off && sizeof(REAL) == 4 && d->solver == SOL_NEWTON && d->nv <= 16 && d->nefc > 0) ? 1 : 0;
+    static const bool incr_off = [] { const char* e = getenv("MJH_SOL2_INCR"); return e && e[0] == '0'; }();
+    M.sol2_incr = (!incr_off && d->solver == SOL_NEWTON && d->nv <= 16 && d->nefc > 0) ? 1 : 0;
   }
   // convex pairs and the LDS scratch their wave needs (layout in mjh_convex.h)
   std::vector<int> cvx_pairs;
