@@ -229,6 +229,7 @@ struct KArgs {
   int do_step;
   int rk_stage;        // -1: Euler / forward only; 0..3: RK4 stage
   int state_from_cur;  // qpos/qvel/act of this pass come from `cur` (RK stages >= 1) instead of `in`
+  int sns_epw;          // sensor kernel: environments per wavefront
   REAL* hs;             // small models with one contact condim (DevModel::crow_by_con): per-environment hand-over of the constraint phase to the register solver (workspace, hs_reals each): [nda | contact -> compact slot (ncon) | efc_D (nd) | efc_aref (nd) | efc_J rows (nd * nv)] of the ACTIVE contacts' rows in compact order, so that the solver's loads are ONE round of fixed addresses instead of contact_dist -> compaction -> D / aref gather -> row gather (four dependent trips: 45 % of the ant's solver kernel).  NULL: the solver reads the leaves
   int hs_reals;
   REAL* cand;           // max_contact_points over convex pairs: candidate contacts of the convex narrow phase, [B, ncand] dist | [B, ncand, 3] pos | [B, ncand, 9] frame (workspace)

@@ -296,23 +296,35 @@ __global__ __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && FULL == 0) ? MJH_SE
   // trips instead of 13 dependent tests on 8 lanes), then every sensordata slot is produced by one lane
   extern __shared__ double rf_x[];
   const int nsd = M.nsensordata, nrf = M.nrfq;
-  {  // one workgroup per environment, no grid-stride loop (the host launches per 2^20 environments)
-    const int64_t e = KA.env_begin + blockIdx.x;
+  // KArgs::sns_epw environments per wavefront (round 5): the ant's 20 slots left 44 lanes idle in the slot phase and 16384 one-environment workgroups cost 8 us of
+  // launch alone.  Ray tasks and slots of the wave's environments are laid end to end over the lanes: task t = (environment t / nrf, ray test t % nrf), slot t likewise.
+  {  // no grid-stride loop (the host launches per 2^20 workgroups)
+    const int epw = KA.sns_epw;
+    const int64_t e0 = KA.env_begin + (int64_t)blockIdx.x * epw;
+    const int here = (int)((KA.env_begin + KA.env_count - e0) < epw ? (KA.env_begin + KA.env_count - e0) : epw);  // environments of this workgroup
+    const float inv_nrf = 1.0f / (float)(nrf > 0 ? nrf : 1), inv_nsd = 1.0f / (float)(nsd > 0 ? nsd : 1);
 #ifdef MJH_SENSOR_ABLATE
     if (!(KA.flags & 0x100))
 #endif
-    for (int q = lane_id(); q < nrf; q += MJH_WAVE) rf_x[q] = rf_task<REAL>(e, q);
+    for (int t = lane_id(); t < here * nrf; t += MJH_WAVE) {
+      int k, q;
+      split_index(t, nrf, inv_nrf, k, q);
+      rf_x[k * (nrf + 1) + q] = rf_task<REAL>(e0 + k, q);
+    }
     wave_sync();
 #ifdef MJH_SENSOR_ABLATE
     if (!(KA.flags & 0x200))
 #endif
-    for (int k = lane_id(); k < nsd; k += MJH_WAVE) {
+    for (int t = lane_id(); t < here * nsd; t += MJH_WAVE) {
+      int ke, k;
+      split_index(t, nsd, inv_nsd, ke, k);
+      const int64_t e = e0 + ke;
       const int s = M.slot_sensor[k];
       REAL v;
       if (s < 0) {
         v = in.sensordata ? in.sensordata[e * nsd + k] : (REAL)0;  // slot keeps the caller's value
       } else {
-        v = sensor_value<REAL, FULL != 0>(e, s, k - M.sns_adr[s], rf_x);
+        v = sensor_value<REAL, FULL != 0>(e, s, k - M.sns_adr[s], rf_x + ke * (nrf + 1));
         const REAL cutoff = M.sns_cutoff[s];
         const int dt = M.sns_datatype[s];
         if (cutoff > 0) {  // _apply_cutoff :41-53

@@ -935,14 +935,21 @@ int launch_convex(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 template <typename REAL>
 int launch_sensor_kernel(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   (void)m;
-  for (int64_t e0 = 0; e0 < a.B; e0 += max_grid()) {
-    const int64_t grid = a.B - e0 < max_grid() ? a.B - e0 : max_grid();
-    a.env_begin = e0;
-    if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
-    else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), sizeof(double) * (size_t)(a.M.nrfq + 1), stream, a);
+  // environments per wavefront: two when their slots fit the 64 lanes of the slot phase (MJH_SENSOR_EPW overrides).  Measured (MI355X, ant B = 16384, 27 slots and 104 ray tests per environment):
+  // one 36.8 - 37.1 us, two 28.8 - 29.0, four 35.6 - 35.7 (a quarter of the workgroups: too few waves to hide the kernel's two dependent load chains) -- profiles/r05/notes.md
+  static const int epw_env = [] { const char* e = getenv("MJH_SENSOR_EPW"); return e ? atoi(e) : 0; }();
+  int epw = epw_env > 0 ? epw_env : (a.M.nsensordata > 0 ? MJH_WAVE / a.M.nsensordata : 1);
+  epw = epw < 1 ? 1 : (epw_env > 0 ? (epw > 8 ? 8 : epw) : (epw > 2 ? 2 : epw));
+  a.sns_epw = epw;
+  const size_t lds = sizeof(double) * (size_t)(a.M.nrfq + 1) * (size_t)epw;
+  for (int64_t e0 = 0; e0 < a.B; e0 += epw * max_grid()) {
+    const int64_t n = a.B - e0 < epw * max_grid() ? a.B - e0 : epw * max_grid(), grid = (n + epw - 1) / epw;
+    a.env_begin = e0; a.env_count = n;
+    if (a.M.sns_full) hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 1>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a);
+    else hipLaunchKernelGGL((mjh_sensor_kernel<REAL, 0>), dim3((unsigned)grid), dim3(MJH_WAVE), lds, stream, a);
     HIP_TRY(hipGetLastError());
   }
-  a.env_begin = 0;
+  a.env_begin = 0; a.env_count = a.B;
   return 0;
 }
 
