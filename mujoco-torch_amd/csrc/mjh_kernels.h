@@ -927,6 +927,7 @@ struct Env {
   }
   LdsView<REAL> S;
   int64_t e;      // environment index
+  REAL ho_g[12];  // whole-pass kernel: this lane's geom frame (position, matrix) as the kinematics formed it, handed to the constraint stage in registers (lane g <-> geom g, ngeom <= W)
   // from here on the environment index is news to the optimiser: the address arithmetic of a store section (e * leaf width, one 64-bit value per leaf) is
   // formed where the stores are instead of at the kernel's head, where it sat in registers -- or in scratch -- across the whole phase
   __device__ __forceinline__ void rebind() { late_bind<W>(e); }
@@ -972,7 +973,7 @@ struct Env {
     put(out.subtree_com, S.subtree_com(), 3 * M.nbody); put(out.cinert, S.cinert(), 10 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv);
   }
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
-  template <bool DEFER = false>
+  template <bool DEFER = false, bool KEEPG = false>
   __device__ __forceinline__ void kinematics(bool with_cams) {
     const int l = lane_here();
     // joint-local rotations first, one lane per joint: the trigonometry and the quaternion normalisations leave the
@@ -1110,6 +1111,12 @@ struct Env {
       const int b = M.geom_bodyid[g];
       REAL p[3], mat[9];
       local_to_global(S.xpos() + 3 * b, S.xquat() + 4 * b, M.geom_pos + 3 * g, M.geom_quat + 4 * g, p, mat);
+      if constexpr (KEEPG) if (g == l) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) ho_g[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < 9; i++) ho_g[3 + i] = mat[i];
+      }
       if (out.geom_xpos) for (int i = 0; i < 3; i++) out.geom_xpos[(e * M.ngeom + g) * 3 + i] = p[i];
       if (out.geom_xmat) for (int i = 0; i < 9; i++) out.geom_xmat[(e * M.ngeom + g) * 9 + i] = mat[i];
     }
@@ -1385,9 +1392,14 @@ struct Env {
   }
 
   bool con_inputs_loaded_ = false;  // collision() already fetched what make_constraint() reads (plain instantiation)
-  template <int PRE_NMAX = 0>
+  bool ho_on_ = false;              // whole-pass kernel: this model's constraint-stage inputs travel on chip (DevModel::all_handoff)
+  // HANDOFF (whole-pass kernel): the geom frames, qvel, subtree_com and cdof are already in the arena -- the first half of the kernel handed them over on chip
+  template <int PRE_NMAX = 0, bool HANDOFF = false>
   __device__ __forceinline__ void collision(Sol2Pre<REAL, (PRE_NMAX > 0 ? PRE_NMAX : 1)>* pre = nullptr) {
     const int l = lane_here();
+    if (HANDOFF && ho_on_) {
+      con_inputs_loaded_ = true;
+    } else
     if (!FRIC && (KA.stages & 0x78) && M.nefc > 0) {
       // plain instantiation with the rows to follow: qvel, subtree_com and cdof ride in the same round trip as the geom frames -- loaded at the
       // head of make_constraint() they were a second, fully exposed trip behind the narrow phase (16 k of the phase's 77 k cycles on the humanoid)
@@ -3479,13 +3491,13 @@ struct Env {
   }
 
   // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
-  template <bool DEFER = false>
+  template <bool DEFER = false, bool KEEPG = false>
   __device__ __forceinline__ void run_kin() {
     STAMP0();
     load_qpos(true);
     wave_sync();
     STAMP(1);
-    kinematics<DEFER>(KA.rk_stage <= 0);
+    kinematics<DEFER, KEEPG>(KA.rk_stage <= 0);
     com_pos<DEFER>();
   }
   __device__ __forceinline__ void run_crb() { crb_factor<false>(); }
@@ -3695,18 +3707,22 @@ struct Env {
   // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the rows of the active contacts, efc_D / efc_aref and the
   // narrow phase's distances never leave the arena between the two (the leaves are still stored -- nothing waits for them), and the factor rows, qfrc_smooth
   // and the state arrive while the constraint stage computes.  Serves models of the plain constraint phase whose dense rows fit one slot per lane.
-  template <int NMAX, int RPL, bool ONE = false>
+  template <int NMAX, int RPL, bool ONE = false, bool HANDOFF = false>
   __device__ __forceinline__ void run_con_sol2() {
     static_assert(W == 32 && !FRIC && !DIRECT, "plain constraint stage, two environments per wavefront");
     Sol2Pre<REAL, NMAX> pre;
     Sol2Con<REAL> con;
     STAMP0();
-    collision<NMAX>(&pre);
+    collision<NMAX, HANDOFF>(&pre);
 #if MJH_CS_PF == 1
     sol2_prefetch<NMAX>(pre);
 #endif
     make_constraint_cs<NMAX>(pre, con);
 #if MJH_CS_PF == 3
+    if (HANDOFF && ho_on_) {  // what the solver reads back of the first half's leaves (factor rows, qfrc_smooth, qpos, act_dot; qM later): its stores landed while the constraint stage ran
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     sol2_prefetch<NMAX>(pre);
 #endif
     wave_sync();
@@ -4686,18 +4702,48 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
         // every wave of the second requesting its inputs at the same moment.  Here an environment's wave goes straight on: what the second half reads of the first
         // (geom frames, subtree_com, cdof, the factor, qM, qfrc_smooth, the normalised qpos) it reads back from the leaves THIS wave has just stored -- behind a
         // release / acquire pair at the scope of its own CU -- through the arena layout of the second half.
-        E.template run_kin<false>();
+        E.template run_kin<false, true>();
         wave_sync();
         E.template crb_factor<true, NMAX>();
         wave_sync();
         E.template run_vel<false, true>();
+        if (K.M.all_handoff) {
+          // Round 5: the constraint stage's inputs -- geom frames, qvel, subtree_com, cdof -- cross the seam ON CHIP.  Read back from the leaves (round 4) the stage's first loads queued behind
+          // the velocity stage's 25 KB of stores (vmcnt is in order): ~15 k of the environment's 307 k cycles.  The geom frames ride in registers from the kinematics (lane g <-> geom g), the
+          // three arena arrays are lifted into registers under the first layout and put down under the second; the release / acquire pair for everything ELSE the second half reads back
+          // (factor rows, qfrc_smooth, qpos, qM) sits behind the constraint stage, where the stores have long landed (Env::run_con_sol2).
+          const int l = (int)(threadIdx.x & (W - 1));
+          const int nv6 = 6 * K.M.nv, nb3 = 3 * K.M.nbody, ng = K.M.ngeom;
+          REAL h_cd[6], h_sc[3], h_qv;
+#pragma unroll
+          for (int k = 0; k < 6; k++) h_cd[k] = l + W * k < nv6 ? E.S.cdof()[l + W * k] : (REAL)0;
+#pragma unroll
+          for (int k = 0; k < 3; k++) h_sc[k] = l + W * k < nb3 ? E.S.subtree_com()[l + W * k] : (REAL)0;
+          h_qv = l < K.M.nv ? E.S.qvel()[l] : (REAL)0;
+          wave_sync();
+          E.S.off = &K.off2;
+#pragma unroll
+          for (int k = 0; k < 6; k++) if (l + W * k < nv6) E.S.cdof()[l + W * k] = h_cd[k];
+#pragma unroll
+          for (int k = 0; k < 3; k++) if (l + W * k < nb3) E.S.subtree_com()[l + W * k] = h_sc[k];
+          if (l < K.M.nv) E.S.qvel()[l] = h_qv;
+          if (l < ng) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) E.S.geom_xpos()[3 * l + i] = E.ho_g[i];
+#pragma unroll
+            for (int i = 0; i < 9; i++) E.S.geom_xmat()[9 * l + i] = E.ho_g[3 + i];
+          }
+          E.ho_on_ = true;
+          wave_sync();
+        } else {
         // (workgroup scope = this CU: its waves share ONE write-through L1, so a wave's loads see its own landed stores; agent scope would write back and invalidate the
         //  XCD's L2 on every wave -- measured: 228.9 us against 167 us for the two launches)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         wave_sync();
         E.S.off = &K.off2;
-        E.template run_con_sol2<NMAX, RPL, ONE>();
+        }
+        E.template run_con_sol2<NMAX, RPL, ONE, true>();
       } else
       if constexpr (CS) E.template run_con_sol2<NMAX, RPL, ONE>();
       else E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();

@@ -207,6 +207,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
   const int NW = nv > 64 ? (nv + 63) / 64 : 1;  // 64-bit words per dof mask
   M.mask_words = NW;
   M.big = nv > 64 ? 1 : 0;
+  {
+    static const bool ho_off = [] { const char* e = getenv("MJH_ALL_HANDOFF"); return e && e[0] == '0'; }();
+    M.all_handoff = (!ho_off && d->ngeom <= 32 && d->nbody <= 32 && nv <= 32) ? 1 : 0;
+  }
   {  // small plain models (the ones that run four environments per wavefront, no optional physics): a leaner arena (DevModel::lds_diet).  MJH_LDS_DIET=0: off
     static const bool diet_off = [] { const char* e = getenv("MJH_LDS_DIET"); return e && e[0] == '0'; }();
     M.lds_diet = (!diet_off && d->nbody <= 16 && d->njnt <= 16 && nv <= 16 && !M.has_fluid && !M.has_gravcomp && d->ntendon == 0) ? 1 : 0;
