@@ -322,6 +322,56 @@ print("split ok")
     assert r.returncode == 0 and "split ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_kernel_selection_switches_are_bit_identical():
+    """Round 5 changed WHICH kernels a step launches (the whole pass in one kernel, kernel 13 on two wavefronts, the leaner arena, the hand-over block, on-chip seam).  Every one of
+    those choices must be invisible in the results: with each switch turned the other way two steps of the same inputs are bit-identical, every leaf (the incremental Newton Hessian is
+    the one tolerance-level choice: the models it does not touch must not move; the mesh scene's parity with it is checked against the oracle)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import torch as _t
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+from _util import load_model, REAL_LEAVES, INT_LEAVES
+out = {}
+for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("humanoid", {"solver": 1, "iterations": 3}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
+                    ("mesh_contact", {}, torch.float32), ("hopper", {}, torch.float64)):
+    mx = load_model(xml, ov, dt)
+    B = 64
+    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+    if dt != torch.float64: d = d.to(dt)
+    mdev = mx.to("cuda")
+    got = mt.step(mdev, mt.step(mdev, d.to("cuda")))
+    out[xml + str(sorted(ov.items()))] = {n: native.data_field_tensor(got, n).cpu() for n in REAL_LEAVES + INT_LEAVES}
+torch.save(out, sys.argv[1])
+print("ran")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    switches = [{}, {"MJH_FUSE_ALL": "0"}, {"MJH_FUSE_ALL": "0", "MJH_CS_ONE": "0"}, {"MJH_ALL_HANDOFF": "0"}, {"MJH_KCV2": "0"}, {"MJH_KCV2": "1"}, {"MJH_LDS_DIET": "0"},
+                {"MJH_HANDOVER": "0"}, {"MJH_SENSOR_EPW": "1"}, {"MJH_SOL2_INCR": "0"}]
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for i, env in enumerate(switches):
+            f = os.path.join(td, f"{i}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ran" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-1500:])
+            res.append(_t.load(f))
+    for env, other in zip(switches[1:], res[1:]):
+        for case in res[0]:
+            for n, t in res[0][case].items():
+                o = other[case][n]
+                if "MJH_SOL2_INCR" in env and "mesh" in case:
+                    continue  # (tolerance-level by design, and two steps of resting boxes amplify a last-bit difference to O(1e-2): its parity is the oracle's to judge -- config 5, the campaign)
+                else:
+                    assert _t.equal(t, o) or (t.is_floating_point() and _t.equal(_t.nan_to_num(t), _t.nan_to_num(o))), (env, case, n)
+
+
 def test_batches_past_one_launch_are_cut_on_the_host():
     """The kernels run one unit of work per workgroup (no grid-stride loops since round 5): a batch of more than 2^20 workgroups is cut into several launches by the host.
     MJH_MAX_GRID_LOG2=3 brings that limit down to 8 workgroups, so a batch of 203 environments takes every multi-launch path -- packed / paired / odd-tail phase kernels, both
