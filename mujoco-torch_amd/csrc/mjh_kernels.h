@@ -28,6 +28,14 @@ struct LdsView {
 #undef X
 };
 
+// Leaves nobody reads again inside the step (frames, spatial inertias, contact geometry and constants, zero rows of efc_J, forces ...) are stored with the non-temporal hint: written as
+// ordinary stores the ant's stage-0 constraint phase (287 MB of outputs) pushed what the NEXT kernels read out of L2 / the memory-side cache -- kernel 13 of RK4 stage 1 ran 64.8 us
+// against 50.5 in stages 2 / 3; with the hint 57.1 (ant 23.9 -> 24.5 M env-steps/s; profiles/r05/notes.md).  -DMJH_NO_NT turns the hint off.
+#ifndef MJH_NO_NT
+#define MJH_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define MJH_NT_STORE(v, p) (*(p) = (v))
+#endif
 // carve the arena of one phase on the host; returns the number of REALs used.
 template <typename MM>
 inline int lds_carve(const MM& m, int phase_bit, LdsOff& o, int* kv_defer_ok = nullptr) {
@@ -285,7 +293,7 @@ __device__ __forceinline__ void late_bind(int64_t& v) {
 }
 // ---- helpers: coalesced row copy between LDS and the environment's global row -------------------------------------------
 // Four independent transfers are issued per trip so one HBM/L2 (or LDS) round trip covers 256 elements.
-template <int W, typename REAL>
+template <int W, bool NT = false, typename REAL>
 __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t env) {
   if (!g) return;
   // (the row's address is formed HERE: left to the optimiser, the address arithmetic of every leaf store of a phase is hoisted to the kernel's head,
@@ -296,9 +304,10 @@ __device__ __forceinline__ void row_store(REAL* g, const REAL* l, int n, int64_t
   asm volatile("" : "+v"(i));
   for (; i + 3 * W < n; i += 4 * W) {
     const REAL a = l[i], b = l[i + W], c = l[i + 2 * W], d = l[i + 3 * W];
-    dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = c; dst[i + 3 * W] = d;
+    if (NT) { MJH_NT_STORE(a, &dst[i]); MJH_NT_STORE(b, &dst[i + W]); MJH_NT_STORE(c, &dst[i + 2 * W]); MJH_NT_STORE(d, &dst[i + 3 * W]); }
+    else { dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = c; dst[i + 3 * W] = d; }
   }
-  for (; i < n; i += W) dst[i] = l[i];
+  for (; i < n; i += W) { if (NT) MJH_NT_STORE(l[i], &dst[i]); else dst[i] = l[i]; }
 }
 // global -> global copy of a model constant into a leaf (the source is L2-resident): eight requests in flight per trip
 template <int W, typename REAL>
@@ -313,18 +322,18 @@ __device__ __forceinline__ void row_copy_const(REAL* g, const REAL* c, int n, in
 #pragma unroll
     for (int q = 0; q < 16; q++) t[q] = c[i + q * W];
 #pragma unroll
-    for (int q = 0; q < 16; q++) dst[i + q * W] = t[q];
+    for (int q = 0; q < 16; q++) MJH_NT_STORE(t[q], &dst[i + q * W]);
   }
   for (; i + 7 * W < n; i += 8 * W) {
     REAL t[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) t[q] = c[i + q * W];
 #pragma unroll
-    for (int q = 0; q < 8; q++) dst[i + q * W] = t[q];
+    for (int q = 0; q < 8; q++) MJH_NT_STORE(t[q], &dst[i + q * W]);
   }
   for (; i + 3 * W < n; i += 4 * W) {
     const REAL a = c[i], b = c[i + W], cc = c[i + 2 * W], d = c[i + 3 * W];
-    dst[i] = a; dst[i + W] = b; dst[i + 2 * W] = cc; dst[i + 3 * W] = d;
+    MJH_NT_STORE(a, &dst[i]); MJH_NT_STORE(b, &dst[i + W]); MJH_NT_STORE(cc, &dst[i + 2 * W]); MJH_NT_STORE(d, &dst[i + 3 * W]);
   }
   for (; i < n; i += W) dst[i] = c[i];
 }
@@ -343,7 +352,7 @@ __device__ __forceinline__ void multi_copy_const(REAL* const (&dst)[K], const RE
 #pragma unroll
   for (int k = 0; k < K; k++) {
 #pragma unroll
-    for (int t = 0; t < T; t++) { const int i = l + t * W; if (dst[k] && i < n[k]) dst[k][env * n[k] + i] = v[k][t]; }
+    for (int t = 0; t < T; t++) { const int i = l + t * W; if (dst[k] && i < n[k]) MJH_NT_STORE(v[k][t], &dst[k][env * n[k] + i]); }
   }
 #pragma unroll
   for (int k = 0; k < K; k++)
@@ -941,6 +950,8 @@ struct Env {
   // every phase streams the leaves it produces to the Data being computed (`out` == KArgs::cur)
   template <typename T>
   __device__ __forceinline__ void put(T* g, const REAL* l, int n) { row_store<W>(g, l, n, e); }
+  template <typename T>
+  __device__ __forceinline__ void putnt(T* g, const REAL* l, int n) { row_store<W, true>(g, l, n, e); }  // a leaf no later kernel of the step reads: non-temporal
 
   // ---- state loads (+ _check_state, forward.py:44-59, on the caller's state) ------------------------------------------------
   __device__ __forceinline__ REAL checked(REAL x, REAL fallback) const {
@@ -965,12 +976,12 @@ struct Env {
   }
 
   __device__ __forceinline__ void frame_stores() {
-    put(out.xpos, S.xpos(), 3 * M.nbody); put(out.xquat, S.xquat(), 4 * M.nbody); if (!M.lds_diet) put(out.xmat, S.xmat(), 9 * M.nbody);  // (lds_diet: the two matrices went out from the registers that formed them)
-    put(out.xipos, S.xipos(), 3 * M.nbody); if (!M.lds_diet) put(out.ximat, S.ximat(), 9 * M.nbody);
-    put(out.xanchor, S.xanchor(), 3 * M.njnt); put(out.xaxis, S.xaxis(), 3 * M.njnt);
+    putnt(out.xpos, S.xpos(), 3 * M.nbody); putnt(out.xquat, S.xquat(), 4 * M.nbody); if (!M.lds_diet) putnt(out.xmat, S.xmat(), 9 * M.nbody);  // (lds_diet: the two matrices went out from the registers that formed them)
+    putnt(out.xipos, S.xipos(), 3 * M.nbody); if (!M.lds_diet) putnt(out.ximat, S.ximat(), 9 * M.nbody);
+    putnt(out.xanchor, S.xanchor(), 3 * M.njnt); putnt(out.xaxis, S.xaxis(), 3 * M.njnt);
   }
   __device__ __forceinline__ void com_stores() {
-    put(out.subtree_com, S.subtree_com(), 3 * M.nbody); put(out.cinert, S.cinert(), 10 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv);
+    put(out.subtree_com, S.subtree_com(), 3 * M.nbody); putnt(out.cinert, S.cinert(), 10 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv);
   }
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
   template <bool DEFER = false, bool KEEPG = false>
@@ -1081,11 +1092,11 @@ struct Env {
         local_to_global(pos, quat, M.body_ipos + 3 * b, M.body_iquat + 4 * b, S.xipos() + 3 * b, xim);
         if (out.xmat) {
 #pragma unroll
-          for (int i = 0; i < 9; i++) out.xmat[(e * M.nbody + b) * 9 + i] = xm[i];
+          for (int i = 0; i < 9; i++) MJH_NT_STORE(xm[i], &out.xmat[(e * M.nbody + b) * 9 + i]);
         }
         if (out.ximat) {
 #pragma unroll
-          for (int i = 0; i < 9; i++) out.ximat[(e * M.nbody + b) * 9 + i] = xim[i];
+          for (int i = 0; i < 9; i++) MJH_NT_STORE(xim[i], &out.ximat[(e * M.nbody + b) * 9 + i]);
         }
       } else {
       quat_to_mat(quat, S.xmat() + 9 * b);
@@ -1328,7 +1339,7 @@ struct Env {
       }
     }
     STAMP(14);
-    put(out.crb, S.crb(), 10 * nb);
+    putnt(out.crb, S.crb(), 10 * nb);
     wave_sync();
     STAMP(15);
     chol_factor<W, REAL, MAXN, true>(S.qMp(), S.qLD(), nv);            // S.qLD() overlays the arrays above (lds_carve).  (Four environments per wavefront: nv <= 16 -- the 24 / 28 / 32-row register variants are not compiled in)
@@ -1536,7 +1547,7 @@ struct Env {
     }
     {
       const int nc = M.ncon;
-      put(out.contact_dist, S.con_dist(), nc); put(out.contact_pos, S.con_pos(), 3 * nc); put(out.contact_frame, S.con_frame(), 9 * nc);
+      put(out.contact_dist, S.con_dist(), nc); putnt(out.contact_pos, S.con_pos(), 3 * nc); putnt(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
       if constexpr (PRE_NMAX > 0) return;  // fused constraint + solver kernel: the constant leaves are copied at the kernel's end (contact_const_stores), off the path to the solve
       contact_const_stores();
@@ -1871,7 +1882,7 @@ struct Env {
             split_index(w, gpr, 1.0f / (float)gpr, q, g);
             int qc = q, unused_;
             if (M.crow_by_con) split_index(q, M.con_rows, inv_rows_, qc, unused_);
-            if (!row_act[qc]) reinterpret_cast<zvec*>(Jdst)[w] = z;  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+            if (!row_act[qc]) MJH_NT_STORE(z, &reinterpret_cast<zvec*>(Jdst)[w]);  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
           }
         } else
         for (int w = l; w < nd * nv; w += W) {
@@ -2504,7 +2515,7 @@ struct Env {
       const int d00 = l < nb ? M.body_dofadr[l] : 0, nd0 = (l < nb && depth0 > 0) ? M.body_dofnum[l] : 0;
       if (DEFER && M.kv_defer) {  // (same reasoning as in front of the com_vel sweep: the rest of the kinematics stage's leaves and the two velocity leaves that are final by now)
         com_stores();
-        put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv);
+        put(out.cvel, S.cvel(), 6 * nb); putnt(out.cdof_dot, S.cdof_dot(), 6 * nv);
       }
       for (int b0 = 0; b0 < nb; b0 += W) {
         const int b = b0 + l;
@@ -2586,8 +2597,8 @@ struct Env {
   __device__ __forceinline__ void velocity_stores() {
     const int nv = M.nv, nb = M.nbody, nu = M.nu;
     put(out.actuator_length, S.act_length(), nu); put(out.actuator_velocity, S.act_velocity(), nu);
-    if (!(DEFER && W > 16 && M.kv_defer)) { put(out.cvel, S.cvel(), 6 * nb); put(out.cdof_dot, S.cdof_dot(), 6 * nv); }  // (else: in front of the rne sweep)
-    put(out.qfrc_passive, S.qfrc_passive(), nv); put(out.qfrc_bias, S.qfrc_bias(), nv);
+    if (!(DEFER && W > 16 && M.kv_defer)) { put(out.cvel, S.cvel(), 6 * nb); putnt(out.cdof_dot, S.cdof_dot(), 6 * nv); }  // (else: in front of the rne sweep)
+    putnt(out.qfrc_passive, S.qfrc_passive(), nv); putnt(out.qfrc_bias, S.qfrc_bias(), nv);
     if (M.act_simple) row_copy_const<W>(out.actuator_moment, M.act_moment, nu * nv, e);  // the constant moment matrix (smooth.py:535-591): 4.5 KB per humanoid
   }
 
@@ -3685,7 +3696,7 @@ struct Env {
       for (int r = 0; r < nl; r++) {
         const int col = sub_read<W>(C.ldof, r);
         const REAL v = sub_read<W>(C.jl, r);
-        if (dof) gJ[r * nv + l] = (l == col) ? v : (REAL)0;
+        if (dof) MJH_NT_STORE((l == col) ? v : (REAL)0, &gJ[r * nv + l]);
       }
       const int* slot = reinterpret_cast<const int*>(S.i_crow_act());
       const REAL* Jc = S.efc_Jc();
@@ -3697,11 +3708,11 @@ struct Env {
 #pragma unroll
           for (int t = 0; t < 4; t++) v[t] = (at >= 0 && sub + t < rows && dof) ? Jc[(at * rows + sub + t) * nv + l] : (REAL)0;
 #pragma unroll
-          for (int t = 0; t < 4; t++) if (sub + t < rows && dof) gC[(c * rows + sub + t) * nv + l] = v[t];
+          for (int t = 0; t < 4; t++) if (sub + t < rows && dof) MJH_NT_STORE(v[t], &gC[(c * rows + sub + t) * nv + l]);
         }
       }
     }
-    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) out.efc_frictionloss[e * nefc + r] = (REAL)0;
+    if (out.efc_frictionloss) for (int r = l; r < nefc; r += W) MJH_NT_STORE((REAL)0, &out.efc_frictionloss[e * nefc + r]);
     if (M.ncon > 0) contact_const_stores();
   }
   // constraint stage + register solver + integrator in ONE kernel (two environments per wavefront): the rows of the active contacts, efc_D / efc_aref and the
@@ -4575,7 +4586,7 @@ struct Env {
         if (out.qfrc_constraint) out.qfrc_constraint[e * nv + l] = qfrc;
       }
       if (out.efc_force) {  // Data order; the rows of inactive contacts carry exact zeros
-        if (lim) out.efc_force[e * nefc + l] = frl;
+        if (lim) MJH_NT_STORE(frl, &out.efc_force[e * nefc + l]);
         if constexpr (CS) {
           const int* slot = reinterpret_cast<const int*>(S.i_crow_act());
           const int rows = M.con_rows;
@@ -4584,10 +4595,10 @@ struct Env {
             int c, sub;
             split_index(r, rows, inv_rows, c, sub);
             const int at = slot[c];
-            out.efc_force[e * nefc + nl + r] = at >= 0 ? fs[at * rows + sub] : (REAL)0;
+            MJH_NT_STORE(at >= 0 ? fs[at * rows + sub] : (REAL)0, &out.efc_force[e * nefc + nl + r]);
           }
         } else
-        for (int r = l; r < nd; r += W) { const int q = rdst[r]; out.efc_force[e * nefc + nl + r] = q != 0xffff ? fs[q] : (REAL)0; }
+        for (int r = l; r < nd; r += W) { const int q = rdst[r]; MJH_NT_STORE(q != 0xffff ? fs[q] : (REAL)0, &out.efc_force[e * nefc + nl + r]); }
       }
       // (requesting the tail's rows of qM ahead of these stores, into the registers the factor has just left, was measured: 116 -> 240 B of scratch, kernel 78.0 -> 83.6 us)
       if constexpr (CS) cs_deferred_stores(*con);
