@@ -1926,11 +1926,11 @@ struct Env {
           for (int ed = 0; ed < nedge; ed++) {
             const REAL f = fric[ed >> 1] * ((ed & 1) ? (REAL)-1 : (REAL)1);
             const REAL v = diff[0] + diff[1 + (ed >> 1)] * f;
-            if (dstA) dstA[ed * nv] = v;
+            if (dstA) { if (dstB) MJH_NT_STORE(v, &dstA[ed * nv]); else dstA[ed * nv] = v; }  // (with a hand-over the solver reads THAT copy: the leaf is output only)
             if (dstB) dstB[ed * nv] = v;
           }
         } else {  // _instantiate_contact_elliptic :519-583
-          for (int r = 0; r < dim; r++) { if (dstA) dstA[r * nv] = diff[r]; if (dstB) dstB[r * nv] = diff[r]; }
+          for (int r = 0; r < dim; r++) { if (dstA) { if (dstB) MJH_NT_STORE(diff[r], &dstA[r * nv]); else dstA[r * nv] = diff[r]; } if (dstB) dstB[r * nv] = diff[r]; }
         }
       }
     } else

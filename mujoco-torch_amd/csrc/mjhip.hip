@@ -1088,7 +1088,11 @@ int run_launches_one(const mjhModel* m, const DevModel<REAL>& M, const mjhData* 
 #undef X
     };
     for (size_t i = 0; i < m->leaf_count.size(); i++)
-      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) { slots[i] = w; w += m->leaf_count[i] * B; }
+      if (is_stage_leaf(names[i], M.ncvxpair > 0, M.has_fluid != 0, M.ne > 0, M.topk != 0)) {
+        // (kernel 13 keeps cinert / xipos in its arena from the kinematics to the crb and velocity stages: no later LAUNCH of a stage reads their workspace copies -- left NULL, the stores are skipped)
+        if (!(m->fuse_kcv && B <= m->kcv_max_envs && (!strcmp(names[i], "cinert") || !strcmp(names[i], "xipos")))) slots[i] = w;
+        w += m->leaf_count[i] * B;
+      }
   }
   a.W.qvel0 = w; w += (int64_t)M.nv * B;
   a.W.kqvel = w; w += (int64_t)M.nv * B;
