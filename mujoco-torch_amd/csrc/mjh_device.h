@@ -173,6 +173,7 @@ struct DevModel {
   const int* lim_dof;                      // nf+nl: dof of single-column row r (frictionloss rows, then joint-limit rows)
   int sol_qm_lds;                          // solver keeps qM in LDS (many iterations) instead of re-reading it from L2
   int con_rows;                            // constraint rows of every contact when they all have the same number (one condim), else 0
+  int nt_all;                              // the model's full passes run as the whole-pass kernel with the on-chip seam: geom frames, subtree_com, cdof, contact_dist are output only (non-temporal stores)
   int all_handoff;                         // whole-pass kernel: the constraint stage's inputs cross the seam on chip (ngeom, nbody <= 32; MJH_ALL_HANDOFF=0: off)
   int lds_diet;                            // small models (four environments per wavefront): xmat / ximat are stored from registers and recomputed from xquat where read again, the subtree force sums fold into qfrc_bias -- the arena of kernel 13 drops from 3064 to 2272 B for the ant, i.e. 16 four-environment workgroups per CU fit (one round of waves at B = 16384 instead of two)
   int crow_by_con;                         // ... and the contact rows are in contact order, no gaps: dense row q belongs to contact q / con_rows (the small-model constraint phase then keeps its activity flags per CONTACT)

@@ -981,7 +981,9 @@ struct Env {
     putnt(out.xanchor, S.xanchor(), 3 * M.njnt); putnt(out.xaxis, S.xaxis(), 3 * M.njnt);
   }
   __device__ __forceinline__ void com_stores() {
-    put(out.subtree_com, S.subtree_com(), 3 * M.nbody); putnt(out.cinert, S.cinert(), 10 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv);
+    if (M.nt_all) { putnt(out.subtree_com, S.subtree_com(), 3 * M.nbody); putnt(out.cdof, S.cdof(), 6 * M.nv); }
+    else { put(out.subtree_com, S.subtree_com(), 3 * M.nbody); put(out.cdof, S.cdof(), 6 * M.nv); }
+    putnt(out.cinert, S.cinert(), 10 * M.nbody);
   }
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
   template <bool DEFER = false, bool KEEPG = false>
@@ -1128,8 +1130,13 @@ struct Env {
 #pragma unroll
         for (int i = 0; i < 9; i++) ho_g[3 + i] = mat[i];
       }
+      if (M.nt_all) {  // (whole-pass kernel: nothing reads the geom frames back -- they cross the seam in registers)
+        if (out.geom_xpos) for (int i = 0; i < 3; i++) MJH_NT_STORE(p[i], &out.geom_xpos[(e * M.ngeom + g) * 3 + i]);
+        if (out.geom_xmat) for (int i = 0; i < 9; i++) MJH_NT_STORE(mat[i], &out.geom_xmat[(e * M.ngeom + g) * 9 + i]);
+      } else {
       if (out.geom_xpos) for (int i = 0; i < 3; i++) out.geom_xpos[(e * M.ngeom + g) * 3 + i] = p[i];
       if (out.geom_xmat) for (int i = 0; i < 9; i++) out.geom_xmat[(e * M.ngeom + g) * 9 + i] = mat[i];
+      }
     }
     {
       if (out.site_xpos || out.site_xmat)  // (RK4 stages 1..3 keep no site frames: nothing reads them there)
@@ -1547,7 +1554,8 @@ struct Env {
     }
     {
       const int nc = M.ncon;
-      put(out.contact_dist, S.con_dist(), nc); putnt(out.contact_pos, S.con_pos(), 3 * nc); putnt(out.contact_frame, S.con_frame(), 9 * nc);
+      if (M.nt_all) putnt(out.contact_dist, S.con_dist(), nc); else put(out.contact_dist, S.con_dist(), nc);
+      putnt(out.contact_pos, S.con_pos(), 3 * nc); putnt(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
       if constexpr (PRE_NMAX > 0) return;  // fused constraint + solver kernel: the constant leaves are copied at the kernel's end (contact_const_stores), off the path to the solve
       contact_const_stores();
@@ -3677,8 +3685,8 @@ struct Env {
       REAL rr = invweight * (1 - imp) / imp;
       rr = rr > (REAL)MINVAL_CACHED ? rr : (REAL)MINVAL_CACHED;
       const REAL aref_r = -b * jv - k * imp * pos, D_r = 1 / rr;
-      if (out.efc_aref) out.efc_aref[e * nefc + r] = aref_r;
-      if (out.efc_D) out.efc_D[e * nefc + r] = D_r;
+      if (out.efc_aref) MJH_NT_STORE(aref_r, &out.efc_aref[e * nefc + r]);  // (fused kernels: the solve takes both from the arena / registers)
+      if (out.efc_D) MJH_NT_STORE(D_r, &out.efc_D[e * nefc + r]);
       if (r < nl) { C.Dl = D_r; C.arl = aref_r; }
       else if (crow >= 0) { S.efc_aref()[crow] = aref_r; S.efc_D()[crow] = D_r; }  // (over subtree_com / cdof, which nobody reads any more)
     }

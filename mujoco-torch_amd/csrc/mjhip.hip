@@ -760,6 +760,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       out->lds_all = out->lds_kcv > out->lds_cs ? out->lds_kcv : out->lds_cs;
       if (2 * out->lds_all <= 64 * 1024) {
         out->fuse_all = 1;
+        M.nt_all = M.all_handoff;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 34>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_all));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 28, 1, 36>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * out->lds_all));
       }
