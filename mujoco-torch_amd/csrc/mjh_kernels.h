@@ -1110,6 +1110,17 @@ struct Env {
     // the frames go out now, ahead of the geom / site / camera loops: a phase's leaf stores are bursts of tens of MB issued by every wave at the same
     // moment, and the first table read behind one waits until L2 has taken it (vmcnt is in order) -- several smaller bursts with arithmetic between them drain
     // in the background where one large one does not
+    // cameras that track / target a subtree's centre of mass read the CALLER's subtree_com (previous step, smooth.py:162-166): requested here, ahead of this stage's stores -- behind
+    // them the read waited for 25 leaf stores to land (vmcnt is in order)
+    REAL cam_com[3] = {0, 0, 0};
+    if (with_cams && l < M.ncam && in.subtree_com) {
+      const int mode = M.cam_mode[l], tgt = M.cam_targetbodyid[l];
+      const int sb = mode == CAM_TRACKCOM ? M.cam_bodyid[l] : ((mode == CAM_TARGETBODYCOM && tgt >= 0) ? tgt : -1);
+      if (sb >= 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) cam_com[i] = in.subtree_com[(e * M.nbody + sb) * 3 + i];
+      }
+    }
     if (!(DEFER && W > 16 && M.kv_defer)) frame_stores();  // (fused with the velocity stage: they go out in front of its LDS-only sweep, see velocity())
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += W) {
@@ -1159,11 +1170,11 @@ struct Env {
             // subtree_com of the CALLER's Data (previous step), smooth.py:162-166
             REAL r[3];
             rotate(M.cam_pos + 3 * c, S.xquat() + 4 * b, r);
-            for (int i = 0; i < 3; i++) cp[i] = (in.subtree_com ? in.subtree_com[(e * M.nbody + b) * 3 + i] : (REAL)0) + r[i];
+            for (int i = 0; i < 3; i++) cp[i] = (c == l ? cam_com[i] : (in.subtree_com ? in.subtree_com[(e * M.nbody + b) * 3 + i] : (REAL)0)) + r[i];
           } else if ((mode == CAM_TARGETBODY || mode == CAM_TARGETBODYCOM) && tgt >= 0) {
             REAL tp[3];
             for (int i = 0; i < 3; i++)
-              tp[i] = (mode == CAM_TARGETBODY) ? S.xpos()[3 * tgt + i] : (in.subtree_com ? in.subtree_com[(e * M.nbody + tgt) * 3 + i] : (REAL)0);
+              tp[i] = (mode == CAM_TARGETBODY) ? S.xpos()[3 * tgt + i] : (c == l ? cam_com[i] : (in.subtree_com ? in.subtree_com[(e * M.nbody + tgt) * 3 + i] : (REAL)0));
             REAL f[3] = {tp[0] - cp[0], tp[1] - cp[1], tp[2] - cp[2]};
             normalize_n<REAL, 3>(f);
             REAL up_hint[3] = {0, 0, 1}, right[3], up[3];
