@@ -1574,6 +1574,9 @@ struct Env {
   }
   __device__ __forceinline__ void contact_const_stores() {
     const int l = lane_here();
+    // (RK4 stages 1..3 keep none of these leaves: without this test the integer tables were still READ there -- 4.5 us of the ant's constraint phase per stage)
+    if (!(out.contact_includemargin || out.contact_solref || out.contact_solreffriction || out.contact_friction || out.contact_solimp || out.contact_dim || out.contact_geom1 ||
+          out.contact_geom2 || out.contact_geom || out.contact_efc_address)) return;
     {
       const int nc = M.ncon;
       // model-constant contact leaves (collision_driver.py:553-568 / :691-793)
@@ -4808,7 +4811,6 @@ __global__ void __launch_bounds__((PHASE == 17 ? 2 * MJH_WAVE : MJH_WAVE), ((siz
       wave_sync(); __builtin_amdgcn_s_barrier(); wave_sync();  // (an LDS-only fence on both sides: __syncthreads() would also wait for the kinematics stage's leaf stores to land)
       if (role == 0) E.template run_vel<false, true>();
       else E.template crb_factor<true>();
-      wave_sync(); __builtin_amdgcn_s_barrier();               // the next block of the grid-stride loop reuses the arenas
     }
     else if (PHASE == 12) { E.template run_kin<true>(); wave_sync(); E.template run_vel<false, true, true>(); }  // kinematics + velocity in one launch (the velocity phase needs nothing of CRB / CON)
     else E.run_sol();                                 // 4: solver phase; 6: solver phase of models with dof-frictionloss rows
