@@ -404,8 +404,12 @@ def main(args):
           "uuid": str(getattr(props, "uuid", "")), "cus": props.multi_processor_count, "HIP_VISIBLE_DEVICES": os.environ.get("HIP_VISIBLE_DEVICES"), "ROCR_VISIBLE_DEVICES": os.environ.get("ROCR_VISIBLE_DEVICES")}
     ranks = [me]
     if world > 1:
-        ranks = [None] * world
-        dist.all_gather_object(ranks, me)
+        try:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, me)
+            ranks = gathered
+        except Exception as ex:  # noqa: BLE001  (a report field must never cost the run its measurement)
+            ranks = [dict(me, note=f"all_gather_object failed: {type(ex).__name__}")]
 
     wl, B, dtype, mx, mdev, loop = setup_workload(args.workload, args.batch, device, rank)
     loop.bufs, loop.cur = [loop.d.clone(), loop.d.clone()], 0   # the out= loop starts from the same state (solver work depends on it)
@@ -471,7 +475,7 @@ def main(args):
             "device_allocations_in_timed_region": allocs_in_region,  # hipMalloc calls of torch's caching allocator between the two synchronizes (each one stalls the host for ~1 ms at these sizes)
         }
         line["ranks"] = ranks
-        line["one_device_per_rank"] = len({(r["uuid"] or r["device_index"]) for r in ranks}) == world  # false only under the one-GPU test hook (MJH_BENCH_SHARE_GPU=1)
+        line["one_device_per_rank"] = len(ranks) == world and len({(r["uuid"] or r["device_index"]) for r in ranks}) == world  # false only under the one-GPU test hook (MJH_BENCH_SHARE_GPU=1)
         if per_rank is not None:
             line["per_rank_ms_per_step"] = per_rank  # every rank's own K steps, fastest and slowest (the bracket above is max-reduced)
         if long_run is not None:
