@@ -178,6 +178,7 @@ struct DevModel {
   int lds_diet;                            // small models (four environments per wavefront): xmat / ximat are stored from registers and recomputed from xquat where read again, the subtree force sums fold into qfrc_bias -- the arena of kernel 13 drops from 3064 to 2272 B for the ant, i.e. 16 four-environment workgroups per CU fit (one round of waves at B = 16384 instead of two)
   int crow_by_con;                         // ... and the contact rows are in contact order, no gaps: dense row q belongs to contact q / con_rows (the small-model constraint phase then keeps its activity flags per CONTACT)
   int sol2_row_cap;                        // only while the arena of the register solver's first tier is carved (mjhip.hip): dense rows it keeps; 0 otherwise
+  int pair_cull_on;                        // non-zero: collision() in RK4 stages 1..3 narrow-phases only the pairs whose bounding spheres are within reach (MJH_PAIR_CULL=0: off)
   int sol2_incr;                           // non-zero: the register solver updates the Newton Hessian by the rows whose activity flipped instead of rebuilding it every iteration (MJH_SOL2_INCR=0: off)
   int sol2_hs;                             // non-zero: the register solver builds the Newton Hessian with block matrix instructions (float32, nv <= 16)
   // static per-row / per-contact tables of the plain constraint phase (no max_contact_points: slot c IS candidate c), so that a lane reaches
@@ -187,6 +188,7 @@ struct DevModel {
   int ncrow;                               // contact rows = nefc - (rows ahead of the contacts)
   const int* con_body;                     // 4 * ncon: body1, body2, root body of body1, of body2
   const unsigned long long* con_dmask;     // 2 * ncon: body_dofmask of body1, body2
+  const REAL* pair_cull;                   // 2 * npair: [reach^2, r1 + r2] of the bounding-sphere test RK4 stages 1..3 put before the narrow phase (reach^2 < 0: never culled)
   const int* cvx_pairs;                    // ncvxpair: indices (into pair_*) of the pairs with a convex pair function
   int ncvxpair;
 };

@@ -268,6 +268,11 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
 #define MJH_SOL2_CAPS_ON 0
 #endif
 #ifdef MJH_STAMPS
+#ifdef MJH_STAMPS_STAGE  /* -DMJH_STAMPS_STAGE=2: only the launches of that RK4 stage are recorded */
+#define MJH_STAMPS_STAGE_OK (KA.rk_stage == MJH_STAMPS_STAGE)
+#else
+#define MJH_STAMPS_STAGE_OK true
+#endif
 // each STAMP adds the shader-clock time since the previous STAMP of this environment's phase to its slot: sections inside loops
 // accumulate over the iterations
 #define STAMP(slot)                                                                                  \
@@ -275,7 +280,7 @@ __device__ __forceinline__ const KArgs<REAL>& kargs() {
     __builtin_amdgcn_sched_barrier(0);                                                               \
     unsigned long long t_ = __builtin_amdgcn_s_memtime();                                            \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                                              \
-    if (KA.stamps && lane() == 0) KA.stamps[e * 128 + (slot)] += t_ - stamp_prev;                   \
+    if (KA.stamps && lane() == 0 && MJH_STAMPS_STAGE_OK) KA.stamps[e * 128 + (slot)] += t_ - stamp_prev; \
     stamp_prev = __builtin_amdgcn_s_memtime();                                                       \
     __builtin_amdgcn_sched_barrier(0);                                                               \
   } while (0)
@@ -1463,7 +1468,46 @@ struct Env {
     if constexpr (PRE_NMAX > 0) sol2_prefetch<PRE_NMAX>(*pre);  // fused constraint + solver kernel: requested BEHIND this stage's own inputs (vmcnt is in order: the narrow phase does not wait for them)
 #endif
     wave_sync();
-    for (int p = l; p < M.npair; p += W) {
+    STAMP(22);
+    // Workspace Data of an RK4 stage (1..3): nothing of a contact leaves the launch but whether it is active (dist < includemargin) and, for the
+    // active ones, the rows built from pos / frame.  A pair whose bounding spheres are further apart than the margin cannot be active, whatever its
+    // exact distance: those pairs get the sphere gap as their dist (inactive, like the exact value) and the rest are packed into one dense list, so
+    // the lanes run the narrow phase over the near pairs only (the ant has 56 capsule pairs per environment and a handful of them anywhere near
+    // each other: two passes of the lanes became one).  Stage 0 and Euler steps publish dist / pos / frame of every contact and take no part in this.
+    const bool cull = !FRIC && DIRECT && M.pair_cull_on && KA.rk_stage > 0 && M.ncvxpair == 0 && M.con_rows > 0;  // (the consumer builds rows of ACTIVE contacts only: pos / frame of the others are never read)
+    int npair_run = M.npair;
+    int* const near_list = reinterpret_cast<int*>(S.i_con_act());  // (free until make_constraint's compaction; ncon >= npair entries)
+    if (cull) {
+      int nnear = 0;
+      for (int p0 = 0; p0 < M.npair; p0 += W) {
+        const int p = p0 + l;
+        bool near = false;
+        if (p < M.npair) {
+          // DevModel::pair_cull: [reach^2, r1 + r2] per pair -- reach = 1.01 (r1 + r2 + margin) + 1e-3 over the bounding spheres (a hundred thousand
+          // times the rounding of this test), negative for the pairs that are always narrow-phased (planes, hulls)
+          const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], k = M.pair_ncon[p], c0 = M.pair_dst[p * MJH_MAX_PAIR_CONTACTS], c1 = M.pair_dst[p * MJH_MAX_PAIR_CONTACTS + 1];
+          const REAL reach2 = M.pair_cull[2 * p], rsum = M.pair_cull[2 * p + 1];
+          const REAL *p1 = S.geom_xpos() + 3 * g1, *p2 = S.geom_xpos() + 3 * g2;
+          const REAL d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+          const REAL d2 = dot3(d, d);
+          near = !(reach2 >= 0 && d2 > reach2);
+          if (!near) {
+            const REAL gap = r_sqrt<REAL>(d2) - rsum;  // <= the exact distance, > includemargin: inactive like the exact value
+            S.con_dist()[c0] = gap;
+            if (k > 1) S.con_dist()[c1] = gap;
+          }
+        }
+        int tot;
+        const int at = sub_prefix_count<W>(near, tot) + nnear;
+        if (near) near_list[at] = p;
+        nnear += tot;
+      }
+      npair_run = nnear;
+      wave_sync();
+    }
+    STAMP(24);
+    for (int it = l; it < npair_run; it += W) {
+      const int p = cull ? near_list[it] : it;
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p], fn = M.pair_fn[p], k = M.pair_ncon[p];
       if (fn >= MJH_FN_PLANE_CONVEX) continue;
       const REAL *p1 = S.geom_xpos() + 3 * g1, *m1 = S.geom_xmat() + 9 * g1, *s1 = M.geom_size + 3 * g1;

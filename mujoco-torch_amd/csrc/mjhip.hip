@@ -334,6 +334,21 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     }
     fix.push_back({(const void**)&M.con_body, bb.add(cbody.data(), sizeof(int) * cbody.size())});
     fix.push_back({(const void**)&M.con_dmask, bb.add(cmask.data(), sizeof(unsigned long long) * cmask.size())});
+    // bounding-sphere reach of the sphere / capsule pairs (collision(): the cull ahead of the narrow phase in RK4 stages 1..3)
+    std::vector<REAL> pcull((size_t)2 * (d->npair > 0 ? d->npair : 1), (REAL)-1);
+    for (int p = 0; p < d->npair; p++) {
+      const int fn = d->pair_fn[p], g1 = d->pair_geom1[p], g2 = d->pair_geom2[p];
+      if (fn != MJH_FN_SPHERE_SPHERE && fn != MJH_FN_SPHERE_CAPSULE && fn != MJH_FN_CAPSULE_CAPSULE) continue;
+      const double r1 = d->geom_size[3 * g1] + (fn == MJH_FN_CAPSULE_CAPSULE ? d->geom_size[3 * g1 + 1] : 0.0);
+      const double r2 = d->geom_size[3 * g2] + (fn == MJH_FN_SPHERE_SPHERE ? 0.0 : d->geom_size[3 * g2 + 1]);
+      double margin = 0;
+      for (int q = 0; q < d->pair_ncon[p] && q < MJH_MAX_PAIR_CONTACTS; q++) margin = std::max(margin, (double)d->con_includemargin[d->pair_dst[p * MJH_MAX_PAIR_CONTACTS + q]]);
+      const double reach = (r1 + r2 + margin) * 1.01 + 1e-3;
+      pcull[2 * p] = (REAL)(reach * reach); pcull[2 * p + 1] = (REAL)(r1 + r2);
+    }
+    fix.push_back({(const void**)&M.pair_cull, bb.add(pcull.data(), sizeof(REAL) * pcull.size())});
+    static const bool cull_off = [] { const char* e = getenv("MJH_PAIR_CULL"); return e && e[0] == '0'; }();  // MJH_PAIR_CULL=0: RK4 stages 1..3 narrow-phase every pair like stage 0
+    M.pair_cull_on = cull_off ? 0 : 1;
   }
   {
     int max_jnt = 1;

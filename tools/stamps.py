@@ -13,7 +13,8 @@ lib = os.path.join(R, "mujoco-torch_amd", "lib", "libmjhip_stamps.so")
 src = [os.path.join(R, "mujoco-torch_amd", "csrc", f) for f in os.listdir(os.path.join(R, "mujoco-torch_amd", "csrc")) if f.endswith((".h", ".hip"))]
 if not os.path.exists(lib) or (os.environ.get("MJH_STAMPS_NOBUILD") != "1" and os.path.getmtime(lib) < max(os.path.getmtime(f) for f in src)):  # build it in the container: it travels with the snapshot
     csrc = os.path.join(R, "mujoco-torch_amd", "csrc")
-    subprocess.run([os.path.join(csrc, "build.sh"), "-DMJH_STAMPS"], check=True, env=dict(os.environ, MJH_BUILD_DIR=os.path.join(csrc, "build", "stamps"), MJH_BUILD_OUT=lib))
+    subprocess.run([os.path.join(csrc, "build.sh"), "-DMJH_STAMPS"] + os.environ.get("MJH_STAMPS_FLAGS", "").split(), check=True,  # e.g. MJH_STAMPS_FLAGS=-DMJH_STAMPS_STAGE=2
+                   env=dict(os.environ, MJH_BUILD_DIR=os.path.join(csrc, "build", "stamps"), MJH_BUILD_OUT=lib))
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     sys.exit(0)
 from mujoco_torch_amd import native
@@ -37,7 +38,7 @@ native.load_library().mjh_debug_set_stamps(None)
 st = stamps.cpu().numpy().astype(np.float64)
 names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, geoms, sites, cams", 4: "stores kin", 5: "subtree com", 6: "cinert + cdof", 7: "stores com",
          10: "CRB start", 11: "loads", 12: "crb subtree sums", 13: "inert_mul", 14: "qM", 15: "stores", 16: "chol_factor", 17: "store qLD",
-         19: "CON start", 20: "load geoms + narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
+         19: "CON start", 22: "load geoms (+ the rows' inputs)", 24: "pair cull (RK4 stages 1..3)", 20: "narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
          30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
          50: "SOL start", 51: "all loads issued + waited", 52: "inv_diag + chol_solve (qacc_smooth)", 53: "store qacc_smooth", 54: "warm/smooth contexts", 55: "main context (+gradient)", 57: "LS: mulM, mulJ, dots", 58: "LS: quad", 59: "LS: points + loop + update", 60: "(linesearch end)", 61: "update_constraint/gradient/search", 62: "solve stores"}
 names.update({70: "sol2: J rows gather (+ rest of the loads)", 71: "sol2: qacc_smooth solve", 72: "sol2: contexts (mulM2, mulJ2, costs, qfrc)", 73: "sol2: H build", 74: "sol2: H Cholesky",
