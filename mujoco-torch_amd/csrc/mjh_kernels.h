@@ -1428,7 +1428,8 @@ struct Env {
   bool con_inputs_loaded_ = false;  // collision() already fetched what make_constraint() reads (plain instantiation)
   bool ho_on_ = false;              // whole-pass kernel: this model's constraint-stage inputs travel on chip (DevModel::all_handoff)
   // HANDOFF (whole-pass kernel): the geom frames, qvel, subtree_com and cdof are already in the arena -- the first half of the kernel handed them over on chip
-  template <int PRE_NMAX = 0, bool HANDOFF = false>
+  // DEFER_CONST: the caller copies the model-constant contact leaves itself, behind the rows (contact_const_stores)
+  template <int PRE_NMAX = 0, bool HANDOFF = false, bool DEFER_CONST = false>
   __device__ __forceinline__ void collision(Sol2Pre<REAL, (PRE_NMAX > 0 ? PRE_NMAX : 1)>* pre = nullptr) {
     const int l = lane_here();
     if (HANDOFF && ho_on_) {
@@ -1612,7 +1613,7 @@ struct Env {
       if (M.nt_all) putnt(out.contact_dist, S.con_dist(), nc); else put(out.contact_dist, S.con_dist(), nc);
       putnt(out.contact_pos, S.con_pos(), 3 * nc); putnt(out.contact_frame, S.con_frame(), 9 * nc);
       STAMP(21);
-      if constexpr (PRE_NMAX > 0) return;  // fused constraint + solver kernel: the constant leaves are copied at the kernel's end (contact_const_stores), off the path to the solve
+      if constexpr (PRE_NMAX > 0 || DEFER_CONST) return;  // fused constraint + solver kernel: the constant leaves are copied at the kernel's end (contact_const_stores), off the path to the solve
       contact_const_stores();
     }
   }
@@ -3580,8 +3581,11 @@ struct Env {
   __device__ __forceinline__ void run_crb() { crb_factor<false>(); }
   __device__ __forceinline__ void run_con() {
     STAMP0();
-    if (M.ncon > 0) collision();
+    // the model-constant contact leaves (5 KB per environment for the ant's 60 contacts) go out LAST: copied between the narrow phase and the rows, every table read of the
+    // rows queued behind that burst (vmcnt is in order) -- at the end nothing of this wave waits for it, and the next wave's arithmetic runs while it drains
+    if (M.ncon > 0) collision<0, false, true>();
     if (KA.stages & 0x78) make_constraint();
+    if (M.ncon > 0 && !(FRIC && M.topk)) contact_const_stores();
   }
   // the solver's loads that depend on nothing this kernel computes (fused constraint + solver kernel)
   template <int NMAX>
