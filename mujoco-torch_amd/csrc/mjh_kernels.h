@@ -3998,6 +3998,9 @@ struct Env {
       if (!(rows_active > KA.row_lo && rows_active <= KA.row_hi)) return;
     }
     // ---- every global load of the phase, issued before the first wait -------------------------------------------------------------------------
+    // (the one table read that ADDRESSES a later load -- the dof of this lane's limit row, for its single Jacobian entry -- goes first: it is back while the rest is being requested)
+    int ldof_t = 0;
+    if constexpr (!CS) if (solving && nefc > 0 && lim) ldof_t = M.lim_dof[l];
     const REAL f = CS ? pre->f : ((dof && out.qfrc_smooth) ? out.qfrc_smooth[e * nv + l] : (REAL)0);              // qfrc_smooth
     TriPack<REAL, NMAX> T;
     if constexpr (CS) {
@@ -4043,14 +4046,16 @@ struct Env {
 #pragma unroll
       for (int j = 0; j < NQS; j++) qp[j] = l + W * j < nq ? gq[l + W * j] : (REAL)0;
       if (dof) qv = (from_in ? in.qvel : KA.cur.qvel)[e * nv + l];
-      if (from_in && KA.do_step) qv = checked(qv, (REAL)0);  // _check_state
       if (l < na) { const REAL* ga = KA.state_from_cur ? KA.cur.act : in.act; ac = ga ? ga[e * na + l] : (REAL)0; ad = out.act_dot ? out.act_dot[e * na + l] : (REAL)0; }
       }
-      // the state only feeds the integrator tail: parked in the arena (its own slots, not under the constraint rows)
+      // (the check of qvel and the copies of the state into the arena wait for these loads -- and, vmcnt being in order, for every load requested before them: they
+      // follow the rest of the requests, below.  Round 5 stamps of the ant's solver launch: 24 k of its 55 k cycles were SIX dependent round trips of this prologue.)
+      constexpr int NSLOT = 4;   // contact -> slot entries of the hand-over held in registers (contacts l + W j, j < NSLOT; more contacts than that: the loop below)
+      REAL slotv[NSLOT];
+      REAL nda_f = 0;
 #pragma unroll
-      for (int j = 0; j < NQS; j++) if (l + W * j < nq) S.qpos()[l + W * j] = qp[j];
-      if (dof) S.qvel()[l] = qv;
-      if (l < na) { S.act()[l] = ac; S.act_dot()[l] = ad; }
+      for (int j = 0; j < NSLOT; j++) slotv[j] = -1;
+      if constexpr (!CS) if (nefc > 0 && KA.hs && M.crow_by_con) hsp = KA.hs + e * KA.hs_reals;
       if (nefc > 0) {
         const REAL* gJ = out.efc_J + e * nefc * nv;
         if constexpr (CS) {
@@ -4058,23 +4063,47 @@ struct Env {
           if (lim) { ldof = con->ldof; Dl = con->Dl; arl = con->arl; Jl = con->jl; }
         } else {
         if (dof && KA.warm_src) warm = KA.warm_src[e * nv + l];
-        if (lim) { ldof = M.lim_dof[l]; Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; Jl = gJ[l * nv + ldof]; }
-        }
-        if (dof) limrow = M.dof_limrow[2 * l];
-        STAMP(81);
-        if constexpr (!CS) if (KA.hs && M.crow_by_con) hsp = KA.hs + e * KA.hs_reals;
-        if constexpr (CS) nda = con->nda;  // (the constraint stage built the rows in compact order)
-        else if (hsp) {
-          // The constraint phase handed the active contacts' rows over in compact order (KArgs::hs): every address below is fixed, so the whole solver input is ONE round of loads --
+        if (lim) { Dl = out.efc_D[e * nefc + l]; arl = out.efc_aref[e * nefc + l]; }
+        if (hsp) {
+          // The constraint phase handed the active contacts' rows over in compact order (KArgs::hs): every address is fixed, so the whole solver input is ONE round of loads --
           // the count, the contact -> slot table (for the Data-order efc_force store at the end), D / aref of this lane's rows; the rows themselves follow behind the tier test.
-          const int ncon = M.ncon, rows = M.con_rows;
-          nda = (int)hsp[0];
+          const int ncon = M.ncon;
+          nda_f = hsp[0];
 #pragma unroll
           for (int j = 0; j < RPL; j++) {
             const int r = l + W * j;
             if (r < ndc) { Dd[j] = hsp[1 + ncon + r]; ard[j] = hsp[1 + ncon + nd + r]; }
           }
-          for (int c = l; c < ncon; c += W) {
+#pragma unroll
+          for (int j = 0; j < NSLOT; j++) { const int c = l + W * j; if (c < ncon) slotv[j] = hsp[1 + c]; }
+        }
+        if (lim) { ldof = ldof_t; Jl = gJ[l * nv + ldof]; }  // (waits for the table read at the head only)
+        }
+        if (dof) limrow = M.dof_limrow[2 * l];
+      }
+      // ---- first uses ----
+      if constexpr (!CS) if (from_in && KA.do_step) qv = checked(qv, (REAL)0);  // _check_state
+      // the state only feeds the integrator tail: parked in the arena (its own slots, not under the constraint rows)
+#pragma unroll
+      for (int j = 0; j < NQS; j++) if (l + W * j < nq) S.qpos()[l + W * j] = qp[j];
+      if (dof) S.qvel()[l] = qv;
+      if (l < na) { S.act()[l] = ac; S.act_dot()[l] = ad; }
+      if (nefc > 0) {
+        STAMP(81);
+        if constexpr (CS) nda = con->nda;  // (the constraint stage built the rows in compact order)
+        else if (hsp) {
+          const int ncon = M.ncon, rows = M.con_rows;
+          nda = (int)nda_f;
+#pragma unroll
+          for (int j = 0; j < NSLOT; j++) {
+            const int c = l + W * j;
+            if (c < ncon) {
+              const int at = (int)slotv[j];
+              const int start = c * rows;
+              for (int k = 0; k < rows; k++) rdst[start + k] = at >= 0 ? (unsigned short)(at * rows + k) : (unsigned short)0xffff;
+            }
+          }
+          for (int c = l + W * NSLOT; c < ncon; c += W) {
             const int at = (int)hsp[1 + c];
             const int start = c * rows;
             for (int k = 0; k < rows; k++) rdst[start + k] = at >= 0 ? (unsigned short)(at * rows + k) : (unsigned short)0xffff;
