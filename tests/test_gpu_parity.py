@@ -372,6 +372,58 @@ print("ran")
                     assert _t.equal(t, o) or (t.is_floating_point() and _t.equal(_t.nan_to_num(t), _t.nan_to_num(o))), (env, case, n)
 
 
+def test_pair_cull_of_rk4_stages_is_invisible_on_scrambled_poses():
+    """RK4 stages 1..3 narrow-phase only the sphere / capsule pairs whose bounding spheres are within reach (DevModel::pair_cull); the far pairs get the sphere gap as their dist.
+    Nothing of that may show in a step's outputs: ant (56 capsule pairs) and a capsule humanoid under RK4, joint angles scrambled over their whole ranges so that limbs cross and
+    many pairs are near or in contact, three steps, every leaf bit-identical with MJH_PAIR_CULL=0."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import torch as _t
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+from _util import load_model, REAL_LEAVES, INT_LEAVES
+out = {}
+for xml, ov, dt in (("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float64), ("humanoid", {"integrator": 1, "solver": 1}, torch.float64)):
+    mx = load_model(xml, ov, dt)
+    B = 192
+    rs = np.random.RandomState(7)
+    d0 = mt.make_data(mx)
+    qpos = np.repeat(np.asarray(d0.qpos, dtype=np.float64)[None], B, 0)
+    qpos[:, 7:] += rs.uniform(-1.2, 1.2, size=(B, mx.nq - 7))   # hinges: far beyond the limits for many -- legs fold through each other
+    qpos[:, 2] += rs.uniform(-0.3, 0.1, size=B)
+    d = d0.expand(B).clone().replace(qpos=torch.tensor(qpos), qvel=torch.tensor(0.3 * rs.randn(B, mx.nv)))
+    if dt != torch.float64: d = d.to(dt)
+    mdev = mx.to("cuda")
+    got = d.to("cuda")
+    for _ in range(3): got = mt.step(mdev, got)
+    nact = int((native.data_field_tensor(got, "contact_dist") < 0).sum())
+    out[xml + str(dt)] = {n: native.data_field_tensor(got, n).cpu() for n in REAL_LEAVES + INT_LEAVES}
+    out[xml + str(dt)]["_touching"] = torch.tensor(nact)
+torch.save(out, sys.argv[1])
+print("ran")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for i, env in enumerate(({}, {"MJH_PAIR_CULL": "0"})):
+            f = os.path.join(td, f"{i}.pt")
+            r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ran" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-1500:])
+            res.append(_t.load(f))
+    for case in res[0]:
+        assert int(res[0][case]["_touching"]) > 50, (case, int(res[0][case]["_touching"]))  # the poses do put geoms in contact
+        for n, t in res[0][case].items():
+            o = res[1][case][n]
+            assert _t.equal(t, o) or (t.is_floating_point() and _t.equal(_t.nan_to_num(t), _t.nan_to_num(o))), (case, n)
+
+
 def test_batches_past_one_launch_are_cut_on_the_host():
     """The kernels run one unit of work per workgroup (no grid-stride loops since round 5): a batch of more than 2^20 workgroups is cut into several launches by the host.
     MJH_MAX_GRID_LOG2=3 brings that limit down to 8 workgroups, so a batch of 203 environments takes every multi-launch path -- packed / paired / odd-tail phase kernels, both
