@@ -138,6 +138,10 @@ struct DevModel {
   const int* chain_dof;        // nbody*max_depth: dofadr | dofnum << 16 of the k-th body on the path world -> b
   const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none
   int max_jnt;
+  // kinematics by pointer jumping (null: every lane walks world -> its body), one allocation -- the kernel argument block is at its 4 KiB limit:
+  //   int  anc[R][nbody]   the ancestor 2^r levels above body b, 0 where that is the world or beyond; R = ceil(log2(max_depth))
+  //   REAL start[nbody][7] body_pos, body_quat (from byte offset 8 * ((R * nbody + 1) / 2)); for children of the world composed with the world body's own frame
+  const int* kin_tab;
   const int* efc_row_con;                  // nefc: contact index of a contact row, -1 for limit rows
   const int* rf_sensor;                    // nrfq: rangefinder (sns_* index) of entry q of rf_geom
   const int* rf_site;                      // nrfq: ... its site

@@ -1013,10 +1013,111 @@ struct Env {
       for (int i = 0; i < 4; i++) S.jquat()[4 * j + i] = q[i];
     }
     wave_sync();
+    // Pointer jumping (DevModel::kin_tab; models with one body per lane).  The serial walk below has every lane compose its whole ancestor chain -- ~7 levels and ~10 joints of
+    // dependent float64 rotations for the humanoid, 35 k of the kernel's 309 k cycles, the same chain recomputed by every lane.  Here each lane first composes the frame of ITS body
+    // relative to its parent (body offset, then its own joints: smooth.py:85-120 in the parent's frame), then ceil(log2(depth)) rounds replace "relative to the ancestor 2^r levels
+    // up" by "relative to the ancestor 2^(r+1) levels up" (frame(a) o frame(b), through the xpos / xquat arrays of the arena), and the joints' anchors and axes, formed in the
+    // parent's frame, are carried to the world by one more rotation.  The same compositions as the walk in a different association: results agree to rounding (1e-16 relative),
+    // not bit for bit -- the parity bounds of the leaves upstream of the solver are 1e-9 (float64) / 2e-4 (float32).
+    const bool jump = M.kin_tab != nullptr && M.nbody <= W;
+    const int* const kin_anc = M.kin_tab;
+    if (jump) {
+      const int nb = M.nbody, md = M.max_depth;
+      int R = 0;
+      while ((1 << R) < md) R++;
+      const REAL* const kin_start = reinterpret_cast<const REAL*>(reinterpret_cast<const unsigned char*>(M.kin_tab) + 8 * (((size_t)R * nb + 1) / 2));
+      const int b = l;
+      const bool body = b > 0 && b < nb;
+      REAL pos[3] = {0, 0, 0}, quat[4] = {1, 0, 0, 0};
+      int anc_r = 0;
+      if (body) {
+        anc_r = R > 0 ? kin_anc[b] : 0;
+#pragma unroll
+        for (int i = 0; i < 3; i++) pos[i] = kin_start[7 * b + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) quat[i] = kin_start[7 * b + 3 + i];
+        const int jn = M.body_jntnum[b], j0 = M.body_jntadr[b];
+        for (int jj = 0; jj < jn; jj++) {
+          const int j = j0 + jj, t = M.jnt_type[j], qa = M.jnt_qposadr[j];
+          const REAL jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+          const REAL jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
+          const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
+          REAL anchor[3], axis[3];
+          if (t == JNT_FREE) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
+            axis[0] = 0; axis[1] = 0; axis[2] = 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) quat[i] = ql[i];
+          } else {
+            REAL r[3];
+            rotate(jpos, quat, r);
+#pragma unroll
+            for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
+            rotate(jaxis, quat, axis);
+            if (t == JNT_BALL || t == JNT_HINGE) {
+              quat_mul(quat, ql, quat);
+              rotate(jpos, quat, r);
+#pragma unroll
+              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+            } else {
+              const REAL dq = ql[0];
+#pragma unroll
+              for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }  // (in the parent's frame: carried to the world below)
+        }
+      }
+      if (b == 0) {  // the world body: the frame the walk starts from
+#pragma unroll
+        for (int i = 0; i < 3; i++) pos[i] = M.body_pos[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) quat[i] = M.body_quat[i];
+      }
+      if (b < nb) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) S.xquat()[4 * b + i] = quat[i];
+      }
+      wave_sync();
+      for (int r = 0; r < R; r++) {  // (uniform trip count)
+        const int a = anc_r;
+        REAL pa[3] = {0, 0, 0}, qa4[4] = {1, 0, 0, 0};
+        if (a > 0) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) pa[i] = S.xpos()[3 * a + i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) qa4[i] = S.xquat()[4 * a + i];
+        }
+        if (r + 1 < R) anc_r = body ? kin_anc[(r + 1) * nb + b] : 0;
+        wave_sync();  // every lane has read its ancestor's frame of this round
+        if (a > 0) {
+          REAL rr[3];
+          rotate(pos, qa4, rr);
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = pa[i] + rr[i];
+          quat_mul(qa4, quat, quat);
+#pragma unroll
+          for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) S.xquat()[4 * b + i] = quat[i];
+        }
+        wave_sync();
+      }
+    }
     for (int b = l; b < M.nbody; b += W) {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
       const int depth = M.body_depth[b], md = M.max_depth;
+      if (jump) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) pos[i] = S.xpos()[3 * b + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) quat[i] = S.xquat()[4 * b + i];
+      } else {
       // the constants of level k + 1 are requested while level k is computed: the chain ids depend on (b, k) only
       int c_n = depth > 0 ? M.body_chain[b * md] : 0;
       REAL bp_n[3] = {M.body_pos[3 * c_n], M.body_pos[3 * c_n + 1], M.body_pos[3 * c_n + 2]};
@@ -1077,6 +1178,7 @@ struct Env {
           }
         }
       }
+      }
       if (M.nmocap > 0) {  // mocap bodies take the caller's pose after the tree pass (smooth.py:105-113); children of the world, no joints
         const int k = M.body_mocapid[b];
         if (k >= 0) {
@@ -1111,6 +1213,23 @@ struct Env {
       }
     }
     wave_sync();
+    if (jump) {  // anchors and axes of the joints of bodies below the first level: from the parent's frame to the world (the mocap override above touches no parent: mocap bodies have no children here)
+      for (int j = l; j < M.njnt; j += W) {
+        const int p = kin_anc[M.jnt_bodyid[j]];  // (round 0 of the table: the parent, 0 = the world; one level deep models have no table rows and no such joints)
+        if (M.max_depth > 1 && p > 0) {
+          const REAL* pq = S.xquat() + 4 * p;
+          const REAL* pp = S.xpos() + 3 * p;
+          REAL al[3], xl[3], r[3], x[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++) { al[i] = S.xanchor()[3 * j + i]; xl[i] = S.xaxis()[3 * j + i]; }
+          rotate(al, pq, r);
+          rotate(xl, pq, x);
+#pragma unroll
+          for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = pp[i] + r[i]; S.xaxis()[3 * j + i] = x[i]; }
+        }
+      }
+      wave_sync();
+    }
     STAMP(2);
     // the frames go out now, ahead of the geom / site / camera loops: a phase's leaf stores are bursts of tens of MB issued by every wave at the same
     // moment, and the first table read behind one waits until L2 has taken it (vmcnt is in order) -- several smaller bursts with arithmetic between them drain

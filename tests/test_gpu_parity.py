@@ -424,6 +424,66 @@ print("ran")
             assert _t.equal(t, o) or (t.is_floating_point() and _t.equal(_t.nan_to_num(t), _t.nan_to_num(o))), (case, n)
 
 
+def test_pointer_jumping_kinematics_agrees_with_the_serial_walk():
+    """Deep trees of few-iteration models compose their body frames by pointer jumping (DevModel::kin_tab) instead of every lane walking world -> its body: the same
+    compositions in another association.  Forced on for every tree (MJH_KIN_JUMP=1) and off (=0), the kinematic leaves of 17 models -- free, ball, slide and hinge joints,
+    mocap bodies, several joints per body, trees one to eight levels deep -- agree to 1e-13 of their scale in float64 on scrambled poses, and the default selection
+    (no variable) equals one of the two bit for bit."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    import torch as _t
+
+    code = r'''
+import sys
+sys.path.insert(0, "tests"); sys.path.insert(0, "mujoco-torch_amd"); sys.path.insert(0, "oracle")
+import numpy as np, torch, mujoco_torch_amd as mt
+from mujoco_torch_amd import native
+from _util import load_model
+out = {}
+LEAVES = ["xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "site_xpos", "subtree_com", "cdof", "cinert", "qpos"]
+for xml in ("humanoid", "walker2d", "hopper", "halfcheetah", "ant", "swimmer", "pendula", "ball_limits", "ball_free_actuators", "mocap_target", "satellite_large", "centipede",
+            "gravcomp_arm", "sensor_rig2", "equality_loops", "tendon_spatial", "cartpole"):
+    mx = load_model(xml, {}, torch.float64)
+    B = 32
+    rs = np.random.RandomState(11)
+    d0 = mt.make_data(mx)
+    qpos = np.repeat(np.asarray(d0.qpos, dtype=np.float64)[None], B, 0) + rs.uniform(-0.7, 0.7, size=(B, mx.nq))
+    kw = dict(qpos=torch.tensor(qpos), qvel=torch.tensor(0.1 * rs.randn(B, mx.nv)))
+    if mx.nmocap:
+        kw["mocap_pos"] = torch.tensor(rs.uniform(-1, 1, size=(B, mx.nmocap, 3)))
+        kw["mocap_quat"] = torch.tensor(rs.randn(B, mx.nmocap, 4))
+    d = d0.expand(B).clone().replace(**kw)
+    got = mt.forward(mx.to("cuda"), d.to("cuda"))
+    out[xml] = {n: native.data_field_tensor(got, n).cpu() for n in LEAVES}
+torch.save(out, sys.argv[1])
+print("ran")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = []
+        for i, env in enumerate(({"MJH_KIN_JUMP": "0"}, {"MJH_KIN_JUMP": "1"}, {})):
+            f = os.path.join(td, f"{i}.pt")
+            e = {k: v for k, v in os.environ.items() if k != "MJH_KIN_JUMP"}
+            r = subprocess.run([sys.executable, "-c", code, f], cwd=root, env=dict(e, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ran" in r.stdout, (env, r.stdout[-1500:] + r.stderr[-1500:])
+            res.append(_t.load(f))
+    walk, jump, default = res
+    moved = 0
+    for case in walk:
+        for n, t in walk[case].items():
+            o = jump[case][n]
+            scale = max(float(t.abs().max()), 1e-3) if t.numel() else 1.0
+            err = float((t - o).abs().max()) if t.numel() else 0.0
+            assert err <= 1e-13 * max(scale, 1.0), (case, n, err, scale)
+            moved += int(err > 0)
+            dflt = default[case][n]
+            assert _t.equal(dflt, t) or _t.equal(dflt, o), (case, n, "the default selection is neither form")
+    assert moved > 20  # the two forms do differ in the last bits: the comparison is not of a path with itself
+
+
 def test_batches_past_one_launch_are_cut_on_the_host():
     """The kernels run one unit of work per workgroup (no grid-stride loops since round 5): a batch of more than 2^20 workgroups is cut into several launches by the host.
     MJH_MAX_GRID_LOG2=3 brings that limit down to 8 workgroups, so a batch of 203 environments takes every multi-launch path -- packed / paired / odd-tail phase kernels, both
