@@ -223,6 +223,10 @@ def timed(fn, steps, device, world, backend):
     if world > 1:
         dist.barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # torch creates the HIP event behind an Event at its FIRST record(): 0.2 - 0.5 ms for the first timing events of a process (measured, tools/window_probe.py) -- inside the
+    # bracket that was 7 - 15 % of the driver's 20-step window, charged to the steps.  Both events are recorded once here, outside the bracket; recording them again is cheap.
+    ev0.record()
+    ev1.record()
     torch.cuda.synchronize(device)
     ms0 = torch.cuda.memory_stats(device)
     a0, r0 = ms0.get("num_device_alloc", 0), ms0.get("reserved_bytes.all.current", 0)
