@@ -374,7 +374,7 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       M.kin_tab = nullptr;
       int R = 0;
       while ((1 << R) < max_depth) R++;
-      if (on && nb > 1) {
+      if (on && nb > 1 && nb <= 32) {  // (one body per lane in EVERY instantiation the model can run at -- 16 lanes per environment only with nbody <= 16, else 32 or 64 -- so that which kernel a batch size or an odd tail selects never changes a bit)
         const size_t anc_bytes = 8 * (((size_t)R * nb + 1) / 2);
         std::vector<unsigned char> tab(anc_bytes + sizeof(REAL) * (size_t)nb * 7, 0);
         int* anc = reinterpret_cast<int*>(tab.data());
