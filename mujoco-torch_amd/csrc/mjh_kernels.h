@@ -1019,6 +1019,41 @@ struct Env {
     // up" by "relative to the ancestor 2^(r+1) levels up" (frame(a) o frame(b), through the xpos / xquat arrays of the arena), and the joints' anchors and axes, formed in the
     // parent's frame, are carried to the world by one more rotation.  The same compositions as the walk in a different association: results agree to rounding (1e-16 relative),
     // not bit for bit -- the parity bounds of the leaves upstream of the solver are 1e-9 (float64) / 2e-4 (float32).
+    // one joint of a body (smooth.py:85-120): its anchor and axis in the frame (pos, quat) reached so far, then that frame moved by the joint
+    auto joint_step = [&](int j, REAL* pos, REAL* quat, bool keep) {
+      const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
+      const REAL jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+      const REAL jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
+      const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
+      REAL anchor[3], axis[3];
+      if (t == JNT_FREE) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
+        axis[0] = 0; axis[1] = 0; axis[2] = 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) quat[i] = ql[i];
+      } else {
+        REAL r[3];
+        rotate(jpos, quat, r);
+#pragma unroll
+        for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
+        rotate(jaxis, quat, axis);
+        if (t == JNT_BALL || t == JNT_HINGE) {
+          quat_mul(quat, ql, quat);
+          rotate(jpos, quat, r);
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+        } else {
+          const REAL dq = ql[0];
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
+        }
+      }
+      if (keep) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }
+      }
+    };
     const bool jump = M.kin_tab != nullptr && M.nbody <= W;
     const int* const kin_anc = M.kin_tab;
     if (jump) {
@@ -1037,38 +1072,7 @@ struct Env {
 #pragma unroll
         for (int i = 0; i < 4; i++) quat[i] = kin_start[7 * b + 3 + i];
         const int jn = M.body_jntnum[b], j0 = M.body_jntadr[b];
-        for (int jj = 0; jj < jn; jj++) {
-          const int j = j0 + jj, t = M.jnt_type[j], qa = M.jnt_qposadr[j];
-          const REAL jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
-          const REAL jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
-          const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
-          REAL anchor[3], axis[3];
-          if (t == JNT_FREE) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
-            axis[0] = 0; axis[1] = 0; axis[2] = 1;
-#pragma unroll
-            for (int i = 0; i < 4; i++) quat[i] = ql[i];
-          } else {
-            REAL r[3];
-            rotate(jpos, quat, r);
-#pragma unroll
-            for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
-            rotate(jaxis, quat, axis);
-            if (t == JNT_BALL || t == JNT_HINGE) {
-              quat_mul(quat, ql, quat);
-              rotate(jpos, quat, r);
-#pragma unroll
-              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
-            } else {
-              const REAL dq = ql[0];
-#pragma unroll
-              for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }  // (in the parent's frame: carried to the world below)
-        }
+        for (int jj = 0; jj < jn; jj++) joint_step(j0 + jj, pos, quat, true);  // (anchors / axes in the parent's frame: carried to the world below)
       }
       if (b == 0) {  // the world body: the frame the walk starts from
 #pragma unroll
@@ -1143,40 +1147,7 @@ struct Env {
           for (int i = 0; i < 3; i++) pos[i] = pos[i] + r[i];
           quat_mul(quat, bq, quat);
         }
-        for (int jj = 0; jj < jn; jj++) {
-          const int j = j0 + jj, t = M.jnt_type[j], qa = M.jnt_qposadr[j];
-          const REAL jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
-          const REAL jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
-          const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
-          REAL anchor[3], axis[3];
-          if (t == JNT_FREE) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
-            axis[0] = 0; axis[1] = 0; axis[2] = 1;
-#pragma unroll
-            for (int i = 0; i < 4; i++) quat[i] = ql[i];
-          } else {
-            REAL r[3];
-            rotate(jpos, quat, r);
-#pragma unroll
-            for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
-            rotate(jaxis, quat, axis);
-            if (t == JNT_BALL || t == JNT_HINGE) {
-              quat_mul(quat, ql, quat);
-              rotate(jpos, quat, r);
-#pragma unroll
-              for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
-            } else {
-              const REAL dq = ql[0];
-#pragma unroll
-              for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
-            }
-          }
-          if (own) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }
-          }
-        }
+        for (int jj = 0; jj < jn; jj++) joint_step(j0 + jj, pos, quat, own);
       }
       }
       if (M.nmocap > 0) {  // mocap bodies take the caller's pose after the tree pass (smooth.py:105-113); children of the world, no joints
