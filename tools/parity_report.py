@@ -45,7 +45,7 @@ for name, (xml, ov, dt, B) in CONFIGS.items():
         best = {}
         for n in SOLVER_LEAVES:  # per leaf on each environment's accepted branch
             best[n] = max(rel_err(got[n][e], c["alts"][int(c["which"][e])][n][e], solver_floor(n, {"efc_force": c["alts"][int(c["which"][e])]["efc_force"][e]})) for e in range(B))
-        steps.append({"pre_solver_leaves": {n: c["pre"][n] for n in PRE_SOLVER}, "integer_leaves_bit_exact": bool(c["ints_ok"]),
+        steps.append({"pre_solver_leaves": {n: c["pre"][n] for n in PRE_SOLVER}, "pre_solver_leaves_elementwise": {n: c["pre_elem"][n] for n in PRE_SOLVER}, "integer_leaves_bit_exact": bool(c["ints_ok"]),
                       "solver_leaves_vs_natural_oracle_run": c["leaf_nat"], "solver_leaves_on_accepted_branch": best,
                       "state_leaves_elementwise_on_accepted_branch": float(c["elem_best"].max()),
                       "envs_on_non_natural_branch": float((c["err_nat"] > (1e-8 if dt == torch.float64 else 2e-3)).mean()),
@@ -53,6 +53,7 @@ for name, (xml, ov, dt, B) in CONFIGS.items():
         dg = og
     out["configs"][name] = {"xml": xml, "overrides": ov, "dtype": str(dt)[6:], "envs": B, "steps": steps}
     out["summary"][name] = {"dtype": str(dt)[6:], "max_pre_solver": max(max(s["pre_solver_leaves"].values()) for s in steps),
+                            "max_pre_solver_elementwise": max(max(s["pre_solver_leaves_elementwise"].values()) for s in steps),
                             "max_solver_on_accepted_branch": max(max(s["solver_leaves_on_accepted_branch"].values()) for s in steps),
                             "max_state_qpos_qvel_on_accepted_branch": max(max(s["solver_leaves_on_accepted_branch"][k] for k in ("qpos", "qvel")) for s in steps),
                             "max_state_elementwise_on_accepted_branch": max(s["state_leaves_elementwise_on_accepted_branch"] for s in steps),
