@@ -90,6 +90,10 @@ WORKLOADS = {
     "cartpole": dict(xml="cartpole", overrides={}, dtype=torch.float64, batch=4096, name="cartpole.xml Euler float64"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# SURVEY.md section 8(d), "ALGORITHMIC bytes per env-step" as printed there (consumed + produced Data leaves; the survey's probe counts qpos under
+# kinematics AND _advance and leaves sensordata out, so its figures sit 56 - 224 B off the leaf arithmetic of algorithmic_bytes_per_env_step below,
+# which the line carries beside them).  `roofline.achieved` / `frac` are computed from THESE so that they can be reproduced from the survey's text.
+SURVEY_8D_BYTES = {("humanoid", "f64"): 50392, ("humanoid32k", "f64"): 50392, ("ant", "f32"): 26392, ("mesh", "f32"): 13076, ("cartpole", "f64"): 2448}
 
 
 def algorithmic_bytes_per_env_step(mx, dtype):
@@ -165,13 +169,57 @@ def build_inputs(mx, B, dtype, device, seed=42):
     return d.to(device)
 
 
+def usable_cpus():
+    """What this process may actually run on: the affinity mask, the cgroup CPU quota (v2 cpu.max / v1 cfs_quota_us) and the physical cores behind
+    the mask (SMT siblings share one core's FP pipes).  `omp_get_max_threads()` reports none of these: round 5's all-threads leg ran 128 threads and
+    scaled 6.2 x."""
+    import math
+
+    aff = sorted(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = set()
+    try:
+        for c in aff:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id") as f:
+                cid = f.read().strip()
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                pkg = f.read().strip()
+            cores.add((pkg, cid))
+    except OSError:
+        cores = set()
+    threads = len(aff)
+    if quota is not None:
+        threads = max(1, min(threads, int(math.floor(quota + 1e-9)) or 1))
+    return {"affinity_cpus": len(aff), "cgroup_cpu_quota": quota, "physical_cores_in_mask": len(cores) or None, "os_cpu_count": os.cpu_count(),
+            "loadavg_1min": os.getloadavg()[0], "threads": threads}
+
+
 def cpu_baseline(mx, dtype, B_sample, steps):
-    """Times the CPU oracle (scalar C restatement of the reference step, OpenMP over envs) on host cores: every hardware thread of the
-    box (the figure moves with whatever else the host is running) and ONE thread (load-independent)."""
+    """Times the CPU oracle (scalar C restatement of the reference step, OpenMP over envs) on the host cores this process may use -- the affinity
+    mask capped by the cgroup quota, NOT the machine's hardware-thread count -- and on ONE thread (load-independent).  When the
+    all-threads leg scales worse than half of threads x single-thread (SMT siblings, a loaded shared host), smaller thread counts are tried and
+    the BEST is reported with the count that produced it; if even that stays under half of (physical cores used) x single-thread the object says so
+    loudly (`healthy: false`, stderr) instead of printing a strawman beside the GPU figure."""
     import pyoracle
 
     pyoracle.build()
-    threads = pyoracle.lib().mjo_max_threads()
+    cpus = usable_cpus()
+    threads = cpus["threads"]
 
     def sample(nB, nthreads, min_steps, t_min, t_max):
         d = mt.make_data(mx).expand(nB).clone()
@@ -180,15 +228,35 @@ def cpu_baseline(mx, dtype, B_sample, steps):
             d = d.to(dtype)
         return pyoracle.time_steps(mx, d, nthreads, min_steps, t_min, t_max)  # the C step only: packed once, buffers ping-pong
 
-    v, done, dt = sample(B_sample, threads, steps, 10.0, 30.0)
     n1 = min(B_sample, 256)
     v1, done1, dt1 = sample(n1, 1, 2, 4.0, 12.0)
-    # the one-thread figure comes first: it is the load-independent one (the all-threads figure swings 126 - 223 k with what else the shared host runs)
-    return dict(single_thread=dict(value=v1, unit="env-steps/s", cores=1, sample=f"{n1} envs x {done1} steps on one thread ({dt1:.1f} s)",
-                                   note="load-independent: quote this one when comparing boxes"),
-                value=v, unit="env-steps/s", cores=threads, kind="port",
-                sample=f"{B_sample} envs x {done} steps of one trajectory, oracle/mjoracle.c (mjo_step calls only) with OpenMP over environments ({dt:.1f} s); "
-                       "moves with the shared host's load")
+    tried = []
+    v, done, dt = sample(B_sample, threads, steps, 8.0, 24.0)
+    tried.append({"threads": threads, "value": v, "seconds": dt})
+    best = (v, done, dt, threads)
+    phys = cpus["physical_cores_in_mask"] or threads
+    for t in sorted({max(1, min(threads, phys)), max(1, threads // 2), max(1, threads // 4)} - {threads}, reverse=True):
+        if best[0] >= 0.5 * best[3] * v1:
+            break
+        vt, donet, dtt = sample(B_sample, t, steps, 4.0, 10.0)
+        tried.append({"threads": t, "value": vt, "seconds": dtt})
+        if vt > best[0]:
+            best = (vt, donet, dtt, t)
+    v, done, dt, used = best
+    eff_threads = v / (used * v1)
+    eff_cores = v / (min(used, phys) * v1)
+    healthy = eff_cores >= 0.5
+    out = dict(single_thread=dict(value=v1, unit="env-steps/s", cores=1, sample=f"{n1} envs x {done1} steps on one thread ({dt1:.1f} s)",
+                                  note="load-independent: quote this one when comparing boxes"),
+               value=v, unit="env-steps/s", cores=used, kind="port",
+               sample=f"{B_sample} envs x {done} steps of one trajectory, oracle/mjoracle.c (mjo_step calls only) with OpenMP over environments on {used} threads ({dt:.1f} s)",
+               host=cpus, thread_counts_tried=tried, scaling_vs_single_thread=v / v1, parallel_efficiency_per_thread=eff_threads,
+               parallel_efficiency_per_physical_core=eff_cores, healthy=healthy)
+    if not healthy:
+        out["error"] = (f"all-threads CPU leg reached only {v / v1:.1f} x one thread on {used} threads ({min(used, phys)} physical cores): below half of linear; "
+                        "the host is loaded or the mask / quota is wrong -- do not quote `value`, quote single_thread")
+        print("bench.py: CPU BASELINE UNHEALTHY: " + out["error"], file=sys.stderr, flush=True)
+    return out
 
 
 class Loop:
@@ -263,7 +331,7 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 
 
-PROFILE_ROUND = "r05"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
+PROFILE_ROUND = "r06"   # profiles/<round>/: where this round's committed PMC traffic and parity summaries live
 
 
 def setup_workload(key, B, device, rank):
@@ -308,7 +376,10 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
         with open(tfile) as f:
             tj = json.load(f)
     in_b, out_b = algorithmic_bytes_per_env_step(mx, dtype)
-    alg = in_b + out_b
+    alg_leaves = in_b + out_b
+    dkey = "f64" if dtype == torch.float64 else "f32"
+    plain = not os.environ.get("BENCH_OPT") and not (ARGS is not None and getattr(ARGS, "dtype", ""))
+    alg = SURVEY_8D_BYTES.get((key, dkey), alg_leaves) if plain else alg_leaves
     achieved = alg * B / (kernel_ms * 1e-3) / 1e9
     rname = "double" if dtype == torch.float64 else "float"
     kio = kernel_algorithmic_bytes(nm)
@@ -317,8 +388,16 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
         rd, wr = kio.get(k, (0, 0))
         gbs = (rd + wr) * B / (t["avg_ms"] * 1e-3) / 1e9
         per_kernel.append({"kernel": KERNEL_NAME[k].format(r=rname), "id": k, "avg_us": 1e3 * t["avg_ms"], "launches_per_step": t["launches_per_step"],
-                           "algorithmic_bytes_per_env": rd + wr, "read_bytes_per_env": rd, "written_bytes_per_env": wr, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS})
+                           "kernel_io_bytes_per_env": rd + wr, "read_bytes_per_env": rd, "written_bytes_per_env": wr, "kernel_io_achieved": gbs, "kernel_io_frac": gbs / HBM_PEAK_GBS})
     dom = per_kernel[0]
+    # the step's algorithmic bytes over the launch(es) that move them.  A one-launch step (the headline humanoid) prices its kernel at the
+    # whole figure: 50,392 B x B / that kernel's average launch duration.  A step of several launches has no per-kernel split of the figure in the survey
+    # (RK4 stages 1..3 and the hand-overs between phases move no algorithmic byte at all), so the dominant kernel is priced at the step's figure over
+    # the SUM of the step's launch durations -- the number VERDICT r05 computed by hand; the library's own per-kernel account stays as kernel_io_*.
+    launches_ms = sum(t["ms_per_step"] for t in kernels.values())
+    one_launch = len(kernels) == 1 and abs(dom["launches_per_step"] - 1.0) < 1e-9
+    d8_ms = dom["avg_us"] * 1e-3 if one_launch else launches_ms
+    d8_achieved = alg * B / (d8_ms * 1e-3) / 1e9
     ktraffic, traffic, tsrc = None, None, None
     if tj is not None:
         stale = tj.get("lib_fingerprint") != fp
@@ -339,8 +418,13 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
                     ktraffic = kb
     # dominant kernel of the step: the global-memory bytes its code reads + writes per launch / its average launch duration (HIP
     # events around each launch, on the launch stream); "step" = the same for the whole launch sequence (SURVEY 8(d) per-unit figure)
-    return {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"], "traffic": ktraffic,
-            "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_env"] * B,
+    return {"bound": "hbm", "achieved": d8_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d8_achieved / HBM_PEAK_GBS, "traffic": ktraffic if one_launch else traffic,
+            "kernel": dom["kernel"], "kernel_avg_us": dom["avg_us"], "algorithmic_bytes_per_launch": alg * B if one_launch else None,
+            "frac_is": (f"SURVEY 8(d) {alg} B/env-step x {B} envs / the one launch of the step ({dom['avg_us']:.1f} us, HIP events on the launch stream)" if one_launch else
+                        f"SURVEY 8(d) {alg} B/env-step x {B} envs / the sum of the step's launch durations ({1e3 * launches_ms:.1f} us over {sum(t['launches_per_step'] for t in kernels.values()):.0f} launches, HIP events on the launch stream); `kernel` names the longest of them"),
+            "algorithmic_bytes_per_env_step": alg, "algorithmic_bytes_per_env_step_from_leaf_sizes": alg_leaves,
+            "kernel_io_frac": dom["kernel_io_frac"], "kernel_io_achieved": dom["kernel_io_achieved"], "kernel_io_bytes_per_launch": dom["kernel_io_bytes_per_env"] * B,
+            "kernel_io_is": "the library's own account of the global-memory extents the dominant kernel's code reads + writes (csrc/mjh_io.h; counts re-reads of leaves the same launch wrote): traffic-like, not SURVEY 8(d)",
             "traffic_source": tsrc, "per_kernel": per_kernel,
             "step": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_env_step": alg,
                      "algorithmic_bytes_per_step": alg * B, "device_ms_per_step": kernel_ms,

@@ -24,6 +24,9 @@
 
 #include "../include/mjhip.h"
 
+#define MJO_KNIFE_BAND_F64 1e-11
+#define MJO_KNIFE_BAND_F32 1e-4
+
 /* contact hint of the next run (see "narrow-phase ties" in mjoracle_impl.h): the caller's expected contact leaves
    [B, ncon(,3|,9)] in the run's dtype, and an int32 [B] that receives the number of pairs resolved non-naturally */
 static const void *g_hint_dist, *g_hint_pos, *g_hint_frame;
@@ -42,6 +45,31 @@ void mjo_set_stage_tie_flip(unsigned mask, int32_t* counts) { g_stage_tie_flip =
    line-search iterations, non-trivial constraint rows summed over the calls; NULL = off */
 static int32_t* g_work_stats;
 void mjo_set_work_stats(int32_t* stats) { g_work_stats = stats; }
+
+/* the line search's knife band (mjoracle_impl.h, linesearch): a candidate whose derivative is below band x |d0(0)| counts as a rounding-noise candidate.
+   Defaults justified by the histogram below (profiles/r06/knife_hist_*.txt); settable for the experiment "no verdict changes at another band" */
+static double g_knife_band_f64 = MJO_KNIFE_BAND_F64, g_knife_band_f32 = MJO_KNIFE_BAND_F32;
+void mjo_set_knife_band(double f64, double f32) { g_knife_band_f64 = f64 > 0 ? f64 : MJO_KNIFE_BAND_F64; g_knife_band_f32 = f32 > 0 ? f32 : MJO_KNIFE_BAND_F32; }
+void mjo_get_knife_band(double* f64, double* f32) { *f64 = g_knife_band_f64; *f32 = g_knife_band_f32; }
+/* histogram of |d0| / |d0(0)| over EVERY line-search candidate of the next runs (tools/knife_hist.py): int64 [MJO_KNIFE_BINS] -- bin 0: exactly zero,
+   bin 1 + k: 1e(k - 30) <= ratio < 1e(k - 29) (k = 0 collects everything below 1e-29), last bin: ratio >= 1e2; a second array of the same shape counts
+   only candidates that are NOT an end point of the current bracket (the ones the band can flag); NULL = off */
+#define MJO_KNIFE_BINS 34
+static int64_t *g_knife_hist, *g_knife_hist_fresh;
+void mjo_set_knife_hist(int64_t* all, int64_t* fresh) { g_knife_hist = all; g_knife_hist_fresh = fresh; }
+static void mjo_knife_hist_add(double d0, double d00, int fresh) {
+  if (!g_knife_hist) return;
+  double r = fabs(d0) / (fabs(d00) + 1e-300);
+  int bin;
+  if (d0 == 0) bin = 0;
+  else { int k = (int)floor(log10(r)) + 30; if (k < 0) k = 0; if (k > 32) k = 32; bin = 1 + k; }
+#pragma omp atomic
+  g_knife_hist[bin]++;
+  if (fresh && g_knife_hist_fresh) {
+#pragma omp atomic
+    g_knife_hist_fresh[bin]++;
+  }
+}
 
 #define REAL double
 #define SFX _f64

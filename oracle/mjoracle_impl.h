@@ -1975,13 +1975,14 @@ static void FN(linesearch)(const FN(MjoModel) * M, FN(MjoWork) * w, FN(SolveCtx)
     {
       /* knife-edge bookkeeping (test diagnostics; natural behaviour when knife_policy < 0) */
 #ifdef REAL_IS_FLOAT
-      REAL noise = (REAL)1e-4 * (R_FABS(p0.d0) + (REAL)1e-30);
+      REAL noise = (REAL)g_knife_band_f32 * (R_FABS(p0.d0) + (REAL)1e-30);
 #else
-      REAL noise = (REAL)1e-8 * (R_FABS(p0.d0) + (REAL)1e-300);
+      REAL noise = (REAL)g_knife_band_f64 * (R_FABS(p0.d0) + (REAL)1e-300);
 #endif
       FN(LSPoint)* cands[3] = {&lo_next, &hi_next, &mid};
       for (int q = 0; q < 3; q++) {
         FN(LSPoint)* cd = cands[q];
+        mjo_knife_hist_add((double)cd->d0, (double)p0.d0, cd->alpha != lo.alpha && cd->alpha != hi.alpha);
         if (R_FABS(cd->d0) < noise && cd->alpha != lo.alpha && cd->alpha != hi.alpha) {
           if (w->knife_policy >= (1 << 30)) {
             /* "every Newton candidate that lands on the root rounds to exactly zero": only derivatives at the rounding floor of their own sum (a few ulp of

@@ -41,6 +41,12 @@ def lib():
         _lib.mjo_set_contact_hint.restype = None
         _lib.mjo_set_stage_tie_flip.argtypes = [ctypes.c_uint, ctypes.c_void_p]
         _lib.mjo_set_stage_tie_flip.restype = None
+        _lib.mjo_set_knife_band.argtypes = [ctypes.c_double, ctypes.c_double]
+        _lib.mjo_set_knife_band.restype = None
+        _lib.mjo_get_knife_band.argtypes = [ctypes.POINTER(ctypes.c_double)] * 2
+        _lib.mjo_get_knife_band.restype = None
+        _lib.mjo_set_knife_hist.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        _lib.mjo_set_knife_hist.restype = None
     return _lib
 
 
@@ -153,6 +159,47 @@ def time_steps(m, d, nthreads, min_steps, t_min, t_max):
         if (done >= min_steps and el >= t_min) or el >= t_max:
             break
     return B * done / el, done, el
+
+
+KNIFE_BINS = 34  # mjoracle.c: bin 0 = exactly zero, bin 1 + k = [1e(k-30), 1e(k-29)) (k = 0: everything below 1e-29), last bin = >= 1e2
+
+
+def knife_band(dtype=None):
+    """The line search's noise band in force, (float64, float32) or the one of `dtype`."""
+    f64, f32 = ctypes.c_double(), ctypes.c_double()
+    lib().mjo_get_knife_band(ctypes.byref(f64), ctypes.byref(f32))
+    return (f64.value, f32.value) if dtype is None else (f64.value if dtype == torch.float64 else f32.value)
+
+
+def knife_histogram(m, d, steps, nthreads=0, band=None):
+    """`steps` steps of the oracle's natural run from the batched Data `d` (state carried, buffers ping-pong) with the line-search candidate histogram on:
+    -> (hist[KNIFE_BINS] over every candidate, the same over candidates that are not a bracket end point, [steps, B] flagged-candidate counts).
+    `band`: (float64, float32) bands for this run only."""
+    dtype = d.qpos.dtype
+    desc, keep = native.pack_model(m, dtype)
+    a = data_to_numpy(d)
+    b = {n: np.array(x, copy=True) for n, x in a.items()}
+    B = int(np.prod(tuple(d.qpos.shape[:-1])))
+    pa, pb = _ptrs(a), _ptrs(b)
+    dt = 0 if dtype == torch.float64 else 1
+    L = lib()
+    L.mjo_set_contact_hint(None, None, None, None)
+    L.mjo_set_stage_tie_flip(0, None)
+    hist, fresh = np.zeros(KNIFE_BINS, np.int64), np.zeros(KNIFE_BINS, np.int64)
+    knife = np.zeros((steps, B), np.int32)
+    old = knife_band()
+    if band is not None:
+        L.mjo_set_knife_band(*band)
+    L.mjo_set_knife_hist(hist.ctypes.data, fresh.ctypes.data)
+    try:
+        for s in range(steps):
+            if _call(True, desc, pa, pb, B, dt, native.STAGE_ALL, 0, nthreads, knife[s], -1) != 0:
+                raise RuntimeError("oracle failed")
+            pa, pb = pb, pa
+    finally:
+        L.mjo_set_knife_hist(None, None)
+        L.mjo_set_knife_band(*old)
+    return hist, fresh, knife
 
 
 def apply(d, out):

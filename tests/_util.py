@@ -467,6 +467,25 @@ def load_outlier(name, extra_overrides=None):
     return mx, d.replace(contact=d.contact.replace(**con)), meta
 
 
+def f32_accuracy_of(mx, xml, overrides, d, got_env):
+    """A float32 environment against the float64 oracle of the SAME inputs (the yardstick of test_float32_stall_case_is_float32_accuracy, for ONE environment):
+    solver-leaf distances GPU-vs-float32-oracle, float32-oracle-vs-float64-oracle, GPU-vs-float64-oracle, and the worst pre-solver leaf of stage 0 against the float32
+    oracle.  `d`: unbatched float32 Data on the CPU, `got_env`: {leaf: the HIP step's output for that environment}."""
+    import pyoracle
+
+    assert d.qpos.dtype == torch.float32
+    mx64 = load_model(xml, overrides, torch.float64)
+    d2 = torch.stack([d, d])
+    w32 = pyoracle.run(mx, d2, step=True, nthreads=1)
+    w64 = pyoracle.run(mx64, d2.to(torch.float64), step=True, nthreads=1)
+    env = lambda a: {n: np.asarray(a[n])[0] for n in SOLVER_LEAVES}
+    got = {n: np.asarray(got_env[n]) for n in SOLVER_LEAVES}
+    pre = max(rel_err(got_env[n], w32[n][0]) for n in PRE_SOLVER if n in got_env)
+    ints = all(np.array_equal(np.asarray(got_env[n]), w32[n][0]) for n in INT_LEAVES if n in got_env)
+    return dict(gpu_vs_f32_oracle=solver_err(got, env(w32)), f32_oracle_vs_f64=solver_err(env(w32), env(w64)), gpu_vs_f64=solver_err(got, env(w64)),
+                pre_solver_vs_f32_oracle=pre, ints_equal=bool(ints))
+
+
 def policy_spread(model, d, **kw):
     """How far apart the oracle's OWN admissible outcomes of one step are (max over the line-search knife policies of the
     solver-leaf difference to the natural run): the size of the reference's implementation-defined band at this state."""

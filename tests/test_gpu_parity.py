@@ -970,6 +970,18 @@ def test_pinned_campaign_outliers(name, oracle_lib):
       on every pre-solver leaf, lie inside that band, and match at 1e-8 once the same solve is allowed to converge."""
     mx, d, meta = load_outlier(name)
     got = gpu_out_to_numpy(mt.step(mx.to("cuda"), d.to("cuda")))
+    if meta.get("rule") == "f32_accuracy":
+        # round 5's 8192 x 4 campaign, the one environment no outcome and no tail rule accepts (VERDICT r05 weak 1): the LIVE step agrees with the float32 oracle on everything
+        # upstream of the solver and is no further from the float64 solution of the same inputs than the float32 oracle is (tests/test_oracle_golden.py holds the recorded outputs
+        # to the same statement on the CPU); no tail rule involved
+        from _cases import FUZZ_TOL_PRE
+        from _util import f32_accuracy_of
+
+        acc = f32_accuracy_of(mx, meta["xml"], meta["overrides"], d, got)
+        print(name, acc)
+        assert acc["ints_equal"] and acc["pre_solver_vs_f32_oracle"] <= FUZZ_TOL_PRE[torch.float32], acc
+        assert acc["gpu_vs_f64"] <= acc["f32_oracle_vs_f64"], acc
+        return
     if "_r04_" in name:
         # round 4, tools/fuzz_parity.py at 2048 x 5 and 4096 x 4: the environment-steps that matched no outcome of the batch enumeration, each pinned with the rule of
         # check_against_oracle that accounts for it (DESIGN.md section 4, "the campaign's tail"; tools/pin_outlier.py records the rule): the live step must be accepted by

@@ -20,7 +20,9 @@ def _functions_passing(path, keyword):
 def test_tail_rules_stay_with_the_pinned_outliers():
     """`check_against_oracle(..., tail_rules=True)` (the campaign's tail: ulp / ulp_band / f64 / cost / frame_cond acceptances) is triage for the
     builder-run campaign and the environments pinned from it.  No golden, seeded or in-suite campaign test may pass it."""
-    allowed = {"test_gpu_parity.py": {"test_pinned_campaign_outliers"}, "test_oracle_golden.py": {"test_campaign_tail_rules_on_recorded_outputs"}}
+    allowed = {"test_gpu_parity.py": {"test_pinned_campaign_outliers"}, "test_oracle_golden.py": {"test_campaign_tail_rules_on_recorded_outputs",
+                                                                                                   # (passes it only inside pytest.raises: the pinned round-5 environment must be REJECTED with the rules on too)
+                                                                                                   "test_float32_accuracy_outliers_on_recorded_outputs"}}
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".py") and f not in ("_util.py", "test_hygiene.py"):
             assert _functions_passing(os.path.join(HERE, f), "tail_rules") <= allowed.get(f, set()), f

@@ -117,3 +117,53 @@ def test_campaign_tail_rules_on_recorded_outputs(name, oracle_lib):
         if meta["rule"] != "deep" and FUZZ_BAND.get(meta["xml"]) is None:  # (a model with a campaign band is also accepted by the band once the deeper enumeration has widened it)
             with pytest.raises(AssertionError):  # ... and without the tail rules it is the mismatch the campaign reported
                 check_against_oracle(mx, d2, got2, FUZZ_TOL_PRE[d.qpos.dtype], tol, **kw)
+
+
+@pytest.mark.parametrize("name", [c for c in OUTLIER_CASES if "_r05_" in c])
+def test_float32_accuracy_outliers_on_recorded_outputs(name, oracle_lib):
+    """the ONE environment-step of the 8192 x 4 campaign (1.25 M environment-steps, profiles/r05/fuzz_parity_8192.txt) that no outcome and no tail rule of
+    the checker accepts -- the ant's RK4 + Newton elliptic float32 case, a scrambled deeply penetrating pose whose objective (3.5e8) float32 resolves to +-21.  Pinned with the GPU's
+    recorded outputs and held to the float64 oracle of the SAME inputs, the yardstick of test_float32_stall_case_is_float32_accuracy: everything upstream of the solver and every
+    integer leaf agrees with the float32 oracle, and the GPU is NO FURTHER from the float64 solution than the float32 oracle itself is (1.8e-2 against 5.0e-2).  No rule was
+    added for it: with and without `tail_rules` the checker still reports it."""
+    import json
+
+    from _cases import FUZZ_BAND, FUZZ_TOL_PRE
+    from _util import GOLD, check_against_oracle, f32_accuracy_of
+
+    mx, d, meta = load_outlier(name)
+    assert meta["rule"] == "f32_accuracy" and meta["dtype"] == "float32"
+    z = np.load(os.path.join(GOLD, "outliers", name + ".npz"))
+    got = {k[4:]: z[k] for k in z.files if k.startswith("got/")}
+    acc = f32_accuracy_of(mx, meta["xml"], meta["overrides"], d, got)
+    assert acc["ints_equal"] and acc["pre_solver_vs_f32_oracle"] <= FUZZ_TOL_PRE[torch.float32], acc
+    assert acc["gpu_vs_f64"] <= acc["f32_oracle_vs_f64"], acc
+    for k, v in meta["measured"].items():  # the oracle in this container reproduces what was measured when the environment was pinned
+        assert acc[k] == v or abs(acc[k] - v) <= 1e-6 * max(abs(v), 1e-12), (k, acc[k], v)
+    got2, d2 = {n: np.stack([a, a]) for n, a in got.items()}, torch.stack([d, d])
+    for tail_rules in (False, True):
+        with pytest.raises(AssertionError):
+            check_against_oracle(mx, d2, got2, FUZZ_TOL_PRE[torch.float32], 5e-3, what=name, band=FUZZ_BAND.get(meta["xml"]), tail_rules=tail_rules, tail_out={})
+
+
+def test_knife_band_sits_in_the_empty_decades(oracle_lib):
+    """the band below which a line-search candidate counts as rounding noise (the reference branches on `d0 == 0.0`, solver.py:424-467) was 1e-8 of |d0(0)|
+    in float64 with nothing that showed where the flagged candidates sit.  profiles/r06/knife_hist_humanoid.txt (BASELINE config 2 at its full batch, 163,840 environment-steps):
+    every candidate below 1e-8 is below 1e-14 -- the rounding cluster of a Newton step that lands on the root of a quadratic piece -- and SIX decades [1e-14, 1e-8) are empty
+    (this seeded batch, with controls: a handful of cluster candidates reach 1e-13).  The band is now 1e-11 = 100 x the cluster's upper edge.  Held here on the seeded humanoid
+    batch (one-iteration CG, the knife-edged benchmark case): the decades between the cluster and the old band stay empty, and the per-environment flags are THE SAME under 1e-8,
+    1e-11 and 1e-12 -- no verdict of a test depends on the choice."""
+    from _cases import seeded_batch
+
+    assert pyoracle.knife_band() == (1e-11, 1e-4)
+    mx, d = seeded_batch("humanoid", {"solver": 1}, torch.float64, 256)
+    hist, fresh, knife = pyoracle.knife_histogram(mx, d, 12, nthreads=4)
+    lo = 1 + (-13 + 30)  # bin of [1e-13, 1e-12)
+    hi = 1 + (-8 + 30)   # bin of [1e-8, 1e-7)
+    assert fresh[1:lo].sum() + fresh[0] > 1000, fresh          # the cluster (and the exact zeros) is populated: the case is knife-edged
+    assert fresh[lo:hi].sum() == 0, fresh[lo:hi]               # ... and nothing sits between it and the old band
+    assert (knife > 0).mean() > 0.2
+    for band in (1e-8, 1e-12):
+        _, _, k2 = pyoracle.knife_histogram(mx, d, 12, nthreads=4, band=(band, 1e-4))
+        assert np.array_equal(k2, knife), band
+    assert pyoracle.knife_band() == (1e-11, 1e-4)              # (the per-run override is restored)

@@ -14,7 +14,8 @@ import torch  # noqa: E402
 from _cases import FUZZ_BAND, FUZZ_TOL_PRE  # noqa: E402
 from _util import INT_LEAVES, REAL_LEAVES, check_against_oracle, leaf, load_model  # noqa: E402
 
-for name in sys.argv[1:]:
+F32_ACC = "--f32-accuracy" in sys.argv
+for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
     t = torch.load(os.path.join(ROOT, "gpurun_out", "triage", name + ".pt"), weights_only=False)
     dt = torch.float32 if "32" in t["dtype"] else torch.float64
     mx = load_model(t["xml"], t["ov"], dt)
@@ -26,6 +27,17 @@ for name in sys.argv[1:]:
             arrs["in/" + n] = x.numpy()
     for n, v in t["got"].items():
         arrs["got/" + n] = np.asarray(v)[0]
+    if F32_ACC:
+        from _util import f32_accuracy_of
+
+        parts = name.split("_")
+        short = f"{t['xml']}_r05_{parts[-2]}_{parts[-1]}"
+        acc = f32_accuracy_of(mx, t["xml"], t["ov"], d, {n: np.asarray(v)[0] for n, v in t["got"].items()})
+        meta = dict(xml=t["xml"], overrides=t["ov"], dtype=str(dt)[6:], rule="f32_accuracy", measured=acc,
+                    source=f"tools/fuzz_parity.py 8192 4 (round 5, profiles/r05/fuzz_parity_8192.txt), case {name}")
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", "outliers", short + ".npz"), meta=json.dumps(meta), **arrs)
+        print(short, "rule: f32_accuracy", acc, flush=True)
+        continue
     d2 = torch.cat([t["d"], t["d"]])
     got2 = {n: np.concatenate([t["got"][n]] * 2) for n in t["got"]}
     tail = {}
