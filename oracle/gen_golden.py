@@ -83,6 +83,8 @@ CASES = {
     # mocap bodies (smooth.py:105-113): a free capsule resting on a mocap-driven sphere and pad over a plane
     "mocap_f64": ("mocap_target", {}, "float64", 3, 3, "mocap"),
     "mocap_rk4_f32": ("mocap_target", {"integrator": 1}, "float32", 2, 2, "mocap"),
+    # a mocap body that carries a jointed subtree (round 6): the children hang off the static body_pos / body_quat chain, the override comes after the scan
+    "mocap_child_f64": ("mocap_child", {}, "float64", 3, 3, "mocap"),
     # gravity compensation (passive.py:148-156, forward.py:206-207): passive on two links, through the actuator channel on the third
     "gravcomp_f64": ("gravcomp_arm", {}, "float64", 3, 3, "generic"),
     "gravcomp_rk4_f32": ("gravcomp_arm", {"integrator": 1}, "float32", 2, 2, "generic"),

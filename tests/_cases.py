@@ -166,6 +166,9 @@ FUZZ_CASES = [  # (xml, overrides, dtype, solver tolerance)
 # float32 cases of the campaign: near-degenerate contact normals amplify eps under these perturbations (pre-solver 1e-3); qfrc_constraint /
 # efc_force of the ant cancel forces of ~1e5, the dynamics leaves carry the comparison there
 FUZZ_TOL_PRE = {F64: 1e-9, F32: 1e-3}
+# (quantile, bound) beside a case's worst-environment bound: the float32 RK4 + CG pendula case states its float32 accuracy (2e-2) for the WORST environment; 99 % of
+# the environments stay inside the old 5e-3 (measured 1.1e-3 .. 1.6e-3 at the 99 % quantile over 4096 x 4 environment-steps, 2.8e-3 .. 4.5e-3 at 99.9 %: profiles/r05/yardstick_pendula.txt)
+FUZZ_QUANTILE = {("pendula", F32): (0.99, 5e-3)}
 # convex_primitives under the campaign's perturbations runs Newton into its 10-iteration cap on ~0.6 % of the environments: the reference's own
 # admissible outcomes are 2e-6 .. 0.76 apart there (tests/test_oracle_golden.py::test_iteration_capped_newton_states_are_implementation_defined,
 # test_pinned_campaign_outliers): those environments are held to the oracle's own spread instead (band), the rest to 1e-8

@@ -283,7 +283,7 @@ def compare_with_oracle(model, d_cpu, got, step=True, max_policies=None, **kw):
                 n_alts=len(alts), tie_pairs=tie_pairs, leaf_nat=leaf_nat, alts=alts, knife=knife, elem_best=elem_best)
 
 
-def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, max_tie_frac=1.0, band=None, tail_rules=False, tail_out=None, **kw):
+def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=True, max_alt_frac=1.0, max_tie_frac=1.0, band=None, tail_rules=False, tail_out=None, quantile_tol=None, **kw):
     """HIP outputs `got` (dict of numpy, batched) vs the oracle on the same inputs.
 
     * leaves upstream of the solver and all integer leaves: must agree outright (tol_pre / exact);
@@ -398,6 +398,10 @@ def check_against_oracle(model, d_cpu, got, tol_pre, tol_solver, what="", step=T
     B = len(c["err_best"])
     worst_env = int(np.argmax(c["err_best"]))
     assert c["err_best"].max() <= tol_solver, f"{what} env {worst_env}: solver outputs match no admissible oracle branch: best {c['err_best'][worst_env]:.3e}, natural {c['err_nat'][worst_env]:.3e}"
+    if quantile_tol is not None:  # (q, tol): a case whose worst-environment bound states an accuracy limit keeps a TIGHT bound on its high quantile, so that a regression below the worst-case bound is seen
+        q, tq = quantile_tol
+        eq = float(np.quantile(c["err_best"], q))
+        assert eq <= tq, f"{what}: {100 * q:g} % quantile of the solver error {eq:.3e} beyond {tq:g} (worst {c['err_best'].max():.3e})"
     if d_cpu.qpos.dtype == torch.float64 and band is None:
         # ... and ELEMENT-wise on the state leaves (qpos, qvel, qacc): every entry within the tolerance of max(|entry|, 1e-3 of its leaf's largest)
         we = int(np.argmax(c["elem_best"]))

@@ -22,7 +22,7 @@ from _util import check_against_oracle, gpu_out_to_numpy  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-from _cases import FUZZ_BAND, FUZZ_CASES as CASES, FUZZ_TOL_PRE as TOL_PRE  # noqa: E402  (the bounds of the in-suite campaign, tests/test_gpu_parity.py::test_differential_campaign)
+from _cases import FUZZ_BAND, FUZZ_QUANTILE, FUZZ_CASES as CASES, FUZZ_TOL_PRE as TOL_PRE  # noqa: E402  (the bounds of the in-suite campaign, tests/test_gpu_parity.py::test_differential_campaign)
 import _util  # noqa: E402
 
 ONLY = {int(x) for x in sys.argv[3].split(",")} if len(sys.argv) > 3 else None
@@ -37,7 +37,7 @@ for ci, (xml, ov, dt, tol_sol) in enumerate(CASES):
         fracs, tail = [], {}
         for s in range(STEPS):
             og = mt.step(mdev, dg)
-            frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dt], tol_sol, what=f"{xml} step{s}", nthreads=16, band=FUZZ_BAND.get(xml), tail_rules=True, tail_out=tail)
+            frac, worst = check_against_oracle(mx, dg.cpu(), gpu_out_to_numpy(og), TOL_PRE[dt], tol_sol, what=f"{xml} step{s}", nthreads=16, band=FUZZ_BAND.get(xml), tail_rules=True, tail_out=tail, quantile_tol=FUZZ_QUANTILE.get((xml, dt)))
             fracs.append((round(frac, 3), float(f"{worst:.1e}")))
             dg = og
         print(f"ok   {xml:22s} {str(ov):55s} {str(dt)[6:]:8s} B={B} (alt-branch frac, worst solver err) per step: {fracs}  tail {tail}  [{time.time() - t0:.0f}s]", flush=True)
