@@ -151,6 +151,7 @@ struct DevModel {
   int nrfq;                                // entries of rf_geom = (rangefinder, geom) ray tests per environment
   const int* efc_row_eq;                   // ne: eq_* table entry of an equality row
   int max_depth;
+  int kin_lvl;                             // kinematics as a level sweep with every lane's constants read up front (one body per lane in every instantiation the model runs at; bit-identical to the walk).  (Sits in the padding behind max_depth: the kernel argument block is at its 4 KiB limit.)
   const int* qm_pair;                      // nqmpair: i << 8 | j (j <= i) of the inertia-matrix entries that can be non-zero
   int nqmpair;
   const int* qm_slot;                      // nv*nv: packed lower-triangle slot holding entry (i, j), -1 where qM is structurally zero

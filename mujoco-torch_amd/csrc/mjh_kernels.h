@@ -1013,6 +1013,7 @@ struct Env {
       for (int i = 0; i < 4; i++) S.jquat()[4 * j + i] = q[i];
     }
     wave_sync();
+    STAMP(8);
     // Pointer jumping (DevModel::kin_tab; models with one body per lane).  The serial walk below has every lane compose its whole ancestor chain -- ~7 levels and ~10 joints of
     // dependent float64 rotations for the humanoid, 35 k of the kernel's 309 k cycles, the same chain recomputed by every lane.  Here each lane first composes the frame of ITS body
     // relative to its parent (body offset, then its own joints: smooth.py:85-120 in the parent's frame), then ceil(log2(depth)) rounds replace "relative to the ancestor 2^r levels
@@ -1054,6 +1055,100 @@ struct Env {
         for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }
       }
     };
+    // Level sweep (DevModel::kin_lvl; round 6; models with one body per lane).  The serial walk below has every lane recompute its whole ancestor chain, and -- what costs the
+    // time -- reads the constants of every level and of every joint on it (chain id -> body offset -> joint type / address / anchor / axis: dependent table reads through L2) INSIDE
+    // that dependent chain: 35 k of the humanoid kernel's 278 k cycles for ~10 joints of arithmetic.  Here lane b owns body b: it reads ITS constants once, up front and all at once
+    // (nothing of them depends on another lane), then the levels of the tree are swept in order -- at level L the lanes whose body sits L below the world take their parent's
+    // finished frame from the arena, apply their own offset and joints, and put their frame down.  Every body's frame is formed by exactly the operations of the walk in exactly its
+    // order (the walk recomputes the parent's frame with the same operations on the same inputs): bit-identical leaves, unlike the pointer-jumping form below.
+    // (Compiled into the whole-pass kernel only -- KEEPG -- for now: in the stand-alone kinematics kernels the constants' registers set the allocation, 80 -> 150 VGPRs in float32.)
+    const bool lvl = KEEPG && M.kin_lvl != 0 && M.nbody <= W && M.kin_tab == nullptr;
+    if constexpr (KEEPG) if (lvl) {
+      const int nb = M.nbody, md = M.max_depth;
+      const int b = l;
+      const bool body = b > 0 && b < nb;
+      int depth = 0, par = 0, jn = 0, j0 = 0;
+      REAL bp[3] = {0, 0, 0}, bq[4] = {1, 0, 0, 0};
+      constexpr int KJ = 3;  // joints of a body whose constants ride in registers (more: read at use)
+      int jt[KJ], jqa[KJ];
+      REAL jp[KJ][3], jx[KJ][3];
+      if (body) {
+        depth = M.body_depth[b]; par = M.body_parentid[b]; jn = M.body_jntnum[b]; j0 = M.body_jntadr[b];
+#pragma unroll
+        for (int i = 0; i < 3; i++) bp[i] = M.body_pos[3 * b + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) bq[i] = M.body_quat[4 * b + i];
+      }
+#pragma unroll
+      for (int jj = 0; jj < KJ; jj++) {
+        const int j = (body && jj < jn) ? j0 + jj : 0;
+        jt[jj] = M.jnt_type[j]; jqa[jj] = M.jnt_qposadr[j];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { jp[jj][i] = M.jnt_pos[3 * j + i]; jx[jj][i] = M.jnt_axis[3 * j + i]; }
+      }
+      if (b == 0) {  // the world body: the frame the walk starts from
+#pragma unroll
+        for (int i = 0; i < 3; i++) S.xpos()[i] = M.body_pos[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) S.xquat()[i] = M.body_quat[i];
+      }
+      wave_sync();
+      // one joint with its constants in registers: joint_step's operations, in its order
+      auto joint_reg = [&](int j, int t, int qa, const REAL* jpos, const REAL* jaxis, REAL* pos, REAL* quat) {
+        const REAL ql[4] = {S.jquat()[4 * j], S.jquat()[4 * j + 1], S.jquat()[4 * j + 2], S.jquat()[4 * j + 3]};
+        REAL anchor[3], axis[3];
+        if (t == JNT_FREE) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) { anchor[i] = S.qpos()[qa + i]; pos[i] = S.qpos()[qa + i]; }
+          axis[0] = 0; axis[1] = 0; axis[2] = 1;
+#pragma unroll
+          for (int i = 0; i < 4; i++) quat[i] = ql[i];
+        } else {
+          REAL r[3];
+          rotate(jpos, quat, r);
+#pragma unroll
+          for (int i = 0; i < 3; i++) anchor[i] = r[i] + pos[i];
+          rotate(jaxis, quat, axis);
+          if (t == JNT_BALL || t == JNT_HINGE) {
+            quat_mul(quat, ql, quat);
+            rotate(jpos, quat, r);
+#pragma unroll
+            for (int i = 0; i < 3; i++) pos[i] = anchor[i] - r[i];
+          } else {
+            const REAL dq = ql[0];
+#pragma unroll
+            for (int i = 0; i < 3; i++) pos[i] = pos[i] + axis[i] * dq;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { S.xanchor()[3 * j + i] = anchor[i]; S.xaxis()[3 * j + i] = axis[i]; }
+      };
+      for (int L = 1; L <= md; L++) {  // (uniform trip count)
+        if (body && depth == L) {
+          REAL pos[3], quat[4];
+#pragma unroll
+          for (int i = 0; i < 3; i++) pos[i] = S.xpos()[3 * par + i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) quat[i] = S.xquat()[4 * par + i];
+          {
+            REAL r[3];
+            rotate(bp, quat, r);
+#pragma unroll
+            for (int i = 0; i < 3; i++) pos[i] = pos[i] + r[i];
+            quat_mul(quat, bq, quat);
+          }
+#pragma unroll
+          for (int jj = 0; jj < KJ; jj++) if (jj < jn) joint_reg(j0 + jj, jt[jj], jqa[jj], jp[jj], jx[jj], pos, quat);
+          for (int jj = KJ; jj < jn; jj++) joint_step(j0 + jj, pos, quat, true);
+#pragma unroll
+          for (int i = 0; i < 3; i++) S.xpos()[3 * b + i] = pos[i];
+#pragma unroll
+          for (int i = 0; i < 4; i++) S.xquat()[4 * b + i] = quat[i];
+        }
+        wave_sync();
+      }
+      STAMP(9);
+    }
     const bool jump = M.kin_tab != nullptr && M.nbody <= W;
     const int* const kin_anc = M.kin_tab;
     if (jump) {
@@ -1116,7 +1211,7 @@ struct Env {
       REAL pos[3] = {M.body_pos[0], M.body_pos[1], M.body_pos[2]};
       REAL quat[4] = {M.body_quat[0], M.body_quat[1], M.body_quat[2], M.body_quat[3]};
       const int depth = M.body_depth[b], md = M.max_depth;
-      if (jump) {
+      if (jump || lvl) {
 #pragma unroll
         for (int i = 0; i < 3; i++) pos[i] = S.xpos()[3 * b + i];
 #pragma unroll

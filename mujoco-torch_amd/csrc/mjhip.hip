@@ -377,6 +377,10 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       for (int b = 1; b < nb; b++) if (d->body_parentid[b] > 0 && d->body_mocapid[d->body_parentid[b]] >= 0) mocap_parent = true;
       const bool on = mode == 1 && max_depth >= 2 && !mocap_parent;
       M.kin_tab = nullptr;
+      {  // the level sweep (Env::kinematics): same operations per body as the walk, bit-identical; MJH_KIN_LEVEL=0 keeps the walk (A / B runs)
+        static const int lv = [] { const char* e = getenv("MJH_KIN_LEVEL"); return e ? (e[0] != '0') : 1; }();
+        M.kin_lvl = (lv && nb > 1 && nb <= 32 && !on) ? 1 : 0;  // (nb <= 32: one body per lane in EVERY instantiation the model can run at, as for the jump form below)
+      }
       int R = 0;
       while ((1 << R) < max_depth) R++;
       if (on && nb > 1 && nb <= 32) {  // (one body per lane in EVERY instantiation the model can run at -- 16 lanes per environment only with nbody <= 16, else 32 or 64 -- so that which kernel a batch size or an odd tail selects never changes a bit)

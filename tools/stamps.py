@@ -36,7 +36,7 @@ native.load_library().mjh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 dg = mt.step(mdev, dg); torch.cuda.synchronize()
 native.load_library().mjh_debug_set_stamps(None)
 st = stamps.cpu().numpy().astype(np.float64)
-names = {0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, geoms, sites, cams", 4: "stores kin", 5: "subtree com", 6: "cinert + cdof", 7: "stores com",
+names = {8: "joint-local quats (sincos) + sync", 9: "level sweep: constants + levels", 0: "KIN start", 1: "load qpos", 2: "chain walk + frames", 3: "quat wb, geoms, sites, cams", 4: "stores kin", 5: "subtree com", 6: "cinert + cdof", 7: "stores com",
          10: "CRB start", 11: "loads", 12: "crb subtree sums", 13: "inert_mul", 14: "qM", 15: "stores", 16: "chol_factor", 17: "store qLD",
          19: "CON start", 22: "load geoms (+ the rows' inputs)", 24: "pair cull (RK4 stages 1..3)", 20: "narrow phase", 21: "contact stores", 23: "loads + zero rows", 25: "limit + contact rows", 26: "kbi / aref rows", 27: "efc stores",
          30: "VEL start", 31: "loads", 32: "transmission", 33: "com_vel chain", 35: "passive", 36: "rne cacc chain + local frc", 37: "cfrc subtree sums", 38: "qfrc_bias", 39: "stores", 40: "actuator forces", 41: "qfrc_actuator, xfrc, smooth", 42: "chol_solve + stores",
