@@ -100,8 +100,10 @@ enum { DYN_NONE = 0, DYN_INTEGRATOR = 1, DYN_FILTER = 2, DYN_FILTEREXACT = 3, DY
   X(r_vs, m.nv, PH_SOL2) X(r_vs2, m.nv, PH_SOL2) /* register solver: vectors staged for broadcast reads */     \
   X(r_src, MJH_JC_ROWS(m), PH_SOL2) /* compact dense row -> Data row (ints; as many as this tier keeps rows) */ X(r_dst, (m.nefc - m.nl + 1) / 2, PH_SOL2) /* Data row -> compact row, 16-bit entries, 0xffff = inactive */ X(r_pg, 2 * m.nv, PH_SOL2) /* previous gradient pair of the Polak-Ribiere step */ X(r_fs, MJH_JC_ROWS(m) + m.nl, PH_SOL2) /* ... and the row forces: dense rows first, then J * force of the single-column rows */
 
+// (16-bit entries, round 6: offsets are counted in REALs and an arena is at most 160 KB = 40 K floats; as ints two of these tables filled 744 B of the 4 KiB kernel-argument
+//  block and left no room for the third one the stage kernel of RK4 models needs)
 struct LdsOff {
-#define X(n, c, p) int n;
+#define X(n, c, p) unsigned short n;
   MJH_LDS_ARRAYS(X, _)
 #undef X
 };

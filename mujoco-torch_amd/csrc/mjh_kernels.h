@@ -224,6 +224,8 @@ struct KArgs {
   DevModel<REAL> M;
   LdsOff off;          // arena of this launch's phase
   LdsOff off2;         // whole-pass kernel (mjh_sol2_kernel<.., 34>): the arena layout of its second half (constraint stage + solver: PH_CS); `off` is its first half's (PH_KCV)
+  LdsOff off3;         // stage kernel (mjh_sol2_kernel<.., 18>, one launch per RK4 stage of a small model): `off` = kernel 13's arena (four environments per wavefront), `off2` = the constraint phase's (kernel 8, two per wavefront), `off3` = the register solver's first tier
+  int lds_reals2, lds_reals3;  // ... and the REALs between the arenas of a wavefront's environments in its second and third part
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
   StatePtrs<REAL> nxt; // where an RK stage writes the next stage's state (workspace Data)
@@ -4945,9 +4947,10 @@ struct Env {
 #define MJH_SOL2_F64_WAVES 1  /* float64 instantiations for <= 16 dofs (the twins of configs 3 / 5): at two waves per SIMD they spilled 80 - 600 B per lane to scratch memory; at ONE the unified register file holds the overflow in AGPRs (24 - 150 of them, no scratch).  Measured (MI355X, solver phase): mesh scene float64 B = 4096 190.6 -> 186.9 us, B = 16384 501 -> 463 us; ant float64 29.3 -> 28.3 / 54.9 -> 53.8 us */
 #endif
 template <typename REAL, int NMAX, int RPL, int WT>
-__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT < 33 && RPL * (WT == 17 ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : ((sizeof(REAL) == 8 && NMAX <= 16) ? MJH_SOL2_F64_WAVES : 2)) mjh_sol2_kernel(KArgs<REAL> args) {
-  constexpr int W = WT == 17 ? 16 : (WT >= 33 ? 32 : WT);
-  constexpr bool NEWTON_ONLY = WT == 17;
+__global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && WT < 33 && RPL * ((WT == 17 || WT == 18) ? 16 : WT) == 32) ? (WT != 32 ? MJH_SOL2_W16_WAVES : MJH_SOL2_T1_WAVES) : ((sizeof(REAL) == 8 && NMAX <= 16) ? MJH_SOL2_F64_WAVES : 2)) mjh_sol2_kernel(KArgs<REAL> args) {
+  constexpr int W = (WT == 17 || WT == 18) ? 16 : (WT >= 33 ? 32 : WT);
+  constexpr bool NEWTON_ONLY = WT == 17 || WT == 18;
+  constexpr bool STAGE = WT == 18;  // WT = 18: one RK4 stage of a small Newton model in ONE launch -- kernel 13's stages, the constraint phase and the solver's first tier behind one another (round 6)
   constexpr bool ONE = WT == 35 || WT == 36;             // WT = 35: WT = 33 for models with opt.iterations == 1 (the humanoid benchmark, solver.py:534-535): the solver loop's body is straight-line code -- the factor of M is dead behind the one preconditioning step instead of crossing the line search in 56 VGPRs
   constexpr bool CS = WT >= 33;  // WT = 33: two environments per wavefront, the constraint stage in front of the solve (Env::run_con_sol2)
   constexpr bool ALL = WT == 34 || WT == 36;  // WT = 34 (36: its one-iteration form, as 35 is to 33): ... and kinematics + crb / factor + velocity in front of that: the whole forward pass + integrator of an environment in one kernel
@@ -4985,6 +4988,44 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
   // One workgroup per NSUB environments, no grid-stride loop (the host launches per 2^20 workgroups): nothing is live across the body for a next trip -- with the loop the whole-pass
   // kernel took 256 VGPRs + 48 B of scratch, without it 153 (see mjh_phase_kernel)
   const int64_t blk = blockIdx.x;
+  if constexpr (STAGE) {
+    // One RK4 stage of a small model used to be three launches (kernel 13: kinematics + crb / factor + velocity at four environments per wavefront; kernel 8: collision +
+    // constraint rows at two; the register solver's first tier at four) with a device-wide barrier, a launch and a burst of input loads between each pair -- 45 % of the solver
+    // launch's cycles were its input loads (in-kernel stamps, profiles/r06/notes.md).  Here a wavefront takes its four environments through all three parts: the parts are the SAME
+    // stage functions on the same leaves and workspace blocks (bit-identical results), what a part reads of the previous one it reads back through this CU's write-through L1 / L2
+    // behind a release / acquire pair at workgroup scope (as the first whole-pass kernel of round 4 did), the constraint phase runs its two-per-wavefront code twice (environments
+    // 0, 1 then 2, 3 of the wave), and the arena is carved three times.  Environments the first tier leaves are marked for the second tier's launch as before.
+    const int64_t idx = blk * NSUB + sub;
+    if (idx < K.env_count) {
+      Env<REAL, 16, false> A(lds, K.env_begin + idx, K.flags);
+      A.template run_kin<false>(); wave_sync(); A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+    {
+      const int sub2 = (int)(threadIdx.x >> 5);
+      REAL* lds2 = reinterpret_cast<REAL*>(lds_raw) + sub2 * K.lds_reals2;
+      for (int p = 0; p < 2; p++) {  // (uniform trip count)
+        const int64_t i2 = blk * NSUB + 2 * p + sub2;
+        if (i2 < K.env_count) {
+          Env<REAL, 32, false, true> C(lds2, K.env_begin + i2, K.flags);
+          C.S.off = &K.off2;
+          C.run_con();
+        }
+        wave_sync();
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    wave_sync();
+    if (idx < K.env_count) {
+      REAL* lds3 = reinterpret_cast<REAL*>(lds_raw) + sub * K.lds_reals3;
+      Env<REAL, 16, false> E(lds3, K.env_begin + idx, K.flags);
+      E.S.off = &K.off3;
+      E.template run_sol2<NMAX, RPL, NEWTON_ONLY>();
+    }
+  } else
   {
     const int64_t idx = blk * NSUB + sub;
     if (idx < K.env_count) {

@@ -80,6 +80,8 @@ struct mjhModel {
   int lds_tier = 0;
   int fuse_all = 0;                        // ... and the whole pass as ONE kernel (mjh_sol2_kernel<.., 34>, timing id 16): kernel 13's stages in front of kernel 14's, one arena of max(lds_kcv, lds_cs)
   int lds_all = 0;
+  int fuse_stage = 0;                      // RK4 stages 1..3 of a small Newton model run as ONE launch each (mjh_sol2_kernel<.., 18>, timing id 18): kernel 13's stages, the constraint phase (kernel 8) and the register solver's first tier
+  int lds_stage = 0;                       // ... dynamic LDS of one of its four-environment workgroups
   int fuse_cs = 0;                         // constraint stage + register solver + integrator run as ONE kernel (mjh_sol2_kernel<.., 33>, timing id 14) from an arena of its own
   LdsOff off_cs;
   int lds_cs = 0;
@@ -827,6 +829,23 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       }
     }
   }
+  {  // One launch per RK4 stage (stages 1..3) for small Newton models: kernel 13 at four environments per wavefront, the direct constraint phase (kernel 8, two per wavefront: run twice
+     // per wave) and the solver's packed Newton tier at four, behind one another in mjh_sol2_kernel<.., 18>.  MJH_FUSE_STAGE=0: the three launches.
+    static const bool off = [] { const char* e = getenv("MJH_FUSE_STAGE"); return e && e[0] == '0'; }();
+    out->fuse_stage = 0;
+    if (!off && d->integrator == INT_RK4 && d->solver == SOL_NEWTON && out->fuse_kcv && out->pack4[1] && M.con_direct && out->pack2[2] && out->sol2_tiers && out->sol2_w16_nmax == 8 &&
+        (out->sol2_w16_rpl == 2 || out->sol2_w16_rpl == 5) && M.ncvxpair == 0 && out->sort_reals == 0 && d->nefc > 0 && !(MJH_SOL2_CAPS_ON && out->sol2_it_cap > 0)) {
+      int need = 4 * out->lds_kcv;
+      if (2 * out->lds_bytes[2] > need) need = 2 * out->lds_bytes[2];
+      if (4 * out->lds_tier > need) need = 4 * out->lds_tier;
+      if (need <= 64 * 1024) {
+        out->fuse_stage = 1;
+        out->lds_stage = need;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 8, 2, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 8, 5, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+      }
+    }
+  }
   return 0;
 }
 
@@ -878,7 +897,7 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 
 // the solver phase through the register solver: two (or, first tier of a small model, four) environments per wavefront
 template <typename REAL>
-int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, bool first_done = false) {  // first_done: the stage kernel has run the first tier (and marked what it left): only the second tier is launched
   a.env_begin = 0; a.env_count = a.B;
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
@@ -900,7 +919,8 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
       const size_t lds = (size_t)(4 * m->lds_tier);
       const bool capped = MJH_SOL2_CAPS_ON && m->sol2_it_cap > 0 && !(a.flags & MJH_FLAG_FIXED_ITERATIONS) && a.cur.qacc;  // (a build with -DMJH_SOL2_CAPS; MJH_SOL2_ITCAP / MJH_SOL2_LSCAP then set the caps)
       a.it_cap = capped ? m->sol2_it_cap : 0; a.ls_cap = capped ? m->sol2_ls_cap : 0;
-      if (m->sol2_w16_nmax == 8) { if (m->sol2_w16_rpl == 2) GOW(8, 2); else GOW(8, 5); }
+      if (first_done) {}
+      else if (m->sol2_w16_nmax == 8) { if (m->sol2_w16_rpl == 2) GOW(8, 2); else GOW(8, 5); }
       else if (m->sol2_w16_nmax == 12) { if (m->sol2_w16_rpl == 2) GOW(12, 2); else GOW(12, 5); }
       else { if (m->sol2_w16_rpl == 2) GOW(16, 2); else GOW(16, 5); }
       a.it_cap = a.ls_cap = 0;
@@ -943,8 +963,29 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 #undef GO
 #undef GOW
 #undef CHUNKED
-  timing_mark(stream, 9);  // both tiers under one mark: the solver phase
+  if (!(first_done && !second)) timing_mark(stream, 9);  // both tiers under one mark: the solver phase (behind the stage kernel: the second tier alone, when there is one)
   return 0;
+}
+
+// one RK4 stage of a small Newton model in one launch (mjhModel::fuse_stage), then the solver's second tier for what the first left
+template <typename REAL>
+int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+  a.off = m->off_kcv; a.lds_reals = m->lds_kcv / (int)sizeof(REAL);
+  a.off2 = m->off[2]; a.lds_reals2 = m->lds_bytes[2] / (int)sizeof(REAL);
+  a.off3 = m->off_tier; a.lds_reals3 = m->lds_tier / (int)sizeof(REAL);
+  a.row_lo = -1; a.row_hi = 16 * m->sol2_w16_rpl;
+  a.mark_leftover = (m->sol2_tiers && a.cur.qacc != nullptr) ? 1 : 0;
+  a.scan_marks = 0; a.it_cap = a.ls_cap = 0; a.fallback_only = 0;
+  for (int64_t e0 = 0; e0 < a.B; e0 += 4 * max_grid()) {  // (no grid-stride loop in the kernels: one launch per 2^20 workgroups)
+    const int64_t n = a.B - e0 < 4 * max_grid() ? a.B - e0 : 4 * max_grid();
+    a.env_begin = e0; a.env_count = n;
+    if (m->sol2_w16_rpl == 2) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 8, 2, 18>), dim3((unsigned)(n / 4)), dim3(MJH_WAVE), (size_t)m->lds_stage, stream, a);
+    else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 8, 5, 18>), dim3((unsigned)(n / 4)), dim3(MJH_WAVE), (size_t)m->lds_stage, stream, a);
+    HIP_TRY(hipGetLastError());
+  }
+  a.env_begin = 0; a.env_count = a.B;
+  timing_mark(stream, 18);
+  return launch_sol2<REAL>(m, a, stream, true);
 }
 
 // constraint stage + register solver + integrator in one launch (mjhModel::fuse_cs)
@@ -1048,6 +1089,18 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   if (m->fuse_all && (st & 0x7f) == 0x7f && a.B >= 2 && (a.B & 1) == 0 && a.B <= 2 * max_grid() /* one workgroup per pair: the kernel has no grid-stride loop */ && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && a.cur.qM && a.cur.qLD) return launch_all<REAL>(m, a, stream);
   // MJH_DAG=1 (experiment): kinematics -> {crb / factor || velocity (+ sensors) || convex + constraint phase} -> solver, the two side branches on internal
   // streams forked from and joined into the caller's.  Needs the stand-alone kernels: run with MJH_FUSE_KV=0 (and so no kernel 13 / whole-pass kernel).  profiles/r05/notes.md has the numbers.
+  // MJH_FUSE_STAGE0=0: stage 0 (which writes the returned Data in full) keeps its three launches.  Its sensors (they read leaves of the kinematics and velocity stages only) follow the
+  // stage kernel: in an RK4 step nothing of stage 0 writes the returned state -- the final advance is stage 3's -- so the jointpos / ballquat readers of out.qpos race nothing.
+  static const bool stage0_off = [] { const char* e = getenv("MJH_FUSE_STAGE0"); return e && e[0] == '0'; }();
+  if (m->fuse_stage && a.rk_stage >= (stage0_off ? 1 : 0) && (st & 0x7f) == 0x7f && a.B >= 4 && (a.B & 3) == 0 && !a.sol_perm && !g_stamps && a.cur.qM && a.cur.qLD && a.cur.qfrc_smooth && a.cur.contact_dist &&
+      a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref) {
+    if ((rc = launch_stage<REAL>(m, a, stream))) return rc;
+    if (a.M.nsensor > 0 && a.rk_stage == 0 && a.cur.sensordata) {
+      if ((rc = launch_sensor_kernel<REAL>(m, a, stream))) return rc;
+      timing_mark(stream, 11);
+    }
+    return 0;
+  }
   static const bool dag = [] { const char* e = getenv("MJH_DAG"); return e && e[0] == '1'; }();
   if (dag && !m->fuse_kv && (st & 0x7f) == 0x7f && !g_timing.on && !g_stamps) {
     {
@@ -1430,6 +1483,7 @@ int mjh_model_leaf_counts(const mjhModel* m, int64_t* counts, int max) {
 }
 
 static thread_local bool g_io_inner = false;
+static thread_local int g_io_stage = 0;  // 2: the accounts asked for are those of RK4 stages 1..3 alone (the stage kernel's parts)
 static int mjh_model_kernel_io_impl(const mjhModel* m, int kernel, int64_t* read_write_bytes) {
   const bool prev = g_io_inner;
   g_io_inner = true;
@@ -1450,7 +1504,9 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     int rc = f64 ? mjh_kernel_io<double>(m->m64, k, 1, &a[0], &a[1]) : mjh_kernel_io<float>(m->m32, k, 1, &a[0], &a[1]);
     if (rc == 0 && rk4 && k != 11) {
       rc = f64 ? mjh_kernel_io<double>(m->m64, k, 2, &b[0], &b[1]) : mjh_kernel_io<float>(m->m32, k, 2, &b[0], &b[1]);
-      a[0] = (a[0] + 3 * b[0]) / 4; a[1] = (a[1] + 3 * b[1]) / 4;
+      if (g_io_stage == 2) { a[0] = b[0]; a[1] = b[1]; }                      // the stage kernel: launches of stages 1..3 only
+      else if (m->fuse_stage) {}                                               // ... whose model launches kernels 13 / 8 / 9 in stage 0 only
+      else { a[0] = (a[0] + 3 * b[0]) / 4; a[1] = (a[1] + 3 * b[1]) / 4; }
     }
     return rc;
   };
@@ -1461,6 +1517,17 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     const mjhModel* mm = m;
     if (mjh_model_kernel_io_impl(mm, 13, a13) != 0 || mjh_model_kernel_io_impl(mm, 14, a14) != 0) return -2;
     read_write_bytes[0] = a13[0] + a14[0]; read_write_bytes[1] = a13[1] + a14[1];
+    return 0;
+  }
+  if (kernel == 18) {  // one RK4 stage in one launch: the stage accounts of kernel 13, the constraint phase and the register solver (what a part reads of the previous one it still reads from the workspace leaves)
+    if (!m->fuse_stage) return -2;
+    int64_t a13[2] = {0, 0}, a8[2] = {0, 0}, a9[2] = {0, 0};
+    const int prev = g_io_stage;
+    g_io_stage = 2;
+    const int rc = (mjh_model_kernel_io_impl(m, 13, a13) != 0 || mjh_model_kernel_io_impl(m, 8, a8) != 0 || mjh_model_kernel_io_impl(m, 9, a9) != 0) ? -2 : 0;
+    g_io_stage = prev;
+    if (rc) return rc;
+    read_write_bytes[0] = a13[0] + a8[0] + a9[0]; read_write_bytes[1] = a13[1] + a8[1] + a9[1];
     return 0;
   }
   if ((kernel == 13 || kernel == 14) && m->fuse_all && !g_io_inner) return -2;
