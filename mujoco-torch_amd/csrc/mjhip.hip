@@ -1092,7 +1092,7 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   // MJH_FUSE_STAGE0=0: stage 0 (which writes the returned Data in full) keeps its three launches.  Its sensors (they read leaves of the kinematics and velocity stages only) follow the
   // stage kernel: in an RK4 step nothing of stage 0 writes the returned state -- the final advance is stage 3's -- so the jointpos / ballquat readers of out.qpos race nothing.
   static const bool stage0_off = [] { const char* e = getenv("MJH_FUSE_STAGE0"); return e && e[0] == '0'; }();
-  if (m->fuse_stage && a.rk_stage >= (stage0_off ? 1 : 0) && (st & 0x7f) == 0x7f && a.B >= 4 && (a.B & 3) == 0 && !a.sol_perm && !g_stamps && a.cur.qM && a.cur.qLD && a.cur.qfrc_smooth && a.cur.contact_dist &&
+  if (m->fuse_stage && a.rk_stage >= (stage0_off ? 1 : 0) && (st & 0x7f) == 0x7f && a.B >= 4 && (a.B & 3) == 0 && !a.sol_perm && a.cur.qM && a.cur.qLD && a.cur.qfrc_smooth && a.cur.contact_dist &&
       a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref) {
     if ((rc = launch_stage<REAL>(m, a, stream))) return rc;
     if (a.M.nsensor > 0 && a.rk_stage == 0 && a.cur.sensordata) {

@@ -30,7 +30,7 @@ def lib_fingerprint():
     return h.hexdigest()[:16]
 line = json.loads([x for x in open(f"/tmp/pmc_{w}_WRITE_SIZE.log").read().splitlines() if x.startswith('{"metric"')][-1])
 # steps the process ran = forward passes / passes per step (RK4: four); every forward pass launches the kinematics kernel once
-kin = sum(n for k, (m, n) in res["WRITE_SIZE"].items() if ("mjh_phase_kernel" in k and (", 0, " in k or ", 12, " in k or ", 13, " in k or ", 17, " in k)) or ("mjh_sol2_kernel" in k and (", 34>" in k or ", 36>" in k)))  # 12 / 13 / 17: kinematics fused with the velocity (and crb) stages; sol2 <.., 34 | 36>: the whole pass in one kernel
+kin = sum(n for k, (m, n) in res["WRITE_SIZE"].items() if ("mjh_phase_kernel" in k and (", 0, " in k or ", 12, " in k or ", 13, " in k or ", 17, " in k)) or ("mjh_sol2_kernel" in k and (", 34>" in k or ", 36>" in k or ", 18>" in k)))  # 12 / 13 / 17: kinematics fused with the velocity (and crb) stages; sol2 <.., 34 | 36>: the whole pass in one kernel; <.., 18>: one RK4 stage in one kernel
 steps_total = kin / (4 if "RK4" in line["config"]["workload"] else 1)
 # per-step launches of each kernel = dispatches / steps (RK4 launches each phase four times per step)
 fetch_kb = sum(m * n for m, n in res["FETCH_SIZE"].values()) / steps_total

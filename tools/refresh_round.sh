@@ -2,7 +2,7 @@
 # GPU box: regenerates every measured artefact of a round under gpurun_out/<round>/ (copy to profiles/<round>/ afterwards):
 # rocprofv3 kernel stats, PMC traffic (stamped with the library fingerprint bench.py checks), parity report, counter calibration,
 # and the bench lines of the three BASELINE workloads.  Usage: MJH_GIT_COMMIT=<sha> bash tools/refresh_round.sh r03
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/$R
 mkdir -p $O
 uptime > $O/host_load.txt  # the boxes' hosts are shared: a loaded host starves the calling thread of the drop-in loop (profiles/r03/notes.md)
