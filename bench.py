@@ -122,6 +122,7 @@ KERNEL_NAME = {0: "mjh_phase_kernel<{r}, 0, W> (kinematics)", 1: "mjh_phase_kern
                15: "mjh_sort_kernel (environments ordered by last step's solver iteration counts)",
                16: "mjh_sol2_kernel<{r}, 28, 1, 34 | 36> (the whole pass in one launch: kinematics + crb / factor + velocity + collision / constraint + register solver + integrator; 36: opt.iterations == 1)",
                17: "mjh_phase_kernel<{r}, 17, W> (kernel 13 on two wavefronts per workgroup: kinematics, then velocity beside crb / factor)",
+               19: "mjh_sol2_kernel<{r}, NMAX, RPL, 18> (parts 2 | 4: collision / constraint + the register solver's first tier + integrator in one launch)",
                18: "mjh_sol2_kernel<{r}, 8, RPL, 18> (one RK4 stage in one launch: kinematics + crb / factor + velocity, collision / constraint, the register solver's first tier + integrator)"}
 
 
@@ -131,7 +132,7 @@ def kernel_algorithmic_bytes(nm):
     import ctypes
 
     out = {}
-    for k in range(19):
+    for k in range(20):
         rw = (ctypes.c_int64 * 2)()
         if nm.lib.mjh_model_kernel_io(nm.handle, k, rw) == 0:
             out[k] = (int(rw[0]), int(rw[1]))
@@ -408,7 +409,7 @@ def roofline_of(key, B, dtype, mx, mdev, loop, device, kernel_ms, steps):
             traffic = tj.get("hbm_bytes_per_step")
             best_disp = 0
             for name, v in tj.get("kernels", {}).items():  # PMC bytes per launch of the dominant kernel (FETCH_SIZE corrected x2)
-                pat = "mjh_sol2_kernel<" if dom["id"] in (9, 14, 16, 18) else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
+                pat = "mjh_sol2_kernel<" if dom["id"] in (9, 14, 16, 18, 19) else ("mjh_convex_kernel<" if dom["id"] == 10 else ("mjh_sensor_kernel<" if dom["id"] == 11 else f"mjh_phase_kernel<{rname}, {dom['id']},"))
                 if pat not in name:
                     continue
                 kb = 2 * 1024 * v["FETCH_SIZE_KB_raw_mean"] + 1024 * v["WRITE_SIZE_KB_mean"]

@@ -35,7 +35,7 @@ export HERE OBJ HIPCC FLAGS SRC_HASH FLAG_HASH MJH_BUILD_ONLY
 
 LIST=""
 # the heavy groups (register solver: 7 8 9, fused kinematics + velocity: 3) start first
-for g in 17 19 7 8 10 13 11 14 9 16 3 12 18 4 5 0 1 2 6 15; do [ "$g" -lt "$NG" ] && LIST="$LIST $g:d $g:f"; done
+for g in 17 21 20 19 7 8 10 13 11 14 9 16 3 12 18 4 5 0 1 2 6 15; do [ "$g" -lt "$NG" ] && LIST="$LIST $g:d $g:f"; done
 echo $LIST | tr ' ' '\n' | xargs -P "$JOBS" -I{} bash -c 'IFS=: read g t <<< "{}"; compile_one $g $t'
 $HIPCC $FLAGS -c -o "$OBJ/mjhip.o" "$HERE/mjhip.hip" 2> "$OBJ/mjhip.log" || { cat "$OBJ/mjhip.log" >&2; exit 1; }
 OBJS="$OBJ/mjhip.o"

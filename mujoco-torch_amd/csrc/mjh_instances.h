@@ -26,8 +26,10 @@
 #define MJH_INST_G17(X, S, C, N, R) S(R, 28, 1, 34) S(R, 28, 1, 36)  /* the whole pass -- kinematics + crb + velocity + constraint stage + register solver + integrator -- in one kernel (W = 34) */
 #define MJH_INST_G18(X, S, C, N, R) X(R, 17, 32) X(R, 17, 16)  /* kernel 13 on two wavefronts per workgroup: kinematics, then velocity beside crb / factor */
 #define MJH_INST_G19(X, S, C, N, R) S(R, 8, 2, 18) S(R, 8, 5, 18)  /* one RK4 stage of a small Newton model in one launch: kernel 13's stages + constraint phase + the solver's first tier (W = 18) */
-#define MJH_INST_NGROUPS 20
+#define MJH_INST_G20(X, S, C, N, R) S(R, 12, 2, 18) S(R, 12, 5, 18)
+#define MJH_INST_G21(X, S, C, N, R) S(R, 16, 2, 18) S(R, 16, 5, 18)
+#define MJH_INST_NGROUPS 22
 
 #define MJH_INST_ALL(X, S, C, N, R)                                                                                              \
   MJH_INST_G0(X, S, C, N, R) MJH_INST_G1(X, S, C, N, R) MJH_INST_G2(X, S, C, N, R) MJH_INST_G3(X, S, C, N, R) MJH_INST_G4(X, S, C, N, R) \
-  MJH_INST_G5(X, S, C, N, R) MJH_INST_G6(X, S, C, N, R) MJH_INST_G7(X, S, C, N, R) MJH_INST_G8(X, S, C, N, R) MJH_INST_G9(X, S, C, N, R) MJH_INST_G10(X, S, C, N, R) MJH_INST_G11(X, S, C, N, R) MJH_INST_G12(X, S, C, N, R) MJH_INST_G13(X, S, C, N, R) MJH_INST_G14(X, S, C, N, R) MJH_INST_G15(X, S, C, N, R) MJH_INST_G16(X, S, C, N, R) MJH_INST_G17(X, S, C, N, R) MJH_INST_G18(X, S, C, N, R) MJH_INST_G19(X, S, C, N, R)
+  MJH_INST_G5(X, S, C, N, R) MJH_INST_G6(X, S, C, N, R) MJH_INST_G7(X, S, C, N, R) MJH_INST_G8(X, S, C, N, R) MJH_INST_G9(X, S, C, N, R) MJH_INST_G10(X, S, C, N, R) MJH_INST_G11(X, S, C, N, R) MJH_INST_G12(X, S, C, N, R) MJH_INST_G13(X, S, C, N, R) MJH_INST_G14(X, S, C, N, R) MJH_INST_G15(X, S, C, N, R) MJH_INST_G16(X, S, C, N, R) MJH_INST_G17(X, S, C, N, R) MJH_INST_G18(X, S, C, N, R) MJH_INST_G19(X, S, C, N, R) MJH_INST_G20(X, S, C, N, R) MJH_INST_G21(X, S, C, N, R)

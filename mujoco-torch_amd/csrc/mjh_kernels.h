@@ -226,6 +226,7 @@ struct KArgs {
   LdsOff off2;         // whole-pass kernel (mjh_sol2_kernel<.., 34>): the arena layout of its second half (constraint stage + solver: PH_CS); `off` is its first half's (PH_KCV)
   LdsOff off3;         // stage kernel (mjh_sol2_kernel<.., 18>, one launch per RK4 stage of a small model): `off` = kernel 13's arena (four environments per wavefront), `off2` = the constraint phase's (kernel 8, two per wavefront), `off3` = the register solver's first tier
   int lds_reals2, lds_reals3;  // ... and the REALs between the arenas of a wavefront's environments in its second and third part
+  int stage_parts;             // ... and which parts this launch runs: 1 = kinematics + crb / factor + velocity, 2 = collision + constraint rows, 4 = solver tier + integrator (7: a whole RK4 stage; 6: the tail of a pass behind the convex narrow phase)
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
   StatePtrs<REAL> nxt; // where an RK stage writes the next stage's state (workspace Data)
@@ -4996,6 +4997,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     // behind a release / acquire pair at workgroup scope (as the first whole-pass kernel of round 4 did), the constraint phase runs its two-per-wavefront code twice (environments
     // 0, 1 then 2, 3 of the wave), and the arena is carved three times.  Environments the first tier leaves are marked for the second tier's launch as before.
     const int64_t idx = blk * NSUB + sub;
+    if (K.stage_parts & 1) {
     if (idx < K.env_count) {
       Env<REAL, 16, false> A(lds, K.env_begin + idx, K.flags);
       A.template run_kin<false>(); wave_sync(); A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>();
@@ -5003,6 +5005,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     wave_sync();
+    }
     {
       const int sub2 = (int)(threadIdx.x >> 5);
       REAL* lds2 = reinterpret_cast<REAL*>(lds_raw) + sub2 * K.lds_reals2;

@@ -82,6 +82,8 @@ struct mjhModel {
   int lds_all = 0;
   int fuse_stage = 0;                      // RK4 stages 1..3 of a small Newton model run as ONE launch each (mjh_sol2_kernel<.., 18>, timing id 18): kernel 13's stages, the constraint phase (kernel 8) and the register solver's first tier
   int lds_stage = 0;                       // ... dynamic LDS of one of its four-environment workgroups
+  int fuse_tail = 0;                       // the tail of a pass -- constraint phase + the solver's first tier + integrator -- as ONE launch of the same kernel (parts 2 | 4): small Newton models whose pass cannot be one launch (convex narrow phase or sensors between the parts, Euler)
+  int lds_tail = 0;
   int fuse_cs = 0;                         // constraint stage + register solver + integrator run as ONE kernel (mjh_sol2_kernel<.., 33>, timing id 14) from an arena of its own
   LdsOff off_cs;
   int lds_cs = 0;
@@ -841,9 +843,25 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
       if (need <= 64 * 1024) {
         out->fuse_stage = 1;
         out->lds_stage = need;
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 8, 2, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, 8, 5, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
       }
+    }
+    // ... and the tail of a pass alone (MJH_FUSE_TAIL=0: the two launches)
+    // Measured (MI355X, profiles/r06/notes.md): mesh scene (12 dofs: the tier's instantiation takes 227 VGPRs, two waves per SIMD, and the constraint phase inherits that) 219.6 us
+    // against 167.9 + 49.2 in two launches -- default for 8-dof tiers only, whose kernel sits at the constraint phase's own four waves per SIMD; MJH_FUSE_TAIL=1 / 0 forces it on / off.
+    static const int tail_sw = [] { const char* e = getenv("MJH_FUSE_TAIL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    const bool tail_off = tail_sw == 0 || (tail_sw < 0 && out->sol2_w16_nmax != 8);
+    out->fuse_tail = 0;
+    if (!tail_off && d->solver == SOL_NEWTON && M.con_direct && out->pack2[2] && out->sol2_tiers && out->sol2_w16_rpl > 0 && out->sort_reals == 0 && d->nefc > 0 && !M.topk &&
+        !(MJH_SOL2_CAPS_ON && out->sol2_it_cap > 0)) {
+      int need = 2 * out->lds_bytes[2];
+      if (4 * out->lds_tier > need) need = 4 * out->lds_tier;
+      if (need <= 64 * 1024) { out->fuse_tail = 1; out->lds_tail = need; }
+    }
+    if (out->fuse_stage || out->fuse_tail) {
+      const int need = out->lds_stage > out->lds_tail ? out->lds_stage : out->lds_tail;
+#define SET_ST(N, R) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&mjh_sol2_kernel<REAL, N, R, 18>), hipFuncAttributeMaxDynamicSharedMemorySize, need));
+      SET_ST(8, 2) SET_ST(8, 5) SET_ST(12, 2) SET_ST(12, 5) SET_ST(16, 2) SET_ST(16, 5)
+#undef SET_ST
     }
   }
   return 0;
@@ -969,7 +987,8 @@ int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, bool firs
 
 // one RK4 stage of a small Newton model in one launch (mjhModel::fuse_stage), then the solver's second tier for what the first left
 template <typename REAL>
-int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
+int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, int parts = 7) {  // parts 6: the tail of a pass (constraint phase + first solver tier) behind launches of its own for the rest
+  a.stage_parts = parts;
   a.off = m->off_kcv; a.lds_reals = m->lds_kcv / (int)sizeof(REAL);
   a.off2 = m->off[2]; a.lds_reals2 = m->lds_bytes[2] / (int)sizeof(REAL);
   a.off3 = m->off_tier; a.lds_reals3 = m->lds_tier / (int)sizeof(REAL);
@@ -979,12 +998,17 @@ int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   for (int64_t e0 = 0; e0 < a.B; e0 += 4 * max_grid()) {  // (no grid-stride loop in the kernels: one launch per 2^20 workgroups)
     const int64_t n = a.B - e0 < 4 * max_grid() ? a.B - e0 : 4 * max_grid();
     a.env_begin = e0; a.env_count = n;
-    if (m->sol2_w16_rpl == 2) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 8, 2, 18>), dim3((unsigned)(n / 4)), dim3(MJH_WAVE), (size_t)m->lds_stage, stream, a);
-    else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 8, 5, 18>), dim3((unsigned)(n / 4)), dim3(MJH_WAVE), (size_t)m->lds_stage, stream, a);
+    const size_t lds = (size_t)(parts == 7 ? m->lds_stage : m->lds_tail);
+    const dim3 g((unsigned)(n / 4)), b(MJH_WAVE);
+#define GOS(N, R) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, N, R, 18>), g, b, lds, stream, a)
+    if (m->sol2_w16_nmax == 8) { if (m->sol2_w16_rpl == 2) GOS(8, 2); else GOS(8, 5); }
+    else if (m->sol2_w16_nmax == 12) { if (m->sol2_w16_rpl == 2) GOS(12, 2); else GOS(12, 5); }
+    else { if (m->sol2_w16_rpl == 2) GOS(16, 2); else GOS(16, 5); }
+#undef GOS
     HIP_TRY(hipGetLastError());
   }
   a.env_begin = 0; a.env_count = a.B;
-  timing_mark(stream, 18);
+  timing_mark(stream, parts == 7 ? 18 : 19);
   return launch_sol2<REAL>(m, a, stream, true);
 }
 
@@ -1140,6 +1164,15 @@ int forward_pass(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   }
   if ((st & 0x7e) && !fused_kcv && (rc = launch_phase<REAL, 1>(m, a, stream))) return rc;
   const bool fused_cs = m->fuse_cs && (st & 0x7c) && (st & 0x40) && a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref;  // the whole tail of the pass is asked for: constraint stage and solve share a kernel
+  const bool fused_tail = !fused_cs && m->fuse_tail && (st & 0x7c) == 0x7c && a.B >= 4 && (a.B & 3) == 0 && !a.sol_perm && a.cur.qM && a.cur.qLD && a.cur.qfrc_smooth && a.cur.contact_dist &&
+                          a.cur.efc_J && a.cur.efc_D && a.cur.efc_aref && !(a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) && fused_kv;  // (the velocity stage has run: it rode with the kinematics)
+  if (fused_tail) {  // small Newton models: constraint phase + first solver tier + integrator in one launch (their sensors read leaves of the kinematics / velocity stages only: first)
+    if ((st & 0x40) && a.M.nsensor > 0 && a.rk_stage <= 0 && a.cur.sensordata) {
+      if ((rc = launch_sensor_kernel<REAL>(m, a, stream))) return rc;
+      timing_mark(stream, 11);
+    }
+    return launch_stage<REAL>(m, a, stream, 6);
+  }
   if (!fused_cs && (st & 0x7c) && (a.M.ncon > 0 || a.M.nefc > 0) &&
       (rc = a.M.con_general ? launch_phase<REAL, 7>(m, a, stream) : (a.M.con_direct ? launch_phase<REAL, 8>(m, a, stream) : launch_phase<REAL, 2>(m, a, stream)))) return rc;
   if ((st & 0x70) && !fused_kv && (rc = (a.M.has_fluid || a.M.has_gravcomp || a.M.ntendon > 0 || a.M.big) ? launch_phase<REAL, 5>(m, a, stream) : launch_phase<REAL, 3>(m, a, stream))) return rc;
@@ -1528,6 +1561,13 @@ int mjh_model_kernel_io(const mjhModel* m, int kernel, int64_t* read_write_bytes
     g_io_stage = prev;
     if (rc) return rc;
     read_write_bytes[0] = a13[0] + a8[0] + a9[0]; read_write_bytes[1] = a13[1] + a8[1] + a9[1];
+    return 0;
+  }
+  if (kernel == 19) {  // the tail of a pass in one launch: the accounts of the constraint phase and the register solver
+    if (!m->fuse_tail) return -2;
+    int64_t a8[2] = {0, 0}, a9[2] = {0, 0};
+    if (mjh_model_kernel_io_impl(m, 8, a8) != 0 || mjh_model_kernel_io_impl(m, 9, a9) != 0) return -2;
+    read_write_bytes[0] = a8[0] + a9[0]; read_write_bytes[1] = a8[1] + a9[1];
     return 0;
   }
   if ((kernel == 13 || kernel == 14) && m->fuse_all && !g_io_inner) return -2;
