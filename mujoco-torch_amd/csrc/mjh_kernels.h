@@ -942,6 +942,14 @@ struct Env {
     if (r < s2 + ne + nlb) return r - s2 + nf + nft;    // ne + nf + nft + (r - s2 - ne)
     return r;                                           // tendon limits and contacts sit at the same index in both orders
   }
+  // S.i_crow_act of the small-model constraint phase has two meanings: per dense ROW a 0 / 1 activity flag, or -- DevModel::crow_by_con: every contact has con_rows rows and
+  // dense row q belongs to contact q / con_rows -- per CONTACT 0 = inactive, else its place in the compact list of active contacts + 1.  Every reader goes through these two:
+  __device__ __forceinline__ static int crow_entry(const int* row_act, int q, float inv_rows) {  // non-zero iff dense row q is a row of an active contact
+    int qc = q, sub_;
+    if (M.crow_by_con) split_index(q, M.con_rows, inv_rows, qc, sub_);
+    return row_act[qc];
+  }
+  __device__ __forceinline__ static int crow_slot_of_contact(const int* row_act, int c) { return row_act[c] - 1; }  // crow_by_con only: compact slot of contact c, -1 = inactive
   LdsView<REAL> S;
   int64_t e;      // environment index
   REAL ho_g[12];  // whole-pass kernel: this lane's geom frame (position, matrix) as the kinematics formed it, handed to the constraint stage in registers (lane g <-> geom g, ngeom <= W)
@@ -2115,7 +2123,7 @@ struct Env {
       if (KA.hs && M.crow_by_con) hs = KA.hs + e * KA.hs_reals;
       if (hs) {
         if (l == 0) hs[0] = (REAL)(nact * M.con_rows);
-        for (int c = l; c < ncon; c += W) hs[1 + c] = (REAL)(row_act[c] - 1);
+        for (int c = l; c < ncon; c += W) hs[1 + c] = (REAL)crow_slot_of_contact(row_act, c);
       }
       if (hs) hsJ = hs + 1 + ncon + 2 * nd;
       REAL* const Jdst = out.efc_J + (e * nefc + nl) * nv;  // row 0 = first contact row
@@ -2135,17 +2143,13 @@ struct Env {
           for (int w = l; w < nd * gpr; w += W) {
             int q, g;
             split_index(w, gpr, 1.0f / (float)gpr, q, g);
-            int qc = q, unused_;
-            if (M.crow_by_con) split_index(q, M.con_rows, inv_rows_, qc, unused_);
-            if (!row_act[qc]) MJH_NT_STORE(z, &reinterpret_cast<zvec*>(Jdst)[w]);  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
+            if (!crow_entry(row_act, q, inv_rows_)) MJH_NT_STORE(z, &reinterpret_cast<zvec*>(Jdst)[w]);  // inactive contact: every entry is (something) * 0 in the reference -- the Jacobians are not formed
           }
         } else
         for (int w = l; w < nd * nv; w += W) {
           int q, d;
           split_index(w, nv, M.inv_nv, q, d);
-          int qc = q, unused_;
-          if (M.crow_by_con) split_index(q, M.con_rows, inv_rows_, qc, unused_);
-          if (!row_act[qc]) Jdst[w] = 0;
+          if (!crow_entry(row_act, q, inv_rows_)) Jdst[w] = 0;
         }
       }
       for (int w = l; w < nact * nv; w += W) {
@@ -2291,7 +2295,7 @@ struct Env {
         const REAL active = (REAL)(dist < 0);
         con_row_active = dist < 0;
         if (KA.rk_stage > 0 && !con_row_active) continue;  // workspace Data of an RK4 stage: nobody reads D / aref of an inactive row (see above)
-        if (hs && con_row_active) hs_row = (reinterpret_cast<const int*>(S.i_crow_act())[c] - 1) * M.con_rows + sub;  // this row's place in the hand-over
+        if (hs && con_row_active) hs_row = crow_slot_of_contact(reinterpret_cast<const int*>(S.i_crow_act()), c) * M.con_rows + sub;  // this row's place in the hand-over
         if (!(info >> 24)) { pos = dist * active; pos_norm = dist * active; }
         else { pos = (sub == 0 ? dist : (REAL)0) * active; pos_norm = dist; }
       } else {  // contact row: its scalars are functions of the contact (constraint.py:440-451, 480-487, 547-561), recomputed here

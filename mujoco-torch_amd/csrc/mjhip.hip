@@ -675,7 +675,8 @@ int build(const mjhModelDesc* d, mjhModel* out, DevModel<REAL>& M) {
     const int64_t nd = (int64_t)d->nefc - d->nl;
     // Measured (MI355X, profiles/r05/notes.md): ant (RK4: stages 1..3 write the hand-over INSTEAD of their workspace leaves) solver phase 44.7 -> 42.3 us per stage, constraint phase unchanged;
     // mesh scene (Euler: the leaves AND the hand-over) solver 197.9 -> 194.4 us but constraint phase 47.2 -> 52.0: RK4 models only.
-    out->hs_reals = (!off && d->integrator == INT_RK4 && M.con_direct && M.crow_by_con && out->sol2_nmax && !out->fuse_cs && nd > 0) ? ((1 + (int64_t)d->ncon + 2 * nd + nd * d->nv + 3) & ~(int64_t)3) : 0;
+    // (a -DMJH_SOL2_CAPS build bypasses the hand-over in the solver: it is not written there either -- ADVICE r05)
+    out->hs_reals = (!off && !MJH_SOL2_CAPS_ON && d->integrator == INT_RK4 && M.con_direct && M.crow_by_con && out->sol2_nmax && !out->fuse_cs && nd > 0) ? ((1 + (int64_t)d->ncon + 2 * nd + nd * d->nv + 3) & ~(int64_t)3) : 0;
     out->work_reals += out->hs_reals;
   }
   out->cand_reals = (d->topk && M.ncvxpair > 0) ? 13 * (int64_t)d->ncand : 0;  // candidate contacts of the convex narrow phase (dist, pos, frame)
