@@ -5004,7 +5004,10 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     if (K.stage_parts & 1) {
     if (idx < K.env_count) {
       Env<REAL, 16, false> A(lds, K.env_begin + idx, K.flags);
-      A.template run_kin<false>(); wave_sync(); A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>();
+      A.template run_kin<false>(); wave_sync();
+      // (out of lockstep, as in the whole-pass kernel: workgroups of odd parity under the mask of flags bits 16..27 run the velocity stage before crb / factor)
+      if (!((__builtin_popcount((unsigned)blockIdx.x & (((unsigned)K.flags >> 16) & 0xfffu)) & 1) != 0)) { A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>(); }
+      else { A.template run_vel<false, true>(); wave_sync(); A.template crb_factor<true>(); }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -5041,15 +5044,30 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
       const int64_t env = (W == 16 && K.sol_perm) ? (int64_t)K.sol_perm[idx] : idx;
       Env<REAL, W, false> E(lds, K.env_begin + env, K.flags);
       if constexpr (ALL) {
+        // Out of lockstep (round 6).  A batch of one round of waves starts every wave at the same moment on the same program: all of them are in an arithmetic section, then all of them in
+        // a store burst (a lone wave runs the kernel in 108 us, 2048 of them in 142; delaying half of the workgroups by 19 us cost 4 us: profiles/r06/notes.md).  crb / factor and the
+        // velocity stage both depend on the kinematics only (forward.py:73-99), so the workgroups whose index has odd parity under a mask (flags bits 16..27; host: MJH_XSWAP) run the
+        // velocity stage FIRST: the same operations on the same inputs -- every leaf bit-identical -- while half of the chip is in one stage and half in the other.
+        const bool swap_cv = (__builtin_popcount((unsigned)blockIdx.x & (((unsigned)K.flags >> 16) & 0xfffu)) & 1) != 0;
         // The two halves of the pass used to be two launches (kernels 13 and 14): a device-wide barrier between them -- the slowest wave of the first, the launch, and
         // every wave of the second requesting its inputs at the same moment.  Here an environment's wave goes straight on: what the second half reads of the first
         // (geom frames, subtree_com, cdof, the factor, qM, qfrc_smooth, the normalised qpos) it reads back from the leaves THIS wave has just stored -- behind a
         // release / acquire pair at the scope of its own CU -- through the arena layout of the second half.
         E.template run_kin<false, true>();
         wave_sync();
-        E.template crb_factor<true, NMAX>();
-        wave_sync();
-        E.template run_vel<false, true>();
+        REAL h_qv_early = 0;  // (velocity first: qvel sits in the overlay the crb stage writes over -- lifted before it)
+        if (!swap_cv) {
+          E.template crb_factor<true, NMAX>();
+          wave_sync();
+          E.template run_vel<false, true>();
+        } else {
+          E.template run_vel<false, true>();
+          wave_sync();
+          { const int l_ = (int)(threadIdx.x & (W - 1)); h_qv_early = l_ < K.M.nv ? E.S.qvel()[l_] : (REAL)0; }
+          wave_sync();
+          E.template crb_factor<true, NMAX>();
+          wave_sync();
+        }
         if (K.M.all_handoff) {
           // Round 5: the constraint stage's inputs -- geom frames, qvel, subtree_com, cdof -- cross the seam ON CHIP.  Read back from the leaves (round 4) the stage's first loads queued behind
           // the velocity stage's 25 KB of stores (vmcnt is in order): ~15 k of the environment's 307 k cycles.  The geom frames ride in registers from the kinematics (lane g <-> geom g), the
@@ -5062,7 +5080,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
           for (int k = 0; k < 6; k++) h_cd[k] = l + W * k < nv6 ? E.S.cdof()[l + W * k] : (REAL)0;
 #pragma unroll
           for (int k = 0; k < 3; k++) h_sc[k] = l + W * k < nb3 ? E.S.subtree_com()[l + W * k] : (REAL)0;
-          h_qv = l < K.M.nv ? E.S.qvel()[l] : (REAL)0;
+          h_qv = swap_cv ? h_qv_early : (l < K.M.nv ? E.S.qvel()[l] : (REAL)0);
           wave_sync();
           E.S.off = &K.off2;
 #pragma unroll
