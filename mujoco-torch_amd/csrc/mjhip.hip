@@ -917,9 +917,11 @@ int launch_phase(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
 // MJH_XSWAP=mask (12 bits of the workgroup index; 0: off): in the whole-pass kernel and the stage kernel, workgroups of odd parity under the mask run the velocity stage before
 // crb / factor (mjh_sol2_kernel: "out of lockstep").  Default 0x100: workgroups 256 apart, i.e. different wave slots of the same CUs under the round-robin placement.  Measured
 // (MI355X, humanoid B = 4096, profiles/r06/notes.md): 141.5 - 144.0 us -> 137.0 - 137.6 us whatever the mask (0x1 .. 0xfff); B = 32768 (eight rounds: the waves drift apart by themselves) unchanged.
-static int xswap_flags() {
+// Launches of more than 4096 workgroups keep one order: B = 32768 (eight rounds, the waves drift apart by themselves) measured 1015 us in one order against 1033 us with the swap.
+static int xswap_flags(int64_t workgroups) {
   static const int f = [] { const char* e = getenv("MJH_XSWAP"); const long v = e ? strtol(e, nullptr, 0) : 0x100; return (int)((v & 0xfff) << 16); }();
-  return f;
+  static const bool forced = getenv("MJH_XSWAP") != nullptr;  // (an explicit mask applies at every size: the bit-identity tests)
+  return (forced || workgroups <= 4096) ? f : 0;
 }
 
 // the solver phase through the register solver: two (or, first tier of a small model, four) environments per wavefront
@@ -999,7 +1001,7 @@ template <typename REAL>
 int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, int parts = 7) {  // parts 6: the tail of a pass (constraint phase + first solver tier) behind launches of its own for the rest
   a.stage_parts = parts;
   const int keep_flags_ = a.flags;
-  a.flags |= xswap_flags();
+  a.flags |= xswap_flags(a.B / 4);
   struct RestoreF_ { KArgs<REAL>& a; int f; ~RestoreF_() { a.flags = f; } } restore_f_{a, keep_flags_};
   a.off = m->off_kcv; a.lds_reals = m->lds_kcv / (int)sizeof(REAL);
   a.off2 = m->off[2]; a.lds_reals2 = m->lds_bytes[2] / (int)sizeof(REAL);
@@ -1056,7 +1058,7 @@ int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int64_t blocks = (a.B + 1) / 2;
   const int64_t grid = blocks < (int64_t)1 << 20 ? blocks : (int64_t)1 << 20;
   const int keep_flags_ = a.flags;
-  a.flags |= xswap_flags();
+  a.flags |= xswap_flags(grid);
   struct RestoreF_ { KArgs<REAL>& a; int f; ~RestoreF_() { a.flags = f; } } restore_f_{a, keep_flags_};
   if (a.M.iterations == 1) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 36>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
   else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 34>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
