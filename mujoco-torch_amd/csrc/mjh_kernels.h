@@ -226,6 +226,7 @@ struct KArgs {
   LdsOff off2;         // whole-pass kernel (mjh_sol2_kernel<.., 34>): the arena layout of its second half (constraint stage + solver: PH_CS); `off` is its first half's (PH_KCV)
   LdsOff off3;         // stage kernel (mjh_sol2_kernel<.., 18>, one launch per RK4 stage of a small model): `off` = kernel 13's arena (four environments per wavefront), `off2` = the constraint phase's (kernel 8, two per wavefront), `off3` = the register solver's first tier
   int lds_reals2, lds_reals3;  // ... and the REALs between the arenas of a wavefront's environments in its second and third part
+  int xswap_k;                 // whole-pass kernel, out of lockstep in the kinematics stage: workgroups of odd parity under this mask of their index run com_pos before the geom / site / camera frames (0: one order)
   int stage_parts;             // ... and which parts this launch runs: 1 = kinematics + crb / factor + velocity, 2 = collision + constraint rows, 4 = solver tier + integrator (7: a whole RK4 stage; 6: the tail of a pass behind the convex narrow phase)
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
@@ -1002,8 +1003,10 @@ struct Env {
     putnt(out.cinert, S.cinert(), 10 * M.nbody);
   }
   // ---- kinematics (smooth.py:34-207): each lane walks world -> its body along the ancestor chain ---------------------------------
-  template <bool DEFER = false, bool KEEPG = false>
-  __device__ __forceinline__ void kinematics(bool with_cams) {
+  // com_first (whole-pass kernel, out of lockstep: KArgs::xswap_k): com_pos() runs HERE, between the body frames and the geom / site / camera / light frames -- both only read the body frames --
+  // instead of behind this function (the caller then skips it): the same operations on the same inputs, while the other workgroups are in the other section
+  template <bool DEFER = false, bool KEEPG = false, bool XK = KEEPG>
+  __device__ __forceinline__ void kinematics(bool with_cams, bool com_first = false) {
     const int l = lane_here();
     // joint-local rotations first, one lane per joint: the trigonometry and the quaternion normalisations leave the
     // serial ancestor walk below (same expressions, smooth.py:85-120)
@@ -1323,6 +1326,7 @@ struct Env {
       }
     }
     if (!(DEFER && W > 16 && M.kv_defer)) frame_stores();  // (fused with the velocity stage: they go out in front of its LDS-only sweep, see velocity())
+    if constexpr (XK) if (com_first) { com_pos<DEFER>(); wave_sync(); }
     // normalised free / ball quaternions are written back into qpos (smooth.py:60-70); one lane per joint
     for (int j = l; j < M.njnt; j += W) {
       const int t = M.jnt_type[j], qa = M.jnt_qposadr[j];
@@ -3761,14 +3765,15 @@ struct Env {
   }
 
   // ---- phase drivers ------------------------------------------------------------------------------------------------------------------------------------------------
-  template <bool DEFER = false, bool KEEPG = false>
+  template <bool DEFER = false, bool KEEPG = false, bool XK = KEEPG>  // XK: the out-of-lockstep order of the kinematics stage is compiled in (whole-pass and stage kernels)
   __device__ __forceinline__ void run_kin() {
     STAMP0();
     load_qpos(true);
     wave_sync();
     STAMP(1);
-    kinematics<DEFER, KEEPG>(KA.rk_stage <= 0);
-    com_pos<DEFER>();
+    const bool com_first = XK && (__builtin_popcount((unsigned)blockIdx.x & (unsigned)KA.xswap_k) & 1) != 0;
+    kinematics<DEFER, KEEPG, XK>(KA.rk_stage <= 0, com_first);
+    if (!com_first) com_pos<DEFER>();
   }
   __device__ __forceinline__ void run_crb() { crb_factor<false>(); }
   __device__ __forceinline__ void run_con() {
@@ -5004,7 +5009,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     if (K.stage_parts & 1) {
     if (idx < K.env_count) {
       Env<REAL, 16, false> A(lds, K.env_begin + idx, K.flags);
-      A.template run_kin<false>(); wave_sync();
+      A.template run_kin<false, false, true>(); wave_sync();
       // (out of lockstep, as in the whole-pass kernel: workgroups of odd parity under the mask of flags bits 16..27 run the velocity stage before crb / factor)
       if (!((__builtin_popcount((unsigned)blockIdx.x & (((unsigned)K.flags >> 16) & 0xfffu)) & 1) != 0)) { A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>(); }
       else { A.template run_vel<false, true>(); wave_sync(); A.template crb_factor<true>(); }

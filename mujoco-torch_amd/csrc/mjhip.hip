@@ -924,6 +924,14 @@ static int xswap_flags(int64_t workgroups) {
   return (forced || workgroups <= 4096) ? f : 0;
 }
 
+// MJH_XSWAP_K=mask (default 0x200; 0: off): the same idea inside the kinematics stage -- workgroups of odd parity under this mask run com_pos before the geom / site / camera frames
+// (Env::kinematics, com_first).  Measured (MI355X, humanoid B = 4096, profiles/r06/notes.md): 138.8 -> 136.0 us on top of MJH_XSWAP; bit-identical.
+static int xswap_k_mask(int64_t workgroups) {
+  static const int f = [] { const char* e = getenv("MJH_XSWAP_K"); return e ? (int)(strtol(e, nullptr, 0) & 0xfff) : 0x200; }();
+  static const bool forced = getenv("MJH_XSWAP_K") != nullptr;
+  return (forced || workgroups <= 4096) ? f : 0;
+}
+
 // the solver phase through the register solver: two (or, first tier of a small model, four) environments per wavefront
 template <typename REAL>
 int launch_sol2(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, bool first_done = false) {  // first_done: the stage kernel has run the first tier (and marked what it left): only the second tier is launched
@@ -1003,6 +1011,7 @@ int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, int part
   const int keep_flags_ = a.flags;
   a.flags |= xswap_flags(a.B / 4);
   struct RestoreF_ { KArgs<REAL>& a; int f; ~RestoreF_() { a.flags = f; } } restore_f_{a, keep_flags_};
+  a.xswap_k = xswap_k_mask(a.B / 4);
   a.off = m->off_kcv; a.lds_reals = m->lds_kcv / (int)sizeof(REAL);
   a.off2 = m->off[2]; a.lds_reals2 = m->lds_bytes[2] / (int)sizeof(REAL);
   a.off3 = m->off_tier; a.lds_reals3 = m->lds_tier / (int)sizeof(REAL);
@@ -1060,6 +1069,7 @@ int launch_all(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream) {
   const int keep_flags_ = a.flags;
   a.flags |= xswap_flags(grid);
   struct RestoreF_ { KArgs<REAL>& a; int f; ~RestoreF_() { a.flags = f; } } restore_f_{a, keep_flags_};
+  a.xswap_k = xswap_k_mask(grid);
   if (a.M.iterations == 1) hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 36>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
   else hipLaunchKernelGGL((mjh_sol2_kernel<REAL, 28, 1, 34>), dim3((unsigned)grid), dim3(MJH_WAVE), (size_t)(2 * m->lds_all), stream, a);
   HIP_TRY(hipGetLastError());
