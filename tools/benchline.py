@@ -3,6 +3,8 @@ import json, os, sys
 args = sys.argv[1:]
 if args and os.path.exists(args[0]):  # a file instead of a pipe
     text, args = open(args[0]).read(), args[1:]
+elif args and (args[0].endswith(".json") or "/" in args[0]):  # a file that is not there (round 6: a missing path was taken for a label and the tool sat on an inherited stdin for 25 GPU-minutes)
+    sys.exit(f"benchline: no such file: {args[0]}")
 elif sys.stdin.isatty():              # a digest tool must never hang a GPU box waiting on a terminal
     sys.exit("benchline: no input (pipe a bench line in or pass a file)")
 else:
