@@ -508,12 +508,12 @@ out = {}
 for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("humanoid", {"solver": 1, "iterations": 3}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
                     ("mesh_contact", {}, torch.float32), ("sensor_rig2", {}, torch.float64), ("equality_loops", {}, torch.float64), ("centipede", {}, torch.float64)):
     mx = load_model(xml, ov, dt)
-    B = 203
-    d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
-    if dt != torch.float64: d = d.to(dt)
-    mdev = mx.to("cuda")
-    got = mt.step(mdev, mt.step(mdev, d.to("cuda")))
-    out[xml + str(sorted(ov.items()))] = {n: native.data_field_tensor(got, n).cpu() for n in REAL_LEAVES + INT_LEAVES}
+    for B in ((203, 204) if xml == "ant" else (203,)):  # (204: a multiple of four -- the ant's one-launch-per-RK4-stage kernel, cut into launches of 8 workgroups)
+        d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
+        if dt != torch.float64: d = d.to(dt)
+        mdev = mx.to("cuda")
+        got = mt.step(mdev, mt.step(mdev, d.to("cuda")))
+        out[xml + str(sorted(ov.items())) + str(B)] = {n: native.data_field_tensor(got, n).cpu() for n in REAL_LEAVES + INT_LEAVES}
 torch.save(out, sys.argv[1])
 print("ran")
 '''
@@ -900,6 +900,38 @@ def test_bench_gpus_2_on_one_shared_device():
     c4 = line["config4"]
     assert c4["envs_per_gpu"] == 32768 and c4["global_batch"] == 65536 and c4["steps"] >= 20 and c4["value"] > 0
     assert line["roofline"]["frac"] > 0 and "cpu_baseline" not in line  # the CPU leg runs at N = 1 only
+
+
+def test_launch_sequences_of_the_baseline_workloads():
+    """DESIGN.md section 3.1 as a test: which kernels one `step` launches for the BASELINE workloads, in launch order (timing ids of `mjh_debug_phase_times`): the humanoid's whole pass
+    is ONE launch (16); an ant RK4 step is one launch per stage (18) each followed by the solver's second tier (9), the sensors (11) behind stage 0 -- nine launches where round 5
+    needed seventeen; the mesh scene runs the two-wave kernel 13 (17), the convex narrow phase (10), the direct constraint phase (8) and the solver tiers (9)."""
+    import ctypes
+
+    from mujoco_torch_amd import native
+    from _cases import seeded_batch
+
+    lib = native.load_library()
+
+    def ids_of(xml, ov, dt, B):
+        mx, d = seeded_batch(xml, ov, dt, B)
+        mdev, dg = mx.to("cuda"), d.to("cuda")
+        dg = mt.step(mdev, dg)
+        lib.mjh_debug_phase_timing(1)
+        try:
+            mt.step(mdev, dg)
+            ms, ids = (ctypes.c_float * 96)(), (ctypes.c_int * 96)()
+            n = lib.mjh_debug_phase_times(ms, ids, 96)
+            assert n >= 0, lib.mjh_last_error().decode()
+            return [ids[i] for i in range(n)]
+        finally:
+            lib.mjh_debug_phase_timing(0)
+
+    assert ids_of("humanoid", {"solver": 1}, torch.float64, 64) == [16]
+    assert ids_of("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 64) == [18, 9, 11, 18, 9, 18, 9, 18, 9]
+    odd = ids_of("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 63)  # (not a multiple of four: the stage kernel does not serve it -- kernels 13 / 17, 8, 9 per stage, packed groups + tails)
+    assert 18 not in odd and odd.count(11) == 1 and odd.count(9) == 4, odd
+    assert ids_of("mesh_contact", {}, torch.float32, 64) == [17, 10, 8, 9]
 
 
 def test_bench_rccl_path_on_one_gpu():
