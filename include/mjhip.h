@@ -400,8 +400,9 @@ int mjh_model_lds_bytes(const mjhModel* m, int phase);
  * with frictionloss / equality / dense limit rows, 7 constraint phase with those rows or max_contact_points, 8 constraint phase of small
  * models (contact rows straight to the leaf), 9 solver phase as the register solver (mjh_sol2_kernel: two environments per wavefront),
  * 10 convex narrow phase, 11 sensors, 12 kinematics + velocity phases as one kernel -- then 0 and 3 do not appear --, 13 kinematics + crb / factor + velocity as one kernel: small float32
- * models while the batch is one round of its waves, then 12 and 1 do not appear).  Returns
- * the number of launches (<= max) or a negative code. */
+ * models while the batch is one round of its waves, then 12 and 1 do not appear; 14 constraint stage + register solver + integrator as one kernel, 15 the solver's
+ * environment sort (opt-in), 16 the whole pass as one kernel (humanoid-class models), 17 kernel 13 on two wavefronts per workgroup, 18 one RK4 stage of a small Newton model
+ * as one kernel, 19 that kernel running the constraint phase + first solver tier only).  Returns the number of launches (<= max) or a negative code. */
 int mjh_debug_phase_timing(int enable);
 int mjh_debug_phase_times(float* ms, int* kernel_ids, int max);
 
