@@ -4823,6 +4823,81 @@ struct Env {
           if (p1.d0 < p0.d0) { hi = p0; lo = p1; } else { hi = p1; lo = p0; }
           bool swap = !early;
           int ls_iter = 0;
+          // Wide tiers (RPL >= 4: the mesh scene's 80-row tier, ~10 iterations per search): the three candidates of an iteration are evaluated WITHOUT their cost -- it is only ever read of
+          // the two bracket ends the search finishes with (:491-495) -- and carry the two sums the cost needs (t1, t2); the cost of a surviving candidate is formed at the end from the same
+          // expression on the same values (one more pass over the rows for the constant term): every output bit-identical, a third of the row work and of the reductions of an iteration less.
+          constexpr bool LAZY = RPL >= 4;
+          if constexpr (LAZY) {
+            struct LP { REAL alpha, cost, d0, d1, t1, t2; bool hc; };
+            auto point_nc = [&](REAL alpha) -> LP {
+              REAL q1 = 0, q2 = 0;
+              {
+                const REAL x = jal + alpha * jvl;
+                const REAL act = (REAL)(lim && x < 0);
+                q1 += ql1 * act; q2 += ql2 * act;
+              }
+#pragma unroll
+              for (int j = 0; j < RPL; j++) {
+                const REAL x = jad[j] + alpha * jvd[j];
+                const REAL act = (REAL)((l + W * j < nda) && x < 0);
+                q1 += qd1[j] * act; q2 += qd2[j] * act;
+              }
+              q1 = sub_sum<W>(q1); q2 = sub_sum<W>(q2);
+              const REAL t1 = (qg1 + q1) + 0, t2 = (qg2 + q2) + 0;
+              LP p;
+              p.alpha = alpha; p.cost = 0; p.t1 = t1; p.t2 = t2; p.hc = false;
+              p.d0 = 2 * alpha * t2 + t1;
+              p.d1 = 2 * t2 + (REAL)(t2 == 0) * (REAL)mjMINVAL;
+              return p;
+            };
+            auto cost_of = [&](const LP& p) -> REAL {
+              REAL q0 = 0;
+              {
+                const REAL x = jal + p.alpha * jvl;
+                const REAL act = (REAL)(lim && x < 0);
+                q0 += ql0 * act;
+              }
+#pragma unroll
+              for (int j = 0; j < RPL; j++) {
+                const REAL x = jad[j] + p.alpha * jvd[j];
+                const REAL act = (REAL)((l + W * j < nda) && x < 0);
+                q0 += qd0[j] * act;
+              }
+              q0 = sub_sum<W>(q0);
+              const REAL t0 = (qg0 + q0) + 0;
+              return p.alpha * p.alpha * p.t2 + p.alpha * p.t1 + t0;
+            };
+            LP lo2{lo.alpha, lo.cost, lo.d0, lo.d1, 0, 0, true}, hi2{hi.alpha, hi.cost, hi.d0, hi.d1, 0, 0, true};
+            for (;;) {
+              if (fixed) { if (ls_iter >= M.ls_iterations) break; }
+              else {
+                bool done = ls_iter >= M.ls_iterations;
+                done |= !swap;
+                done |= (lo2.d0 < 0) && (lo2.d0 > -gtol);
+                done |= (hi2.d0 > 0) && (hi2.d0 < gtol);
+                if (done) break;
+              }
+              const LP lo_next = point_nc(lo2.alpha - lo2.d0 / lo2.d1);
+              const LP hi_next = point_nc(hi2.alpha - hi2.d0 / hi2.d1);
+              const LP mid = point_nc((REAL)0.5 * (lo2.alpha + hi2.alpha));
+              const bool nb = (lo2.d0 < 0) == (hi2.d0 < 0);
+              const bool s1 = ls_swap(lo2.d0, lo_next.d0, nb); if (s1) lo2 = lo_next;
+              const bool s2 = ls_swap(lo2.d0, mid.d0, nb); if (s2) lo2 = mid;
+              const bool s3 = ls_swap(lo2.d0, hi_next.d0, nb); if (s3) lo2 = hi_next;
+              const bool s4 = ls_swap(hi2.d0, hi_next.d0, nb); if (s4) hi2 = hi_next;
+              const bool s5 = ls_swap(hi2.d0, mid.d0, nb); if (s5) hi2 = mid;
+              const bool s6 = ls_swap(hi2.d0, lo_next.d0, nb); if (s6) hi2 = lo_next;
+              swap = s1 | s2 | s3 | s4 | s5 | s6;
+              ls_iter++;
+              if (it_cap > 0 && ls_total + ls_iter >= ls_cap) { bail = true; break; }
+            }
+            if (!bail) {  // (the bracket ends are the same in every lane of the environment: uniform branches around the reductions)
+              if (!lo2.hc) lo2.cost = cost_of(lo2);
+              if (!hi2.hc) hi2.cost = cost_of(hi2);
+            }
+            lo.alpha = lo2.alpha; lo.cost = lo2.cost; lo.d0 = lo2.d0; lo.d1 = lo2.d1;
+            hi.alpha = hi2.alpha; hi.cost = hi2.cost; hi.d0 = hi2.d0; hi.d1 = hi2.d1;
+          } else
           for (;;) {
             if (fixed) { if (ls_iter >= M.ls_iterations) break; }
             else {
