@@ -85,6 +85,9 @@ CASES = {
     "mocap_rk4_f32": ("mocap_target", {"integrator": 1}, "float32", 2, 2, "mocap"),
     # a mocap body that carries a jointed subtree (round 6): the children hang off the static body_pos / body_quat chain, the override comes after the scan
     "mocap_child_f64": ("mocap_child", {}, "float64", 3, 3, "mocap"),
+    # ... and a 20-dof chain under a mocap body: the humanoid-class kernels (whole pass in one launch, level-sweep kinematics) on such a tree
+    "mocap_chain_f64": ("mocap_chain", {}, "float64", 3, 3, "mocap"),
+    "mocap_chain_cg1_f64": ("mocap_chain", {"solver": 1, "iterations": 1, "ls_iterations": 4}, "float64", 2, 3, "mocap"),
     # gravity compensation (passive.py:148-156, forward.py:206-207): passive on two links, through the actuator channel on the third
     "gravcomp_f64": ("gravcomp_arm", {}, "float64", 3, 3, "generic"),
     "gravcomp_rk4_f32": ("gravcomp_arm", {"integrator": 1}, "float32", 2, 2, "generic"),

@@ -342,7 +342,7 @@ from mujoco_torch_amd import native
 from _util import load_model, REAL_LEAVES, INT_LEAVES
 out = {}
 for xml, ov, dt in (("humanoid", {"solver": 1}, torch.float64), ("humanoid", {"solver": 1, "iterations": 3}, torch.float64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32),
-                    ("mesh_contact", {}, torch.float32), ("hopper", {}, torch.float64)):
+                    ("mesh_contact", {}, torch.float32), ("hopper", {}, torch.float64), ("mocap_chain", {"solver": 1, "iterations": 1, "ls_iterations": 4}, torch.float64)):  # (mocap_chain: the whole-pass kernel on a tree that hangs off a mocap body)
     mx = load_model(xml, ov, dt)
     B = 64
     d = mt.make_data(mx).expand(B).clone().replace(qvel=torch.tensor(0.05 * np.random.RandomState(0).randn(B, mx.nv)))
@@ -928,6 +928,7 @@ def test_launch_sequences_of_the_baseline_workloads():
             lib.mjh_debug_phase_timing(0)
 
     assert ids_of("humanoid", {"solver": 1}, torch.float64, 64) == [16]
+    assert ids_of("mocap_chain", {"solver": 1, "iterations": 1, "ls_iterations": 4}, torch.float64, 64) == [16]  # (a 20-dof chain under a mocap body: the same kernel, level-sweep kinematics)
     assert ids_of("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 64) == [18, 9, 11, 18, 9, 18, 9, 18, 9]
     odd = ids_of("ant", {"integrator": 1, "solver": 2, "cone": 1}, torch.float32, 63)  # (not a multiple of four: the stage kernel does not serve it -- kernels 13 / 17, 8, 9 per stage, packed groups + tails)
     assert 18 not in odd and odd.count(11) == 1 and odd.count(9) == 4, odd

@@ -15,7 +15,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("humanoid", {"solver": 1}, "float64", 96), ("humanoid", {}, "float64", 64), ("humanoid", {"solver": 1, "iterations": 3}, "float64", 64), ("humanoid", {"solver": 1}, "float32", 64),
          ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float32", 160), ("ant", {}, "float64", 64), ("ant", {"integrator": 1, "solver": 2, "cone": 1}, "float64", 64),
          ("mesh_contact", {}, "float32", 96), ("mesh_contact", {"integrator": 1}, "float64", 64), ("hopper", {}, "float64", 64), ("walker2d", {"integrator": 1}, "float64", 64),
-         ("halfcheetah", {}, "float64", 64), ("sensor_rig2", {}, "float64", 64), ("mocap_target", {}, "float64", 64), ("mocap_child", {}, "float64", 64), ("equality_loops", {}, "float64", 64),
+         ("halfcheetah", {}, "float64", 64), ("sensor_rig2", {}, "float64", 64), ("mocap_target", {}, "float64", 64), ("mocap_child", {}, "float64", 64), ("mocap_chain", {"solver": 1, "iterations": 1, "ls_iterations": 4}, "float64", 64), ("equality_loops", {}, "float64", 64),
          ("tendon_fixed", {}, "float64", 64), ("muscle_arm", {}, "float64", 64), ("convex_primitives", {}, "float64", 64), ("centipede", {}, "float64", 33), ("cartpole", {}, "float64", 64),
          ("pendula", {"integrator": 1, "solver": 1}, "float32", 64), ("capsules_topk", {}, "float64", 64), ("gravcomp_arm", {"integrator": 1}, "float64", 64)]
 CHILD = r'''
