@@ -227,6 +227,7 @@ struct KArgs {
   LdsOff off3;         // stage kernel (mjh_sol2_kernel<.., 18>, one launch per RK4 stage of a small model): `off` = kernel 13's arena (four environments per wavefront), `off2` = the constraint phase's (kernel 8, two per wavefront), `off3` = the register solver's first tier
   int lds_reals2, lds_reals3;  // ... and the REALs between the arenas of a wavefront's environments in its second and third part
   int xswap_k;                 // whole-pass kernel, out of lockstep in the kinematics stage: workgroups of odd parity under this mask of their index run com_pos before the geom / site / camera frames (0: one order)
+  int xswap_c;                 // stage kernel, out of lockstep in stage 0: workgroups of odd parity under this mask store the model-constant contact leaves (a third of what the constraint phase of stage 0 writes) at the kernel's HEAD instead of behind the constraint rows (0: all behind)
   int stage_parts;             // ... and which parts this launch runs: 1 = kinematics + crb / factor + velocity, 2 = collision + constraint rows, 4 = solver tier + integrator (7: a whole RK4 stage; 6: the tail of a pass behind the convex narrow phase)
   DevData<REAL> in;    // the caller's Data: external inputs (ctrl, applied forces, warm start) and stage-0 state
   DevData<REAL> cur;   // the Data being computed: `out` for a forward / RK stage 0, the workspace Data for RK stages 1..3
@@ -952,6 +953,7 @@ struct Env {
   }
   __device__ __forceinline__ static int crow_slot_of_contact(const int* row_act, int c) { return row_act[c] - 1; }  // crow_by_con only: compact slot of contact c, -1 = inactive
   LdsView<REAL> S;
+  bool consts_done_ = false;  // stage kernel: this workgroup stored the model-constant contact leaves at the kernel's head (KArgs::xswap_c)
   int64_t e;      // environment index
   REAL ho_g[12];  // whole-pass kernel: this lane's geom frame (position, matrix) as the kinematics formed it, handed to the constraint stage in registers (lane g <-> geom g, ngeom <= W)
   // from here on the environment index is news to the optimiser: the address arithmetic of a store section (e * leaf width, one 64-bit value per leaf) is
@@ -3782,7 +3784,7 @@ struct Env {
     // rows queued behind that burst (vmcnt is in order) -- at the end nothing of this wave waits for it, and the next wave's arithmetic runs while it drains
     if (M.ncon > 0) collision<0, false, true>();
     if (KA.stages & 0x78) make_constraint();
-    if (M.ncon > 0 && !(FRIC && M.topk)) contact_const_stores();
+    if (M.ncon > 0 && !(FRIC && M.topk) && !consts_done_) contact_const_stores();
   }
   // the solver's loads that depend on nothing this kernel computes (fused constraint + solver kernel)
   template <int NMAX>
@@ -5081,9 +5083,12 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
     // behind a release / acquire pair at workgroup scope (as the first whole-pass kernel of round 4 did), the constraint phase runs its two-per-wavefront code twice (environments
     // 0, 1 then 2, 3 of the wave), and the arena is carved three times.  Environments the first tier leaves are marked for the second tier's launch as before.
     const int64_t idx = blk * NSUB + sub;
+    // (the constant contact leaves depend on nothing: for half of the workgroups they leave at the head of the kernel, while the others' go out behind their constraint rows as before)
+    const bool consts_early = (K.stage_parts & 1) && (__builtin_popcount((unsigned)blockIdx.x & (unsigned)K.xswap_c) & 1) != 0;
     if (K.stage_parts & 1) {
     if (idx < K.env_count) {
       Env<REAL, 16, false> A(lds, K.env_begin + idx, K.flags);
+      if (consts_early && K.M.ncon > 0 && !K.M.topk) A.contact_const_stores();
       A.template run_kin<false, false, true>(); wave_sync();
       // (out of lockstep, as in the whole-pass kernel: workgroups of odd parity under the mask of flags bits 16..27 run the velocity stage before crb / factor)
       if (!((__builtin_popcount((unsigned)blockIdx.x & (((unsigned)K.flags >> 16) & 0xfffu)) & 1) != 0)) { A.template crb_factor<true>(); wave_sync(); A.template run_vel<false, true>(); }
@@ -5101,6 +5106,7 @@ __global__ void __launch_bounds__(MJH_WAVE, (sizeof(REAL) == 4 && NMAX == 8 && W
         if (i2 < K.env_count) {
           Env<REAL, 32, false, true> C(lds2, K.env_begin + i2, K.flags);
           C.S.off = &K.off2;
+          C.consts_done_ = consts_early;
           C.run_con();
         }
         wave_sync();

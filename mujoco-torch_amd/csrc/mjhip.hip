@@ -1012,6 +1012,8 @@ int launch_stage(const mjhModel* m, KArgs<REAL>& a, hipStream_t stream, int part
   a.flags |= xswap_flags(a.B / 4);
   struct RestoreF_ { KArgs<REAL>& a; int f; ~RestoreF_() { a.flags = f; } } restore_f_{a, keep_flags_};
   a.xswap_k = xswap_k_mask(a.B / 4);
+  static const int xswap_c = [] { const char* e = getenv("MJH_XSWAP_C"); return e ? (int)(strtol(e, nullptr, 0) & 0xfff) : 0x400; }();  // MJH_XSWAP_C=mask (0: off; see KArgs::xswap_c): measured ant 30.9 -> 31.1 M env-steps/s
+  a.xswap_c = a.rk_stage == 0 ? xswap_c : 0;
   a.off = m->off_kcv; a.lds_reals = m->lds_kcv / (int)sizeof(REAL);
   a.off2 = m->off[2]; a.lds_reals2 = m->lds_bytes[2] / (int)sizeof(REAL);
   a.off3 = m->off_tier; a.lds_reals3 = m->lds_tier / (int)sizeof(REAL);
