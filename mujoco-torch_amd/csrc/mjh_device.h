@@ -140,7 +140,7 @@ struct DevModel {
   const int* chain_dof;        // nbody*max_depth: dofadr | dofnum << 16 of the k-th body on the path world -> b
   const int* chain_jnt;        // nbody*max_depth*max_jnt: (type + 1) | dofadr << 8 of that body's joints in order, 0 = none
   int max_jnt;
-  // kinematics by pointer jumping (null: every lane walks world -> its body), one allocation -- the kernel argument block is at its 4 KiB limit:
+  // kinematics by pointer jumping (null: every lane walks world -> its body), one allocation (the kernel argument block was at its 4 KiB limit when this was added; 3,936 B since the arena offset tables went to 16-bit entries in round 6):
   //   int  anc[R][nbody]   the ancestor 2^r levels above body b, 0 where that is the world or beyond; R = ceil(log2(max_depth))
   //   REAL start[nbody][7] body_pos, body_quat (from byte offset 8 * ((R * nbody + 1) / 2)); for children of the world composed with the world body's own frame
   const int* kin_tab;
@@ -153,7 +153,7 @@ struct DevModel {
   int nrfq;                                // entries of rf_geom = (rangefinder, geom) ray tests per environment
   const int* efc_row_eq;                   // ne: eq_* table entry of an equality row
   int max_depth;
-  int kin_lvl;                             // kinematics as a level sweep with every lane's constants read up front (one body per lane in every instantiation the model runs at; bit-identical to the walk).  (Sits in the padding behind max_depth: the kernel argument block is at its 4 KiB limit.)
+  int kin_lvl;                             // kinematics as a level sweep with every lane's constants read up front (one body per lane in every instantiation the model runs at; bit-identical to the walk).  (Sits in the padding behind max_depth.)
   const int* qm_pair;                      // nqmpair: i << 8 | j (j <= i) of the inertia-matrix entries that can be non-zero
   int nqmpair;
   const int* qm_slot;                      // nv*nv: packed lower-triangle slot holding entry (i, j), -1 where qM is structurally zero
