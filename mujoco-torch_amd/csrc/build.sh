@@ -2,7 +2,7 @@
 # Builds libmjhip.so for gfx950 in-tree (mujoco-torch_amd/lib/).
 #  -ffp-contract=off : keep the reference's separate multiply/add rounding (no FMA contraction) so results
 #                      track the float64 oracle to ~1e-15.
-# The kernels are compiled as 20 translation units (mjh_instances.h: 10 groups x 2 dtypes) by parallel hipcc processes
+# The kernels are compiled as 44 translation units (mjh_instances.h: 22 groups x 2 dtypes) by parallel hipcc processes
 # (MJH_BUILD_JOBS, default: the number of CPUs), objects cached under csrc/build/ by a hash of the sources and flags; mjhip.hip
 # is the host side.  `build.sh -DFOO` passes extra flags to every compile.  MJH_BUILD_ONLY="3d 7f" rebuilds only those groups
 # (d = double, f = float) and relinks with the cached rest -- for iterating on one kernel.
