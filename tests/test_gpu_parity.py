@@ -357,7 +357,7 @@ print("ran")
     switches = [{}, {"MJH_FUSE_ALL": "0"}, {"MJH_FUSE_ALL": "0", "MJH_CS_ONE": "0"}, {"MJH_ALL_HANDOFF": "0"}, {"MJH_KCV2": "0"}, {"MJH_KCV2": "1"}, {"MJH_LDS_DIET": "0"},
                 {"MJH_HANDOVER": "0"}, {"MJH_SENSOR_EPW": "1"}, {"MJH_SOL2_INCR": "0"}, {"MJH_PAIR_CULL": "0"},
                 {"MJH_FUSE_STAGE": "0"}, {"MJH_FUSE_STAGE0": "0"},  # (round 6: one launch per RK4 stage of the ant -- kernel 13's stages, constraint phase and solver tier behind one another -- against its three launches, with and without stage 0)
-                {"MJH_XSWAP": "0", "MJH_XSWAP_K": "0", "MJH_XSWAP_C": "0"}, {"MJH_XSWAP": "0x1", "MJH_XSWAP_K": "0x3"}, {"MJH_XSWAP": "0xfff"},  # (round 6: workgroups of odd parity under a mask run the whole-pass kernel's velocity stage before crb / factor)
+                {"MJH_XSWAP": "0", "MJH_XSWAP_K": "0", "MJH_XSWAP_C": "0"}, {"MJH_XSWAP": "0x1", "MJH_XSWAP_K": "0x3", "MJH_XSWAP_C": "0x1"}, {"MJH_XSWAP": "0xfff", "MJH_XSWAP_C": "0x6"},  # (small masks: at B = 64 the default ones -- bits 8, 9, 10 of the workgroup index -- select nobody)  # (round 6: workgroups of odd parity under a mask run the whole-pass kernel's velocity stage before crb / factor)
                 {"MJH_KIN_LEVEL": "0"}]  # (round 6: the kinematics of the whole-pass kernel as a level sweep with the constants read up front -- the walk's operations per body, in its order)
     with tempfile.TemporaryDirectory() as td:
         res = []
